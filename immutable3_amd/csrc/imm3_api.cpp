@@ -1,0 +1,850 @@
+// imm3_api.cpp -- the C ABI of include/imm3.h: host-side planning (validation that mirrors the reference's
+// exceptions, predicate folding, batch layout) and launch orchestration of the HIP kernels.
+// Compiled with hipcc for gfx950.  There is NO CPU fallback: without a HIP device every entry point that
+// touches data fails with IMM3_ERR_DEVICE.
+#include "../../include/imm3.h"
+#include "imm3_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+using namespace imm3;
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail(IMM3_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------------------------
+struct TimingRecord {
+    int32_t kernel_id;
+    hipEvent_t start, stop;
+};
+
+struct imm3_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int filter_variant = 0;
+    int grid_blocks = 0;
+    bool timing = false;
+    std::vector<TimingRecord> pool; // pre-created event pairs
+    size_t used = 0;
+};
+
+struct SegCol {
+    int32_t codec = 0, width = 0;
+    uint8_t *d_data = nullptr;
+    bool owned = false;
+    uint64_t bytes = 0;
+    std::vector<int32_t> offsets;
+};
+
+struct imm3_segment {
+    imm3_ctx *ctx = nullptr;
+    std::vector<SegCol> cols;
+    uint64_t device_bytes = 0;
+};
+
+struct FoldedPred { // all SelectOp leaves on one segment column, folded
+    int32_t seg_col = 0;
+    int32_t kind = 0, width = 0;
+    int64_t lo = 0, hi = 0;                // numeric closed interval
+    std::vector<std::string> match;        // string: surviving IN-list values (each exactly width bytes)
+    uint8_t *d_blob = nullptr;             // device copy when it does not fit the kernel arguments
+};
+
+struct imm3_query {
+    imm3_ctx *ctx = nullptr;
+    const imm3_segment *seg = nullptr;
+    std::vector<int32_t> used;     // segment column index of each used column
+    std::vector<int32_t> proj;     // index into `used`
+    int64_t limit = 0;
+    // layout (Scan.scala:55-60)
+    std::vector<int32_t> batch_size, batch_oid;
+    std::vector<int64_t> batch_word_off;
+    int64_t n_rows = 0, n_words = 0, n_tiles = 0, n_chunks = 0;
+    bool ragged = false;
+    bool always_false = false;
+    std::vector<FoldedPred> preds;
+    // device buffers
+    uint64_t *d_bitmap = nullptr;
+    uint32_t *d_tile_counts = nullptr, *d_tile_offsets = nullptr, *d_chunk_sums = nullptr;
+    unsigned long long *d_total = nullptr, *d_n_emit = nullptr; // adjacent: d_n_emit = d_total + 1
+    uint32_t *d_word_row_base = nullptr;
+    uint8_t *d_word_nvalid = nullptr;
+    uint32_t *d_row_index = nullptr;
+    std::vector<uint8_t *> d_proj;
+    uint64_t cap_rows = 0;
+    bool reserved = false;
+    bool ran_select = false, ran_project = false;
+};
+
+// ---------------------------------------------------------------------------------------------
+// scalar rules shared with the reference (JVM d2i / i2b): Select.scala:65,73; SURVEY Appendix A.1 rule 5
+// ---------------------------------------------------------------------------------------------
+static int32_t jvm_d2i(double d) {
+    if (d != d) return 0;
+    if (d >= 2147483647.0) return INT32_MAX;
+    if (d <= -2147483648.0) return INT32_MIN;
+    return (int32_t)d;
+}
+static int32_t jvm_d2b(double d) { return (int32_t)(int8_t)(uint8_t)((uint32_t)jvm_d2i(d) & 0xFFu); }
+
+static const char *cond_name(int c) {
+    switch (c) {
+    case IMM3_MATCH: return "Match";
+    case IMM3_NOTMATCH: return "NotMatch";
+    case IMM3_EQ: return "EQ";
+    case IMM3_GT: return "GT";
+    case IMM3_LT: return "LT";
+    case IMM3_NOOP: return "NoOp";
+    default: return "?";
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// library / context
+// ---------------------------------------------------------------------------------------------
+extern "C" int imm3_abi_version(void) { return IMM3_ABI_VERSION; }
+extern "C" const char *imm3_last_error(void) { return g_err.c_str(); }
+
+extern "C" int imm3_device_count(int *count) {
+    if (!count) return fail(IMM3_ERR_ARG, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(IMM3_ERR_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = n;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_ctx_create(int device, void *stream, imm3_ctx **out) {
+    if (!out) return fail(IMM3_ERR_ARG, "out is null");
+    *out = nullptr;
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (n <= 0) return fail(IMM3_ERR_DEVICE, "no HIP device: the immutable3 GPU path has no CPU fallback");
+    if (device < 0 || device >= n) return fail(IMM3_ERR_ARG, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    std::unique_ptr<imm3_ctx> c(new imm3_ctx());
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    *out = c.release();
+    return IMM3_OK;
+}
+
+extern "C" int imm3_ctx_destroy(imm3_ctx *ctx) {
+    if (!ctx) return IMM3_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &r : ctx->pool) {
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_ctx_sync(imm3_ctx *ctx) {
+    if (!ctx) return fail(IMM3_ERR_ARG, "ctx is null");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return IMM3_OK;
+}
+
+extern "C" int imm3_ctx_stream(imm3_ctx *ctx, void **stream_out) {
+    if (!ctx || !stream_out) return fail(IMM3_ERR_ARG, "null argument");
+    *stream_out = (void *)ctx->stream;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_ctx_set_tuning(imm3_ctx *ctx, int32_t filter_variant, int32_t grid_blocks) {
+    if (!ctx) return fail(IMM3_ERR_ARG, "ctx is null");
+    ctx->filter_variant = filter_variant;
+    ctx->grid_blocks = grid_blocks;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_ctx_timing_enable(imm3_ctx *ctx, int32_t max_records) {
+    if (!ctx) return fail(IMM3_ERR_ARG, "ctx is null");
+    HIPCHK(hipSetDevice(ctx->device));
+    while ((int32_t)ctx->pool.size() < max_records) {
+        TimingRecord r{};
+        HIPCHK(hipEventCreate(&r.start));
+        HIPCHK(hipEventCreate(&r.stop));
+        ctx->pool.push_back(r);
+    }
+    ctx->timing = max_records > 0;
+    ctx->used = 0;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_ctx_timing_reset(imm3_ctx *ctx) {
+    if (!ctx) return fail(IMM3_ERR_ARG, "ctx is null");
+    ctx->used = 0;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_ctx_timing_collect(imm3_ctx *ctx, int32_t kernel_id, float *ms_out, int32_t cap, int32_t *n_out) {
+    if (!ctx || !n_out) return fail(IMM3_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    int32_t n = 0;
+    for (size_t i = 0; i < ctx->used; ++i) {
+        if (ctx->pool[i].kernel_id != kernel_id) continue;
+        if (n < cap && ms_out) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, ctx->pool[i].start, ctx->pool[i].stop));
+            ms_out[n] = ms;
+        }
+        ++n;
+    }
+    *n_out = n;
+    return IMM3_OK;
+}
+
+namespace {
+// Brackets one kernel launch with an event pair on the context's stream when timing is on.
+struct LaunchTimer {
+    imm3_ctx *ctx;
+    TimingRecord *rec = nullptr;
+    LaunchTimer(imm3_ctx *c, int32_t id) : ctx(c) {
+        if (ctx->timing && ctx->used < ctx->pool.size()) {
+            rec = &ctx->pool[ctx->used++];
+            rec->kernel_id = id;
+            (void)hipEventRecord(rec->start, ctx->stream);
+        }
+    }
+    ~LaunchTimer() {
+        if (rec) (void)hipEventRecord(rec->stop, ctx->stream);
+    }
+};
+} // namespace
+
+// ---------------------------------------------------------------------------------------------
+// segment
+// ---------------------------------------------------------------------------------------------
+static constexpr uint64_t kPad = 4096; // readable slack past every column so wide loads never fault
+
+static int segment_build(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, bool wrap, imm3_segment **out) {
+    if (!ctx || !out) return fail(IMM3_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (ncols <= 0 || !cols) return fail(IMM3_ERR_ARG, "a segment needs at least one column");
+    HIPCHK(hipSetDevice(ctx->device));
+    std::unique_ptr<imm3_segment> seg(new imm3_segment());
+    seg->ctx = ctx;
+    seg->cols.resize((size_t)ncols);
+    for (int32_t i = 0; i < ncols; ++i) {
+        const imm3_column &c = cols[i];
+        SegCol &s = seg->cols[(size_t)i];
+        if (c.width <= 0) return fail(IMM3_ERR_ARG, "column width must be positive");
+        if (c.n_offsets < 0 || (c.n_offsets > 0 && !c.block_offsets)) return fail(IMM3_ERR_ARG, "bad block offset table");
+        if (c.dat_bytes > 0 && !c.dat) return fail(IMM3_ERR_ARG, "column data pointer is null");
+        s.codec = c.codec;
+        s.width = c.width;
+        s.bytes = c.dat_bytes;
+        s.offsets.assign(c.block_offsets, c.block_offsets + c.n_offsets);
+        if (wrap) {
+            s.d_data = (uint8_t *)c.dat;
+            s.owned = false;
+        } else {
+            void *p = nullptr;
+            HIPCHK(hipMalloc(&p, c.dat_bytes + kPad));
+            s.d_data = (uint8_t *)p;
+            s.owned = true;
+            seg->device_bytes += c.dat_bytes + kPad;
+            if (c.dat_bytes) HIPCHK(hipMemcpyAsync(s.d_data, c.dat, c.dat_bytes, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipMemsetAsync(s.d_data + c.dat_bytes, 0, kPad, ctx->stream));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream)); // host buffers may be unmapped after we return
+    *out = seg.release();
+    return IMM3_OK;
+}
+
+extern "C" int imm3_segment_create(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, imm3_segment **out) {
+    return segment_build(ctx, cols, ncols, false, out);
+}
+extern "C" int imm3_segment_wrap_device(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, imm3_segment **out) {
+    return segment_build(ctx, cols, ncols, true, out);
+}
+
+extern "C" int imm3_segment_destroy(imm3_segment *seg) {
+    if (!seg) return IMM3_OK;
+    (void)hipSetDevice(seg->ctx->device);
+    (void)hipStreamSynchronize(seg->ctx->stream);
+    for (auto &c : seg->cols)
+        if (c.owned && c.d_data) (void)hipFree(c.d_data);
+    delete seg;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_segment_bytes(const imm3_segment *seg, uint64_t *device_bytes) {
+    if (!seg || !device_bytes) return fail(IMM3_ERR_ARG, "null argument");
+    *device_bytes = seg->device_bytes;
+    return IMM3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// query planning
+// ---------------------------------------------------------------------------------------------
+static void query_free(imm3_query *q) {
+    if (!q) return;
+    (void)hipSetDevice(q->ctx->device);
+    (void)hipStreamSynchronize(q->ctx->stream);
+    (void)hipFree(q->d_bitmap);
+    (void)hipFree(q->d_tile_counts);
+    (void)hipFree(q->d_tile_offsets);
+    (void)hipFree(q->d_chunk_sums);
+    (void)hipFree(q->d_total);
+    (void)hipFree(q->d_word_row_base);
+    (void)hipFree(q->d_word_nvalid);
+    (void)hipFree(q->d_row_index);
+    for (auto p : q->d_proj) (void)hipFree(p);
+    for (auto &p : q->preds) (void)hipFree(p.d_blob);
+    delete q;
+}
+
+static int ensure_row_capacity(imm3_query *q, uint64_t rows) {
+    if (rows <= q->cap_rows && q->d_row_index) return IMM3_OK;
+    if (rows < 1) rows = 1;
+    HIPCHK(hipStreamSynchronize(q->ctx->stream));
+    (void)hipFree(q->d_row_index);
+    q->d_row_index = nullptr;
+    for (auto &p : q->d_proj) {
+        (void)hipFree(p);
+        p = nullptr;
+    }
+    void *p = nullptr;
+    HIPCHK(hipMalloc(&p, rows * sizeof(uint32_t)));
+    q->d_row_index = (uint32_t *)p;
+    q->d_proj.assign(q->proj.size(), nullptr);
+    for (size_t j = 0; j < q->proj.size(); ++j) {
+        const SegCol &sc = q->seg->cols[(size_t)q->used[(size_t)q->proj[j]]];
+        HIPCHK(hipMalloc(&p, rows * (uint64_t)sc.width));
+        q->d_proj[j] = (uint8_t *)p;
+    }
+    q->cap_rows = rows;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_query_create(imm3_ctx *ctx, const imm3_segment *seg,
+                                 const int32_t *used_cols, int32_t n_used,
+                                 const imm3_select *sels, int32_t n_sels,
+                                 const int32_t *proj, int32_t n_proj, int64_t limit,
+                                 int32_t table_block_size, imm3_query **out) {
+    if (!ctx || !seg || !out) return fail(IMM3_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (seg->ctx->device != ctx->device) return fail(IMM3_ERR_ARG, "segment lives on another device");
+    if (n_used <= 0 || !used_cols) return fail(IMM3_ERR_ARG, "a scan needs at least one used column");
+    if (n_sels < 0 || (n_sels > 0 && !sels)) return fail(IMM3_ERR_ARG, "bad select list");
+    if (n_proj < 0 || (n_proj > 0 && !proj)) return fail(IMM3_ERR_ARG, "bad project list");
+    const int32_t nsegcols = (int32_t)seg->cols.size();
+    for (int32_t i = 0; i < n_used; ++i)
+        if (used_cols[i] < 0 || used_cols[i] >= nsegcols) return fail(IMM3_ERR_ARG, "used column index out of range");
+    for (int32_t i = 0; i < n_sels; ++i)
+        if (sels[i].column < 0 || sels[i].column >= n_used) return fail(IMM3_ERR_ARG, "select column is not among the used columns");
+    for (int32_t i = 0; i < n_proj; ++i)
+        if (proj[i] < 0 || proj[i] >= n_used) return fail(IMM3_ERR_ARG, "project column is not among the used columns");
+    HIPCHK(hipSetDevice(ctx->device));
+
+    // (1) SelectOp.iterator (Select.scala:17-23) rejects NotMatch / NoOp when the chain is built,
+    //     whether or not the segment has any block.
+    for (int32_t i = 0; i < n_sels; ++i) {
+        const int c = sels[i].cond;
+        if (c != IMM3_MATCH && c != IMM3_GT && c != IMM3_LT && c != IMM3_EQ)
+            return fail(IMM3_ERR_UNSUPPORTED_CONDITION, std::string("Unsupported condition: ") + cond_name(c));
+        if (c == IMM3_MATCH && sels[i].n_match > 0 && (!sels[i].match_bytes || !sels[i].match_lens))
+            return fail(IMM3_ERR_ARG, "Match without values");
+    }
+
+    std::unique_ptr<imm3_query, void (*)(imm3_query *)> q(new imm3_query(), query_free);
+    q->ctx = ctx;
+    q->seg = seg;
+    q->used.assign(used_cols, used_cols + n_used);
+    q->proj.assign(proj, proj + n_proj);
+    q->limit = limit;
+
+    // (2) batches: the FIRST used column defines them (Scan.scala:55,72); BlockIterator takes each block
+    //     by a relative get from a rewound buffer (Segment.scala:159-168), i.e. from a running cursor.
+    const SegCol &first = seg->cols[(size_t)q->used[0]];
+    const int32_t nb = first.offsets.empty() ? 0 : (int32_t)first.offsets.size() - 1;
+
+    if (nb >= 1) {
+        // ScanOp.next dispatches on the codec of every used column (Scan.scala:37-50) ...
+        for (int32_t i = 0; i < n_used; ++i) {
+            const SegCol &sc = seg->cols[(size_t)q->used[(size_t)i]];
+            if (sc.codec != IMM3_DENSE_INT && sc.codec != IMM3_DENSE_TINYINT && sc.codec != IMM3_DENSE_STRING)
+                return fail(IMM3_ERR_NO_CODEC, "No implementation for codec " + std::to_string(sc.codec));
+            if ((sc.codec == IMM3_DENSE_INT && sc.width != 4) || (sc.codec == IMM3_DENSE_TINYINT && sc.width != 1))
+                return fail(IMM3_ERR_ARG, "width does not match codec");
+        }
+        // ... and each SelectIterator dispatches on the vector type (Select.scala:41,80,118,156).
+        for (int32_t i = 0; i < n_sels; ++i) {
+            const SegCol &sc = seg->cols[(size_t)q->used[(size_t)sels[i].column]];
+            const bool is_str = sc.codec == IMM3_DENSE_STRING;
+            if ((sels[i].cond == IMM3_MATCH) != is_str) return fail(IMM3_ERR_UNSUPPORTED_VECTOR, "Unsupported column vector");
+        }
+    }
+
+    q->batch_size.resize((size_t)nb);
+    q->batch_oid.resize((size_t)nb);
+    q->batch_word_off.resize((size_t)nb);
+    {
+        uint64_t cursor = 0;
+        int64_t words = 0, rows = 0;
+        for (int32_t k = 0; k < nb; ++k) {
+            const int64_t len = (int64_t)first.offsets[(size_t)k + 1] - (int64_t)first.offsets[(size_t)k];
+            if (len < 0) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": negative length (NegativeArraySizeException in the reference)");
+            if (len % first.width) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": byte length is not a multiple of the value width (malformed segment)");
+            if (cursor + (uint64_t)len > first.bytes) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": runs past the segment data (BufferUnderflowException in the reference)");
+            const int64_t n = len / first.width;
+            q->batch_size[(size_t)k] = (int32_t)n;
+            q->batch_oid[(size_t)k] = (int32_t)((uint32_t)k * (uint32_t)table_block_size); // vecCounter * table.blockSize
+            q->batch_word_off[(size_t)k] = words;
+            if (k < nb - 1 && (n % 64)) q->ragged = true;
+            words += (n + 63) / 64;
+            rows += n;
+            cursor += (uint64_t)len;
+        }
+        q->n_rows = rows;
+        q->n_words = words;
+    }
+    if (q->n_rows > 0xFFFFFFFFLL) return fail(IMM3_ERR_LAYOUT, "segment too large");
+    // every other used column must hold the same rows in the same blocks, otherwise the reference either
+    // throws ArrayIndexOutOfBounds (shorter) or silently joins the wrong rows (longer): refused here.
+    for (int32_t i = 1; i < n_used; ++i) {
+        const SegCol &sc = seg->cols[(size_t)q->used[(size_t)i]];
+        const int32_t nbc = sc.offsets.empty() ? 0 : (int32_t)sc.offsets.size() - 1;
+        if (nbc < nb) return fail(IMM3_ERR_LAYOUT, "used column " + std::to_string(i) + " has fewer blocks than the first used column (ArrayIndexOutOfBounds in the reference)");
+        uint64_t cursor = 0;
+        for (int32_t k = 0; k < nb; ++k) {
+            const int64_t len = (int64_t)sc.offsets[(size_t)k + 1] - (int64_t)sc.offsets[(size_t)k];
+            if (len < 0 || len % sc.width || len / sc.width != q->batch_size[(size_t)k])
+                return fail(IMM3_ERR_LAYOUT, "used column " + std::to_string(i) + " block " + std::to_string(k) + " does not hold the same rows as the first used column");
+            if (cursor + (uint64_t)len > sc.bytes) return fail(IMM3_ERR_LAYOUT, "used column " + std::to_string(i) + " block " + std::to_string(k) + " runs past the segment data");
+            cursor += (uint64_t)len;
+        }
+    }
+    q->n_tiles = (q->n_words + kTileWords - 1) / kTileWords;
+    q->n_chunks = (q->n_tiles + kChunkTiles - 1) / kChunkTiles;
+
+    // (3) fold the SelectOp leaves per column.  Every leaf only clears bits (Select.scala:37,68,106,144) and
+    //     runOps ignores AND/OR (Engine.scala:240), so the chain is a conjunction and order is irrelevant.
+    if (nb >= 1) {
+        for (int32_t i = 0; i < n_sels; ++i) {
+            const int32_t sci = q->used[(size_t)sels[i].column];
+            const SegCol &sc = seg->cols[(size_t)sci];
+            FoldedPred *fp = nullptr;
+            for (auto &p : q->preds)
+                if (p.seg_col == sci) fp = &p;
+            const bool fresh = !fp;
+            if (fresh) {
+                q->preds.emplace_back();
+                fp = &q->preds.back();
+                fp->seg_col = sci;
+                fp->width = sc.width;
+                if (sc.codec == IMM3_DENSE_INT) { fp->kind = KIND_I32; fp->lo = INT32_MIN; fp->hi = INT32_MAX; }
+                else if (sc.codec == IMM3_DENSE_TINYINT) { fp->kind = KIND_I8; fp->lo = -128; fp->hi = 127; }
+                else fp->kind = KIND_STR;
+            }
+            if (fp->kind == KIND_STR) {
+                std::vector<std::string> vals;
+                int64_t off = 0;
+                for (int32_t m = 0; m < sels[i].n_match; ++m) {
+                    const int32_t len = sels[i].match_lens[m];
+                    if (len < 0) return fail(IMM3_ERR_ARG, "negative match length");
+                    // String.equals can only hold for a value of exactly `width` bytes (DataType.scala:69-70)
+                    if (len == sc.width) {
+                        std::string v((const char *)sels[i].match_bytes + off, (size_t)len);
+                        if (std::find(vals.begin(), vals.end(), v) == vals.end()) vals.push_back(v);
+                    }
+                    off += len;
+                }
+                if (fresh) fp->match = vals;
+                else {
+                    std::vector<std::string> both;
+                    for (auto &v : fp->match)
+                        if (std::find(vals.begin(), vals.end(), v) != vals.end()) both.push_back(v);
+                    fp->match = both;
+                }
+            } else {
+                const int64_t t = fp->kind == KIND_I32 ? (int64_t)jvm_d2i(sels[i].value) : (int64_t)jvm_d2b(sels[i].value);
+                if (sels[i].cond == IMM3_GT) fp->lo = std::max(fp->lo, t + 1);      // strict >, Select.scala:68,76
+                else if (sels[i].cond == IMM3_LT) fp->hi = std::min(fp->hi, t - 1); // strict <, Select.scala:106,114
+                else { fp->lo = std::max(fp->lo, t); fp->hi = std::min(fp->hi, t); } // ==, Select.scala:144,152
+            }
+        }
+        for (auto &p : q->preds) {
+            if (p.kind == KIND_STR ? p.match.empty() : p.lo > p.hi) q->always_false = true;
+            if (p.kind == KIND_STR && (p.width > 8 || p.match.size() > (size_t)kMaxMatch) && !p.match.empty()) {
+                std::string blob;
+                for (auto &v : p.match) blob += v;
+                void *d = nullptr;
+                HIPCHK(hipMalloc(&d, blob.size()));
+                p.d_blob = (uint8_t *)d;
+                HIPCHK(hipMemcpyAsync(d, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+            }
+        }
+    }
+
+    // (4) device buffers
+    void *p = nullptr;
+    const size_t words_alloc = (size_t)std::max<int64_t>(q->n_tiles * kTileWords, 1);
+    HIPCHK(hipMalloc(&p, words_alloc * sizeof(uint64_t)));
+    q->d_bitmap = (uint64_t *)p;
+    HIPCHK(hipMalloc(&p, (size_t)std::max<int64_t>(q->n_tiles, 1) * sizeof(uint32_t)));
+    q->d_tile_counts = (uint32_t *)p;
+    HIPCHK(hipMalloc(&p, (size_t)std::max<int64_t>(q->n_tiles, 1) * sizeof(uint32_t)));
+    q->d_tile_offsets = (uint32_t *)p;
+    HIPCHK(hipMalloc(&p, (size_t)std::max<int64_t>(q->n_chunks, 1) * sizeof(uint32_t)));
+    q->d_chunk_sums = (uint32_t *)p;
+    HIPCHK(hipMalloc(&p, 2 * sizeof(unsigned long long)));
+    q->d_total = (unsigned long long *)p;
+    q->d_n_emit = q->d_total + 1;
+    HIPCHK(hipMemsetAsync(q->d_total, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(q->d_bitmap, 0, words_alloc * sizeof(uint64_t), ctx->stream));
+    if (q->ragged) {
+        std::vector<uint32_t> base((size_t)q->n_tiles * kTileWords, 0u);
+        std::vector<uint8_t> nvalid((size_t)q->n_tiles * kTileWords, 0);
+        int64_t row = 0;
+        size_t w = 0;
+        for (int32_t k = 0; k < nb; ++k) {
+            const int64_t n = q->batch_size[(size_t)k];
+            for (int64_t r = 0; r < n; r += 64) {
+                base[w] = (uint32_t)(row + r);
+                nvalid[w] = (uint8_t)std::min<int64_t>(64, n - r);
+                ++w;
+            }
+            row += n;
+        }
+        HIPCHK(hipMalloc(&p, base.size() * sizeof(uint32_t) + 4));
+        q->d_word_row_base = (uint32_t *)p;
+        HIPCHK(hipMalloc(&p, nvalid.size() + 4));
+        q->d_word_nvalid = (uint8_t *)p;
+        if (!base.empty()) {
+            HIPCHK(hipMemcpyAsync(q->d_word_row_base, base.data(), base.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipMemcpyAsync(q->d_word_nvalid, nvalid.data(), nvalid.size(), hipMemcpyHostToDevice, ctx->stream));
+        }
+        HIPCHK(hipStreamSynchronize(ctx->stream)); // the host vectors die at scope end
+    }
+    if (n_proj > 0 && limit > 0) {
+        const int rc = ensure_row_capacity(q.get(), (uint64_t)std::min<int64_t>(limit, std::max<int64_t>(q->n_rows, 1)));
+        if (rc) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *out = q.release();
+    return IMM3_OK;
+}
+
+extern "C" int imm3_query_destroy(imm3_query *q) {
+    query_free(q);
+    return IMM3_OK;
+}
+
+extern "C" int imm3_query_reserve_rows(imm3_query *q, uint64_t rows) {
+    if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    HIPCHK(hipSetDevice(q->ctx->device));
+    const int rc = ensure_row_capacity(q, rows);
+    if (rc) return rc;
+    q->reserved = true;
+    return IMM3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// execution
+// ---------------------------------------------------------------------------------------------
+static void fill_colpred(const imm3_query *q, const FoldedPred &fp, ColPred &cp) {
+    std::memset(&cp, 0, sizeof(cp));
+    const SegCol &sc = q->seg->cols[(size_t)fp.seg_col];
+    cp.data = sc.d_data;
+    cp.kind = fp.kind;
+    cp.width = fp.width;
+    cp.lo = (int32_t)fp.lo;
+    cp.hi = (int32_t)fp.hi;
+    cp.n_match = (int32_t)fp.match.size();
+    cp.match_in_args = (fp.kind == KIND_STR && !fp.d_blob) ? 1 : 0;
+    cp.match_blob = fp.d_blob;
+    if (cp.match_in_args) {
+        for (size_t m = 0; m < fp.match.size(); ++m) {
+            uint64_t v = 0;
+            for (int b = 0; b < fp.width; ++b) v |= (uint64_t)(uint8_t)fp.match[m][(size_t)b] << (8 * b);
+            cp.match[m] = v;
+        }
+    }
+}
+
+static int run_select(imm3_query *q) {
+    imm3_ctx *ctx = q->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    HIPCHK(hipMemsetAsync(q->d_total, 0, 2 * sizeof(unsigned long long), s));
+    if (q->always_false || q->n_tiles == 0) {
+        // an empty interval / empty IN-list clears every bit; nothing to read
+        HIPCHK(hipMemsetAsync(q->d_bitmap, 0, (size_t)std::max<int64_t>(q->n_tiles * kTileWords, 1) * sizeof(uint64_t), s));
+        HIPCHK(hipMemsetAsync(q->d_tile_counts, 0, (size_t)std::max<int64_t>(q->n_tiles, 1) * sizeof(uint32_t), s));
+        q->ran_select = true;
+        return IMM3_OK;
+    }
+    const size_t np = q->preds.size();
+    size_t done = 0;
+    int pass = 0;
+    do {
+        FilterArgs a;
+        std::memset(&a, 0, sizeof(a));
+        const size_t take = std::min<size_t>(kMaxPredCols, np - done);
+        for (size_t i = 0; i < take; ++i) fill_colpred(q, q->preds[done + i], a.cols[i]);
+        a.ncols = (int32_t)take;
+        a.and_existing = pass > 0;
+        a.n_rows = q->n_rows;
+        a.n_words = q->n_words;
+        a.n_tiles = q->n_tiles;
+        a.bitmap = q->d_bitmap;
+        a.tile_counts = q->d_tile_counts;
+        a.total = q->d_total;
+        a.word_row_base = q->d_word_row_base;
+        a.word_nvalid = q->d_word_nvalid;
+        // strings and ragged layouts go through the word-at-a-time kernel, numeric columns through the tile kernel
+        bool generic = q->ragged;
+        for (size_t i = 0; i < take; ++i) generic |= (a.cols[i].kind == KIND_STR);
+        if (pass > 0) HIPCHK(hipMemsetAsync(q->d_total, 0, sizeof(unsigned long long), s)); // re-accumulated by the AND pass
+        if (generic) HIPCHK(hipMemsetAsync(q->d_tile_counts, 0, (size_t)q->n_tiles * sizeof(uint32_t), s)); // it adds atomically
+        {
+            LaunchTimer t(ctx, 0);
+            launch_filter(a, generic, ctx->filter_variant, ctx->grid_blocks, s);
+        }
+        HIPCHK(hipGetLastError());
+        done += take;
+        ++pass;
+    } while (done < np);
+    q->ran_select = true;
+    return IMM3_OK;
+}
+
+static int launch_project(imm3_query *q) {
+    imm3_ctx *ctx = q->ctx;
+    hipStream_t s = ctx->stream;
+    GatherArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.bitmap = q->d_bitmap;
+    g.tile_counts = q->d_tile_counts;
+    g.tile_offsets = q->d_tile_offsets;
+    g.chunk_sums = q->d_chunk_sums;
+    g.n_tiles = q->n_tiles;
+    g.n_words = q->n_words;
+    g.limit = q->limit;
+    g.cap_rows = q->cap_rows;
+    g.word_row_base = q->d_word_row_base;
+    // more SELECT-list columns than one launch carries: gather in groups (row indices written by the first)
+    size_t done = 0;
+    const size_t np = q->proj.size();
+    do {
+        const size_t take = std::min<size_t>(kMaxProj, np - done);
+        g.row_index = done == 0 ? q->d_row_index : nullptr;
+        g.n_proj = (int32_t)take;
+        for (size_t j = 0; j < take; ++j) {
+            const SegCol &sc = q->seg->cols[(size_t)q->used[(size_t)q->proj[done + j]]];
+            g.proj[j].src = sc.d_data;
+            g.proj[j].dst = q->d_proj[done + j];
+            g.proj[j].width = sc.width;
+        }
+        {
+            LaunchTimer t(ctx, 2);
+            launch_gather(g, 0, s);
+        }
+        HIPCHK(hipGetLastError());
+        done += take;
+    } while (done < np);
+    return IMM3_OK;
+}
+
+static int run_project(imm3_query *q) {
+    imm3_ctx *ctx = q->ctx;
+    hipStream_t s = ctx->stream;
+    if (q->n_tiles > 0) {
+        ScanArgs sa;
+        std::memset(&sa, 0, sizeof(sa));
+        sa.tile_counts = q->d_tile_counts;
+        sa.tile_offsets = q->d_tile_offsets;
+        sa.chunk_sums = q->d_chunk_sums;
+        sa.n_tiles = q->n_tiles;
+        sa.total = q->d_total;
+        sa.n_emit = q->d_n_emit;
+        sa.limit = q->limit;
+        {
+            LaunchTimer t(ctx, 1);
+            launch_scan(sa, s);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    if (!(q->limit > 0) && !q->reserved) {
+        // unlimited projection with no reservation: the output size is the count -> one synchronisation
+        unsigned long long total = 0;
+        HIPCHK(hipMemcpyAsync(&total, q->d_total, sizeof(total), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        const int rc = ensure_row_capacity(q, total);
+        if (rc) return rc;
+    } else if (!q->d_row_index) {
+        const int rc = ensure_row_capacity(q, 1);
+        if (rc) return rc;
+    }
+    if (q->n_tiles > 0) {
+        const int rc = launch_project(q);
+        if (rc) return rc;
+    }
+    q->ran_project = true;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_query_run_select(imm3_query *q) {
+    if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    q->ran_project = false;
+    return run_select(q);
+}
+
+extern "C" int imm3_query_run(imm3_query *q) {
+    if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    q->ran_project = false;
+    int rc = run_select(q);
+    if (rc) return rc;
+    if (!q->proj.empty()) rc = run_project(q);
+    return rc;
+}
+
+extern "C" int imm3_query_sync(imm3_query *q) {
+    if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    HIPCHK(hipSetDevice(q->ctx->device));
+    HIPCHK(hipStreamSynchronize(q->ctx->stream));
+    return IMM3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// results
+// ---------------------------------------------------------------------------------------------
+extern "C" int imm3_query_layout(const imm3_query *q, int32_t *n_batches, int64_t *total_words, int64_t *n_rows) {
+    if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    if (n_batches) *n_batches = (int32_t)q->batch_size.size();
+    if (total_words) *total_words = q->n_words;
+    if (n_rows) *n_rows = q->n_rows;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_query_batches(const imm3_query *q, int32_t *batch_size, int32_t *batch_oid, int64_t *batch_word_off) {
+    if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    const size_t nb = q->batch_size.size();
+    if (batch_size && nb) std::memcpy(batch_size, q->batch_size.data(), nb * sizeof(int32_t));
+    if (batch_oid && nb) std::memcpy(batch_oid, q->batch_oid.data(), nb * sizeof(int32_t));
+    if (batch_word_off && nb) std::memcpy(batch_word_off, q->batch_word_off.data(), nb * sizeof(int64_t));
+    return IMM3_OK;
+}
+
+extern "C" int imm3_query_count(imm3_query *q, uint64_t *selected_rows) {
+    if (!q || !selected_rows) return fail(IMM3_ERR_ARG, "null argument");
+    if (!q->ran_select) return fail(IMM3_ERR_STATE, "imm3_query_run has not been called");
+    HIPCHK(hipSetDevice(q->ctx->device));
+    unsigned long long total = 0;
+    HIPCHK(hipMemcpyAsync(&total, q->d_total, sizeof(total), hipMemcpyDeviceToHost, q->ctx->stream));
+    HIPCHK(hipStreamSynchronize(q->ctx->stream));
+    *selected_rows = total;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_query_bitmap(imm3_query *q, uint64_t *words_out, int64_t n_words) {
+    if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    if (!q->ran_select) return fail(IMM3_ERR_STATE, "imm3_query_run has not been called");
+    if (n_words < 0 || n_words > q->n_words) return fail(IMM3_ERR_ARG, "n_words exceeds the bitmap");
+    if (n_words && !words_out) return fail(IMM3_ERR_ARG, "words_out is null");
+    HIPCHK(hipSetDevice(q->ctx->device));
+    if (n_words) HIPCHK(hipMemcpyAsync(words_out, q->d_bitmap, (size_t)n_words * sizeof(uint64_t), hipMemcpyDeviceToHost, q->ctx->stream));
+    HIPCHK(hipStreamSynchronize(q->ctx->stream));
+    return IMM3_OK;
+}
+
+static int settle_rows(imm3_query *q, uint64_t *rows) {
+    if (!q->ran_project) return fail(IMM3_ERR_STATE, "no projection has been run (n_proj == 0 or imm3_query_run not called)");
+    HIPCHK(hipSetDevice(q->ctx->device));
+    unsigned long long emit = 0;
+    if (q->n_tiles > 0) {
+        HIPCHK(hipMemcpyAsync(&emit, q->d_n_emit, sizeof(emit), hipMemcpyDeviceToHost, q->ctx->stream));
+        HIPCHK(hipStreamSynchronize(q->ctx->stream));
+    }
+    if (emit > q->cap_rows) {
+        // the reservation was too small: grow and gather again (offsets are still valid)
+        int rc = ensure_row_capacity(q, emit);
+        if (rc) return rc;
+        rc = launch_project(q);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(q->ctx->stream));
+    }
+    *rows = emit;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_query_row_count(imm3_query *q, uint64_t *rows) {
+    if (!q || !rows) return fail(IMM3_ERR_ARG, "null argument");
+    return settle_rows(q, rows);
+}
+
+extern "C" int imm3_query_fetch_rows(imm3_query *q, uint32_t *row_index_out, void *const *col_out, uint64_t max_rows) {
+    if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    uint64_t rows = 0;
+    const int rc = settle_rows(q, &rows);
+    if (rc) return rc;
+    const uint64_t n = std::min(rows, max_rows);
+    hipStream_t s = q->ctx->stream;
+    if (n) {
+        if (row_index_out) HIPCHK(hipMemcpyAsync(row_index_out, q->d_row_index, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        for (size_t j = 0; j < q->proj.size(); ++j) {
+            if (!col_out || !col_out[j]) continue;
+            const SegCol &sc = q->seg->cols[(size_t)q->used[(size_t)q->proj[j]]];
+            HIPCHK(hipMemcpyAsync(col_out[j], q->d_proj[j], n * (uint64_t)sc.width, hipMemcpyDeviceToHost, s));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    return IMM3_OK;
+}
+
+extern "C" int imm3_query_device_ptr(imm3_query *q, int32_t which, void **ptr) {
+    if (!q || !ptr) return fail(IMM3_ERR_ARG, "null argument");
+    switch (which) {
+    case 0: *ptr = q->d_bitmap; return IMM3_OK;
+    case 1: *ptr = q->d_total; return IMM3_OK;
+    case 2: *ptr = q->d_row_index; return IMM3_OK;
+    case 3: *ptr = q->d_n_emit; return IMM3_OK;
+    default:
+        if (which >= 16 && (size_t)(which - 16) < q->d_proj.size()) {
+            *ptr = q->d_proj[(size_t)(which - 16)];
+            return IMM3_OK;
+        }
+        return fail(IMM3_ERR_ARG, "unknown device pointer id");
+    }
+}

@@ -1,0 +1,93 @@
+// imm3_internal.h -- shared between the HIP kernels (imm3_kernels.hip) and the C-ABI (imm3_api.cpp).
+// gfx950 (MI355X, CDNA4) only: wave64, 256 CUs in 8 XCDs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace imm3 {
+
+// A wave owns one TILE = 1024 rows = 16 bitmap words = exactly one 128-byte line of the bitmap,
+// so no two waves (let alone two XCDs, whose L2s are not coherent) ever write the same line.
+constexpr int kTileRows = 1024;
+constexpr int kTileWords = 16;
+constexpr int kWavesPerBlock = 4;   // 256-thread workgroups
+constexpr int kBlockThreads = 256;
+constexpr int kChunkTiles = 1024;   // tiles per offsets-scan chunk (one scan workgroup)
+
+constexpr int kMaxPredCols = 4;     // distinct predicate columns fused per launch (more -> extra AND pass)
+constexpr int kMaxMatch = 8;        // IN-list values carried in kernel arguments
+constexpr int kMaxProj = 8;         // projected columns per gather launch
+
+enum ColKind : int32_t { KIND_I32 = 0, KIND_I8 = 1, KIND_STR = 2 };
+
+// Canonical per-column predicate.  All SelectOp leaves on one column are folded on the host:
+//   numeric: GT/LT/EQ conjunction -> one closed interval [lo, hi] (narrowing of Select.scala:65,73
+//            already applied; empty intervals never reach the kernel),
+//   string : Match IN-lists intersected; values whose length != width can never match and are dropped.
+struct ColPred {
+    const void *data;            // flat column in HBM (DENSE_* decode == little-endian reinterpretation)
+    int32_t kind;                // ColKind
+    int32_t width;               // bytes per value
+    int32_t lo, hi;              // numeric closed interval (int8 values sign-extended)
+    int32_t n_match;             // string: IN-list size
+    int32_t match_in_args;       // 1: width <= 8 and n_match <= kMaxMatch -> values packed in match[]
+    uint64_t match[kMaxMatch];   // value bytes packed little-endian (byte 0 = first character)
+    const uint8_t *match_blob;   // otherwise: n_match * width bytes in device memory
+};
+
+struct FilterArgs {
+    ColPred cols[kMaxPredCols];
+    int32_t ncols;
+    int32_t and_existing;        // 1: AND into the bitmap already in memory (second pass for > kMaxPredCols columns)
+    int64_t n_rows;              // uniform layout: rows of the segment
+    int64_t n_words;             // bitmap words (batch-major)
+    int64_t n_tiles;             // ceil(n_words / 16)
+    uint64_t *bitmap;
+    uint32_t *tile_counts;       // selected rows per tile
+    unsigned long long *total;   // selected rows of the segment (atomically accumulated)
+    // ragged layout only: per bitmap word, first row and number of valid rows (0..64)
+    const uint32_t *word_row_base;
+    const uint8_t *word_nvalid;
+};
+
+struct ScanArgs {
+    const uint32_t *tile_counts;
+    uint32_t *tile_offsets;      // exclusive prefix of tile_counts WITHIN its chunk
+    uint32_t *chunk_sums;        // selected rows per chunk of kChunkTiles tiles
+    int64_t n_tiles;
+    const unsigned long long *total;
+    unsigned long long *n_emit;  // rows ProjectOp emits = limit > 0 ? min(total, limit) : total
+    int64_t limit;
+};
+
+struct ProjCol {
+    const void *src;             // flat column
+    void *dst;                   // packed output, width bytes per emitted row
+    int32_t width;
+    int32_t pad;
+};
+
+struct GatherArgs {
+    const uint64_t *bitmap;
+    const uint32_t *tile_counts;
+    const uint32_t *tile_offsets;
+    const uint32_t *chunk_sums;
+    int64_t n_tiles;
+    int64_t n_words;
+    int64_t limit;               // <= 0: unlimited
+    uint64_t cap_rows;           // capacity of the output buffers
+    uint32_t *row_index;         // segment-global row of each emitted row
+    ProjCol proj[kMaxProj];
+    int32_t n_proj;
+    int32_t pad;
+    const uint32_t *word_row_base; // ragged layout, else null
+};
+
+// launchers (imm3_kernels.hip)
+void launch_filter(const FilterArgs &a, bool generic, int variant, int grid_blocks, hipStream_t s);
+void launch_scan(const ScanArgs &a, hipStream_t s);
+void launch_gather(const GatherArgs &a, int grid_blocks, hipStream_t s);
+void launch_fill_u64(uint64_t *p, uint64_t v, int64_t n, hipStream_t s);
+
+} // namespace imm3

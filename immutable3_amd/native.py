@@ -1,0 +1,328 @@
+"""ctypes binding of libimm3.so (include/imm3.h) -- the only way the host side reaches the GPU.
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is present, the
+calls raise.  The oracle under oracle/ is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libimm3.so")
+
+# CodecType (core/src/main/scala/immutabledb/codec/Codec.scala:21-24)
+PFOR_INT, DENSE_INT, DENSE_TINYINT, DENSE_STRING = 0, 1, 2, 3
+# SelectCondition (core/src/main/scala/immutabledb/Query.scala:3-9)
+MATCH, NOTMATCH, EQ, GT, LT, NOOP = 0, 1, 2, 3, 4, 5
+
+OK = 0
+ERR_UNSUPPORTED_CONDITION, ERR_UNSUPPORTED_VECTOR, ERR_NO_CODEC, ERR_LAYOUT, ERR_ARG, ERR_DEVICE, ERR_STATE = 1, 2, 3, 4, 5, 6, 7
+
+# every symbol include/imm3.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "imm3_abi_version", "imm3_last_error", "imm3_device_count",
+    "imm3_ctx_create", "imm3_ctx_destroy", "imm3_ctx_sync", "imm3_ctx_stream",
+    "imm3_segment_create", "imm3_segment_wrap_device", "imm3_segment_destroy", "imm3_segment_bytes",
+    "imm3_query_create", "imm3_query_destroy", "imm3_query_reserve_rows",
+    "imm3_query_run", "imm3_query_run_select", "imm3_query_sync",
+    "imm3_query_layout", "imm3_query_batches", "imm3_query_count", "imm3_query_bitmap",
+    "imm3_query_row_count", "imm3_query_fetch_rows", "imm3_query_device_ptr",
+    "imm3_ctx_timing_enable", "imm3_ctx_timing_reset", "imm3_ctx_timing_collect", "imm3_ctx_set_tuning",
+]
+
+
+class Imm3Error(Exception):
+    """The reference's `throw new Exception(msg)` as surfaced by the C ABI (status + message)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(msg)
+        self.code = code
+        self.msg = msg
+
+
+class CColumn(C.Structure):
+    _fields_ = [
+        ("codec", C.c_int32),
+        ("width", C.c_int32),
+        ("dat", C.c_void_p),
+        ("dat_bytes", C.c_uint64),
+        ("block_offsets", C.c_void_p),
+        ("n_offsets", C.c_int32),
+    ]
+
+
+class CSelect(C.Structure):
+    _fields_ = [
+        ("column", C.c_int32),
+        ("cond", C.c_int32),
+        ("value", C.c_double),
+        ("match_bytes", C.c_void_p),
+        ("match_lens", C.c_void_p),
+        ("n_match", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libimm3.so; fail loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C immutable3_amd/csrc). "
+            "The immutable3 GPU path has no CPU fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+    P = C.POINTER
+    L.imm3_abi_version.restype = C.c_int
+    L.imm3_last_error.restype = C.c_char_p
+    L.imm3_device_count.argtypes = [P(C.c_int)]
+    L.imm3_ctx_create.argtypes = [C.c_int, vp, P(vp)]
+    L.imm3_ctx_destroy.argtypes = [vp]
+    L.imm3_ctx_sync.argtypes = [vp]
+    L.imm3_ctx_stream.argtypes = [vp, P(vp)]
+    L.imm3_segment_create.argtypes = [vp, P(CColumn), i32, P(vp)]
+    L.imm3_segment_wrap_device.argtypes = [vp, P(CColumn), i32, P(vp)]
+    L.imm3_segment_destroy.argtypes = [vp]
+    L.imm3_segment_bytes.argtypes = [vp, P(u64)]
+    L.imm3_query_create.argtypes = [vp, vp, vp, i32, P(CSelect), i32, vp, i32, i64, i32, P(vp)]
+    L.imm3_query_destroy.argtypes = [vp]
+    L.imm3_query_reserve_rows.argtypes = [vp, u64]
+    L.imm3_query_run.argtypes = [vp]
+    L.imm3_query_run_select.argtypes = [vp]
+    L.imm3_query_sync.argtypes = [vp]
+    L.imm3_query_layout.argtypes = [vp, P(i32), P(i64), P(i64)]
+    L.imm3_query_batches.argtypes = [vp, vp, vp, vp]
+    L.imm3_query_count.argtypes = [vp, P(u64)]
+    L.imm3_query_bitmap.argtypes = [vp, vp, i64]
+    L.imm3_query_row_count.argtypes = [vp, P(u64)]
+    L.imm3_query_fetch_rows.argtypes = [vp, vp, P(vp), u64]
+    L.imm3_query_device_ptr.argtypes = [vp, i32, P(vp)]
+    L.imm3_ctx_timing_enable.argtypes = [vp, i32]
+    L.imm3_ctx_timing_reset.argtypes = [vp]
+    L.imm3_ctx_timing_collect.argtypes = [vp, i32, vp, i32, P(i32)]
+    L.imm3_ctx_set_tuning.argtypes = [vp, i32, i32]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if name not in ("imm3_last_error",):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _check(rc: int):
+    if rc != OK:
+        msg = load().imm3_last_error()
+        raise Imm3Error(rc, msg.decode() if msg else f"imm3 error {rc}")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = load().imm3_device_count(C.byref(n))
+    if rc != OK:
+        return 0
+    return n.value
+
+
+class Context:
+    """imm3_ctx: device id + HIP stream."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._h = C.c_void_p()
+        _check(load().imm3_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        self.device = device
+
+    def sync(self):
+        _check(load().imm3_ctx_sync(self._h))
+
+    @property
+    def stream(self) -> int:
+        s = C.c_void_p()
+        _check(load().imm3_ctx_stream(self._h, C.byref(s)))
+        return s.value or 0
+
+    def set_tuning(self, filter_variant: int = 0, grid_blocks: int = 0):
+        _check(load().imm3_ctx_set_tuning(self._h, filter_variant, grid_blocks))
+
+    def timing_enable(self, max_records: int):
+        _check(load().imm3_ctx_timing_enable(self._h, max_records))
+
+    def timing_reset(self):
+        _check(load().imm3_ctx_timing_reset(self._h))
+
+    def timing_collect(self, kernel_id: int, cap: int = 65536) -> np.ndarray:
+        out = np.zeros(cap, dtype=np.float32)
+        n = C.c_int32(0)
+        _check(load().imm3_ctx_timing_collect(self._h, kernel_id, out.ctypes.data, cap, C.byref(n)))
+        return out[: min(n.value, cap)]
+
+    def close(self):
+        if self._h:
+            load().imm3_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _ccolumns(cols):
+    """cols: sequence of (codec, width, dat (np.uint8 array or int device ptr), dat_bytes, offsets int32 array)"""
+    arr = (CColumn * len(cols))()
+    keep = []
+    for i, (codec, width, dat, nbytes, offsets) in enumerate(cols):
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        keep.append(offsets)
+        arr[i].codec = codec
+        arr[i].width = width
+        if isinstance(dat, (int, np.integer)):
+            arr[i].dat = int(dat)
+        else:
+            dat = np.ascontiguousarray(dat).view(np.uint8).reshape(-1)
+            keep.append(dat)
+            arr[i].dat = dat.ctypes.data if dat.size else None
+        arr[i].dat_bytes = int(nbytes)
+        arr[i].block_offsets = offsets.ctypes.data if offsets.size else None
+        arr[i].n_offsets = int(offsets.size)
+    return arr, keep
+
+
+class DeviceSegment:
+    """imm3_segment: all columns of one segment id, resident in HBM."""
+
+    def __init__(self, ctx: Context, cols, wrap_device: bool = False):
+        self.ctx = ctx
+        self.ncols = len(cols)
+        arr, keep = _ccolumns(cols)
+        self._h = C.c_void_p()
+        fn = load().imm3_segment_wrap_device if wrap_device else load().imm3_segment_create
+        _check(fn(ctx._h, arr, len(cols), C.byref(self._h)))
+        self._keep = keep if wrap_device else None
+        self.widths = [c[1] for c in cols]
+        self.codecs = [c[0] for c in cols]
+
+    @property
+    def device_bytes(self) -> int:
+        n = C.c_uint64(0)
+        _check(load().imm3_segment_bytes(self._h, C.byref(n)))
+        return n.value
+
+    def close(self):
+        if self._h:
+            load().imm3_segment_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceQuery:
+    """imm3_query: ScanOp -> SelectOp* -> ProjectOp over one device segment."""
+
+    def __init__(self, ctx: Context, seg: DeviceSegment, used_cols: Sequence[int],
+                 sels: Sequence[tuple], proj: Sequence[int] = (), limit: int = 0, table_block_size: int = 1024):
+        self.ctx, self.seg = ctx, seg
+        self.used_cols = list(used_cols)
+        self.proj = list(proj)
+        used = np.array(self.used_cols or [0], dtype=np.int32)
+        pj = np.array(self.proj or [0], dtype=np.int32)
+        cs = (CSelect * max(1, len(sels)))()
+        keep = []
+        for i, (col, cond, operand) in enumerate(sels):
+            cs[i].column = col
+            cs[i].cond = cond
+            cs[i].value = 0.0
+            cs[i].n_match = 0
+            if cond in (MATCH, NOTMATCH):
+                vals = [bytes(v) for v in (operand or [])]
+                blob = np.frombuffer(b"".join(vals) or b"\0", dtype=np.uint8).copy()
+                lens = np.array([len(v) for v in vals] or [0], dtype=np.int32)
+                keep += [blob, lens]
+                cs[i].match_bytes = blob.ctypes.data
+                cs[i].match_lens = lens.ctypes.data
+                cs[i].n_match = len(vals)
+            elif operand is not None:
+                cs[i].value = float(operand)
+        self._h = C.c_void_p()
+        _check(load().imm3_query_create(ctx._h, seg._h, used.ctypes.data, len(self.used_cols), cs, len(sels),
+                                        pj.ctypes.data, len(self.proj), limit, table_block_size, C.byref(self._h)))
+        nb, tw, nr = C.c_int32(0), C.c_int64(0), C.c_int64(0)
+        _check(load().imm3_query_layout(self._h, C.byref(nb), C.byref(tw), C.byref(nr)))
+        self.n_batches, self.total_words, self.n_rows = nb.value, tw.value, nr.value
+        self.proj_widths = [seg.widths[self.used_cols[j]] for j in self.proj]
+        self.proj_codecs = [seg.codecs[self.used_cols[j]] for j in self.proj]
+
+    def batches(self):
+        nb = max(self.n_batches, 1)
+        size = np.zeros(nb, np.int32)
+        oid = np.zeros(nb, np.int32)
+        woff = np.zeros(nb, np.int64)
+        _check(load().imm3_query_batches(self._h, size.ctypes.data, oid.ctypes.data, woff.ctypes.data))
+        return size[: self.n_batches], oid[: self.n_batches], woff[: self.n_batches]
+
+    def reserve_rows(self, rows: int):
+        _check(load().imm3_query_reserve_rows(self._h, rows))
+
+    def run(self):
+        _check(load().imm3_query_run(self._h))
+
+    def run_select(self):
+        _check(load().imm3_query_run_select(self._h))
+
+    def sync(self):
+        _check(load().imm3_query_sync(self._h))
+
+    def count(self) -> int:
+        n = C.c_uint64(0)
+        _check(load().imm3_query_count(self._h, C.byref(n)))
+        return n.value
+
+    def bitmap(self) -> np.ndarray:
+        out = np.zeros(max(self.total_words, 1), dtype=np.uint64)
+        _check(load().imm3_query_bitmap(self._h, out.ctypes.data, self.total_words))
+        return out[: self.total_words]
+
+    def row_count(self) -> int:
+        n = C.c_uint64(0)
+        _check(load().imm3_query_row_count(self._h, C.byref(n)))
+        return n.value
+
+    def fetch_rows(self):
+        """(row_index uint32[n], [per projected column uint8[n, width]])"""
+        n = self.row_count()
+        cap = max(n, 1)
+        idx = np.zeros(cap, dtype=np.uint32)
+        cols = [np.zeros((cap, w), dtype=np.uint8) for w in self.proj_widths]
+        ptrs = (C.c_void_p * max(1, len(cols)))(*[c.ctypes.data for c in cols])
+        _check(load().imm3_query_fetch_rows(self._h, idx.ctypes.data, ptrs, n))
+        return idx[:n], [c[:n] for c in cols]
+
+    def device_ptr(self, which: int) -> int:
+        p = C.c_void_p()
+        _check(load().imm3_query_device_ptr(self._h, which, C.byref(p)))
+        return p.value or 0
+
+    def close(self):
+        if self._h:
+            load().imm3_query_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,433 @@
+"""GPU-backed Operator / ScanOp / SelectOp / ProjectOp / Engine -- the host-side mirror of the reference's
+operator interface for the hot path (same names, argument meaning and error behaviour):
+
+    engine/src/main/scala/immutabledb/engine/operator/Operator.scala:14-28   Operator / ColumnVectorOperator / ProjectionOperator
+    engine/src/main/scala/immutabledb/engine/operator/Scan.scala:10-73       ScanOp, mkScanOp
+    engine/src/main/scala/immutabledb/engine/operator/Select.scala:5-165     SelectOp, mkSelectOp
+    engine/src/main/scala/immutabledb/engine/operator/Project.scala:8-81     ProjectOp, mkProjectOp
+    engine/src/main/scala/immutabledb/engine/Engine.scala:85-128,158-262     getColumns / resolveSelectOps / execute / PipelineThread
+    core/src/main/scala/immutabledb/DataVector.scala:15-48                   ColumnVectorBatch family
+
+The operators are PLAN BUILDERS: composing them costs nothing, and the first `iterator` call fuses the
+chain ScanOp -> SelectOp* (-> ProjectOp) of one segment into one imm3_query, i.e. one fused scan+select
+kernel (+ offsets scan + compact/gather) on the segment's HBM-resident columns.  Everything that touches
+data goes through the C ABI (immutable3_amd/native.py -> libimm3.so); there is no CPU evaluation path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import native
+from .native import Imm3Error
+from .query import (EQ, GT, LT, And, Match, NoOp, NoSelect, NotMatch, Or, Project, Query, Select, SelectADT,
+                    SelectCondition)
+from .schema import CodecType, Column, Row, Table
+from .storage import SegmentManager
+
+
+# ------------------------------------------------------------------------------------------
+# vectors (core/.../DataVector.scala)
+# ------------------------------------------------------------------------------------------
+class BitSet:
+    """scala.collection.mutable.BitSet over the uint64 words the GPU produced (bit i <-> word i>>6, bit i&63)."""
+
+    def __init__(self, words: np.ndarray):
+        self.words = words
+
+    def contains(self, i: int) -> bool:
+        w = i >> 6
+        return w < self.words.size and bool((int(self.words[w]) >> (i & 63)) & 1)
+
+    __call__ = contains
+    __contains__ = contains
+
+    @property
+    def size(self) -> int:
+        return int(np.unpackbits(self.words.view(np.uint8)).sum()) if self.words.size else 0
+
+    @property
+    def isEmpty(self) -> bool:
+        return not self.words.any()
+
+    def toList(self) -> List[int]:
+        if not self.words.size:
+            return []
+        bits = np.unpackbits(self.words.view(np.uint8), bitorder="little")
+        return np.flatnonzero(bits).tolist()
+
+    def __iter__(self):
+        return iter(self.toList())
+
+
+@dataclass
+class ColumnVector:                 # IntColumnVector / TinyIntColumnVector / StringColumnVector (:42-48)
+    data: np.ndarray
+
+
+class IntColumnVector(ColumnVector):
+    pass
+
+
+class TinyIntColumnVector(ColumnVector):
+    pass
+
+
+class StringColumnVector(ColumnVector):
+    pass
+
+
+@dataclass
+class FilledColumnVectorBatch:      # DataVector.scala:24-31
+    oid: int
+    size: int
+    columnVectors: List[ColumnVector]
+    columns: List[Column]
+    selected: BitSet
+    selectedInUse: bool
+
+
+ColumnVectorBatch = FilledColumnVectorBatch
+
+
+def _decode_view(col: Column, raw: np.ndarray) -> ColumnVector:
+    """DENSE_* decode is a fixed-width little-endian reinterpretation (DenseCodec.scala:37-73): a view."""
+    if col.codec == CodecType.DENSE_INT:
+        return IntColumnVector(raw.view("<i4"))
+    if col.codec == CodecType.DENSE_TINYINT:
+        return TinyIntColumnVector(raw.view(np.int8))
+    if col.codec == CodecType.DENSE_STRING:
+        return StringColumnVector(raw.reshape(-1, col.width))
+    raise Exception(f"No implementation for {col.codec}")
+
+
+# ------------------------------------------------------------------------------------------
+# device-resident SegmentManager
+# ------------------------------------------------------------------------------------------
+class GpuSegmentManager:
+    """What SegmentManager is to the reference (mmap everything once, keep it for the process lifetime,
+    SegmentManager.scala:20-23), this is to the GPU path: every segment of every table staged into HBM
+    once.  Segment s lives on the context `ctxs[s % len(ctxs)]` (segment-per-GPU sharding)."""
+
+    def __init__(self, sm: SegmentManager, ctxs: Sequence[native.Context] | native.Context | None = None,
+                 segment_filter: Optional[Callable[[str, int], bool]] = None):
+        if ctxs is None:
+            ctxs = [native.Context(0)]
+        if isinstance(ctxs, native.Context):
+            ctxs = [ctxs]
+        self.sm = sm
+        self.ctxs = list(ctxs)
+        self.tables = sm.tables
+        self._segs: Dict[Tuple[str, int], native.DeviceSegment] = {}
+        self._filter = segment_filter
+
+    def getTable(self, tableName: str) -> Table:
+        return self.sm.getTable(tableName)
+
+    def getTableSegmentCount(self, tableName: str) -> int:
+        return self.sm.getTableSegmentCount(tableName)
+
+    def ctx_of(self, segIdx: int) -> native.Context:
+        return self.ctxs[segIdx % len(self.ctxs)]
+
+    def owns(self, tableName: str, segIdx: int) -> bool:
+        return self._filter is None or self._filter(tableName, segIdx)
+
+    def device_segment(self, tableName: str, segIdx: int) -> native.DeviceSegment:
+        key = (tableName, segIdx)
+        if key not in self._segs:
+            t = self.getTable(tableName)
+            cols = []
+            for c in t.columns:
+                k = f"{tableName}.{c.name}"
+                dat = self.sm.segments[k][segIdx]
+                meta = self.sm.segmentsMeta[k][segIdx]
+                cols.append((CodecType.id_of(c.codec), c.width, dat, dat.size, meta.blockOffsets))
+            self._segs[key] = native.DeviceSegment(self.ctx_of(segIdx), cols)
+        return self._segs[key]
+
+    def close(self):
+        for s in self._segs.values():
+            s.close()
+        self._segs.clear()
+
+
+# ------------------------------------------------------------------------------------------
+# operators
+# ------------------------------------------------------------------------------------------
+class Operator:                      # Operator.scala:14-16
+    def iterator(self):
+        raise NotImplementedError
+
+    def __iter__(self):
+        return self.iterator()
+
+
+class ColumnVectorOperator(Operator):  # Operator.scala:18-20
+    pass
+
+
+class ProjectionOperator(Operator):    # Operator.scala:26-28
+    pass
+
+
+def _cond_spec(cond: SelectCondition):
+    if isinstance(cond, Match):
+        return native.MATCH, [v.encode("utf-8") if isinstance(v, str) else bytes(v) for v in cond.values]
+    if isinstance(cond, NotMatch):
+        return native.NOTMATCH, [v.encode("utf-8") if isinstance(v, str) else bytes(v) for v in cond.values]
+    if isinstance(cond, GT):
+        return native.GT, cond.gt
+    if isinstance(cond, LT):
+        return native.LT, cond.lt
+    if isinstance(cond, EQ):
+        return native.EQ, cond.eq
+    return native.NOOP, None
+
+
+class ScanOp(ColumnVectorOperator):
+    """Scan.scala:17: ScanOp(sm, segIdx, tableName, cols)."""
+
+    def __init__(self, sm: GpuSegmentManager, segIdx: int, tableName: str, cols: Sequence[Column]):
+        self.sm, self.segIdx, self.tableName, self.cols = sm, segIdx, tableName, list(cols)
+
+    @staticmethod
+    def mkScanOp(sm: GpuSegmentManager, tableName: str):       # Scan.scala:10-15
+        return lambda cols, segIdx: ScanOp(sm, segIdx, tableName, cols)
+
+    # -- plan pieces used by SelectOp / ProjectOp --
+    def _table(self) -> Table:
+        return self.sm.getTable(self.tableName)
+
+    def _used_indices(self) -> List[int]:
+        t = self._table()
+        names = [c.name for c in t.columns]
+        return [names.index(c.name) for c in self.cols]
+
+    def _query(self, leaves, proj_names: Sequence[str] = (), limit: int = 0) -> native.DeviceQuery:
+        t = self._table()
+        colnames = [c.name for c in self.cols]
+        sels = []
+        for (col, cond) in leaves:
+            # `vec.columns...filter(_.name == col).head` (Select.scala:60): first used column of that name
+            if col not in colnames:
+                raise Exception("NoSuchElementException: next on empty iterator")
+            code, operand = _cond_spec(cond)
+            sels.append((colnames.index(col), code, operand))
+        # Project.scala:32-35: vecCols maps each SELECT-list name to its position among the batch columns
+        proj = []
+        for name in proj_names:
+            if name not in colnames:
+                raise Exception(f"NoSuchElementException: key not found: {name}")
+            proj.append(colnames.index(name))
+        seg = self.sm.device_segment(self.tableName, self.segIdx)
+        return native.DeviceQuery(seg.ctx, seg, self._used_indices(), sels, proj, limit, t.blockSize)
+
+    def _host_vectors(self, k: int, start_row: int, size: int) -> List[ColumnVector]:
+        out = []
+        for c in self.cols:
+            dat = self.sm.sm.segments[f"{self.tableName}.{c.name}"][self.segIdx]
+            out.append(_decode_view(c, np.asarray(dat[start_row * c.width: (start_row + size) * c.width])))
+        return out
+
+    def _batches(self, leaves) -> Iterator[FilledColumnVectorBatch]:
+        q = self._query(leaves)
+        q.run_select()
+        size, oid, woff = q.batches()
+        words = q.bitmap()
+        q.close()
+        row = 0
+        for k in range(q.n_batches):
+            n = int(size[k])
+            nw = (n + 63) // 64
+            sel = BitSet(words[int(woff[k]): int(woff[k]) + nw])
+            # selectedInUse = false when a SelectOp leaves the batch empty (Select.scala:44-47); ScanOp alone yields true
+            in_use = (not sel.isEmpty) if leaves else True
+            yield FilledColumnVectorBatch(int(oid[k]), n, self._host_vectors(k, row, n), list(self.cols), sel, in_use)
+            row += n
+
+    def iterator(self):
+        return self._batches([])
+
+
+class SelectOp(ColumnVectorOperator):
+    """Select.scala:14: SelectOp(col, cond, op).  NotMatch / NoOp are rejected when the iterator is built (:22)."""
+
+    def __init__(self, col: str, cond: SelectCondition, op: ColumnVectorOperator):
+        self.col, self.cond, self.op = col, cond, op
+
+    @staticmethod
+    def mkSelectOp(col: str, cond: SelectCondition):            # Select.scala:5-12
+        return lambda op: SelectOp(col, cond, op)
+
+    def _chain(self):
+        """-> (ScanOp, [(col, cond)] in application order: innermost SelectOp first)."""
+        leaves = []
+        op = self
+        while isinstance(op, SelectOp):
+            leaves.append((op.col, op.cond))
+            op = op.op
+        if not isinstance(op, ScanOp):
+            raise Exception("SelectOp chain must end in a ScanOp for the fused GPU path")
+        leaves.reverse()
+        return op, leaves
+
+    def iterator(self):
+        scan, leaves = self._chain()
+        for (_, cond) in leaves:
+            if not isinstance(cond, (Match, GT, LT, EQ)):
+                raise Exception(f"Unsupported condition: {cond}")   # Select.scala:22
+        return scan._batches(leaves)
+
+
+class ProjectOp(ProjectionOperator):
+    """Project.scala:17: ProjectOp(cols, op, limit = 0)."""
+
+    def __init__(self, cols: Sequence[str], op: ColumnVectorOperator, limit: int = 0):
+        self.cols, self.op, self.limit = list(cols), op, limit
+
+    @staticmethod
+    def mkProjectOp(cols: Sequence[str], limit: int = 0):       # Project.scala:8-15
+        return lambda op: ProjectOp(cols, op, limit)
+
+    def _fused(self):
+        if isinstance(self.op, ScanOp):
+            return self.op, []
+        if isinstance(self.op, SelectOp):
+            return self.op._chain()
+        return None
+
+    def run_columns(self):
+        """Fused execution; returns (row_index uint32[n], [typed numpy array per SELECT-list column])."""
+        scan, leaves = self._fused()
+        for (_, cond) in leaves:
+            if not isinstance(cond, (Match, GT, LT, EQ)):
+                raise Exception(f"Unsupported condition: {cond}")
+        q = scan._query(leaves, self.cols, self.limit)
+        q.run()
+        idx, cols = q.fetch_rows()
+        out = []
+        for raw, codec in zip(cols, q.proj_codecs):
+            if codec == native.DENSE_INT:
+                out.append(raw.reshape(-1).view("<i4"))
+            elif codec == native.DENSE_TINYINT:
+                out.append(raw.reshape(-1).view(np.int8))
+            else:
+                out.append(raw)
+        q.close()
+        return idx, out
+
+    def iterator(self) -> Iterator[Row]:
+        if self._fused() is None:
+            return self._host_iterator()
+        _, cols = self.run_columns()
+        return _rows_from_columns(cols)
+
+    def _host_iterator(self) -> Iterator[Row]:
+        """ProjectIterator over batches from a non-fusable upstream (e.g. a queue of batches from several
+        segments, Engine.scala:190-191).  Row materialisation is Project.scala:50-63; batches without
+        survivors are skipped (the reference faults on them)."""
+        total = 0
+        for vec in self.op.iterator():
+            names = [c.name for c in vec.columns]
+            vec_cols = [names.index(c) for c in self.cols]
+            for pos in vec.selected.toList():
+                if self.limit > 0 and total >= self.limit:
+                    return
+                yield Row(*[_value(vec.columnVectors[j].data[pos]) for j in vec_cols])
+                total += 1
+            if self.limit > 0 and total >= self.limit:
+                return
+
+
+def _value(x):
+    if isinstance(x, np.ndarray):           # fixed-width string: new String(bytes) (DataType.scala:70)
+        return bytes(x).decode("utf-8", errors="replace")
+    return int(x)
+
+
+def _rows_from_columns(cols: List[np.ndarray]) -> Iterator[Row]:
+    n = cols[0].shape[0] if cols else 0
+    for i in range(n):
+        yield Row(*[_value(c[i]) for c in cols])
+
+
+# ------------------------------------------------------------------------------------------
+# Engine (the caller of the hot path; only what the path needs: planning + per-segment fan-out)
+# ------------------------------------------------------------------------------------------
+def getColumns(query: Query, table: Table) -> List[Column]:
+    """Engine.getColumns (Engine.scala:85-106): (selectColumnsSet.toList ++ projectColumns).toSet.toList.
+    Scala's Set1..Set4 keep insertion order, so for <= 4 distinct columns the order is first-seen order
+    (SURVEY A.1 rule 3).  Beyond 4 the reference's order is a HashSet's; first-seen order is used here and
+    is NOT pinned to the reference (it only decides which column is 'first', i.e. defines the batches)."""
+    def rec(sel: SelectADT) -> List[Column]:
+        if isinstance(sel, (And, Or)):
+            out = rec(sel.op1)
+            for c in rec(sel.op2):
+                if c not in out:
+                    out.append(c)
+            return out
+        if isinstance(sel, Select):
+            return [table.getColumn(sel.col)]
+        return []
+
+    cols = rec(query.select)
+    if isinstance(query.project, Project):
+        for name in query.project.cols:
+            c = table.getColumn(name)
+            if c not in cols:
+                cols.append(c)
+    else:
+        raise Exception("Only Project is on the GPU path (ProjectAgg is out of scope, SURVEY 8f)")
+    return cols
+
+
+def resolveSelectOps(query: Query) -> List[Callable[[ColumnVectorOperator], ColumnVectorOperator]]:
+    """Engine.resolveSelectOps + PipelineThread.runOps (Engine.scala:108-128, 237-245) flattened: the PTree is
+    folded left-to-right, PNode(n1, n2, _) => rec(n2) o rec(n1), and the AND/OR tag is ignored."""
+    def rec(sel: SelectADT):
+        if isinstance(sel, (And, Or)):
+            return rec(sel.op1) + rec(sel.op2)
+        if isinstance(sel, Select):
+            return [SelectOp.mkSelectOp(sel.col, sel.cond)]
+        return []                                             # NoSelect => identity
+    return rec(query.select)
+
+
+class Engine:
+    """Engine.execute (Engine.scala:158-197) for Project queries.  One fused pipeline per segment (the
+    reference: one PipelineThread per segment, :176-180); output order across segments is unspecified in
+    the reference (queue interleaving, :255) and defined here as ascending segment index."""
+
+    def __init__(self, sm: GpuSegmentManager):
+        self.sm = sm
+
+    def pipelines(self, query: Query):
+        table = self.sm.getTable(query.table)
+        used = getColumns(query, table)
+        leaves = resolveSelectOps(query)
+        mk_scan = ScanOp.mkScanOp(self.sm, query.table)
+        mk_proj = ProjectOp.mkProjectOp(list(query.project.cols), query.project.limit)
+        for segIdx in range(self.sm.getTableSegmentCount(table.name)):
+            if not self.sm.owns(table.name, segIdx):
+                continue
+            op: ColumnVectorOperator = mk_scan(used, segIdx)
+            for leaf in leaves:
+                op = leaf(op)
+            yield segIdx, mk_proj(op)
+
+    def execute(self, query: Query) -> Iterator[Row]:
+        limit = query.project.limit
+        total = 0
+        for _, proj in self.pipelines(query):
+            for row in proj.iterator():
+                if limit > 0 and total >= limit:
+                    return
+                yield row
+                total += 1
+
+    def execute_columns(self, query: Query):
+        """Columnar result per segment: [(segIdx, row_index, [column arrays])] (no Row boxing)."""
+        return [(segIdx, *proj.run_columns()) for segIdx, proj in self.pipelines(query)]

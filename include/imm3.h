@@ -1,0 +1,168 @@
+/*
+ * imm3.h -- C ABI of the MI355X-native scan / filter / project path of immutable3.
+ *
+ * This is the drop-in boundary.  The reference (markosski/immutable3) has NO FFI: the path sits
+ * behind Scala traits (engine/src/main/scala/immutabledb/engine/operator/Operator.scala:14-28)
+ * and three factories wired in Engine.execute (engine/.../engine/Engine.scala:167-173):
+ *     ScanOp.mkScanOp(sm, table)        engine/.../operator/Scan.scala:10-15
+ *     SelectOp.mkSelectOp(col, cond)    engine/.../operator/Select.scala:5-12
+ *     ProjectOp.mkProjectOp(cols,limit) engine/.../operator/Project.scala:8-15
+ * The entry points below are what a JNI shim for GpuScanOp / GpuSelectOp / GpuProjectOp binds
+ * (INTEGRATION.md shows the Scala + JNI side).  Plain pointers and sizes only; no torch types.
+ *
+ * Threading: one PipelineThread per segment calls the path (Engine.scala:176-180, 247-262), so
+ * every handle is independent; calls on DIFFERENT handles are re-entrant.  A context carries its
+ * device id and HIP stream; there is no global mutable state except the thread-local error text.
+ *
+ * Errors: the reference throws Exception(msg) (Scan.scala:49, Select.scala:22,41,80,118,156).
+ * Here every call returns an int status (0 = ok) and imm3_last_error() returns the message for
+ * the calling thread; a JNI shim turns non-zero into ThrowNew(java/lang/Exception, msg).
+ *
+ * Citations: core/ = core/src/main/scala/immutabledb, engine/ = engine/src/main/scala/immutabledb.
+ */
+#ifndef IMM3_H
+#define IMM3_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMM3_ABI_VERSION 1
+
+/* CodecType (core/codec/Codec.scala:21-24), in enumeration order */
+enum { IMM3_PFOR_INT = 0, IMM3_DENSE_INT = 1, IMM3_DENSE_TINYINT = 2, IMM3_DENSE_STRING = 3 };
+
+/* SelectCondition (core/Query.scala:3-9) */
+enum { IMM3_MATCH = 0, IMM3_NOTMATCH = 1, IMM3_EQ = 2, IMM3_GT = 3, IMM3_LT = 4, IMM3_NOOP = 5 };
+
+/* status codes */
+enum {
+    IMM3_OK = 0,
+    IMM3_ERR_UNSUPPORTED_CONDITION = 1, /* "Unsupported condition: ..."   Select.scala:22            */
+    IMM3_ERR_UNSUPPORTED_VECTOR = 2,    /* "Unsupported column vector"    Select.scala:41,80,118,156 */
+    IMM3_ERR_NO_CODEC = 3,              /* "No implementation for ..."    Scan.scala:49              */
+    IMM3_ERR_LAYOUT = 4,                /* block tables the reference would fault on / mis-join      */
+    IMM3_ERR_ARG = 5,                   /* bad handle / index / null pointer                         */
+    IMM3_ERR_DEVICE = 6,                /* HIP runtime error (message carries hipGetErrorString)     */
+    IMM3_ERR_STATE = 7                  /* result requested before imm3_query_run()                  */
+};
+
+typedef struct imm3_ctx imm3_ctx;         /* device + stream + scratch                                   */
+typedef struct imm3_segment imm3_segment; /* one segment's columns resident in HBM (SegmentManager role) */
+typedef struct imm3_query imm3_query;     /* one PipelineThread: ScanOp -> SelectOp* -> ProjectOp        */
+
+/* One column of one segment as the reference stores it: `<col>_<id>.dat` bytes + the
+ * `blockOffset` array of `<col>_<id>.meta` (core/storage/Segment.scala:33-58, 154-181;
+ * core/storage/SegmentManager.scala:81-111) + the codec of core/Column.scala:18,57-63. */
+typedef struct {
+    int32_t codec;                /* IMM3_DENSE_INT / _TINYINT / _STRING                         */
+    int32_t width;                /* bytes per value: 4, 1, or dtypeAttrs("size") for strings      */
+    const void *dat;              /* host pointer to the (mmap'd) .dat bytes                       */
+    uint64_t dat_bytes;
+    const int32_t *block_offsets; /* N+1 byte offsets, first 0 (SegmentMeta.blockOffsets)          */
+    int32_t n_offsets;
+} imm3_column;
+
+/* One SelectOp leaf (engine/.../operator/Select.scala:14-23).  Leaves are applied in array order,
+ * which is the order PipelineThread.runOps composes them (Engine.scala:237-245); the AND/OR tag is
+ * ignored there, so every tree is a conjunction. */
+typedef struct {
+    int32_t column;             /* index into the query's used-column list                           */
+    int32_t cond;               /* IMM3_GT / IMM3_LT / IMM3_EQ / IMM3_MATCH (others -> error)         */
+    double value;               /* GT/LT/EQ operand as the Query ADT carries it (core/Query.scala:6-8);
+                                   narrowed per column type INSIDE the library: Int column d.toInt,
+                                   TinyInt column d.toByte (Select.scala:65,73)                      */
+    const uint8_t *match_bytes; /* MATCH: the IN-list values, concatenated                            */
+    const int32_t *match_lens;  /* MATCH: byte length of each value                                   */
+    int32_t n_match;
+} imm3_select;
+
+/* ---- library ---- */
+int imm3_abi_version(void);
+const char *imm3_last_error(void); /* thread-local; valid until the next failing call on this thread */
+int imm3_device_count(int *count);
+
+/* ---- context: device id + stream ---- */
+/* stream: a hipStream_t to launch on (e.g. the caller's current stream), or NULL to create one. */
+int imm3_ctx_create(int device, void *stream, imm3_ctx **out);
+int imm3_ctx_destroy(imm3_ctx *ctx);
+int imm3_ctx_sync(imm3_ctx *ctx);
+int imm3_ctx_stream(imm3_ctx *ctx, void **stream_out);
+
+/* ---- segment: what SegmentManager.getSegment(id, table, col) hands to ScanOp, for every column
+ * of one segment id, staged into HBM once and kept resident (the reference keeps the mmaps for the
+ * process lifetime, SegmentManager.scala:22,81-87).  The library owns the device copy; the host
+ * buffers may be unmapped after the call returns. ---- */
+int imm3_segment_create(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, imm3_segment **out);
+/* same, but `dat` fields are DEVICE pointers that stay owned by the caller (no copy; they must be
+ * readable for 4 KiB past dat_bytes, or padded; see DESIGN.md "data layout"). */
+int imm3_segment_wrap_device(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, imm3_segment **out);
+int imm3_segment_destroy(imm3_segment *seg);
+int imm3_segment_bytes(const imm3_segment *seg, uint64_t *device_bytes);
+
+/* ---- query: one PipelineThread (Engine.scala:235-262) over one segment ----
+ *   used_cols   indices into the segment's columns, in Engine.getColumns order (Engine.scala:85-106);
+ *               the FIRST one defines the batches (Scan.scala:55,72)
+ *   sels        SelectOp leaves in application order (may be empty: NoSelect)
+ *   proj        indices into used_cols of the SELECT-list columns in SELECT-list order
+ *               (Project.scala:55-57); n_proj == 0 -> no ProjectOp (bitmap/count only)
+ *   limit       Project limit; <= 0 = unlimited (Project.scala:73-80)
+ *   table_block_size  Table.blockSize, only used for oid = vecCounter * blockSize (Scan.scala:60)
+ * Validation mirrors the reference: NotMatch/NoOp always fail (SelectOp.iterator, Select.scala:22);
+ * a condition on the wrong vector type or an unknown codec fails iff the segment has >= 1 batch. */
+int imm3_query_create(imm3_ctx *ctx, const imm3_segment *seg,
+                      const int32_t *used_cols, int32_t n_used,
+                      const imm3_select *sels, int32_t n_sels,
+                      const int32_t *proj, int32_t n_proj, int64_t limit,
+                      int32_t table_block_size, imm3_query **out);
+int imm3_query_destroy(imm3_query *q);
+
+/* Pre-size the projected-row buffers so that imm3_query_run() never has to wait for the count
+ * (fully asynchronous run).  Without it an unlimited projection synchronises once to size them. */
+int imm3_query_reserve_rows(imm3_query *q, uint64_t rows);
+
+/* Enqueue the whole pipeline on the context's stream: scan+select kernel (selection bitmap, per-tile
+ * counts, total count), then -- if n_proj > 0 -- offsets scan and compact+gather.  Asynchronous
+ * unless rows must be sized (see above).  May be called repeatedly on the same query. */
+int imm3_query_run(imm3_query *q);
+/* Only the ScanOp -> SelectOp* part (selection bitmap + count). */
+int imm3_query_run_select(imm3_query *q);
+int imm3_query_sync(imm3_query *q);
+
+/* ---- results ---- */
+/* Batches as ScanOp yields them (FilledColumnVectorBatch, core/DataVector.scala:24-31): */
+int imm3_query_layout(const imm3_query *q, int32_t *n_batches, int64_t *total_words, int64_t *n_rows);
+/* per batch: size (rows), oid, and the offset of its BitSet words in the batch-major bitmap
+ * (ceil(size/64) words per batch; bit i of a batch <-> word i>>6, bit i&63 = mutable.BitSet) */
+int imm3_query_batches(const imm3_query *q, int32_t *batch_size, int32_t *batch_oid, int64_t *batch_word_off);
+int imm3_query_count(imm3_query *q, uint64_t *selected_rows);               /* sum of selected.size    */
+int imm3_query_bitmap(imm3_query *q, uint64_t *words_out, int64_t n_words); /* device -> host copy     */
+/* Rows ProjectOp emits for this segment, in emission order (batch order, ascending position): */
+int imm3_query_row_count(imm3_query *q, uint64_t *rows);
+/* row_index_out: segment-global row number of each emitted row (may be NULL);
+ * col_out[j]: packed values of projected column j, width bytes per row (int32 LE / int8 / raw bytes) */
+int imm3_query_fetch_rows(imm3_query *q, uint32_t *row_index_out, void *const *col_out, uint64_t max_rows);
+
+/* Device-resident results for callers that stay on the GPU (RCCL count reduce, chained kernels).
+ * which: 0 = bitmap (uint64 words), 1 = total count (one uint64), 2 = row indices (uint32),
+ *        3 = emitted row count (one uint64), 16+j = projected column j */
+int imm3_query_device_ptr(imm3_query *q, int32_t which, void **ptr);
+
+/* ---- live kernel timing (HIP events on the context's stream) ----
+ * When enabled, every kernel launch of this context is bracketed by an event pair.
+ * kernel ids: 0 = scan+select, 1 = offsets scan, 2 = compact+gather. */
+int imm3_ctx_timing_enable(imm3_ctx *ctx, int32_t max_records);
+int imm3_ctx_timing_reset(imm3_ctx *ctx);
+/* Synchronises, then writes up to cap durations (ms) of launches of `kernel_id`, oldest first. */
+int imm3_ctx_timing_collect(imm3_ctx *ctx, int32_t kernel_id, float *ms_out, int32_t cap, int32_t *n_out);
+
+/* Tuning knobs (0 = default): filter variant, grid size in workgroups.  For experiments/bench. */
+int imm3_ctx_set_tuning(imm3_ctx *ctx, int32_t filter_variant, int32_t grid_blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMM3_H */

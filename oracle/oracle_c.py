@@ -1,0 +1,220 @@
+"""ctypes binding of the C CPU oracle (oracle/imm3_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  May be imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package (immutable3_amd/).  Parity statement: see
+oracle/imm3_oracle.h (unpinned by reference tests -- the reference has none; pinned by SURVEY
+Appendix B known-answer vectors and the independent numpy restatement oracle_np.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libimm3_oracle.so")
+
+PFOR_INT, DENSE_INT, DENSE_TINYINT, DENSE_STRING = 0, 1, 2, 3
+MATCH, NOTMATCH, EQ, GT, LT, NOOP = 0, 1, 2, 3, 4, 5
+
+OK, ERR_UNSUPPORTED_CONDITION, ERR_UNSUPPORTED_VECTOR, ERR_NO_CODEC, ERR_INDEX, ERR_ARG = range(6)
+
+
+class OracleError(Exception):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class _CColumn(C.Structure):
+    _fields_ = [
+        ("dat", C.c_void_p),
+        ("dat_bytes", C.c_uint64),
+        ("block_offsets", C.c_void_p),
+        ("n_offsets", C.c_int32),
+        ("codec", C.c_int32),
+        ("width", C.c_int32),
+    ]
+
+
+class _CSelect(C.Structure):
+    _fields_ = [
+        ("column", C.c_int32),
+        ("cond", C.c_int32),
+        ("value", C.c_double),
+        ("match_bytes", C.c_void_p),
+        ("match_lens", C.c_void_p),
+        ("n_match", C.c_int32),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with its own Makefile (gcc -O2).  Building the checker is not using it."""
+    src = os.path.join(_HERE, "imm3_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
+        os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "imm3_oracle.h"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.imm3o_bytes_to_int.restype = C.c_int32
+        L.imm3o_bytes_to_int.argtypes = [C.c_void_p]
+        L.imm3o_int_to_bytes.restype = None
+        L.imm3o_int_to_bytes.argtypes = [C.c_int32, C.c_void_p]
+        L.imm3o_d2i.restype = C.c_int32
+        L.imm3o_d2i.argtypes = [C.c_double]
+        L.imm3o_d2b.restype = C.c_int8
+        L.imm3o_d2b.argtypes = [C.c_double]
+        L.imm3o_n_batches.restype = C.c_int32
+        L.imm3o_n_batches.argtypes = [C.POINTER(_CColumn)]
+        L.imm3o_layout.restype = C.c_int64
+        L.imm3o_layout.argtypes = [C.POINTER(_CColumn), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.imm3o_scan_select.restype = C.c_int
+        L.imm3o_scan_select.argtypes = [
+            C.POINTER(_CColumn), C.c_int32, C.POINTER(_CSelect), C.c_int32, C.c_int32, C.c_int32,
+            C.c_void_p, C.POINTER(C.c_uint64), C.c_char_p,
+        ]
+        L.imm3o_project.restype = C.c_int64
+        L.imm3o_project.argtypes = [
+            C.POINTER(_CColumn), C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p,
+            C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int64, C.POINTER(C.c_int32),
+        ]
+        _lib = L
+    return _lib
+
+
+@dataclass
+class OColumn:
+    """One used column of one segment: raw .dat bytes + .meta blockOffset table."""
+    dat: np.ndarray            # uint8, C-contiguous
+    block_offsets: np.ndarray  # int32, N+1 entries
+    codec: int
+    width: int
+
+    def __post_init__(self):
+        self.dat = np.ascontiguousarray(np.frombuffer(self.dat, dtype=np.uint8) if not isinstance(self.dat, np.ndarray) else self.dat.view(np.uint8).reshape(-1))
+        self.block_offsets = np.ascontiguousarray(self.block_offsets, dtype=np.int32)
+
+
+# a select leaf: (column index, cond, operand) where operand is a float (GT/LT/EQ) or a list of bytes (MATCH)
+SelectSpec = Tuple[int, int, Union[float, Sequence[bytes], None]]
+
+
+def bytes_to_int(b: bytes) -> int:
+    buf = (C.c_uint8 * 4)(*b)
+    return lib().imm3o_bytes_to_int(buf)
+
+
+def int_to_bytes(v: int) -> bytes:
+    buf = (C.c_uint8 * 4)()
+    lib().imm3o_int_to_bytes(v, buf)
+    return bytes(buf)
+
+
+def d2i(d: float) -> int:
+    return lib().imm3o_d2i(d)
+
+
+def d2b(d: float) -> int:
+    return lib().imm3o_d2b(d)
+
+
+def _ccols(cols: Sequence[OColumn]):
+    arr = (_CColumn * len(cols))()
+    for i, c in enumerate(cols):
+        arr[i].dat = c.dat.ctypes.data
+        arr[i].dat_bytes = c.dat.size
+        arr[i].block_offsets = c.block_offsets.ctypes.data
+        arr[i].n_offsets = c.block_offsets.size
+        arr[i].codec = c.codec
+        arr[i].width = c.width
+    return arr
+
+
+def _csels(sels: Sequence[SelectSpec]):
+    arr = (_CSelect * max(1, len(sels)))()
+    keep = []
+    for i, (col, cond, operand) in enumerate(sels):
+        arr[i].column = col
+        arr[i].cond = cond
+        arr[i].value = 0.0
+        arr[i].n_match = 0
+        if cond in (MATCH, NOTMATCH):
+            vals = [bytes(v) for v in (operand or [])]
+            blob = np.frombuffer(b"".join(vals) or b"\0", dtype=np.uint8).copy()
+            lens = np.array([len(v) for v in vals] or [0], dtype=np.int32)
+            keep += [blob, lens]
+            arr[i].match_bytes = blob.ctypes.data
+            arr[i].match_lens = lens.ctypes.data
+            arr[i].n_match = len(vals)
+        elif operand is not None:
+            arr[i].value = float(operand)
+    return arr, keep
+
+
+def layout(first: OColumn, block_size: int):
+    """(batch_size[int32], batch_oid[int32], batch_word_off[int64], total_words)"""
+    cc = _ccols([first])
+    nb = lib().imm3o_n_batches(cc)
+    size = np.zeros(max(nb, 1), dtype=np.int32)
+    oid = np.zeros(max(nb, 1), dtype=np.int32)
+    woff = np.zeros(max(nb, 1), dtype=np.int64)
+    tw = lib().imm3o_layout(cc, block_size, size.ctypes.data, oid.ctypes.data, woff.ctypes.data)
+    return size[:nb], oid[:nb], woff[:nb], int(tw)
+
+
+def scan_select(cols: Sequence[OColumn], sels: Sequence[SelectSpec], block_size: int, flavour: int = 1):
+    """ScanOp -> SelectOp* over one segment.  Returns (words[uint64, batch-major], count)."""
+    _, _, _, tw = layout(cols[0], block_size)
+    words = np.zeros(max(tw, 1), dtype=np.uint64)
+    count = C.c_uint64(0)
+    msg = C.create_string_buffer(256)
+    cc = _ccols(cols)
+    cs, keep = _csels(sels)
+    rc = lib().imm3o_scan_select(cc, len(cols), cs, len(sels), block_size, flavour,
+                                 words.ctypes.data, C.byref(count), msg)
+    del keep
+    if rc != OK:
+        raise OracleError(rc, msg.value.decode())
+    return words[:tw], int(count.value)
+
+
+def project(cols: Sequence[OColumn], proj: Sequence[int], limit: int, block_size: int, words: np.ndarray,
+            cap_rows: Optional[int] = None):
+    """ProjectOp.  Returns (n_rows, batch[int32], pos[int32], [per-proj-col uint8 array (n,width)], would_throw)."""
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    if cap_rows is None:
+        cap_rows = int(sum(bin(int(w)).count("1") for w in words)) if words.size < 4096 else int(
+            np.unpackbits(words.view(np.uint8)).sum())
+        if limit > 0:
+            cap_rows = min(cap_rows, limit)
+    cap = max(cap_rows, 1)
+    batch = np.zeros(cap, dtype=np.int32)
+    pos = np.zeros(cap, dtype=np.int32)
+    widths = [4 if cols[j].codec == DENSE_INT else cols[j].width for j in proj]
+    vals = [np.zeros((cap, w), dtype=np.uint8) for w in widths]
+    ptrs = (C.c_void_p * max(1, len(proj)))(*[v.ctypes.data for v in vals])
+    projarr = np.array(list(proj) or [0], dtype=np.int32)
+    wt = C.c_int32(0)
+    cc = _ccols(cols)
+    n = lib().imm3o_project(cc, len(cols), projarr.ctypes.data, len(proj), limit, block_size,
+                            words.ctypes.data if words.size else None, batch.ctypes.data, pos.ctypes.data,
+                            ptrs, cap_rows, C.byref(wt))
+    if n < 0:
+        raise OracleError(int(-n), "project failed")
+    n = int(n)
+    return n, batch[:n], pos[:n], [v[:n] for v in vals], bool(wt.value)

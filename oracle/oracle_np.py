@@ -1,0 +1,198 @@
+"""Second, independent CPU restatement of the reference hot path in numpy / pure Python.
+
+TEST INFRASTRUCTURE ONLY (same rule as oracle_c.py: tests/, smoke() and bench's cpu_baseline leg).
+Written from the reference's Scala semantics without looking at imm3_oracle.c's structure: it
+works on whole decoded vectors with numpy instead of per-row loops, so an error shared by both
+restatements would have to be an error in reading the reference, not a coding slip.  Parity vs
+the reference itself is UNPINNED by reference tests (the reference has none; see imm3_oracle.h).
+
+Citations: core/ = core/src/main/scala/immutabledb, engine/ = engine/src/main/scala/immutabledb.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+DENSE_INT, DENSE_TINYINT, DENSE_STRING = 1, 2, 3
+MATCH, NOTMATCH, EQ, GT, LT, NOOP = 0, 1, 2, 3, 4, 5
+
+
+class RefException(Exception):
+    """Stands for the reference's `throw new Exception(msg)` / JVM runtime exceptions."""
+
+
+def to_int(d: float) -> int:
+    """Scala Double.toInt (JVM d2i): NaN->0, saturating, truncation toward zero (Select.scala:65)."""
+    if math.isnan(d):
+        return 0
+    if d >= 2147483647:
+        return 2147483647
+    if d <= -2147483648:
+        return -2147483648
+    return int(math.trunc(d))
+
+
+def to_byte(d: float) -> int:
+    """Scala Double.toByte: toInt then keep the low 8 bits as a signed byte (Select.scala:73)."""
+    b = to_int(d) & 0xFF
+    return b - 256 if b >= 128 else b
+
+
+def bytes_to_int(b: bytes) -> int:
+    """Conversions.bytesToInt (core/util/Conversions.scala:17-24): ((((b3)<<8 + b2)<<8 + b1)<<8) + b0, 32-bit wrap."""
+    r = 0
+    for i in (3, 2, 1):
+        r = ((r + (b[i] & 0xFF)) << 8) & 0xFFFFFFFF
+    r = (r + (b[0] & 0xFF)) & 0xFFFFFFFF
+    return r - (1 << 32) if r & 0x80000000 else r
+
+
+def int_to_bytes(v: int) -> bytes:
+    """IntType.valueToBytes (core/DataType.scala:40-47)."""
+    v &= 0xFFFFFFFF
+    return bytes([v & 0xFF, (v >> 8) & 0xFF, (v >> 16) & 0xFF, (v >> 24) & 0xFF])
+
+
+def _block_bounds(offsets: np.ndarray) -> List[Tuple[int, int]]:
+    """Segment.BlockIterator (core/storage/Segment.scala:158-180): block k holds
+    blockOffsets(k+1)-blockOffsets(k) bytes taken by RELATIVE gets from a rewound buffer."""
+    lens = np.diff(offsets.astype(np.int64))
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]]) if lens.size else np.zeros(0, dtype=np.int64)
+    return [(int(s), int(l)) for s, l in zip(starts, lens)]
+
+
+def decode_block(raw: np.ndarray, codec: int, width: int) -> np.ndarray:
+    """DenseCodec*.decode (core/codec/DenseCodec.scala:37-73).  Returns int32[n], int8[n] or uint8[n,width].
+    A trailing partial element re-uses the previous chunk's tail bytes (read() count ignored)."""
+    n_full = raw.size // width
+    rem = raw.size - n_full * width
+    body = raw[: n_full * width]
+    if rem:
+        prev = raw[(n_full - 1) * width: n_full * width] if n_full else np.zeros(width, dtype=np.uint8)
+        last = prev.copy()
+        last[:rem] = raw[n_full * width:]
+        body = np.concatenate([body, last])
+    if codec == DENSE_INT:
+        return body.view("<i4").astype(np.int32)
+    if codec == DENSE_TINYINT:
+        return body.view(np.int8)
+    if codec == DENSE_STRING:
+        return body.reshape(-1, width)
+    raise RefException(f"No implementation for {codec}")  # Scan.scala:49
+
+
+def layout(first_offsets: np.ndarray, first_width: int, block_size: int):
+    sizes, oids, woffs = [], [], []
+    w = 0
+    for k, (_, ln) in enumerate(_block_bounds(first_offsets)):
+        n = -(-ln // first_width) if ln > 0 else 0
+        sizes.append(n)
+        oids.append(k * block_size)  # vecCounter * table.blockSize, Scan.scala:60
+        woffs.append(w)
+        w += -(-n // 64)
+    return np.array(sizes, np.int32), np.array(oids, np.int32), np.array(woffs, np.int64), w
+
+
+def _predicate(vec: np.ndarray, codec: int, width: int, cond: int, operand) -> np.ndarray:
+    """Boolean KEEP mask of one SelectOp over one decoded vector (Select.scala:25-165)."""
+    if cond in (GT, LT, EQ):
+        if codec == DENSE_INT:
+            t = np.int32(to_int(float(operand)))
+        elif codec == DENSE_TINYINT:
+            t = np.int8(to_byte(float(operand)))
+        else:
+            raise RefException("Unsupported column vector")
+        if cond == GT:
+            return vec > t
+        if cond == LT:
+            return vec < t
+        return vec == t
+    if cond == MATCH:
+        if codec != DENSE_STRING:
+            raise RefException("Unsupported column vector")
+        keep = np.zeros(vec.shape[0], dtype=bool)
+        for v in operand:
+            v = bytes(v)
+            if len(v) == width:
+                keep |= (vec == np.frombuffer(v, dtype=np.uint8)).all(axis=1)
+        return keep
+    raise RefException(f"Unsupported condition: {cond}")  # Select.scala:22
+
+
+def scan_select(cols: Sequence[Tuple[np.ndarray, np.ndarray, int, int]], sels, block_size: int):
+    """cols: [(dat uint8, offsets int32, codec, width)] in used-column order; sels: [(col, cond, operand)].
+    Returns (words uint64 batch-major, count, per-batch list of bool keep masks)."""
+    for (_, cond, _) in sels:  # SelectOp.iterator rejects these when the chain is built (Select.scala:17-23)
+        if cond not in (MATCH, GT, LT, EQ):
+            raise RefException(f"Unsupported condition: {cond}")
+    bounds = [_block_bounds(c[1]) for c in cols]
+    nb = len(bounds[0])
+    words: List[np.ndarray] = []
+    masks: List[np.ndarray] = []
+    count = 0
+    for k in range(nb):
+        vecs = []
+        for ci, (dat, _, codec, width) in enumerate(cols):
+            if k >= len(bounds[ci]):
+                raise RefException("ArrayIndexOutOfBounds")
+            s, ln = bounds[ci][k]
+            if codec not in (DENSE_INT, DENSE_TINYINT, DENSE_STRING):
+                raise RefException(f"No implementation for {codec}")  # Scan.scala:49, first batch only
+            if ln < 0 or s + ln > dat.size:
+                raise RefException("BufferUnderflow")
+            vecs.append(decode_block(dat[s: s + ln], codec, width))
+        size = vecs[0].shape[0]  # Scan.scala:55
+        keep = np.ones(size, dtype=bool)  # Scan.scala:56-57
+        for (ci, cond, operand) in sels:
+            if cond in (NOTMATCH, NOOP):
+                raise RefException(f"Unsupported condition: {cond}")
+            v = vecs[ci]
+            codec, width = cols[ci][2], cols[ci][3]
+            if cond in (GT, LT, EQ) and codec == DENSE_STRING or cond == MATCH and codec != DENSE_STRING:
+                raise RefException("Unsupported column vector")
+            if v.shape[0] < size:
+                raise RefException("ArrayIndexOutOfBounds")
+            keep &= _predicate(v[:size], codec, width, cond, operand)
+        masks.append(keep)
+        count += int(keep.sum())
+        nw = -(-size // 64)
+        padded = np.zeros(nw * 64, dtype=np.uint8)
+        padded[:size] = keep
+        # mutable.BitSet: bit i -> word i>>6, bit i&63  == little-endian bit packing
+        words.append(np.packbits(padded, bitorder="little").view("<u8") if nw else np.zeros(0, np.uint64))
+    allw = np.concatenate(words).astype(np.uint64) if words else np.zeros(0, np.uint64)
+    return allw, count, masks
+
+
+def project(cols, proj: Sequence[int], limit: int, masks: Sequence[np.ndarray]):
+    """ProjectOp (engine/engine/operator/Project.scala:37-80) with empty batches skipped.
+    Returns (rows: list of tuples in SELECT-list order, [(batch,pos)], would_throw)."""
+    bounds = [_block_bounds(c[1]) for c in cols]
+    rows, where = [], []
+    would_throw = False
+    for k, keep in enumerate(masks):
+        if limit > 0 and len(rows) >= limit:
+            break
+        idx = np.flatnonzero(keep)
+        if idx.size == 0:
+            would_throw = True
+            continue
+        vecs = {}
+        for j in proj:
+            dat, _, codec, width = cols[j]
+            s, ln = bounds[j][k]
+            vecs[j] = decode_block(dat[s: s + ln], codec, width)
+        for p in idx:
+            if limit > 0 and len(rows) >= limit:
+                break
+            r = []
+            for j in proj:
+                v = vecs[j]
+                if p >= v.shape[0]:
+                    raise RefException("ArrayIndexOutOfBounds")
+                r.append(bytes(v[p]) if cols[j][2] == DENSE_STRING else int(v[p]))
+            rows.append(tuple(r))
+            where.append((k, int(p)))
+    return rows, where, would_throw

@@ -1,0 +1,59 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+# ---- helpers shared by the oracle tests and the GPU parity tests --------------------------------
+DENSE_INT, DENSE_TINYINT, DENSE_STRING = 1, 2, 3
+MATCH, NOTMATCH, EQ, GT, LT, NOOP = 0, 1, 2, 3, 4, 5
+
+
+def offsets_for(block_rows, width):
+    return np.concatenate([[0], np.cumsum(np.array(block_rows, dtype=np.int64) * width)]).astype(np.int32)
+
+
+def blocks_of(n, block_size):
+    full, rem = divmod(n, block_size)
+    return [block_size] * full + ([rem] if rem else [])
+
+
+class RawColumn:
+    """(codec, width, raw bytes, block offsets) of one column of one segment."""
+
+    def __init__(self, codec, width, values, block_rows):
+        self.codec, self.width = codec, width
+        if codec == DENSE_INT:
+            self.dat = np.ascontiguousarray(values, dtype="<i4").view(np.uint8).copy()
+        elif codec == DENSE_TINYINT:
+            self.dat = np.ascontiguousarray(values, dtype=np.int8).view(np.uint8).copy()
+        else:
+            self.dat = np.ascontiguousarray(values, dtype=np.uint8).reshape(-1).copy()
+        self.offsets = offsets_for(block_rows, width)
+        self.values = values
+
+    def ocol(self):
+        from oracle import oracle_c
+        return oracle_c.OColumn(self.dat, self.offsets, self.codec, self.width)
+
+    def npcol(self):
+        return (self.dat, self.offsets, self.codec, self.width)
+
+    def native(self):
+        return (self.codec, self.width, self.dat, self.dat.size, self.offsets)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle_c
+    oracle_c.build()
+    return oracle_c
