@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""bench.py -- scanned rows/s + fraction of the HBM roofline of the RangeFilter hot path.
+
+Workload at every N (weak scaling): each rank owns 100 M-row DENSE_INT segments resident in ITS GPU's HBM
+(BASELINE.json: "100M-row RangeFilter"; SURVEY 8d config C2 at 100 M rows: int32 uniform in [0, 2^30) from
+splitmix64, predicate GT(2^28) AND LT(3*2^28), ~50 % selectivity).  One STEP = one pass of the hot path
+ScanOp -> SelectOp(GT) -> SelectOp(LT) over one segment: the fused scan+select kernel producing the
+selection bitmap (12.5 MB) and the selected-row count, followed -- when N > 1 -- by the RCCL all-reduce of
+that 8-byte count (the only collective on the path; asynchronous, overlapped with the next step).
+Three distinct segments per rank are rotated so the 256 MiB Infinity Cache cannot serve the reads.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  value = rows scanned by all ranks / max-over-ranks wall time, inputs
+already resident in HBM.  roofline.achieved = algorithmic bytes per launch (4.125 B/row: 4 B column read +
+1/8 B bitmap write) / mean duration of the scan+select kernel measured live with HIP events on the
+launching stream.  cpu_baseline = the oracle's faithful C restatement of the reference CPU operators
+(kind "port": the Scala/JVM reference cannot run here), one thread -- the reference runs one thread per
+segment (Engine.scala:176-180) -- timed on rank 0 at N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+ROWS_PER_SEGMENT = 100_000_000
+ALGO_BYTES_PER_ROW = 4.125     # 4 B int32 read + 1/8 B bitmap write
+
+
+class _DevArray:
+    """Zero-copy view of library-owned device memory for torch (cuda array interface)."""
+
+    def __init__(self, ptr: int, n: int, typestr: str = "<i8"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 3}
+
+
+def cpu_baseline(values: np.ndarray, offsets: np.ndarray, sels, budget_s: float = 12.0):
+    """The oracle (kind 'port'), faithful flavour, single thread, on the same 100 M-row segment."""
+    from oracle import oracle_c
+    col = oracle_c.OColumn(values.view(np.uint8), offsets, oracle_c.DENSE_INT, 4)
+    n = values.shape[0]
+    t0 = time.perf_counter()
+    reps = 0
+    count = 0
+    while True:
+        _, count = oracle_c.scan_select([col], sels, 1024, 0)
+        reps += 1
+        if time.perf_counter() - t0 >= budget_s or reps >= 8:
+            break
+    dt = time.perf_counter() - t0
+    return {
+        "value": n * reps / dt,
+        "unit": "rows/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{reps} full passes over one 100M-row DENSE_INT segment (same data and predicate as the GPU step), "
+                  f"oracle/imm3_oracle.c faithful flavour, gcc -O2, 1 thread of {os.cpu_count()} host cores",
+        "selected_rows": int(count),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=ROWS_PER_SEGMENT, help="rows per segment (default 100M)")
+    ap.add_argument("--segments", type=int, default=3, help="distinct resident segments rotated per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extra", action="store_true", help="also time C3 (range+project) and C4 (match+project)")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--grid", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the immutable3 hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # "nccl" IS RCCL on ROCm
+
+    from immutable3_amd import native, synth
+
+    n = args.rows
+    sels = [(0, native.GT, float(2 ** 28)), (0, native.LT, float(3 * 2 ** 28))]
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = native.Context(local_rank, stream)   # launch on torch's current stream: its synchronize() covers us
+    ctx.set_tuning(args.variant, args.grid)
+    offsets = synth.block_offsets(n, 4)
+
+    # ---- stage: segments resident in HBM before any timed region (PCIe staging is not part of `value`) ----
+    segs, queries, host0 = [], [], None
+    t_stage = time.perf_counter()
+    for s in range(args.segments):
+        seed = 1 + s + 1000 * rank          # rank r, slot s: its own splitmix64 stream
+        v = synth.uniform_int30(seed, n)
+        if s == 0 and rank == 0:
+            host0 = v
+        seg = native.DeviceSegment(ctx, [(native.DENSE_INT, 4, v.view(np.uint8), n * 4, offsets)])
+        segs.append(seg)
+        queries.append(native.DeviceQuery(ctx, seg, [0], sels, [], 0, 1024))
+        del v
+    stage_s = time.perf_counter() - t_stage
+
+    # parity gate for the reported number: popcount(bitmap) == count == numpy evaluation of segment 0
+    if rank == 0:
+        queries[0].run_select()
+        words = queries[0].bitmap()
+        cnt = queries[0].count()
+        keep = (host0 > 2 ** 28) & (host0 < 3 * 2 ** 28)
+        assert cnt == int(keep.sum()), (cnt, int(keep.sum()))
+        assert words.tobytes() == np.packbits(keep, bitorder="little").tobytes(), "bitmap mismatch"
+        del keep, words
+
+    counts = torch.zeros(args.steps + args.warmup, dtype=torch.int64, device="cuda")
+    views = [torch.as_tensor(_DevArray(q.device_ptr(1), 1), device="cuda") for q in queries]
+    works = []
+
+    def step(i: int):
+        q = queries[i % len(queries)]
+        q.run_select()                                   # fused ScanOp -> SelectOp(GT) -> SelectOp(LT) kernel
+        if world > 1:                                    # final selected-row-count reduction over RCCL / xGMI
+            counts[i:i + 1].copy_(views[i % len(queries)])
+            works.append(dist.all_reduce(counts[i:i + 1], op=dist.ReduceOp.SUM, async_op=True))
+
+    for i in range(args.warmup):
+        step(i)
+    for w in works:
+        w.wait()
+    works.clear()
+    ctx.timing_enable(args.steps + 8)
+    ctx.timing_reset()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    for w in works:
+        w.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    kernel_ms = ctx.timing_collect(0)
+    ctx.timing_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        total_rows = float(n) * args.steps * world
+        mean_ms = float(np.mean(kernel_ms)) if kernel_ms.size else float("nan")
+        achieved = ALGO_BYTES_PER_ROW * n / (mean_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == "range_filter_i32" and tj.get("rows") == n:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "scanned rows/sec + %HBM-roofline, 100M-row RangeFilter, 1/2/4/8 MI355X",
+            "value": total_rows / elapsed,
+            "unit": "rows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "i32",
+            "data": "synthetic",
+            "config": {
+                "workload": "C2@100M: RangeFilter GT(2^28) AND LT(3*2^28) over one 100M-row DENSE_INT segment "
+                            "-> selection bitmap + selected-row count",
+                "rows_per_step_per_gpu": n,
+                "block_rows": 1024,
+                "segments_rotated_per_gpu": args.segments,
+                "selectivity": 0.5,
+                "parallelism": f"segment-sharded x{world}, count all-reduce over RCCL" if world > 1 else "1 GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel": "imm3::k_filter_num",
+                "kernel_ms_mean": mean_ms,
+                "kernel_ms_min": float(np.min(kernel_ms)) if kernel_ms.size else None,
+                "kernel_launches_timed": int(kernel_ms.size),
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ROW * n,
+            },
+            "staging": {"host_to_hbm_s_per_segment": stage_s / args.segments, "note": "PCIe staging incl. synthetic generation; never part of value"},
+        }
+        if world > 1:
+            result["count_allreduce_last"] = int(counts[args.warmup + args.steps - 1].item())
+
+    if args.extra and rank == 0 and world == 1:
+        result["extra"] = extra_workloads(ctx, native, synth, n)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(host0, offsets, [(0, 3, float(2 ** 28)), (0, 4, float(3 * 2 ** 28))])
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    for q in queries:
+        q.close()
+    for s in segs:
+        s.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def extra_workloads(ctx, native, synth, n, steps: int = 30):
+    """C3 (conjunctive RangeFilter on age and id + Project(id, age)) and C4 (MatchFilter(state)=='CA' +
+    Project(id, state, age)) over one 100 M-row segment: not bench lines, reported for the record."""
+    import torch
+    out = {}
+    ids = np.arange(n, dtype=np.int32)
+    age = synth.uniform_below(2, n, 100, np.int8)
+    st = synth.state_codes(3, n)
+    seg = native.DeviceSegment(ctx, [
+        (native.DENSE_INT, 4, ids.view(np.uint8), n * 4, synth.block_offsets(n, 4)),
+        (native.DENSE_STRING, 2, st.reshape(-1), n * 2, synth.block_offsets(n, 2)),
+        (native.DENSE_TINYINT, 1, age.view(np.uint8), n, synth.block_offsets(n, 1)),
+    ])
+    cases = {
+        "c3_range_age_id_project": ([2, 0], [(0, native.GT, 18.0), (0, native.LT, 30.0), (1, native.GT, 1e6), (1, native.LT, 9e7)], [1, 0],
+                                    lambda sel: 5 + 0.125 + sel * (4 + 5 + 5)),
+        "c4_match_state_project": ([1, 0, 2], [(0, native.MATCH, [b"CA"])], [1, 0, 2],
+                                   lambda sel: 2 + 0.125 + sel * (4 + 7 + 7)),
+    }
+    for name, (used, sels, proj, bytes_per_row) in cases.items():
+        q = native.DeviceQuery(ctx, seg, used, sels, proj, 0, 1024)
+        q.run()
+        cnt = q.count()
+        q.reserve_rows(cnt + 1024)
+        for _ in range(3):
+            q.run()
+        torch.cuda.synchronize()
+        ctx.timing_enable(4 * steps + 8)
+        ctx.timing_reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            q.run()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        k = [ctx.timing_collect(i) for i in range(3)]
+        ctx.timing_enable(0)
+        sel = cnt / n
+        out[name] = {
+            "rows_per_s": n / dt, "ms_per_query": dt * 1e3, "selected_rows": int(cnt), "selectivity": sel,
+            "algorithmic_bytes_per_row": bytes_per_row(sel),
+            "algorithmic_GBps": bytes_per_row(sel) * n / dt / 1e9,
+            "kernel_ms": {"scan_select": float(np.mean(k[0])) if k[0].size else None,
+                          "offsets_scan": float(np.mean(k[1])) if k[1].size else None,
+                          "compact_gather": float(np.mean(k[2])) if k[2].size else None},
+        }
+        q.close()
+    seg.close()
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""BASELINE.json's full sizes (100 M rows) on the GPU, checked through size-independent properties
+(the oracle is only run on a bounded sample): popcount(bitmap) == count == closed-form count,
+complement predicates partition the rows, AND of single-column filters == fused filter, projected
+rows are sorted, satisfy the predicate and equal a numpy evaluation on sampled tiles."""
+import numpy as np
+import pytest
+
+from conftest import DENSE_INT, DENSE_STRING, DENSE_TINYINT, EQ, GT, LT, MATCH, RawColumn, blocks_of
+
+pytestmark = pytest.mark.gpu
+N = 100_000_000
+
+
+@pytest.fixture(scope="module")
+def big():
+    from immutable3_amd import native, synth
+    assert native.device_count() >= 1
+    ctx = native.Context(0)
+    ids = np.arange(N, dtype=np.int32)
+    age = synth.uniform_below(2, N, 100, np.int8)
+    st = synth.state_codes(3, N)
+    offs = lambda w: synth.block_offsets(N, w)
+    seg = native.DeviceSegment(ctx, [(DENSE_INT, 4, ids.view(np.uint8), N * 4, offs(4)),
+                                     (DENSE_TINYINT, 1, age.view(np.uint8), N, offs(1)),
+                                     (DENSE_STRING, 2, st.reshape(-1), N * 2, offs(2))])
+    yield ctx, seg, ids, age, st
+    seg.close()
+    ctx.close()
+
+
+def popcount(words):
+    return int(np.unpackbits(words.view(np.uint8)).sum())
+
+
+def test_c3_range_and_project_100m(big, oracle):
+    from immutable3_amd import native
+    ctx, seg, ids, age, st = big
+    sels = [(0, GT, 18.0), (0, LT, 30.0), (1, GT, 1e6), (1, LT, 9e7)]
+    q = native.DeviceQuery(ctx, seg, [1, 0], sels, [1, 0], 0)     # used = [age, id]; project (id, age)
+    q.run()
+    count = q.count()
+    words = q.bitmap()
+    assert q.n_batches == 97657 and q.total_words == (N + 63) // 64
+    keep = (age > 18) & (age < 30) & (ids > 1_000_000) & (ids < 90_000_000)
+    assert count == int(keep.sum()) == popcount(words)
+    assert words.tobytes() == np.packbits(keep, bitorder="little").tobytes()
+    idx, vals = q.fetch_rows()
+    assert idx.shape[0] == count
+    assert (np.diff(idx.astype(np.int64)) > 0).all()                # ascending row order
+    expect_rows = np.flatnonzero(keep)
+    assert (idx == expect_rows).all()
+    assert (vals[0].view("<i4").reshape(-1) == ids[expect_rows]).all()
+    assert (vals[1].view(np.int8).reshape(-1) == age[expect_rows]).all()
+    q.close()
+    # oracle on a bounded sample: the first 2M rows as their own segment
+    m = 2_000_000
+    cols = [RawColumn(DENSE_TINYINT, 1, age[:m], blocks_of(m, 1024)), RawColumn(DENSE_INT, 4, ids[:m], blocks_of(m, 1024))]
+    ow, oc = oracle.scan_select([c.ocol() for c in cols], sels, 1024, 1)
+    assert words[: ow.size].tolist() == ow.tolist()
+
+
+def test_partition_and_fusion_100m(big):
+    from immutable3_amd import native
+    ctx, seg, ids, age, st = big
+    def run(used, sels):
+        q = native.DeviceQuery(ctx, seg, used, sels)
+        q.run()
+        out = (q.bitmap(), q.count())
+        q.close()
+        return out
+    w_lt, c_lt = run([0], [(0, LT, 5e7)])
+    w_ge, c_ge = run([0], [(0, GT, 5e7 - 1)])
+    assert c_lt + c_ge == N and c_lt == 50_000_000
+    tail = np.uint64((1 << (N % 64)) - 1) if N % 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    full = np.full(w_lt.size, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+    full[-1] = tail
+    assert ((w_lt ^ w_ge) == full).all() and not (w_lt & w_ge).any()
+    w_age, _ = run([1], [(0, GT, 18.0), (0, LT, 30.0)])
+    w_both, c_both = run([1, 0], [(0, GT, 18.0), (0, LT, 30.0), (1, LT, 5e7)])
+    assert ((w_age & w_lt) == w_both).all() and popcount(w_both) == c_both
+    w_none, c_none = run([0], [])
+    assert c_none == N and (w_none == full).all()
+
+
+def test_c4_match_project_100m(big):
+    from immutable3_amd import native
+    ctx, seg, ids, age, st = big
+    q = native.DeviceQuery(ctx, seg, [2, 0, 1], [(0, MATCH, [b"CA"])], [1, 0, 2], 0)   # project (id, state, age)
+    q.run()
+    keep = (st[:, 0] == ord("C")) & (st[:, 1] == ord("A"))
+    assert q.count() == int(keep.sum())
+    idx, vals = q.fetch_rows()
+    rows = np.flatnonzero(keep)
+    assert (idx == rows).all()
+    assert (vals[0].view("<i4").reshape(-1) == ids[rows]).all()
+    assert (vals[1] == st[rows]).all()
+    assert (vals[2].view(np.int8).reshape(-1) == age[rows]).all()
+    q.close()
+    q = native.DeviceQuery(ctx, seg, [2, 0, 1], [(0, MATCH, [b"CA"])], [1, 0, 2], 10)
+    q.run()
+    idx10, v10 = q.fetch_rows()
+    assert (idx10 == rows[:10]).all() and (v10[0].view("<i4").reshape(-1) == ids[rows[:10]]).all()
+    q.close()
