@@ -88,7 +88,7 @@ struct imm3_query {
     std::vector<FoldedPred> preds;
     // device buffers
     uint64_t *d_bitmap = nullptr;
-    uint32_t *d_tile_counts = nullptr, *d_tile_offsets = nullptr, *d_chunk_sums = nullptr;
+    uint32_t *d_tile_counts = nullptr, *d_tile_offsets = nullptr, *d_chunk_sums = nullptr, *d_block_partials = nullptr;
     unsigned long long *d_total = nullptr, *d_n_emit = nullptr; // adjacent: d_n_emit = d_total + 1
     uint32_t *d_word_row_base = nullptr;
     uint8_t *d_word_nvalid = nullptr;
@@ -324,6 +324,7 @@ static void query_free(imm3_query *q) {
     (void)hipFree(q->d_tile_counts);
     (void)hipFree(q->d_tile_offsets);
     (void)hipFree(q->d_chunk_sums);
+    (void)hipFree(q->d_block_partials);
     (void)hipFree(q->d_total);
     (void)hipFree(q->d_word_row_base);
     (void)hipFree(q->d_word_nvalid);
@@ -528,6 +529,8 @@ extern "C" int imm3_query_create(imm3_ctx *ctx, const imm3_segment *seg,
     q->d_tile_offsets = (uint32_t *)p;
     HIPCHK(hipMalloc(&p, (size_t)std::max<int64_t>(q->n_chunks, 1) * sizeof(uint32_t)));
     q->d_chunk_sums = (uint32_t *)p;
+    HIPCHK(hipMalloc(&p, kMaxFilterGrid * sizeof(uint32_t)));
+    q->d_block_partials = (uint32_t *)p;
     HIPCHK(hipMalloc(&p, 2 * sizeof(unsigned long long)));
     q->d_total = (unsigned long long *)p;
     q->d_n_emit = q->d_total + 1;
@@ -607,9 +610,9 @@ static int run_select(imm3_query *q) {
     imm3_ctx *ctx = q->ctx;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    HIPCHK(hipMemsetAsync(q->d_total, 0, 2 * sizeof(unsigned long long), s));
     if (q->always_false || q->n_tiles == 0) {
         // an empty interval / empty IN-list clears every bit; nothing to read
+        HIPCHK(hipMemsetAsync(q->d_total, 0, 2 * sizeof(unsigned long long), s));
         HIPCHK(hipMemsetAsync(q->d_bitmap, 0, (size_t)std::max<int64_t>(q->n_tiles * kTileWords, 1) * sizeof(uint64_t), s));
         HIPCHK(hipMemsetAsync(q->d_tile_counts, 0, (size_t)std::max<int64_t>(q->n_tiles, 1) * sizeof(uint32_t), s));
         q->ran_select = true;
@@ -618,6 +621,7 @@ static int run_select(imm3_query *q) {
     const size_t np = q->preds.size();
     size_t done = 0;
     int pass = 0;
+    int grid = 1;
     do {
         FilterArgs a;
         std::memset(&a, 0, sizeof(a));
@@ -630,22 +634,34 @@ static int run_select(imm3_query *q) {
         a.n_tiles = q->n_tiles;
         a.bitmap = q->d_bitmap;
         a.tile_counts = q->d_tile_counts;
-        a.total = q->d_total;
+        a.block_partials = q->d_block_partials;
         a.word_row_base = q->d_word_row_base;
         a.word_nvalid = q->d_word_nvalid;
         // strings and ragged layouts go through the word-at-a-time kernel, numeric columns through the tile kernel
         bool generic = q->ragged;
         for (size_t i = 0; i < take; ++i) generic |= (a.cols[i].kind == KIND_STR);
-        if (pass > 0) HIPCHK(hipMemsetAsync(q->d_total, 0, sizeof(unsigned long long), s)); // re-accumulated by the AND pass
         if (generic) HIPCHK(hipMemsetAsync(q->d_tile_counts, 0, (size_t)q->n_tiles * sizeof(uint32_t), s)); // it adds atomically
+        grid = filter_grid(a, generic, ctx->grid_blocks);
         {
             LaunchTimer t(ctx, 0);
-            launch_filter(a, generic, ctx->filter_variant, ctx->grid_blocks, s);
+            launch_filter(a, generic, ctx->filter_variant, grid, s);
         }
         HIPCHK(hipGetLastError());
         done += take;
         ++pass;
     } while (done < np);
+    {   // the last pass's per-workgroup partials -> selected-row count (+ rows ProjectOp will emit)
+        TotalArgs ta;
+        std::memset(&ta, 0, sizeof(ta));
+        ta.block_partials = q->d_block_partials;
+        ta.n_partials = grid;
+        ta.total = q->d_total;
+        ta.n_emit = q->d_n_emit;
+        ta.limit = q->limit;
+        LaunchTimer t(ctx, 3);
+        launch_total(ta, s);
+    }
+    HIPCHK(hipGetLastError());
     q->ran_select = true;
     return IMM3_OK;
 }
@@ -697,9 +713,6 @@ static int run_project(imm3_query *q) {
         sa.tile_offsets = q->d_tile_offsets;
         sa.chunk_sums = q->d_chunk_sums;
         sa.n_tiles = q->n_tiles;
-        sa.total = q->d_total;
-        sa.n_emit = q->d_n_emit;
-        sa.limit = q->limit;
         {
             LaunchTimer t(ctx, 1);
             launch_scan(sa, s);

@@ -90,6 +90,20 @@ __device__ __forceinline__ uint64_t words_to_lanes(const uint64_t (&acc)[kTileWo
 // Row-strided loads (lane l reads row 64j + l): the v_cmp result of load j IS bitmap word j, no
 // cross-lane transpose.  16 independent loads per column are in flight per wave.
 // ---------------------------------------------------------------------------------------------
+// Per-workgroup survivor count -> block_partials[blockIdx.x]; k_total sums them.  (One same-address
+// atomicAdd per wave costs ~12 ns serialised: 4096 of them were 40 % of the kernel.)
+__device__ __forceinline__ void block_partial_store(uint32_t *block_partials, uint32_t wave_total, int lane, int wave) {
+    __shared__ uint32_t s_part[kWavesPerBlock];
+    if (lane == 0) s_part[wave] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int i = 0; i < kWavesPerBlock; ++i) t += s_part[i];
+        block_partials[blockIdx.x] = t;
+    }
+}
+
 __device__ __forceinline__ bool eval_num(const ColPred &c, int64_t row) {
     const int32_t x = c.kind == KIND_I32 ? ((const int32_t *)c.data)[row] : (int32_t)((const int8_t *)c.data)[row];
     return in_closed(x, c.lo, c.hi);
@@ -152,7 +166,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_num(const FilterArgs a
             wave_total += cnt;
         }
     }
-    if (lane == 0 && wave_total) atomicAdd(a.total, wave_total);
+    block_partial_store(a.block_partials, (uint32_t)wave_total, lane, wave);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -190,7 +204,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_generic(const FilterAr
         }
         wave_total += cnt;
     }
-    if (lane == 0 && wave_total) atomicAdd(a.total, wave_total);
+    block_partial_store(a.block_partials, (uint32_t)wave_total, lane, wave);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -216,8 +230,26 @@ __global__ __launch_bounds__(kChunkTiles) void k_scan(const ScanArgs a) {
     incl += wave_prefix;
     if (tile < a.n_tiles) a.tile_offsets[tile] = incl - c;
     if (t == kChunkTiles - 1) a.chunk_sums[blockIdx.x] = incl;
-    if (blockIdx.x == 0 && t == 0) {
-        const unsigned long long total = *a.total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_total: one workgroup sums the filter launch's per-workgroup partials -> selected-row count of the
+// segment, and the number of rows ProjectOp will emit.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_total(const TotalArgs a) {
+    __shared__ unsigned long long s_wave[16];
+    const int t = threadIdx.x;
+    unsigned long long v = 0;
+    for (int i = t; i < a.n_partials; i += 1024) v += a.block_partials[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if ((t & 63) == 0) s_wave[t >> 6] = v;
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long total = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) total += s_wave[i];
+        *a.total = total;
         *a.n_emit = (a.limit > 0 && total > (unsigned long long)a.limit) ? (unsigned long long)a.limit : total;
     }
 }
@@ -321,16 +353,21 @@ static inline int clamp_grid(int64_t want, int cap) {
     return (int)(want > cap ? cap : want);
 }
 
-void launch_filter(const FilterArgs &a, bool generic, int variant, int grid_blocks, hipStream_t s) {
+int filter_grid(const FilterArgs &a, bool generic, int grid_blocks) {
+    // 256 CUs x 8 resident 256-thread workgroups; more only lengthens the partials reduction
+    const int cap = grid_blocks > 0 ? (grid_blocks > kMaxFilterGrid ? kMaxFilterGrid : grid_blocks) : 2048;
+    const int64_t units = generic ? a.n_words : a.n_tiles;
+    return clamp_grid((units + kWavesPerBlock - 1) / kWavesPerBlock, cap);
+}
+
+void launch_filter(const FilterArgs &a, bool generic, int variant, int grid, hipStream_t s) {
     (void)variant;
-    const int cap = grid_blocks > 0 ? grid_blocks : 2048; // 256 CUs x 8 resident 256-thread workgroups
-    if (generic) {
-        const int grid = clamp_grid((a.n_words + kWavesPerBlock - 1) / kWavesPerBlock, cap);
-        hipLaunchKernelGGL(k_filter_generic, dim3(grid), dim3(kBlockThreads), 0, s, a);
-    } else {
-        const int grid = clamp_grid((a.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, cap);
-        hipLaunchKernelGGL(k_filter_num, dim3(grid), dim3(kBlockThreads), 0, s, a);
-    }
+    if (generic) hipLaunchKernelGGL(k_filter_generic, dim3(grid), dim3(kBlockThreads), 0, s, a);
+    else hipLaunchKernelGGL(k_filter_num, dim3(grid), dim3(kBlockThreads), 0, s, a);
+}
+
+void launch_total(const TotalArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_total, dim3(1), dim3(1024), 0, s, a);
 }
 
 void launch_scan(const ScanArgs &a, hipStream_t s) {

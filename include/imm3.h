@@ -153,7 +153,7 @@ int imm3_query_device_ptr(imm3_query *q, int32_t which, void **ptr);
 
 /* ---- live kernel timing (HIP events on the context's stream) ----
  * When enabled, every kernel launch of this context is bracketed by an event pair.
- * kernel ids: 0 = scan+select, 1 = offsets scan, 2 = compact+gather. */
+ * kernel ids: 0 = scan+select, 1 = offsets scan, 2 = compact+gather, 3 = count reduce. */
 int imm3_ctx_timing_enable(imm3_ctx *ctx, int32_t max_records);
 int imm3_ctx_timing_reset(imm3_ctx *ctx);
 /* Synchronises, then writes up to cap durations (ms) of launches of `kernel_id`, oldest first. */

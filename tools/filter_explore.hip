@@ -1,0 +1,308 @@
+// tools/filter_explore.hip -- development tool: A/B variants of the int32 range-filter kernel and pure
+// streaming-read ceilings in ONE process (interleaved rounds, hipEvent timing, 3 rotating 400 MB buffers so
+// the 256 MiB Infinity Cache cannot serve the reads).  Not part of the product library.
+//   hipcc --offload-arch=gfx950 -O3 -o tools/filter_explore tools/filter_explore.hip && ./tools/filter_explore
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+extern "C" __device__ int wl_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
+struct Args {
+    const int32_t *data;
+    int64_t n_rows;
+    int64_t n_tiles;
+    int32_t lo, hi;
+    uint64_t *bitmap;
+    uint32_t *tile_counts;
+    unsigned long long *total;
+};
+
+__device__ __forceinline__ bool in_closed(int32_t x, int32_t lo, int32_t hi) {
+    return ((uint32_t)x - (uint32_t)lo) <= ((uint32_t)hi - (uint32_t)lo);
+}
+
+// ---- ceilings -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_read_x4(Args a) { // 16 B / lane streaming read, XOR-reduce
+    const int4 *p = (const int4 *)a.data;
+    const int64_t n4 = a.n_rows / 4;
+    int acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        int4 v = p[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345678) a.tile_counts[0] = acc;
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void k_read_x4_tile(Args a) { // wave owns U KiB contiguous, U x dwordx4 in flight
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_chunks = a.n_rows / (256 * U);
+    int acc = 0;
+    for (int64_t c = (int64_t)blockIdx.x * 4 + wave; c < n_chunks; c += (int64_t)gridDim.x * 4) {
+        const int4 *p = (const int4 *)(a.data + c * 256 * U) + lane;
+        int4 v[U];
+#pragma unroll
+        for (int g = 0; g < U; ++g) v[g] = p[64 * g];
+#pragma unroll
+        for (int g = 0; g < U; ++g) acc ^= v[g].x ^ v[g].y ^ v[g].z ^ v[g].w;
+    }
+    if (acc == 0x12345678) a.tile_counts[0] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_read_x1_tile(Args a) { // wave owns 4 KiB, 16 x dword in flight
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int acc = 0;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < a.n_tiles; t += (int64_t)gridDim.x * 4) {
+        if ((t + 1) * 1024 > a.n_rows) continue;
+        const int32_t *p = a.data + t * 1024 + lane;
+        int32_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = p[64 * j];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc ^= v[j];
+    }
+    if (acc == 0x12345678) a.tile_counts[0] = acc;
+}
+
+// ---- V0: row-strided dword loads, ballot == word ----------------------------------------------------------
+__global__ __launch_bounds__(256) void k_v0(Args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long wave_total = 0;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < a.n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = tile * 1024;
+        if (row0 + 1024 > a.n_rows) continue; // exploration: full tiles only
+        const int32_t *p = a.data + row0 + lane;
+        int32_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = p[64 * j];
+        int lo = 0, hi = 0;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint64_t m = __ballot(in_closed(v[j], a.lo, a.hi));
+            lo = wl_i32((int)(uint32_t)m, j, lo);
+            hi = wl_i32((int)(uint32_t)(m >> 32), j, hi);
+            cnt += __popcll(m);
+        }
+        if (lane < 16) a.bitmap[tile * 16 + lane] = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+        if (lane == 0) a.tile_counts[tile] = cnt;
+        wave_total += cnt;
+    }
+    if (lane == 0) a.total[1 + blockIdx.x * 4 + wave] = wave_total; // per-wave partial, no same-address atomics
+}
+
+// ---- V1: dwordx4 loads (16 B/lane) + in-register transpose ------------------------------------------------
+// load g covers rows g*256 + 4*lane + k.  Word (4g + (lane>>4)) bit 4*(lane&15)+k.  Each lane builds a nibble,
+// shifts it to 4*(lane&7), OR-reduces over its 8-lane group with DPP -> one bitmap dword per 8 lanes.
+__device__ __forceinline__ uint32_t or_reduce8(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true); // row_half_mirror
+    return v;
+}
+
+template <int TILES_PER_ITER>
+__global__ __launch_bounds__(256) void k_v1(Args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sh = 4 * (lane & 7);
+    unsigned long long lane_total = 0;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < a.n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = tile * 1024;
+        if (row0 + 1024 > a.n_rows) continue;
+        const int4 *p = (const int4 *)(a.data + row0) + lane;
+        int4 v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = p[64 * g];
+        uint32_t r[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint32_t nib = (in_closed(v[g].x, a.lo, a.hi) ? 1u : 0u) | (in_closed(v[g].y, a.lo, a.hi) ? 2u : 0u) |
+                           (in_closed(v[g].z, a.lo, a.hi) ? 4u : 0u) | (in_closed(v[g].w, a.lo, a.hi) ? 8u : 0u);
+            r[g] = or_reduce8(nib << sh);
+        }
+        // dword index within the tile's 32 dwords: g*8 + (lane>>3); lane (lane&7)==g' stores r[g'] for g' < 4
+        const int gsel = lane & 7;
+        uint32_t mine = gsel == 0 ? r[0] : gsel == 1 ? r[1] : gsel == 2 ? r[2] : r[3];
+        uint32_t *out = (uint32_t *)(a.bitmap + tile * 16);
+        if (gsel < 4) {
+            out[gsel * 8 + (lane >> 3)] = mine;
+            lane_total += __popc(mine);
+        }
+        // per-tile count: sum over the 32 storing lanes
+        uint32_t c = gsel < 4 ? __popc(mine) : 0;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+        if (lane == 0) a.tile_counts[tile] = c;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) lane_total += __shfl_xor(lane_total, d);
+    if (lane == 0) a.total[1 + blockIdx.x * 4 + wave] = lane_total;
+}
+
+// ---- V2: like V1 but 2 tiles (8 KiB) in flight per wave -------------------------------------------------
+__global__ __launch_bounds__(256) void k_v2(Args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sh = 4 * (lane & 7);
+    const int gsel = lane & 7;
+    unsigned long long lane_total = 0;
+    const int64_t n_pairs = a.n_tiles / 2;
+    for (int64_t pair = (int64_t)blockIdx.x * 4 + wave; pair < n_pairs; pair += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = pair * 2048;
+        if (row0 + 2048 > a.n_rows) continue;
+        const int4 *p = (const int4 *)(a.data + row0) + lane;
+        int4 v[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) v[g] = p[64 * g];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            uint32_t r[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int4 x = v[t * 4 + g];
+                uint32_t nib = (in_closed(x.x, a.lo, a.hi) ? 1u : 0u) | (in_closed(x.y, a.lo, a.hi) ? 2u : 0u) |
+                               (in_closed(x.z, a.lo, a.hi) ? 4u : 0u) | (in_closed(x.w, a.lo, a.hi) ? 8u : 0u);
+                r[g] = or_reduce8(nib << sh);
+            }
+            uint32_t mine = gsel == 0 ? r[0] : gsel == 1 ? r[1] : gsel == 2 ? r[2] : r[3];
+            const int64_t tile = pair * 2 + t;
+            uint32_t *out = (uint32_t *)(a.bitmap + tile * 16);
+            uint32_t c = 0;
+            if (gsel < 4) {
+                out[gsel * 8 + (lane >> 3)] = mine;
+                c = __popc(mine);
+                lane_total += c;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+            if (lane == 0) a.tile_counts[tile] = c;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) lane_total += __shfl_xor(lane_total, d);
+    if (lane == 0) a.total[1 + blockIdx.x * 4 + wave] = lane_total;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+struct Variant {
+    const char *name;
+    void (*launch)(const Args &, int grid, hipStream_t);
+};
+
+#define LAUNCHER(fn, kern) static void fn(const Args &a, int grid, hipStream_t s) { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, a); }
+LAUNCHER(l_read_x4, k_read_x4)
+LAUNCHER(l_read_x4_t4, k_read_x4_tile<4>)
+LAUNCHER(l_read_x4_t8, k_read_x4_tile<8>)
+LAUNCHER(l_read_x1, k_read_x1_tile)
+LAUNCHER(l_v0, k_v0)
+LAUNCHER(l_v1, k_v1<1>)
+LAUNCHER(l_v2, k_v2)
+
+int main(int argc, char **argv) {
+    const int64_t n = argc > 1 ? atoll(argv[1]) : 100000000LL;
+    const int rounds = argc > 2 ? atoi(argv[2]) : 15;
+    const int NB = 3;
+    CHECK(hipSetDevice(0));
+    hipStream_t s;
+    CHECK(hipStreamCreate(&s));
+    std::vector<int32_t> host((size_t)n);
+    int32_t *d[NB];
+    for (int b = 0; b < NB; ++b) {
+        uint64_t x = 0x9E3779B97F4A7C15ULL * (b + 1);
+        for (int64_t i = 0; i < n; ++i) {
+            x += 0x9E3779B97F4A7C15ULL;
+            uint64_t z = x;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+            z ^= z >> 31;
+            host[(size_t)i] = (int32_t)(z >> 34);
+        }
+        CHECK(hipMalloc(&d[b], (size_t)n * 4 + 4096));
+        CHECK(hipMemcpy(d[b], host.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    }
+    const int64_t n_tiles = (n + 1023) / 1024;
+    uint64_t *bitmap;
+    uint32_t *tile_counts;
+    unsigned long long *total;
+    CHECK(hipMalloc(&bitmap, (size_t)n_tiles * 16 * 8));
+    CHECK(hipMalloc(&tile_counts, (size_t)n_tiles * 4));
+    const size_t total_slots = 1 + 4 * (size_t)((n_tiles + 3) / 4 + 1);
+    CHECK(hipMalloc(&total, 8 * total_slots));
+
+    // reference bitmap from the last host buffer (b = NB-1) for V-correctness
+    const int32_t lo = (1 << 28) + 1, hi = 3 * (1 << 28) - 1;
+    const int64_t full_tiles = n / 1024;
+    std::vector<uint64_t> ref((size_t)full_tiles * 16, 0);
+    for (int64_t i = 0; i < full_tiles * 1024; ++i)
+        if (host[(size_t)i] >= lo && host[(size_t)i] <= hi) ref[(size_t)(i >> 6)] |= 1ULL << (i & 63);
+
+    std::vector<Variant> vars = {
+        {"read_x4_flat", l_read_x4}, {"read_x4_tile4K", l_read_x4_t4}, {"read_x4_tile8K", l_read_x4_t8},
+        {"read_x1_tile4K", l_read_x1}, {"v0_dword_ballot", l_v0}, {"v1_x4_dpp", l_v1}, {"v2_x4_dpp_8K", l_v2},
+    };
+    std::vector<int> grids = {1024, 2048, 4096, 8192, (int)((n_tiles + 3) / 4)};
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+
+    // correctness of the filter variants
+    for (auto &v : vars) {
+        if (v.name[0] != 'v') continue;
+        Args a{d[NB - 1], n, n_tiles, lo, hi, bitmap, tile_counts, total};
+        CHECK(hipMemset(bitmap, 0, (size_t)n_tiles * 16 * 8));
+        CHECK(hipMemset(total, 0, 8 * total_slots));
+        v.launch(a, 2048, s);
+        CHECK(hipStreamSynchronize(s));
+        std::vector<uint64_t> got((size_t)full_tiles * 16);
+        CHECK(hipMemcpy(got.data(), bitmap, got.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t = 0;
+        {
+            std::vector<unsigned long long> parts(1 + 4 * 2048);
+            CHECK(hipMemcpy(parts.data(), total, parts.size() * 8, hipMemcpyDeviceToHost));
+            for (size_t i = 1; i < parts.size(); ++i) t += parts[i];
+        }
+        size_t bad = 0;
+        unsigned long long pc = 0;
+        for (size_t i = 0; i < got.size(); ++i) { bad += got[i] != ref[i]; pc += __builtin_popcountll(ref[i]); }
+        printf("check %-18s mismatching words: %zu  count %llu (ref %llu)\n", v.name, bad, t, pc);
+    }
+
+    printf("\n%-18s", "variant \\ grid");
+    for (int g : grids) printf(" %9d", g);
+    printf("   (us median; GB/s at best)\n");
+    std::vector<std::vector<std::vector<float>>> times(vars.size(), std::vector<std::vector<float>>(grids.size()));
+    for (int r = 0; r < rounds + 2; ++r) {
+        for (size_t vi = 0; vi < vars.size(); ++vi) {
+            for (size_t gi = 0; gi < grids.size(); ++gi) {
+                Args a{d[(r + vi + gi) % NB], n, n_tiles, lo, hi, bitmap, tile_counts, total};
+                CHECK(hipEventRecord(e0, s));
+                vars[vi].launch(a, grids[gi], s);
+                CHECK(hipEventRecord(e1, s));
+                CHECK(hipEventSynchronize(e1));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                if (r >= 2) times[vi][gi].push_back(ms * 1000.f);
+            }
+        }
+    }
+    for (size_t vi = 0; vi < vars.size(); ++vi) {
+        printf("%-18s", vars[vi].name);
+        float best = 1e30f;
+        for (size_t gi = 0; gi < grids.size(); ++gi) {
+            auto &t = times[vi][gi];
+            std::sort(t.begin(), t.end());
+            const float med = t[t.size() / 2];
+            best = std::min(best, med);
+            printf(" %9.1f", med);
+        }
+        printf("   %.0f GB/s read (%.1f%% of 8 TB/s)\n", n * 4.0 / best / 1e3, n * 4.0 / best / 1e3 / 80.0);
+    }
+    return 0;
+}
