@@ -150,7 +150,7 @@ def main():
     for w in works:
         w.wait()
     works.clear()
-    ctx.timing_enable(args.steps + 8)
+    ctx.timing_enable(2 * args.steps + 8)   # two launches per step: scan+select, count reduce
     ctx.timing_reset()
 
     if world > 1:
@@ -216,7 +216,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "imm3::k_filter_num",
+                "kernel": "imm3::k_filter_tile<TK_I32>",
                 "kernel_ms_mean": mean_ms,
                 "kernel_ms_min": float(np.min(kernel_ms)) if kernel_ms.size else None,
                 "kernel_launches_timed": int(kernel_ms.size),

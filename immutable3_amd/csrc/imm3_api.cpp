@@ -232,19 +232,17 @@ extern "C" int imm3_ctx_timing_collect(imm3_ctx *ctx, int32_t kernel_id, float *
 }
 
 namespace {
-// Brackets one kernel launch with an event pair on the context's stream when timing is on.
+// Hands out one event pair per launch when timing is on; the launcher stamps it with the kernel's own
+// start and end (hipExtLaunchKernelGGL), so elapsed time == kernel duration as rocprofv3 reports it.
 struct LaunchTimer {
-    imm3_ctx *ctx;
-    TimingRecord *rec = nullptr;
-    LaunchTimer(imm3_ctx *c, int32_t id) : ctx(c) {
+    hipEvent_t start = nullptr, stop = nullptr;
+    LaunchTimer(imm3_ctx *ctx, int32_t id) {
         if (ctx->timing && ctx->used < ctx->pool.size()) {
-            rec = &ctx->pool[ctx->used++];
-            rec->kernel_id = id;
-            (void)hipEventRecord(rec->start, ctx->stream);
+            TimingRecord &rec = ctx->pool[ctx->used++];
+            rec.kernel_id = id;
+            start = rec.start;
+            stop = rec.stop;
         }
-    }
-    ~LaunchTimer() {
-        if (rec) (void)hipEventRecord(rec->stop, ctx->stream);
     }
 };
 } // namespace
@@ -273,6 +271,7 @@ static int segment_build(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, 
         s.bytes = c.dat_bytes;
         s.offsets.assign(c.block_offsets, c.block_offsets + c.n_offsets);
         if (wrap) {
+            if ((uintptr_t)c.dat & 15) return fail(IMM3_ERR_ARG, "wrapped device columns must be 16-byte aligned");
             s.d_data = (uint8_t *)c.dat;
             s.owned = false;
         } else {
@@ -606,6 +605,14 @@ static void fill_colpred(const imm3_query *q, const FoldedPred &fp, ColPred &cp)
     }
 }
 
+// Can this folded predicate go through the tile kernel?
+static int tile_kind(const FoldedPred &fp) {
+    if (fp.kind == KIND_I32) return TK_I32;
+    if (fp.kind == KIND_I8) return TK_I8;
+    if (fp.kind == KIND_STR && fp.width == 2 && !fp.match.empty() && fp.match.size() <= (size_t)kMaxTileMatch) return TK_S2;
+    return TK_NONE;
+}
+
 static int run_select(imm3_query *q) {
     imm3_ctx *ctx = q->ctx;
     HIPCHK(hipSetDevice(ctx->device));
@@ -618,15 +625,72 @@ static int run_select(imm3_query *q) {
         q->ran_select = true;
         return IMM3_OK;
     }
-    const size_t np = q->preds.size();
-    size_t done = 0;
+    // Plan the passes.  Uniform layouts: numeric and 2-byte-string predicates go through the tile kernel, up
+    // to 3 columns (at most one string) per launch; everything else -- other string widths, long IN-lists,
+    // ragged layouts -- through the word-at-a-time kernel, up to 4 columns per launch.  Every pass after the
+    // first ANDs into the bitmap in memory.
+    std::vector<const FoldedPred *> tile_preds, generic_preds;
+    for (const auto &p : q->preds) {
+        if (!q->ragged && ctx->filter_variant != 1 && tile_kind(p) != TK_NONE) tile_preds.push_back(&p);
+        else generic_preds.push_back(&p);
+    }
+    std::stable_sort(tile_preds.begin(), tile_preds.end(),
+                     [](const FoldedPred *x, const FoldedPred *y) { return tile_kind(*x) < tile_kind(*y); });
     int pass = 0;
     int grid = 1;
-    do {
+    // tile passes (a query without predicates is one tile pass with zero columns)
+    size_t ti = 0;
+    const bool need_empty_pass = q->preds.empty() && !q->ragged && ctx->filter_variant != 1;
+    while (ti < tile_preds.size() || (need_empty_pass && pass == 0)) {
+        TileArgs a;
+        std::memset(&a, 0, sizeof(a));
+        int n = 0, n_s2 = 0;
+        for (int k = 0; k < kMaxTileCols; ++k) a.kinds[k] = TK_NONE;
+        std::vector<const FoldedPred *> take;
+        // numeric first (sorted), then at most one S2: scan the remaining list in order
+        for (size_t i = ti; i < tile_preds.size() && n < kMaxTileCols; ++i) {
+            const int tk = tile_kind(*tile_preds[i]);
+            if (tk == TK_S2 && n_s2 == 1) continue;
+            take.push_back(tile_preds[i]);
+            n_s2 += tk == TK_S2;
+            ++n;
+        }
+        // remove the taken ones (they are a prefix unless a second S2 was skipped)
+        for (const FoldedPred *fp : take) tile_preds.erase(std::find(tile_preds.begin(), tile_preds.end(), fp));
+        for (int k = 0; k < n; ++k) {
+            const FoldedPred &fp = *take[(size_t)k];
+            TileCol &c = a.cols[k];
+            c.data = q->seg->cols[(size_t)fp.seg_col].d_data;
+            c.lo = (int32_t)fp.lo;
+            c.hi = (int32_t)fp.hi;
+            a.kinds[k] = tile_kind(fp);
+            if (a.kinds[k] == TK_S2) {
+                c.n_match = (int32_t)fp.match.size();
+                for (size_t m = 0; m < fp.match.size(); ++m)
+                    c.match[m] = (uint32_t)(uint8_t)fp.match[m][0] | ((uint32_t)(uint8_t)fp.match[m][1] << 8);
+            }
+        }
+        a.and_existing = pass > 0;
+        a.n_rows = q->n_rows;
+        a.n_words = q->n_words;
+        a.n_tiles = q->n_tiles;
+        a.bitmap = q->d_bitmap;
+        a.tile_counts = q->d_tile_counts;
+        a.block_partials = q->d_block_partials;
+        grid = filter_grid(q->n_tiles, false, ctx->grid_blocks);
+        LaunchTimer t(ctx, 0);
+        if (!launch_filter_tile(a, grid, s, t.start, t.stop)) return fail(IMM3_ERR_ARG, "internal: no tile kernel for this column combination");
+        HIPCHK(hipGetLastError());
+        ++pass;
+    }
+    // generic passes
+    size_t gi = 0;
+    const bool need_empty_generic = q->preds.empty() && pass == 0;
+    while (gi < generic_preds.size() || (need_empty_generic && pass == 0)) {
         FilterArgs a;
         std::memset(&a, 0, sizeof(a));
-        const size_t take = std::min<size_t>(kMaxPredCols, np - done);
-        for (size_t i = 0; i < take; ++i) fill_colpred(q, q->preds[done + i], a.cols[i]);
+        const size_t take = std::min<size_t>(kMaxPredCols, generic_preds.size() - gi);
+        for (size_t i = 0; i < take; ++i) fill_colpred(q, *generic_preds[gi + i], a.cols[i]);
         a.ncols = (int32_t)take;
         a.and_existing = pass > 0;
         a.n_rows = q->n_rows;
@@ -637,19 +701,16 @@ static int run_select(imm3_query *q) {
         a.block_partials = q->d_block_partials;
         a.word_row_base = q->d_word_row_base;
         a.word_nvalid = q->d_word_nvalid;
-        // strings and ragged layouts go through the word-at-a-time kernel, numeric columns through the tile kernel
-        bool generic = q->ragged;
-        for (size_t i = 0; i < take; ++i) generic |= (a.cols[i].kind == KIND_STR);
-        if (generic) HIPCHK(hipMemsetAsync(q->d_tile_counts, 0, (size_t)q->n_tiles * sizeof(uint32_t), s)); // it adds atomically
-        grid = filter_grid(a, generic, ctx->grid_blocks);
+        HIPCHK(hipMemsetAsync(q->d_tile_counts, 0, (size_t)q->n_tiles * sizeof(uint32_t), s)); // it adds atomically
+        grid = filter_grid(q->n_words, true, ctx->grid_blocks);
         {
             LaunchTimer t(ctx, 0);
-            launch_filter(a, generic, ctx->filter_variant, grid, s);
+            launch_filter_generic(a, grid, s, t.start, t.stop);
         }
         HIPCHK(hipGetLastError());
-        done += take;
+        gi += take;
         ++pass;
-    } while (done < np);
+    }
     {   // the last pass's per-workgroup partials -> selected-row count (+ rows ProjectOp will emit)
         TotalArgs ta;
         std::memset(&ta, 0, sizeof(ta));
@@ -659,7 +720,7 @@ static int run_select(imm3_query *q) {
         ta.n_emit = q->d_n_emit;
         ta.limit = q->limit;
         LaunchTimer t(ctx, 3);
-        launch_total(ta, s);
+        launch_total(ta, s, t.start, t.stop);
     }
     HIPCHK(hipGetLastError());
     q->ran_select = true;
@@ -695,7 +756,7 @@ static int launch_project(imm3_query *q) {
         }
         {
             LaunchTimer t(ctx, 2);
-            launch_gather(g, 0, s);
+            launch_gather(g, 0, s, t.start, t.stop);
         }
         HIPCHK(hipGetLastError());
         done += take;
@@ -715,7 +776,7 @@ static int run_project(imm3_query *q) {
         sa.n_tiles = q->n_tiles;
         {
             LaunchTimer t(ctx, 1);
-            launch_scan(sa, s);
+            launch_scan(sa, s, t.start, t.stop);
         }
         HIPCHK(hipGetLastError());
     }

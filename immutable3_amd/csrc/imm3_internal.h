@@ -14,6 +14,8 @@ constexpr int kTileWords = 16;
 constexpr int kWavesPerBlock = 4;   // 256-thread workgroups
 constexpr int kBlockThreads = 256;
 constexpr int kChunkTiles = 1024;   // tiles per offsets-scan chunk (one scan workgroup)
+constexpr int kSpanTiles = 16;      // tiles per gather workgroup (kChunkTiles % kSpanTiles == 0)
+constexpr int kSpanWords = kSpanTiles * kTileWords;
 
 constexpr int kMaxPredCols = 4;     // distinct predicate columns fused per launch (more -> extra AND pass)
 constexpr int kMaxMatch = 8;        // IN-list values carried in kernel arguments
@@ -34,6 +36,29 @@ struct ColPred {
     int32_t match_in_args;       // 1: width <= 8 and n_match <= kMaxMatch -> values packed in match[]
     uint64_t match[kMaxMatch];   // value bytes packed little-endian (byte 0 = first character)
     const uint8_t *match_blob;   // otherwise: n_match * width bytes in device memory
+};
+
+// ---- tile kernel (compile-time column kinds) ----
+enum TileKind : int32_t { TK_I32 = 0, TK_I8 = 1, TK_S2 = 2, TK_NONE = 3 };
+constexpr int kMaxTileCols = 3;
+constexpr int kMaxTileMatch = 8;
+
+struct TileCol {
+    const void *data;               // flat column in HBM, 16-byte aligned
+    int32_t lo, hi;                 // TK_I32 / TK_I8: closed interval
+    int32_t n_match;                // TK_S2: IN-list size (1..kMaxTileMatch)
+    int32_t pad;
+    uint32_t match[kMaxTileMatch];  // TK_S2: the two value bytes, little-endian
+};
+
+struct TileArgs {
+    TileCol cols[kMaxTileCols];
+    int32_t kinds[kMaxTileCols];    // sorted ascending, TK_NONE last (selects the template instance)
+    int32_t and_existing;
+    int64_t n_rows, n_words, n_tiles;
+    uint64_t *bitmap;
+    uint32_t *tile_counts;
+    uint32_t *block_partials;
 };
 
 struct FilterArgs {
@@ -93,10 +118,12 @@ struct GatherArgs {
 
 // launchers (imm3_kernels.hip)
 constexpr int kMaxFilterGrid = 4096; // capacity of block_partials
-int filter_grid(const FilterArgs &a, bool generic, int grid_blocks);
-void launch_filter(const FilterArgs &a, bool generic, int variant, int grid, hipStream_t s);
-void launch_total(const TotalArgs &a, hipStream_t s);
-void launch_scan(const ScanArgs &a, hipStream_t s);
-void launch_gather(const GatherArgs &a, int grid_blocks, hipStream_t s);
+int filter_grid(int64_t units, bool generic, int grid_blocks);
+// ev0/ev1: optional events stamped with the kernel's own start/end (hipExtLaunchKernelGGL), else null
+bool launch_filter_tile(const TileArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+void launch_filter_generic(const FilterArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+void launch_total(const TotalArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+void launch_scan(const ScanArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+void launch_gather(const GatherArgs &a, int grid_blocks, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 
 } // namespace imm3

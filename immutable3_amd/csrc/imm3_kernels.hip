@@ -7,26 +7,243 @@
 //   SelectOp*.next   clear the bit of every row that fails (engine/.../operator/Select.scala:25-165)
 //   ProjectOp.next   walk the set bits in ascending order and emit the SELECT-list values
 //                    (engine/.../operator/Project.scala:37-64)
-// On the GPU that becomes three launches over HBM-resident flat columns:
-//   k_filter_*   one fused pass over all predicate columns -> selection bitmap (uint64 words, bit i of a
+// On the GPU that becomes, over HBM-resident flat columns:
+//   k_filter_tile<KINDS...> / k_filter_generic
+//                one fused pass over all predicate columns -> selection bitmap (uint64 words, bit i of a
 //                batch <-> word i>>6, bit i&63 == scala.collection.mutable.BitSet == wave64 ballot order),
-//                per-tile survivor counts and the segment's selected-row count
+//                per-tile survivor counts and per-workgroup partial counts
+//   k_total      partial counts -> the segment's selected-row count
 //   k_scan       exclusive prefix of the per-tile counts (chunked)
-//   k_gather     per tile: expand set bits into a dense LDS list in ascending row order, then write
+//   k_gather     per 16-tile span: expand set bits into a dense LDS list in ascending row order, then write
 //                row indices and gather the projected columns with dense, coalesced stores
 // All of it is HBM-bound integer/byte work: no MFMA anywhere.
 #include "imm3_internal.h"
+#include <hip/hip_ext.h>
 
 namespace imm3 {
 
+typedef int v4i __attribute__((ext_vector_type(4)));
+
 // ---------------------------------------------------------------------------------------------
-// predicate evaluation
+// small helpers
 // ---------------------------------------------------------------------------------------------
 
 // x in [lo, hi] (lo <= hi guaranteed by the host) with one subtract and one unsigned compare.
 __device__ __forceinline__ bool in_closed(int32_t x, int32_t lo, int32_t hi) {
     return ((uint32_t)x - (uint32_t)lo) <= ((uint32_t)hi - (uint32_t)lo);
 }
+
+__device__ __forceinline__ uint64_t ballot64(bool p) { return (uint64_t)__ballot(p); }
+
+// clang has no __builtin_amdgcn_writelane; bind the LLVM intrinsic directly (emits v_writelane_b32).
+extern "C" __device__ int imm3_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
+// mask of the first `rem` bits (rem may be <= 0 or >= 64)
+__device__ __forceinline__ uint64_t low_mask(int64_t rem) {
+    return rem >= 64 ? ~0ULL : (rem <= 0 ? 0ULL : ((1ULL << rem) - 1ULL));
+}
+
+// value of `v` in lane `src_lane` (any lane -> any lane, through the LDS crossbar, no memory)
+__device__ __forceinline__ uint32_t lane_read(uint32_t v, int src_lane) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
+}
+
+// Move 16 wave-uniform words into lanes 0..15 (lane j receives word j) with v_writelane.
+__device__ __forceinline__ uint64_t words_to_lanes(const uint64_t (&acc)[kTileWords]) {
+    int lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 0; j < kTileWords; ++j) {
+        lo = imm3_writelane_i32((int)(uint32_t)acc[j], j, lo);
+        hi = imm3_writelane_i32((int)(uint32_t)(acc[j] >> 32), j, hi);
+    }
+    return ((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo;
+}
+
+// Per-workgroup survivor count -> block_partials[blockIdx.x]; k_total sums them.  (One same-address
+// atomicAdd per wave costs ~12 ns serialised: 4096 of them were 40 % of the kernel.)
+__device__ __forceinline__ void block_partial_store(uint32_t *block_partials, uint32_t wave_total, int lane, int wave) {
+    __shared__ uint32_t s_part[kWavesPerBlock];
+    if (lane == 0) s_part[wave] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int i = 0; i < kWavesPerBlock; ++i) t += s_part[i];
+        block_partials[blockIdx.x] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_filter_tile<K0, K1, K2>: the hot kernel.  Uniform layout (every non-final block has rows % 64 == 0,
+// so the batch-major bitmap is flat: word w <-> rows [64w, 64w+64)).  One wave per 1024-row tile,
+// grid-stride; column kinds are compile-time so the descriptors live in SGPRs and ALL loads of a tile
+// (every column) are issued before the first compare.
+//
+//   TK_I32  DENSE_INT      16 row-strided dword loads (lane l reads row 64j + l): the v_cmp result of load j
+//                          IS bitmap word j -- no cross-lane transpose.
+//   TK_I8   DENSE_TINYINT  one 16-byte load per lane (rows 16l .. 16l+15) -> 16 predicate bits per lane;
+//                          lane j < 16 collects word j from lanes 4j .. 4j+3 (ds_bpermute).
+//   TK_S2   DENSE_STRING(2) two 16-byte loads per lane (rows 512g + 8l .. +7) -> 8 bits per lane per load;
+//                          quads are OR-combined with DPP, lane j collects word j with ds_bpermute.
+//
+// Measured on MI355X (tools/filter_explore.hip, 100 M int32 rows, 61 interleaved rounds): the column is
+// read once, so loads are non-temporal (65 us vs 74 us with the default cache policy; read-only ceiling
+// with nt loads 59 us); dword and dwordx4 loads stream at the same rate; the best grid is 512 workgroups
+// = 2 per CU = 8 waves/CU (more waves add DRAM page conflicts, fewer starve the memory pipeline).
+// ---------------------------------------------------------------------------------------------
+template <int KIND>
+struct ColRegs { // TK_NONE: no column
+    __device__ __forceinline__ void load(const TileCol &, int64_t, int) {}
+    __device__ __forceinline__ void eval(const TileCol &, uint64_t (&)[kTileWords], uint64_t &, int) {}
+    __device__ __forceinline__ bool row(const TileCol &, int64_t) { return true; }
+};
+
+template <>
+struct ColRegs<TK_I32> {
+    int32_t v[kTileWords];
+    __device__ __forceinline__ void load(const TileCol &c, int64_t row0, int lane) {
+        const int32_t *p = (const int32_t *)c.data + row0 + lane;
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) v[j] = __builtin_nontemporal_load(p + 64 * j);
+    }
+    __device__ __forceinline__ void eval(const TileCol &c, uint64_t (&acc)[kTileWords], uint64_t &, int) {
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) acc[j] &= ballot64(in_closed(v[j], c.lo, c.hi));
+    }
+    __device__ __forceinline__ bool row(const TileCol &c, int64_t r) { return in_closed(((const int32_t *)c.data)[r], c.lo, c.hi); }
+};
+
+template <>
+struct ColRegs<TK_I8> {
+    v4i v;
+    __device__ __forceinline__ void load(const TileCol &c, int64_t row0, int lane) {
+        v = __builtin_nontemporal_load((const v4i *)((const int8_t *)c.data + row0) + lane);
+    }
+    __device__ __forceinline__ void eval(const TileCol &c, uint64_t (&)[kTileWords], uint64_t &mine, int lane) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int32_t x = (int32_t)(int8_t)((uint32_t)v[k >> 2] >> (8 * (k & 3)));
+            bits |= in_closed(x, c.lo, c.hi) ? (1u << k) : 0u;
+        }
+        const int src = (lane & 15) << 2; // word j <- lanes 4j .. 4j+3, 16 bits each
+        const uint32_t lo = lane_read(bits, src) | (lane_read(bits, src + 1) << 16);
+        const uint32_t hi = lane_read(bits, src + 2) | (lane_read(bits, src + 3) << 16);
+        mine &= ((uint64_t)hi << 32) | lo;
+    }
+    __device__ __forceinline__ bool row(const TileCol &c, int64_t r) { return in_closed((int32_t)((const int8_t *)c.data)[r], c.lo, c.hi); }
+};
+
+template <>
+struct ColRegs<TK_S2> {
+    v4i v[2];
+    __device__ __forceinline__ void load(const TileCol &c, int64_t row0, int lane) {
+        const v4i *p = (const v4i *)((const uint16_t *)c.data + row0) + lane;
+        v[0] = __builtin_nontemporal_load(p);
+        v[1] = __builtin_nontemporal_load(p + 64);
+    }
+    __device__ __forceinline__ bool hit(const TileCol &c, uint32_t x) {
+        bool f = false;
+        for (int m = 0; m < c.n_match; ++m) f |= (x == c.match[m]);
+        return f;
+    }
+    __device__ __forceinline__ void eval(const TileCol &c, uint64_t (&)[kTileWords], uint64_t &mine, int lane) {
+        // IN-list outermost (usually one value): the value pair sits in one SGPR, each dword of the load holds
+        // two rows; x ^ mm has a zero half exactly where a row matches.
+        uint32_t bits[2] = {0u, 0u};
+        for (int m = 0; m < c.n_match; ++m) {
+            const uint32_t mm = c.match[m] | (c.match[m] << 16);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const uint32_t t = (uint32_t)v[g][d] ^ mm;
+                    bits[g] |= ((t & 0xFFFFu) == 0u ? (1u << (2 * d)) : 0u) | ((t >> 16) == 0u ? (2u << (2 * d)) : 0u);
+                }
+            }
+        }
+        uint32_t q[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            uint32_t y = bits[g] << (8 * (lane & 3)); // OR over the quad -> 32 bitmap bits in every lane of the quad
+            y |= (uint32_t)__builtin_amdgcn_mov_dpp((int)y, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
+            y |= (uint32_t)__builtin_amdgcn_mov_dpp((int)y, 0x4E, 0xF, 0xF, true); // quad_perm [2,3,0,1]
+            q[g] = y;
+        }
+        // word j = load (j >> 3), lanes 8(j&7) .. 8(j&7)+7 = two quads
+        const int src = (lane & 7) << 3;
+        const uint32_t lo0 = lane_read(q[0], src), hi0 = lane_read(q[0], src + 4);
+        const uint32_t lo1 = lane_read(q[1], src), hi1 = lane_read(q[1], src + 4);
+        const bool second = (lane & 8) != 0;
+        mine &= ((uint64_t)(second ? hi1 : hi0) << 32) | (second ? lo1 : lo0);
+    }
+    __device__ __forceinline__ bool row(const TileCol &c, int64_t r) { return hit(c, ((const uint16_t *)c.data)[r]); }
+};
+
+template <int K0, int K1, int K2>
+__global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    constexpr bool any_i32 = (K0 == TK_I32) || (K1 == TK_I32) || (K2 == TK_I32);
+    uint32_t wave_total = 0;
+
+    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < a.n_tiles;
+         tile += (int64_t)gridDim.x * kWavesPerBlock) {
+        const int64_t row0 = tile * kTileRows;
+        const bool full = row0 + kTileRows <= a.n_rows; // wave-uniform
+        const int64_t w = tile * kTileWords + lane;      // lane j < 16 owns bitmap word j of the tile
+        ColRegs<K0> c0;
+        ColRegs<K1> c1;
+        ColRegs<K2> c2;
+        uint64_t mine = ~0ULL;
+        if (full) {
+            c0.load(a.cols[0], row0, lane);
+            c1.load(a.cols[1], row0, lane);
+            c2.load(a.cols[2], row0, lane);
+            if (a.and_existing) mine = lane < kTileWords ? a.bitmap[w] : 0ULL;
+            uint64_t acc[kTileWords]; // wave-uniform words (SGPR pairs), fed by the TK_I32 columns
+#pragma unroll
+            for (int j = 0; j < kTileWords; ++j) acc[j] = ~0ULL;
+            c0.eval(a.cols[0], acc, mine, lane);
+            c1.eval(a.cols[1], acc, mine, lane);
+            c2.eval(a.cols[2], acc, mine, lane);
+            if (any_i32) mine &= words_to_lanes(acc);
+        } else { // the one partial tile at the end of the segment: rolled, bounds-checked
+            if (a.and_existing) mine = (lane < kTileWords && w < a.n_words) ? a.bitmap[w] : 0ULL;
+#pragma unroll 1
+            for (int j = 0; j < kTileWords; ++j) {
+                const int64_t row = row0 + 64 * j + lane;
+                const bool valid = row < a.n_rows;
+                const int64_t r = valid ? row : 0;
+                bool keep = valid;
+                if (valid) keep = c0.row(a.cols[0], r) && c1.row(a.cols[1], r) && c2.row(a.cols[2], r);
+                const uint64_t m = ballot64(keep);
+                if (lane == j) mine &= m;
+            }
+            mine &= low_mask(a.n_rows - (row0 + 64 * (int64_t)lane)); // rows past the end are not rows
+        }
+        if (lane >= kTileWords) mine = 0;
+
+        uint32_t cnt = (uint32_t)__popcll(mine);
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d); // lanes 0..15 hold the tile's count
+        if (lane < kTileWords && w < a.n_words) __builtin_nontemporal_store(mine, a.bitmap + w); // 16 lanes x 8 B = one 128-B line
+        if (lane == 0) {
+            a.tile_counts[tile] = cnt;
+            wave_total += cnt;
+        }
+    }
+    block_partial_store(a.block_partials, wave_total, lane, wave);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_filter_generic: any column kind (any string width, long IN-lists), any layout; one wave per bitmap
+// word per iteration.
+//   uniform layout (word_row_base == null): word w covers rows [64w, min(64w+64, n_rows))
+//   ragged layout (arbitrary block sizes, e.g. the loader's trailing 1-row block, SURVEY A.2): each
+//   batch's BitSet starts on a fresh word, word w covers rows [base[w], base[w] + nvalid[w]).
+// tile_counts must be zeroed before the launch.
+// ---------------------------------------------------------------------------------------------
 
 // SelectIteratorMatch (Select.scala:25-51): keep the row iff its `width` raw bytes equal one IN-list value.
 __device__ __forceinline__ bool match_row(const ColPred &c, int64_t row) {
@@ -62,124 +279,10 @@ __device__ __forceinline__ bool eval_row(const ColPred &c, int64_t row) {
     }
 }
 
-__device__ __forceinline__ uint64_t ballot64(bool p) { return (uint64_t)__ballot(p); }
-
-// clang has no __builtin_amdgcn_writelane; bind the LLVM intrinsic directly (emits v_writelane_b32).
-extern "C" __device__ int imm3_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
-
-// mask of the first `rem` bits (rem may be <= 0 or >= 64)
-__device__ __forceinline__ uint64_t low_mask(int64_t rem) {
-    return rem >= 64 ? ~0ULL : (rem <= 0 ? 0ULL : ((1ULL << rem) - 1ULL));
-}
-
-// Move 16 wave-uniform words into lanes 0..15 (lane j receives word j) with v_writelane.
-__device__ __forceinline__ uint64_t words_to_lanes(const uint64_t (&acc)[kTileWords]) {
-    int lo = 0, hi = 0;
-#pragma unroll
-    for (int j = 0; j < kTileWords; ++j) {
-        lo = imm3_writelane_i32((int)(uint32_t)acc[j], j, lo);
-        hi = imm3_writelane_i32((int)(uint32_t)(acc[j] >> 32), j, hi);
-    }
-    return ((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo;
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_filter_num: the hot kernel.  Numeric (DENSE_INT / DENSE_TINYINT) predicate columns only, uniform
-// layout (every non-final block has rows % 64 == 0, so the batch-major bitmap is flat: word w <->
-// rows [64w, 64w+64)).  One wave per 1024-row tile, grid-stride over tiles.
-// Row-strided loads (lane l reads row 64j + l): the v_cmp result of load j IS bitmap word j, no
-// cross-lane transpose.  16 independent loads per column are in flight per wave.
-// ---------------------------------------------------------------------------------------------
-// Per-workgroup survivor count -> block_partials[blockIdx.x]; k_total sums them.  (One same-address
-// atomicAdd per wave costs ~12 ns serialised: 4096 of them were 40 % of the kernel.)
-__device__ __forceinline__ void block_partial_store(uint32_t *block_partials, uint32_t wave_total, int lane, int wave) {
-    __shared__ uint32_t s_part[kWavesPerBlock];
-    if (lane == 0) s_part[wave] = wave_total;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-#pragma unroll
-        for (int i = 0; i < kWavesPerBlock; ++i) t += s_part[i];
-        block_partials[blockIdx.x] = t;
-    }
-}
-
-__device__ __forceinline__ bool eval_num(const ColPred &c, int64_t row) {
-    const int32_t x = c.kind == KIND_I32 ? ((const int32_t *)c.data)[row] : (int32_t)((const int8_t *)c.data)[row];
-    return in_closed(x, c.lo, c.hi);
-}
-
-__global__ __launch_bounds__(kBlockThreads) void k_filter_num(const FilterArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    unsigned long long wave_total = 0;
-
-    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < a.n_tiles;
-         tile += (int64_t)gridDim.x * kWavesPerBlock) {
-        const int64_t row0 = tile * kTileRows;
-        const bool full = row0 + kTileRows <= a.n_rows; // wave-uniform
-        const int64_t w = tile * kTileWords + lane;      // lane j < 16 owns bitmap word j of the tile
-        uint64_t mine = ~0ULL;
-        if (a.and_existing) mine = (lane < kTileWords && w < a.n_words) ? a.bitmap[w] : 0ULL;
-
-        if (full) {
-            uint64_t acc[kTileWords]; // wave-uniform words (SGPR pairs)
-#pragma unroll
-            for (int j = 0; j < kTileWords; ++j) acc[j] = ~0ULL;
-            for (int ci = 0; ci < a.ncols; ++ci) {
-                const ColPred &c = a.cols[ci];
-                int32_t v[kTileWords];
-                if (c.kind == KIND_I32) {
-                    const int32_t *p = (const int32_t *)c.data + row0 + lane;
-#pragma unroll
-                    for (int j = 0; j < kTileWords; ++j) v[j] = p[64 * j];
-                } else {
-                    const int8_t *p = (const int8_t *)c.data + row0 + lane;
-#pragma unroll
-                    for (int j = 0; j < kTileWords; ++j) v[j] = (int32_t)p[64 * j];
-                }
-#pragma unroll
-                for (int j = 0; j < kTileWords; ++j) acc[j] &= ballot64(in_closed(v[j], c.lo, c.hi));
-            }
-            mine &= words_to_lanes(acc);
-        } else { // the one partial tile at the end of the segment: rolled, bounds-checked
-            for (int ci = 0; ci < a.ncols; ++ci) {
-                const ColPred &c = a.cols[ci];
-#pragma unroll 1
-                for (int j = 0; j < kTileWords; ++j) {
-                    const int64_t row = row0 + 64 * j + lane;
-                    const bool valid = row < a.n_rows;
-                    const uint64_t m = ballot64(valid && eval_num(c, valid ? row : 0));
-                    if (lane == j) mine &= m;
-                }
-            }
-            mine &= low_mask(a.n_rows - (row0 + 64 * (int64_t)lane)); // rows past the end are not rows
-        }
-        if (lane >= kTileWords) mine = 0;
-
-        uint32_t cnt = (uint32_t)__popcll(mine);
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d); // lanes 0..15 hold the tile's count
-        if (lane < kTileWords && w < a.n_words) a.bitmap[w] = mine;   // 16 lanes x 8 B = one 128-B line
-        if (lane == 0) {
-            a.tile_counts[tile] = cnt;
-            wave_total += cnt;
-        }
-    }
-    block_partial_store(a.block_partials, (uint32_t)wave_total, lane, wave);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_filter_generic: any column kind, any layout; one wave per bitmap word per iteration.
-//   uniform layout (word_row_base == null): word w covers rows [64w, min(64w+64, n_rows))
-//   ragged layout (arbitrary block sizes, e.g. the loader's trailing 1-row block, SURVEY A.2): each
-//   batch's BitSet starts on a fresh word, word w covers rows [base[w], base[w] + nvalid[w]).
-// tile_counts must be zeroed before the launch.
-// ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlockThreads) void k_filter_generic(const FilterArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    unsigned long long wave_total = 0;
+    uint32_t wave_total = 0;
     for (int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + wave; w < a.n_words;
          w += (int64_t)gridDim.x * kWavesPerBlock) {
         int64_t base;
@@ -200,11 +303,27 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_generic(const FilterAr
         const uint32_t cnt = (uint32_t)__popcll(acc);
         if (lane == 0) {
             a.bitmap[w] = acc;
-            if (cnt) atomicAdd(&a.tile_counts[w / kTileWords], cnt);
+            if (cnt) atomicAdd(&a.tile_counts[w / kTileWords], cnt); // distinct addresses: no serialisation
         }
         wave_total += cnt;
     }
-    block_partial_store(a.block_partials, (uint32_t)wave_total, lane, wave);
+    block_partial_store(a.block_partials, wave_total, lane, wave);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_total: one wave sums the last filter launch's per-workgroup partials -> selected-row count of the
+// segment, and the number of rows ProjectOp will emit.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_total(const TotalArgs a) {
+    const int lane = threadIdx.x;
+    unsigned long long v = 0;
+    for (int i = lane; i < a.n_partials; i += 64) v += a.block_partials[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if (lane == 0) {
+        *a.total = v;
+        *a.n_emit = (a.limit > 0 && v > (unsigned long long)a.limit) ? (unsigned long long)a.limit : v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -233,31 +352,11 @@ __global__ __launch_bounds__(kChunkTiles) void k_scan(const ScanArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_total: one workgroup sums the filter launch's per-workgroup partials -> selected-row count of the
-// segment, and the number of rows ProjectOp will emit.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_total(const TotalArgs a) {
-    __shared__ unsigned long long s_wave[16];
-    const int t = threadIdx.x;
-    unsigned long long v = 0;
-    for (int i = t; i < a.n_partials; i += 1024) v += a.block_partials[i];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    if ((t & 63) == 0) s_wave[t >> 6] = v;
-    __syncthreads();
-    if (t == 0) {
-        unsigned long long total = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) total += s_wave[i];
-        *a.total = total;
-        *a.n_emit = (a.limit > 0 && total > (unsigned long long)a.limit) ? (unsigned long long)a.limit : total;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_gather: ProjectOp.  One wave per tile.  Phase 1 expands the tile's set bits into an ascending list
-// of in-tile positions in LDS (rank of a row = popcount of lower bits: v_mbcnt).  Phase 2 walks that
-// list densely: lane i handles survivor i, so row-index / value stores are contiguous.
+// k_gather: ProjectOp.  One workgroup per SPAN of 16 tiles (256 bitmap words, 16384 rows).
+//   A  thread t loads word t of the span; block-wide exclusive scan of the popcounts
+//   B  every thread expands ITS word's set bits (ctz loop) into an ascending list of in-span positions in LDS
+//   C  the list is walked densely: thread i handles survivor i, so row-index / value stores are contiguous
+//      and the column gathers are ascending.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void copy_elem(const void *src, void *dst, int64_t row, uint64_t out) {
@@ -265,83 +364,80 @@ __device__ __forceinline__ void copy_elem(const void *src, void *dst, int64_t ro
 }
 
 __global__ __launch_bounds__(kBlockThreads) void k_gather(const GatherArgs a) {
-    __shared__ uint16_t s_list[kWavesPerBlock][kTileRows];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    uint16_t *list = s_list[wave];
-    const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
-    const int64_t iters = (a.n_tiles + stride - 1) / stride; // same trip count for every wave of the grid
+    __shared__ uint16_t s_list[kSpanWords * 64]; // 32 KiB
+    __shared__ uint32_t s_wave[kWavesPerBlock];
+    __shared__ unsigned long long s_base;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int64_t n_spans = (a.n_tiles + kSpanTiles - 1) / kSpanTiles;
 
-    for (int64_t it = 0; it < iters; ++it) {
-        const int64_t tile = it * stride + (int64_t)blockIdx.x * kWavesPerBlock + wave;
-        uint32_t cnt = 0;
-        uint64_t base = 0;
-        if (tile < a.n_tiles) {
-            cnt = a.tile_counts[tile];
-            if (cnt) {
-                const int64_t chunk = tile / kChunkTiles;
-                uint64_t part = 0;
-                for (int64_t i = lane; i < chunk; i += 64) part += a.chunk_sums[i];
+    for (int64_t span = blockIdx.x; span < n_spans; span += gridDim.x) { // block-uniform trip count
+        const int64_t tile0 = span * kSpanTiles;
+        const int64_t w = span * kSpanWords + t;
+        uint64_t word = w < a.n_words ? a.bitmap[w] : 0ULL;
+        const uint32_t pc = (uint32_t)__popcll(word);
+        uint32_t incl = pc;
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
-                base = part + a.tile_offsets[tile];
-                if (a.limit > 0) {
-                    if (base >= (uint64_t)a.limit) cnt = 0;
-                    else if (base + cnt > (uint64_t)a.limit) cnt = (uint32_t)((uint64_t)a.limit - base);
-                }
-            }
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
         }
-        if (cnt) { // wave-uniform
-            uint64_t word = 0;
-            const int64_t w = tile * kTileWords + lane;
-            if (lane < kTileWords && w < a.n_words) word = a.bitmap[w];
-            uint32_t incl = (uint32_t)__popcll(word);
-            const uint32_t pc = incl;
+        if (lane == 63) s_wave[wave] = incl;
+        if (wave == 0) { // offset of the span's first survivor among the segment's survivors
+            const int64_t chunk = tile0 / kChunkTiles;
+            unsigned long long part = 0;
+            for (int64_t i = lane; i < chunk; i += 64) part += a.chunk_sums[i];
 #pragma unroll
-            for (int d = 1; d < kTileWords; d <<= 1) {
-                const uint32_t up = __shfl_up(incl, d);
-                if (lane >= d) incl += up;
-            }
-            const uint32_t excl = incl - pc;
+            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+            if (lane == 0) s_base = part + a.tile_offsets[tile0];
+        }
+        __syncthreads();
+        uint32_t off = incl - pc;
+        uint32_t total = 0;
 #pragma unroll
-            for (int j = 0; j < kTileWords; ++j) {
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)word, j);
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(word >> 32), j);
-                const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)excl, j);
-                const uint64_t m = ((uint64_t)hi << 32) | lo;
-                if ((m >> lane) & 1ULL) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-                    list[off + rank] = (uint16_t)(j * 64 + lane);
-                }
+        for (int i = 0; i < kWavesPerBlock; ++i) {
+            if (i < wave) off += s_wave[i];
+            total += s_wave[i];
+        }
+        const unsigned long long base = s_base;
+        uint32_t n_out = total;
+        if (a.limit > 0) {
+            if (base >= (unsigned long long)a.limit) n_out = 0;
+            else if (base + total > (unsigned long long)a.limit) n_out = (uint32_t)((unsigned long long)a.limit - base);
+        }
+        if (n_out) { // block-uniform
+            while (word) {
+                const int b = __builtin_ctzll(word);
+                s_list[off++] = (uint16_t)(t * 64 + b);
+                word &= word - 1;
             }
         }
         __syncthreads();
-        if (cnt) {
-            for (uint32_t i = lane; i < cnt; i += 64) {
-                const uint32_t r = list[i];
-                const uint64_t out = base + i;
-                if (out >= a.cap_rows) continue;
-                const int64_t row = a.word_row_base
-                                        ? (int64_t)a.word_row_base[tile * kTileWords + (r >> 6)] + (r & 63)
-                                        : tile * kTileRows + r;
-                if (a.row_index) a.row_index[out] = (uint32_t)row;
-                for (int pj = 0; pj < a.n_proj; ++pj) {
-                    const ProjCol &pc2 = a.proj[pj];
-                    switch (pc2.width) {
-                    case 4: copy_elem<uint32_t>(pc2.src, pc2.dst, row, out); break;
-                    case 1: copy_elem<uint8_t>(pc2.src, pc2.dst, row, out); break;
-                    case 2: copy_elem<uint16_t>(pc2.src, pc2.dst, row, out); break;
-                    case 8: copy_elem<uint64_t>(pc2.src, pc2.dst, row, out); break;
-                    default: {
-                        const uint8_t *s = (const uint8_t *)pc2.src + row * (int64_t)pc2.width;
-                        uint8_t *d = (uint8_t *)pc2.dst + out * (uint64_t)pc2.width;
-                        for (int b = 0; b < pc2.width; ++b) d[b] = s[b];
-                    }
-                    }
+        for (uint32_t i = t; i < n_out; i += kBlockThreads) {
+            const uint32_t r = s_list[i];
+            const unsigned long long out = base + i;
+            if (out >= a.cap_rows) continue;
+            const int64_t row = a.word_row_base
+                                    ? (int64_t)a.word_row_base[span * kSpanWords + (r >> 6)] + (r & 63)
+                                    : span * (int64_t)(kSpanWords * 64) + r;
+            if (a.row_index) a.row_index[out] = (uint32_t)row;
+            for (int pj = 0; pj < a.n_proj; ++pj) {
+                const ProjCol &pc2 = a.proj[pj];
+                switch (pc2.width) {
+                case 4: copy_elem<uint32_t>(pc2.src, pc2.dst, row, out); break;
+                case 1: copy_elem<uint8_t>(pc2.src, pc2.dst, row, out); break;
+                case 2: copy_elem<uint16_t>(pc2.src, pc2.dst, row, out); break;
+                case 8: copy_elem<uint64_t>(pc2.src, pc2.dst, row, out); break;
+                default: {
+                    const uint8_t *s = (const uint8_t *)pc2.src + row * (int64_t)pc2.width;
+                    uint8_t *d = (uint8_t *)pc2.dst + out * (uint64_t)pc2.width;
+                    for (int b = 0; b < pc2.width; ++b) d[b] = s[b];
+                }
                 }
             }
         }
-        __syncthreads(); // list is reused by the next iteration
+        __syncthreads(); // s_list / s_wave / s_base are reused by the next span
     }
 }
 
@@ -353,32 +449,63 @@ static inline int clamp_grid(int64_t want, int cap) {
     return (int)(want > cap ? cap : want);
 }
 
-int filter_grid(const FilterArgs &a, bool generic, int grid_blocks) {
-    // 256 CUs x 8 resident 256-thread workgroups; more only lengthens the partials reduction
-    const int cap = grid_blocks > 0 ? (grid_blocks > kMaxFilterGrid ? kMaxFilterGrid : grid_blocks) : 2048;
-    const int64_t units = generic ? a.n_words : a.n_tiles;
+int filter_grid(int64_t units, bool generic, int grid_blocks) {
+    // tile kernel: 512 workgroups = 2 per CU (see k_filter_tile); the word-at-a-time kernel keeps 8 per CU
+    const int dflt = generic ? 2048 : 512;
+    const int cap = grid_blocks > 0 ? (grid_blocks > kMaxFilterGrid ? kMaxFilterGrid : grid_blocks) : dflt;
     return clamp_grid((units + kWavesPerBlock - 1) / kWavesPerBlock, cap);
 }
 
-void launch_filter(const FilterArgs &a, bool generic, int variant, int grid, hipStream_t s) {
-    (void)variant;
-    if (generic) hipLaunchKernelGGL(k_filter_generic, dim3(grid), dim3(kBlockThreads), 0, s, a);
-    else hipLaunchKernelGGL(k_filter_num, dim3(grid), dim3(kBlockThreads), 0, s, a);
+// With ev0/ev1 set, hipExtLaunchKernelGGL stamps them with the kernel's own start and end, so the elapsed
+// time is the kernel's duration (what rocprofv3 reports), not launch-to-launch.
+#define IMM3_LAUNCH(kern, grid, block, s, ev0, ev1, args) \
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, s, ev0, ev1, 0, args)
+
+#define IMM3_TILE_CASE(k0, k1, k2)                                                              \
+    if (a.kinds[0] == k0 && a.kinds[1] == k1 && a.kinds[2] == k2) {                             \
+        IMM3_LAUNCH((k_filter_tile<k0, k1, k2>), grid, kBlockThreads, s, ev0, ev1, a);          \
+        return true;                                                                            \
+    }
+
+// kinds must be sorted ascending with TK_NONE (= 3) last; at most one TK_S2 column per launch
+bool launch_filter_tile(const TileArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    IMM3_TILE_CASE(TK_NONE, TK_NONE, TK_NONE)
+    IMM3_TILE_CASE(TK_I32, TK_NONE, TK_NONE)
+    IMM3_TILE_CASE(TK_I8, TK_NONE, TK_NONE)
+    IMM3_TILE_CASE(TK_S2, TK_NONE, TK_NONE)
+    IMM3_TILE_CASE(TK_I32, TK_I32, TK_NONE)
+    IMM3_TILE_CASE(TK_I32, TK_I8, TK_NONE)
+    IMM3_TILE_CASE(TK_I8, TK_I8, TK_NONE)
+    IMM3_TILE_CASE(TK_I32, TK_S2, TK_NONE)
+    IMM3_TILE_CASE(TK_I8, TK_S2, TK_NONE)
+    IMM3_TILE_CASE(TK_I32, TK_I32, TK_I32)
+    IMM3_TILE_CASE(TK_I32, TK_I32, TK_I8)
+    IMM3_TILE_CASE(TK_I32, TK_I8, TK_I8)
+    IMM3_TILE_CASE(TK_I8, TK_I8, TK_I8)
+    IMM3_TILE_CASE(TK_I32, TK_I32, TK_S2)
+    IMM3_TILE_CASE(TK_I32, TK_I8, TK_S2)
+    IMM3_TILE_CASE(TK_I8, TK_I8, TK_S2)
+    return false;
 }
 
-void launch_total(const TotalArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(k_total, dim3(1), dim3(1024), 0, s, a);
+void launch_filter_generic(const FilterArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    IMM3_LAUNCH(k_filter_generic, grid, kBlockThreads, s, ev0, ev1, a);
 }
 
-void launch_scan(const ScanArgs &a, hipStream_t s) {
+void launch_total(const TotalArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    IMM3_LAUNCH(k_total, 1, 64, s, ev0, ev1, a);
+}
+
+void launch_scan(const ScanArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     const int grid = (int)((a.n_tiles + kChunkTiles - 1) / kChunkTiles);
-    hipLaunchKernelGGL(k_scan, dim3(grid < 1 ? 1 : grid), dim3(kChunkTiles), 0, s, a);
+    IMM3_LAUNCH(k_scan, grid < 1 ? 1 : grid, kChunkTiles, s, ev0, ev1, a);
 }
 
-void launch_gather(const GatherArgs &a, int grid_blocks, hipStream_t s) {
-    const int cap = grid_blocks > 0 ? grid_blocks : 4096;
-    const int grid = clamp_grid((a.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, cap);
-    hipLaunchKernelGGL(k_gather, dim3(grid), dim3(kBlockThreads), 0, s, a);
+void launch_gather(const GatherArgs &a, int grid_blocks, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    const int cap = grid_blocks > 0 ? grid_blocks : 1024; // 4 x 32 KiB LDS lists per CU
+    const int64_t n_spans = (a.n_tiles + kSpanTiles - 1) / kSpanTiles;
+    const int grid = clamp_grid(n_spans, cap);
+    IMM3_LAUNCH(k_gather, grid, kBlockThreads, s, ev0, ev1, a);
 }
 
 } // namespace imm3

@@ -99,6 +99,105 @@ __global__ __launch_bounds__(256) void k_v0(Args a) {
     if (lane == 0) a.total[1 + blockIdx.x * 4 + wave] = wave_total; // per-wave partial, no same-address atomics
 }
 
+// ---- V0 ablations: MODE bit0 = nt loads, bit1 = nt stores, bit2 = skip bitmap store, bit3 = skip tile_counts store
+template <int MODE>
+__global__ __launch_bounds__(256) void k_v0m(Args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long wave_total = 0;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < a.n_tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = tile * 1024;
+        if (row0 + 1024 > a.n_rows) continue;
+        const int32_t *p = a.data + row0 + lane;
+        int32_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = (MODE & 1) ? __builtin_nontemporal_load(p + 64 * j) : p[64 * j];
+        int lo = 0, hi = 0;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint64_t m = __ballot(in_closed(v[j], a.lo, a.hi));
+            lo = wl_i32((int)(uint32_t)m, j, lo);
+            hi = wl_i32((int)(uint32_t)(m >> 32), j, hi);
+            cnt += __popcll(m);
+        }
+        const uint64_t mine = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+        if (MODE & 4) {
+            if (mine == 0x123456789abcdefULL && lane < 16) a.bitmap[tile * 16 + lane] = mine;
+        } else if (lane < 16) {
+            if (MODE & 2) __builtin_nontemporal_store(mine, a.bitmap + tile * 16 + lane);
+            else a.bitmap[tile * 16 + lane] = mine;
+        }
+        if (!(MODE & 8) && lane == 0) a.tile_counts[tile] = cnt;
+        wave_total += cnt;
+    }
+    if (lane == 0) a.total[1 + blockIdx.x * 4 + wave] = wave_total;
+}
+
+// ---- V3: nt loads + nt stores, T tiles (T x 16 dword loads) in flight per wave
+template <int T>
+__global__ __launch_bounds__(256) void k_v3(Args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long wave_total = 0;
+    const int64_t n_groups = a.n_tiles / T;
+    for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < n_groups; grp += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = grp * 1024 * T;
+        if (row0 + 1024 * T > a.n_rows) continue;
+        const int32_t *p = a.data + row0 + lane;
+        int32_t v[16 * T];
+#pragma unroll
+        for (int j = 0; j < 16 * T; ++j) v[j] = __builtin_nontemporal_load(p + 64 * j);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            int lo = 0, hi = 0;
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const uint64_t m = __ballot(in_closed(v[t * 16 + j], a.lo, a.hi));
+                lo = wl_i32((int)(uint32_t)m, j, lo);
+                hi = wl_i32((int)(uint32_t)(m >> 32), j, hi);
+                cnt += __popcll(m);
+            }
+            const uint64_t mine = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+            const int64_t tile = grp * T + t;
+            if (lane < 16) __builtin_nontemporal_store(mine, a.bitmap + tile * 16 + lane);
+            if (lane == 0) a.tile_counts[tile] = cnt;
+            wave_total += cnt;
+        }
+    }
+    if (lane == 0) a.total[1 + blockIdx.x * 4 + wave] = wave_total;
+}
+
+__global__ __launch_bounds__(256) void k_read_x1_nt(Args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int acc = 0;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < a.n_tiles; t += (int64_t)gridDim.x * 4) {
+        if ((t + 1) * 1024 > a.n_rows) continue;
+        const int32_t *p = a.data + t * 1024 + lane;
+        int32_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(p + 64 * j);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc ^= v[j];
+    }
+    if (acc == 0x12345678) a.tile_counts[0] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_read_x4_nt(Args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_chunks = a.n_rows / 1024;
+    int acc = 0;
+    for (int64_t c = (int64_t)blockIdx.x * 4 + wave; c < n_chunks; c += (int64_t)gridDim.x * 4) {
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const v4i *p = (const v4i *)(a.data + c * 1024) + lane;
+        v4i v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = __builtin_nontemporal_load(p + 64 * g);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc ^= v[g].x ^ v[g].y ^ v[g].z ^ v[g].w;
+    }
+    if (acc == 0x12345678) a.tile_counts[0] = acc;
+}
+
 // ---- V1: dwordx4 loads (16 B/lane) + in-register transpose ------------------------------------------------
 // load g covers rows g*256 + 4*lane + k.  Word (4g + (lane>>4)) bit 4*(lane&15)+k.  Each lane builds a nibble,
 // shifts it to 4*(lane&7), OR-reduces over its 8-lane group with DPP -> one bitmap dword per 8 lanes.
@@ -109,7 +208,7 @@ __device__ __forceinline__ uint32_t or_reduce8(uint32_t v) {
     return v;
 }
 
-template <int TILES_PER_ITER>
+template <int NT>
 __global__ __launch_bounds__(256) void k_v1(Args a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sh = 4 * (lane & 7);
@@ -117,10 +216,11 @@ __global__ __launch_bounds__(256) void k_v1(Args a) {
     for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < a.n_tiles; tile += (int64_t)gridDim.x * 4) {
         const int64_t row0 = tile * 1024;
         if (row0 + 1024 > a.n_rows) continue;
-        const int4 *p = (const int4 *)(a.data + row0) + lane;
-        int4 v[4];
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const v4i *p = (const v4i *)(a.data + row0) + lane;
+        v4i v[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) v[g] = p[64 * g];
+        for (int g = 0; g < 4; ++g) v[g] = NT ? __builtin_nontemporal_load(p + 64 * g) : p[64 * g];
         uint32_t r[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -133,7 +233,8 @@ __global__ __launch_bounds__(256) void k_v1(Args a) {
         uint32_t mine = gsel == 0 ? r[0] : gsel == 1 ? r[1] : gsel == 2 ? r[2] : r[3];
         uint32_t *out = (uint32_t *)(a.bitmap + tile * 16);
         if (gsel < 4) {
-            out[gsel * 8 + (lane >> 3)] = mine;
+            if (NT) __builtin_nontemporal_store(mine, out + gsel * 8 + (lane >> 3));
+            else out[gsel * 8 + (lane >> 3)] = mine;
             lane_total += __popc(mine);
         }
         // per-tile count: sum over the 32 storing lanes
@@ -202,12 +303,23 @@ LAUNCHER(l_read_x4_t4, k_read_x4_tile<4>)
 LAUNCHER(l_read_x4_t8, k_read_x4_tile<8>)
 LAUNCHER(l_read_x1, k_read_x1_tile)
 LAUNCHER(l_v0, k_v0)
-LAUNCHER(l_v1, k_v1<1>)
+LAUNCHER(l_v1, k_v1<0>)
+LAUNCHER(l_v1nt, k_v1<1>)
+LAUNCHER(l_v3_1, k_v3<1>)
+LAUNCHER(l_v3_2, k_v3<2>)
+LAUNCHER(l_rx1nt, k_read_x1_nt)
+LAUNCHER(l_rx4nt, k_read_x4_nt)
+LAUNCHER(l_v0_ntl, k_v0m<1>)
+LAUNCHER(l_v0_nts, k_v0m<2>)
+LAUNCHER(l_v0_ntls, k_v0m<3>)
+LAUNCHER(l_v0_nobm, k_v0m<4>)
+LAUNCHER(l_v0_nobm_notc, k_v0m<12>)
+LAUNCHER(l_v0_notc, k_v0m<8>)
 LAUNCHER(l_v2, k_v2)
 
 int main(int argc, char **argv) {
     const int64_t n = argc > 1 ? atoll(argv[1]) : 100000000LL;
-    const int rounds = argc > 2 ? atoi(argv[2]) : 15;
+    const int rounds = argc > 2 ? atoi(argv[2]) : 61;
     const int NB = 3;
     CHECK(hipSetDevice(0));
     hipStream_t s;
@@ -244,17 +356,17 @@ int main(int argc, char **argv) {
         if (host[(size_t)i] >= lo && host[(size_t)i] <= hi) ref[(size_t)(i >> 6)] |= 1ULL << (i & 63);
 
     std::vector<Variant> vars = {
-        {"read_x4_flat", l_read_x4}, {"read_x4_tile4K", l_read_x4_t4}, {"read_x4_tile8K", l_read_x4_t8},
-        {"read_x1_tile4K", l_read_x1}, {"v0_dword_ballot", l_v0}, {"v1_x4_dpp", l_v1}, {"v2_x4_dpp_8K", l_v2},
+        {"read_x4_nt", l_rx4nt}, {"read_x1_nt", l_rx1nt},
+        {"f_x1_default", l_v0}, {"f_x1_nt", l_v0_ntls}, {"f_x4_default", l_v1}, {"f_x4_nt", l_v1nt},
     };
-    std::vector<int> grids = {1024, 2048, 4096, 8192, (int)((n_tiles + 3) / 4)};
+    std::vector<int> grids = {320, 384, 448, 512, 640, 768, 1024, 2048};
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
 
     // correctness of the filter variants
     for (auto &v : vars) {
-        if (v.name[0] != 'v') continue;
+        if (v.name[0] != 'v' || strstr(v.name, "no_")) continue;
         Args a{d[NB - 1], n, n_tiles, lo, hi, bitmap, tile_counts, total};
         CHECK(hipMemset(bitmap, 0, (size_t)n_tiles * 16 * 8));
         CHECK(hipMemset(total, 0, 8 * total_slots));
@@ -275,8 +387,8 @@ int main(int argc, char **argv) {
     }
 
     printf("\n%-18s", "variant \\ grid");
-    for (int g : grids) printf(" %9d", g);
-    printf("   (us median; GB/s at best)\n");
+    for (int g : grids) printf(" %10d", g);
+    printf("   (us median/min; GB/s at best median)\n");
     std::vector<std::vector<std::vector<float>>> times(vars.size(), std::vector<std::vector<float>>(grids.size()));
     for (int r = 0; r < rounds + 2; ++r) {
         for (size_t vi = 0; vi < vars.size(); ++vi) {
@@ -300,7 +412,7 @@ int main(int argc, char **argv) {
             std::sort(t.begin(), t.end());
             const float med = t[t.size() / 2];
             best = std::min(best, med);
-            printf(" %9.1f", med);
+            printf(" %5.1f/%4.1f", med, t[0]);
         }
         printf("   %.0f GB/s read (%.1f%% of 8 TB/s)\n", n * 4.0 / best / 1e3, n * 4.0 / best / 1e3 / 80.0);
     }
