@@ -1,0 +1,199 @@
+/*
+ * imm3_jni.c -- JNI shim between the reference's JVM and the C ABI of include/imm3.h.
+ *
+ * Binds immutabledb.gpu.Native (integration/scala/immutabledb/gpu/Native.scala).  Direct ByteBuffers are the
+ * MappedByteBuffers SegmentManager already holds (core/src/main/scala/immutabledb/storage/SegmentManager.scala:81-87);
+ * non-zero statuses become java.lang.Exception(msg), the reference's error convention (Scan.scala:49,
+ * Select.scala:22,41,80).
+ *
+ * NOT COMPILED IN THIS REPOSITORY'S PIPELINE: the build image has no JDK (no jni.h, no libjvm).  The guard
+ * below makes the translation unit empty there.  Build on a host with a JDK:
+ *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude \
+ *       integration/jni/imm3_jni.c -Limmutable3_amd/lib -limm3 -o libimm3_jni.so
+ */
+#if defined(__has_include)
+#if __has_include(<jni.h>)
+#define IMM3_HAVE_JNI 1
+#endif
+#endif
+
+#ifdef IMM3_HAVE_JNI
+#include <jni.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "imm3.h"
+
+static void throw_last(JNIEnv *env) {
+    jclass cls = (*env)->FindClass(env, "java/lang/Exception");
+    if (cls) (*env)->ThrowNew(env, cls, imm3_last_error());
+}
+#define CHECKED(call) do { if ((call) != IMM3_OK) { throw_last(env); goto done; } } while (0)
+
+JNIEXPORT jlong JNICALL Java_immutabledb_gpu_Native_00024_ctxCreate(JNIEnv *env, jobject self, jint device) {
+    imm3_ctx *ctx = NULL;
+    if (imm3_ctx_create(device, NULL, &ctx) != IMM3_OK) throw_last(env);
+    return (jlong)(intptr_t)ctx;
+}
+
+JNIEXPORT void JNICALL Java_immutabledb_gpu_Native_00024_ctxDestroy(JNIEnv *env, jobject self, jlong ctx) {
+    imm3_ctx_destroy((imm3_ctx *)(intptr_t)ctx);
+}
+
+/* dats: Array[ByteBuffer] (direct, the mmaps); offsets: Array[Array[Int]] (SegmentMeta.blockOffsets) */
+JNIEXPORT jlong JNICALL Java_immutabledb_gpu_Native_00024_segmentCreate(JNIEnv *env, jobject self, jlong ctx,
+        jintArray codecs, jintArray widths, jobjectArray dats, jobjectArray offsets) {
+    jsize n = (*env)->GetArrayLength(env, codecs);
+    imm3_column *cols = (imm3_column *)calloc((size_t)n, sizeof(imm3_column));
+    jint *cd = (*env)->GetIntArrayElements(env, codecs, NULL);
+    jint *wd = (*env)->GetIntArrayElements(env, widths, NULL);
+    jintArray *offArrs = (jintArray *)calloc((size_t)n, sizeof(jintArray));
+    jint **offPtrs = (jint **)calloc((size_t)n, sizeof(jint *));
+    imm3_segment *seg = NULL;
+    for (jsize i = 0; i < n; i++) {
+        jobject buf = (*env)->GetObjectArrayElement(env, dats, i);
+        offArrs[i] = (jintArray)(*env)->GetObjectArrayElement(env, offsets, i);
+        offPtrs[i] = (*env)->GetIntArrayElements(env, offArrs[i], NULL);
+        cols[i].codec = cd[i];
+        cols[i].width = wd[i];
+        cols[i].dat = (*env)->GetDirectBufferAddress(env, buf);
+        cols[i].dat_bytes = (uint64_t)(*env)->GetDirectBufferCapacity(env, buf);
+        cols[i].block_offsets = (const int32_t *)offPtrs[i];
+        cols[i].n_offsets = (int32_t)(*env)->GetArrayLength(env, offArrs[i]);
+    }
+    CHECKED(imm3_segment_create((imm3_ctx *)(intptr_t)ctx, cols, (int32_t)n, &seg));
+done:
+    for (jsize i = 0; i < n; i++)
+        if (offPtrs[i]) (*env)->ReleaseIntArrayElements(env, offArrs[i], offPtrs[i], JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, codecs, cd, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, widths, wd, JNI_ABORT);
+    free(offPtrs); free(offArrs); free(cols);
+    return (jlong)(intptr_t)seg;
+}
+
+JNIEXPORT void JNICALL Java_immutabledb_gpu_Native_00024_segmentDestroy(JNIEnv *env, jobject self, jlong seg) {
+    imm3_segment_destroy((imm3_segment *)(intptr_t)seg);
+}
+
+/* selMatch(i): the IN-list of leaf i as Array[Array[Byte]] (String.getBytes of each value), or null */
+JNIEXPORT jlong JNICALL Java_immutabledb_gpu_Native_00024_queryCreate(JNIEnv *env, jobject self, jlong ctx, jlong seg,
+        jintArray usedCols, jintArray selCols, jintArray selConds, jdoubleArray selValues, jobjectArray selMatch,
+        jintArray proj, jlong limit, jint blockSize) {
+    jsize nUsed = (*env)->GetArrayLength(env, usedCols);
+    jsize nSel = (*env)->GetArrayLength(env, selCols);
+    jsize nProj = (*env)->GetArrayLength(env, proj);
+    jint *used = (*env)->GetIntArrayElements(env, usedCols, NULL);
+    jint *sc = (*env)->GetIntArrayElements(env, selCols, NULL);
+    jint *sk = (*env)->GetIntArrayElements(env, selConds, NULL);
+    jdouble *sv = (*env)->GetDoubleArrayElements(env, selValues, NULL);
+    jint *pj = (*env)->GetIntArrayElements(env, proj, NULL);
+    imm3_select *sels = (imm3_select *)calloc((size_t)(nSel > 0 ? nSel : 1), sizeof(imm3_select));
+    uint8_t **blobs = (uint8_t **)calloc((size_t)(nSel > 0 ? nSel : 1), sizeof(uint8_t *));
+    int32_t **lens = (int32_t **)calloc((size_t)(nSel > 0 ? nSel : 1), sizeof(int32_t *));
+    imm3_query *q = NULL;
+    for (jsize i = 0; i < nSel; i++) {
+        sels[i].column = sc[i];
+        sels[i].cond = sk[i];
+        sels[i].value = sv[i];
+        jobjectArray vals = selMatch ? (jobjectArray)(*env)->GetObjectArrayElement(env, selMatch, i) : NULL;
+        if (vals) {
+            jsize nv = (*env)->GetArrayLength(env, vals);
+            size_t total = 0;
+            lens[i] = (int32_t *)calloc((size_t)(nv > 0 ? nv : 1), sizeof(int32_t));
+            for (jsize m = 0; m < nv; m++) {
+                jbyteArray b = (jbyteArray)(*env)->GetObjectArrayElement(env, vals, m);
+                lens[i][m] = (int32_t)(*env)->GetArrayLength(env, b);
+                total += (size_t)lens[i][m];
+            }
+            blobs[i] = (uint8_t *)malloc(total ? total : 1);
+            size_t off = 0;
+            for (jsize m = 0; m < nv; m++) {
+                jbyteArray b = (jbyteArray)(*env)->GetObjectArrayElement(env, vals, m);
+                (*env)->GetByteArrayRegion(env, b, 0, lens[i][m], (jbyte *)(blobs[i] + off));
+                off += (size_t)lens[i][m];
+            }
+            sels[i].match_bytes = blobs[i];
+            sels[i].match_lens = lens[i];
+            sels[i].n_match = (int32_t)nv;
+        }
+    }
+    CHECKED(imm3_query_create((imm3_ctx *)(intptr_t)ctx, (imm3_segment *)(intptr_t)seg, (const int32_t *)used, (int32_t)nUsed,
+                              sels, (int32_t)nSel, (const int32_t *)pj, (int32_t)nProj, (int64_t)limit, blockSize, &q));
+done:
+    for (jsize i = 0; i < nSel; i++) { free(blobs[i]); free(lens[i]); }
+    free(blobs); free(lens); free(sels);
+    (*env)->ReleaseIntArrayElements(env, usedCols, used, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, selCols, sc, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, selConds, sk, JNI_ABORT);
+    (*env)->ReleaseDoubleArrayElements(env, selValues, sv, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, proj, pj, JNI_ABORT);
+    return (jlong)(intptr_t)q;
+}
+
+JNIEXPORT void JNICALL Java_immutabledb_gpu_Native_00024_queryDestroy(JNIEnv *env, jobject self, jlong q) {
+    imm3_query_destroy((imm3_query *)(intptr_t)q);
+}
+
+JNIEXPORT void JNICALL Java_immutabledb_gpu_Native_00024_queryRun(JNIEnv *env, jobject self, jlong q) {
+    if (imm3_query_run((imm3_query *)(intptr_t)q) != IMM3_OK) throw_last(env);
+}
+
+/* returns Array(size..., oid..., wordOffLo/Hi ...) packed as long[3 * nBatches] */
+JNIEXPORT jlongArray JNICALL Java_immutabledb_gpu_Native_00024_queryBatches(JNIEnv *env, jobject self, jlong qh) {
+    imm3_query *q = (imm3_query *)(intptr_t)qh;
+    int32_t nb = 0; int64_t words = 0, rows = 0;
+    jlongArray out = NULL;
+    int32_t *size = NULL, *oid = NULL; int64_t *woff = NULL; jlong *packed = NULL;
+    CHECKED(imm3_query_layout(q, &nb, &words, &rows));
+    size = (int32_t *)calloc((size_t)(nb > 0 ? nb : 1), 4);
+    oid = (int32_t *)calloc((size_t)(nb > 0 ? nb : 1), 4);
+    woff = (int64_t *)calloc((size_t)(nb > 0 ? nb : 1), 8);
+    CHECKED(imm3_query_batches(q, size, oid, woff));
+    packed = (jlong *)calloc((size_t)(3 * nb > 0 ? 3 * nb : 1), sizeof(jlong));
+    for (int32_t k = 0; k < nb; k++) { packed[k] = size[k]; packed[nb + k] = oid[k]; packed[2 * nb + k] = woff[k]; }
+    out = (*env)->NewLongArray(env, 3 * nb);
+    (*env)->SetLongArrayRegion(env, out, 0, 3 * nb, packed);
+done:
+    free(size); free(oid); free(woff); free(packed);
+    return out;
+}
+
+/* the batch-major selection bitmap: slice [wordOff(k), +ceil(size(k)/64)) is batch k's BitSet words */
+JNIEXPORT jlongArray JNICALL Java_immutabledb_gpu_Native_00024_queryBitmap(JNIEnv *env, jobject self, jlong qh) {
+    imm3_query *q = (imm3_query *)(intptr_t)qh;
+    int32_t nb = 0; int64_t words = 0, rows = 0;
+    jlongArray out = NULL;
+    uint64_t *buf = NULL;
+    CHECKED(imm3_query_layout(q, &nb, &words, &rows));
+    buf = (uint64_t *)malloc((size_t)(words > 0 ? words : 1) * 8);
+    CHECKED(imm3_query_bitmap(q, buf, words));
+    out = (*env)->NewLongArray(env, (jsize)words);
+    (*env)->SetLongArrayRegion(env, out, 0, (jsize)words, (const jlong *)buf);
+done:
+    free(buf);
+    return out;
+}
+
+JNIEXPORT jlong JNICALL Java_immutabledb_gpu_Native_00024_queryCount(JNIEnv *env, jobject self, jlong q) {
+    uint64_t n = 0;
+    if (imm3_query_count((imm3_query *)(intptr_t)q, &n) != IMM3_OK) throw_last(env);
+    return (jlong)n;
+}
+
+JNIEXPORT jlong JNICALL Java_immutabledb_gpu_Native_00024_queryRowCount(JNIEnv *env, jobject self, jlong q) {
+    uint64_t n = 0;
+    if (imm3_query_row_count((imm3_query *)(intptr_t)q, &n) != IMM3_OK) throw_last(env);
+    return (jlong)n;
+}
+
+/* cols: Array[ByteBuffer] (direct, capacity >= rows * width each); rowIndex: direct ByteBuffer of rows*4 bytes or null */
+JNIEXPORT void JNICALL Java_immutabledb_gpu_Native_00024_queryFetchRows(JNIEnv *env, jobject self, jlong q,
+        jobject rowIndex, jobjectArray cols, jlong maxRows) {
+    jsize n = (*env)->GetArrayLength(env, cols);
+    void **ptrs = (void **)calloc((size_t)(n > 0 ? n : 1), sizeof(void *));
+    for (jsize j = 0; j < n; j++) ptrs[j] = (*env)->GetDirectBufferAddress(env, (*env)->GetObjectArrayElement(env, cols, j));
+    uint32_t *idx = rowIndex ? (uint32_t *)(*env)->GetDirectBufferAddress(env, rowIndex) : NULL;
+    if (imm3_query_fetch_rows((imm3_query *)(intptr_t)q, idx, ptrs, (uint64_t)maxRows) != IMM3_OK) throw_last(env);
+    free(ptrs);
+}
+#endif /* IMM3_HAVE_JNI */
