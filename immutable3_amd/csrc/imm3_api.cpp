@@ -47,6 +47,7 @@ struct imm3_ctx {
     int filter_variant = 0;
     int grid_blocks = 0;
     bool timing = false;
+    uint32_t timing_mask = 0xFFFFFFFFu;
     std::vector<TimingRecord> pool; // pre-created event pairs
     size_t used = 0;
 };
@@ -207,6 +208,12 @@ extern "C" int imm3_ctx_timing_enable(imm3_ctx *ctx, int32_t max_records) {
     return IMM3_OK;
 }
 
+extern "C" int imm3_ctx_timing_mask(imm3_ctx *ctx, uint32_t kernel_mask) {
+    if (!ctx) return fail(IMM3_ERR_ARG, "ctx is null");
+    ctx->timing_mask = kernel_mask;
+    return IMM3_OK;
+}
+
 extern "C" int imm3_ctx_timing_reset(imm3_ctx *ctx) {
     if (!ctx) return fail(IMM3_ERR_ARG, "ctx is null");
     ctx->used = 0;
@@ -237,7 +244,7 @@ namespace {
 struct LaunchTimer {
     hipEvent_t start = nullptr, stop = nullptr;
     LaunchTimer(imm3_ctx *ctx, int32_t id) {
-        if (ctx->timing && ctx->used < ctx->pool.size()) {
+        if (ctx->timing && ((ctx->timing_mask >> id) & 1u) && ctx->used < ctx->pool.size()) {
             TimingRecord &rec = ctx->pool[ctx->used++];
             rec.kernel_id = id;
             start = rec.start;

@@ -31,7 +31,7 @@ EXPORTS = [
     "imm3_query_run", "imm3_query_run_select", "imm3_query_sync",
     "imm3_query_layout", "imm3_query_batches", "imm3_query_count", "imm3_query_bitmap",
     "imm3_query_row_count", "imm3_query_fetch_rows", "imm3_query_device_ptr",
-    "imm3_ctx_timing_enable", "imm3_ctx_timing_reset", "imm3_ctx_timing_collect", "imm3_ctx_set_tuning",
+    "imm3_ctx_timing_enable", "imm3_ctx_timing_reset", "imm3_ctx_timing_mask", "imm3_ctx_timing_collect", "imm3_ctx_set_tuning",
 ]
 
 
@@ -109,6 +109,7 @@ def load() -> C.CDLL:
     L.imm3_query_device_ptr.argtypes = [vp, i32, P(vp)]
     L.imm3_ctx_timing_enable.argtypes = [vp, i32]
     L.imm3_ctx_timing_reset.argtypes = [vp]
+    L.imm3_ctx_timing_mask.argtypes = [vp, C.c_uint32]
     L.imm3_ctx_timing_collect.argtypes = [vp, i32, vp, i32, P(i32)]
     L.imm3_ctx_set_tuning.argtypes = [vp, i32, i32]
     for name in EXPORTS:
@@ -155,6 +156,9 @@ class Context:
 
     def timing_enable(self, max_records: int):
         _check(load().imm3_ctx_timing_enable(self._h, max_records))
+
+    def timing_mask(self, kernel_mask: int):
+        _check(load().imm3_ctx_timing_mask(self._h, kernel_mask))
 
     def timing_reset(self):
         _check(load().imm3_ctx_timing_reset(self._h))

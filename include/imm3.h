@@ -156,6 +156,8 @@ int imm3_query_device_ptr(imm3_query *q, int32_t which, void **ptr);
  * kernel ids: 0 = scan+select, 1 = offsets scan, 2 = compact+gather, 3 = count reduce. */
 int imm3_ctx_timing_enable(imm3_ctx *ctx, int32_t max_records);
 int imm3_ctx_timing_reset(imm3_ctx *ctx);
+/* Only launches whose kernel id has its bit set in `kernel_mask` are bracketed (default: all). */
+int imm3_ctx_timing_mask(imm3_ctx *ctx, uint32_t kernel_mask);
 /* Synchronises, then writes up to cap durations (ms) of launches of `kernel_id`, oldest first. */
 int imm3_ctx_timing_collect(imm3_ctx *ctx, int32_t kernel_id, float *ms_out, int32_t cap, int32_t *n_out);
 
