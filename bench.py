@@ -291,6 +291,7 @@ def extra_workloads(ctx, native, synth, n, steps: int = 30):
             q.run()
         torch.cuda.synchronize()
         ctx.timing_enable(4 * steps + 8)
+        ctx.timing_mask(0xFFFFFFFF)
         ctx.timing_reset()
         t0 = time.perf_counter()
         for _ in range(steps):

@@ -89,7 +89,7 @@ struct imm3_query {
     std::vector<FoldedPred> preds;
     // device buffers
     uint64_t *d_bitmap = nullptr;
-    uint32_t *d_tile_counts = nullptr, *d_tile_offsets = nullptr, *d_chunk_sums = nullptr, *d_block_partials = nullptr;
+    uint32_t *d_tile_offsets = nullptr, *d_chunk_sums = nullptr, *d_block_partials = nullptr;
     unsigned long long *d_total = nullptr, *d_n_emit = nullptr; // adjacent: d_n_emit = d_total + 1
     uint32_t *d_word_row_base = nullptr;
     uint8_t *d_word_nvalid = nullptr;
@@ -327,7 +327,6 @@ static void query_free(imm3_query *q) {
     (void)hipSetDevice(q->ctx->device);
     (void)hipStreamSynchronize(q->ctx->stream);
     (void)hipFree(q->d_bitmap);
-    (void)hipFree(q->d_tile_counts);
     (void)hipFree(q->d_tile_offsets);
     (void)hipFree(q->d_chunk_sums);
     (void)hipFree(q->d_block_partials);
@@ -530,8 +529,6 @@ extern "C" int imm3_query_create(imm3_ctx *ctx, const imm3_segment *seg,
     HIPCHK(hipMalloc(&p, words_alloc * sizeof(uint64_t)));
     q->d_bitmap = (uint64_t *)p;
     HIPCHK(hipMalloc(&p, (size_t)std::max<int64_t>(q->n_tiles, 1) * sizeof(uint32_t)));
-    q->d_tile_counts = (uint32_t *)p;
-    HIPCHK(hipMalloc(&p, (size_t)std::max<int64_t>(q->n_tiles, 1) * sizeof(uint32_t)));
     q->d_tile_offsets = (uint32_t *)p;
     HIPCHK(hipMalloc(&p, (size_t)std::max<int64_t>(q->n_chunks, 1) * sizeof(uint32_t)));
     q->d_chunk_sums = (uint32_t *)p;
@@ -628,7 +625,6 @@ static int run_select(imm3_query *q) {
         // an empty interval / empty IN-list clears every bit; nothing to read
         HIPCHK(hipMemsetAsync(q->d_total, 0, 2 * sizeof(unsigned long long), s));
         HIPCHK(hipMemsetAsync(q->d_bitmap, 0, (size_t)std::max<int64_t>(q->n_tiles * kTileWords, 1) * sizeof(uint64_t), s));
-        HIPCHK(hipMemsetAsync(q->d_tile_counts, 0, (size_t)std::max<int64_t>(q->n_tiles, 1) * sizeof(uint32_t), s));
         q->ran_select = true;
         return IMM3_OK;
     }
@@ -682,7 +678,6 @@ static int run_select(imm3_query *q) {
         a.n_words = q->n_words;
         a.n_tiles = q->n_tiles;
         a.bitmap = q->d_bitmap;
-        a.tile_counts = q->d_tile_counts;
         a.block_partials = q->d_block_partials;
         grid = filter_grid(q->n_tiles, false, ctx->grid_blocks);
         LaunchTimer t(ctx, 0);
@@ -704,11 +699,9 @@ static int run_select(imm3_query *q) {
         a.n_words = q->n_words;
         a.n_tiles = q->n_tiles;
         a.bitmap = q->d_bitmap;
-        a.tile_counts = q->d_tile_counts;
         a.block_partials = q->d_block_partials;
         a.word_row_base = q->d_word_row_base;
         a.word_nvalid = q->d_word_nvalid;
-        HIPCHK(hipMemsetAsync(q->d_tile_counts, 0, (size_t)q->n_tiles * sizeof(uint32_t), s)); // it adds atomically
         grid = filter_grid(q->n_words, true, ctx->grid_blocks);
         {
             LaunchTimer t(ctx, 0);
@@ -740,7 +733,6 @@ static int launch_project(imm3_query *q) {
     GatherArgs g;
     std::memset(&g, 0, sizeof(g));
     g.bitmap = q->d_bitmap;
-    g.tile_counts = q->d_tile_counts;
     g.tile_offsets = q->d_tile_offsets;
     g.chunk_sums = q->d_chunk_sums;
     g.n_tiles = q->n_tiles;
@@ -777,7 +769,7 @@ static int run_project(imm3_query *q) {
     if (q->n_tiles > 0) {
         ScanArgs sa;
         std::memset(&sa, 0, sizeof(sa));
-        sa.tile_counts = q->d_tile_counts;
+        sa.bitmap = q->d_bitmap;
         sa.tile_offsets = q->d_tile_offsets;
         sa.chunk_sums = q->d_chunk_sums;
         sa.n_tiles = q->n_tiles;

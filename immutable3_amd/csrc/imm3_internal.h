@@ -57,7 +57,6 @@ struct TileArgs {
     int32_t and_existing;
     int64_t n_rows, n_words, n_tiles;
     uint64_t *bitmap;
-    uint32_t *tile_counts;
     uint32_t *block_partials;
 };
 
@@ -69,7 +68,6 @@ struct FilterArgs {
     int64_t n_words;             // bitmap words (batch-major)
     int64_t n_tiles;             // ceil(n_words / 16)
     uint64_t *bitmap;
-    uint32_t *tile_counts;       // selected rows per tile
     uint32_t *block_partials;    // selected rows per workgroup of this launch (no same-address atomics:
                                  // ~12 ns each, serialised -- 4096 of them cost 40 us on MI355X)
     // ragged layout only: per bitmap word, first row and number of valid rows (0..64)
@@ -87,8 +85,8 @@ struct TotalArgs {               // k_total: sum of the filter launch's per-work
 };
 
 struct ScanArgs {
-    const uint32_t *tile_counts;
-    uint32_t *tile_offsets;      // exclusive prefix of tile_counts WITHIN its chunk
+    const uint64_t *bitmap;      // allocated in whole tiles, zero past n_words
+    uint32_t *tile_offsets;      // exclusive prefix of the per-tile survivor counts WITHIN its chunk
     uint32_t *chunk_sums;        // selected rows per chunk of kChunkTiles tiles
     int64_t n_tiles;
 };
@@ -102,7 +100,6 @@ struct ProjCol {
 
 struct GatherArgs {
     const uint64_t *bitmap;
-    const uint32_t *tile_counts;
     const uint32_t *tile_offsets;
     const uint32_t *chunk_sums;
     int64_t n_tiles;

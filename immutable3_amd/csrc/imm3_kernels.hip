@@ -10,10 +10,10 @@
 // On the GPU that becomes, over HBM-resident flat columns:
 //   k_filter_tile<KINDS...> / k_filter_generic
 //                one fused pass over all predicate columns -> selection bitmap (uint64 words, bit i of a
-//                batch <-> word i>>6, bit i&63 == scala.collection.mutable.BitSet == wave64 ballot order),
-//                per-tile survivor counts and per-workgroup partial counts
+//                batch <-> word i>>6, bit i&63 == scala.collection.mutable.BitSet == wave64 ballot order)
+//                and per-workgroup partial counts
 //   k_total      partial counts -> the segment's selected-row count
-//   k_scan       exclusive prefix of the per-tile counts (chunked)
+//   k_scan       per-tile counts from the bitmap + their exclusive prefix (chunked)
 //   k_gather     per 16-tile span: expand set bits into a dense LDS list in ascending row order, then write
 //                row indices and gather the projected columns with dense, coalesced stores
 // All of it is HBM-bound integer/byte work: no MFMA anywhere.
@@ -180,35 +180,67 @@ struct ColRegs<TK_S2> {
     __device__ __forceinline__ bool row(const TileCol &c, int64_t r) { return hit(c, ((const uint16_t *)c.data)[r]); }
 };
 
+// AND the per-kind results of one FULL tile (registers already loaded), store its bitmap line, return in
+// lanes 0..15 the popcount of the words they own.
 template <int K0, int K1, int K2>
+__device__ __forceinline__ uint32_t finish_full_tile(const TileArgs &a, int64_t tile, int lane, ColRegs<K0> &c0,
+                                                     ColRegs<K1> &c1, ColRegs<K2> &c2) {
+    constexpr bool any_i32 = (K0 == TK_I32) || (K1 == TK_I32) || (K2 == TK_I32);
+    const int64_t w = tile * kTileWords + lane; // lane j < 16 owns bitmap word j of the tile
+    uint64_t mine = ~0ULL;
+    if (a.and_existing) mine = lane < kTileWords ? a.bitmap[w] : 0ULL;
+    uint64_t acc[kTileWords]; // wave-uniform words (SGPR pairs), fed by the TK_I32 columns
+#pragma unroll
+    for (int j = 0; j < kTileWords; ++j) acc[j] = ~0ULL;
+    c0.eval(a.cols[0], acc, mine, lane);
+    c1.eval(a.cols[1], acc, mine, lane);
+    c2.eval(a.cols[2], acc, mine, lane);
+    if (any_i32) mine &= words_to_lanes(acc);
+    if (lane >= kTileWords) mine = 0;
+    if (lane < kTileWords) __builtin_nontemporal_store(mine, a.bitmap + w); // 16 lanes x 8 B = one 128-B line
+    return (uint32_t)__popcll(mine);
+}
+
+// T = tiles per wave iteration: narrow columns take several tiles at once so that every wave keeps >= 4 KiB of
+// loads in flight (8 waves/CU x 4 KiB is what saturates HBM, see the header comment).
+template <int K0, int K1, int K2, int T>
 __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    constexpr bool any_i32 = (K0 == TK_I32) || (K1 == TK_I32) || (K2 == TK_I32);
-    uint32_t wave_total = 0;
+    uint32_t lane_total = 0; // lanes 0..15: survivors in the words they stored
+    const int64_t n_full = a.n_rows / kTileRows;
+    const int64_t n_groups = n_full / T;
+    const int64_t wave_id = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
 
-    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < a.n_tiles;
-         tile += (int64_t)gridDim.x * kWavesPerBlock) {
+    for (int64_t grp = wave_id; grp < n_groups; grp += n_waves) {
+        ColRegs<K0> c0[T];
+        ColRegs<K1> c1[T];
+        ColRegs<K2> c2[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int64_t row0 = (grp * T + t) * kTileRows;
+            c0[t].load(a.cols[0], row0, lane);
+            c1[t].load(a.cols[1], row0, lane);
+            c2[t].load(a.cols[2], row0, lane);
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) lane_total += finish_full_tile<K0, K1, K2>(a, grp * T + t, lane, c0[t], c1[t], c2[t]);
+    }
+    // leftovers: fewer than T full tiles, then the one partial tile at the end of the segment
+    for (int64_t tile = n_groups * T + wave_id; tile < a.n_tiles; tile += n_waves) {
         const int64_t row0 = tile * kTileRows;
-        const bool full = row0 + kTileRows <= a.n_rows; // wave-uniform
-        const int64_t w = tile * kTileWords + lane;      // lane j < 16 owns bitmap word j of the tile
         ColRegs<K0> c0;
         ColRegs<K1> c1;
         ColRegs<K2> c2;
-        uint64_t mine = ~0ULL;
-        if (full) {
+        if (tile < n_full) {
             c0.load(a.cols[0], row0, lane);
             c1.load(a.cols[1], row0, lane);
             c2.load(a.cols[2], row0, lane);
-            if (a.and_existing) mine = lane < kTileWords ? a.bitmap[w] : 0ULL;
-            uint64_t acc[kTileWords]; // wave-uniform words (SGPR pairs), fed by the TK_I32 columns
-#pragma unroll
-            for (int j = 0; j < kTileWords; ++j) acc[j] = ~0ULL;
-            c0.eval(a.cols[0], acc, mine, lane);
-            c1.eval(a.cols[1], acc, mine, lane);
-            c2.eval(a.cols[2], acc, mine, lane);
-            if (any_i32) mine &= words_to_lanes(acc);
-        } else { // the one partial tile at the end of the segment: rolled, bounds-checked
+            lane_total += finish_full_tile<K0, K1, K2>(a, tile, lane, c0, c1, c2);
+        } else { // rolled, bounds-checked
+            const int64_t w = tile * kTileWords + lane;
+            uint64_t mine = ~0ULL;
             if (a.and_existing) mine = (lane < kTileWords && w < a.n_words) ? a.bitmap[w] : 0ULL;
 #pragma unroll 1
             for (int j = 0; j < kTileWords; ++j) {
@@ -221,19 +253,14 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
                 if (lane == j) mine &= m;
             }
             mine &= low_mask(a.n_rows - (row0 + 64 * (int64_t)lane)); // rows past the end are not rows
-        }
-        if (lane >= kTileWords) mine = 0;
-
-        uint32_t cnt = (uint32_t)__popcll(mine);
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d); // lanes 0..15 hold the tile's count
-        if (lane < kTileWords && w < a.n_words) __builtin_nontemporal_store(mine, a.bitmap + w); // 16 lanes x 8 B = one 128-B line
-        if (lane == 0) {
-            a.tile_counts[tile] = cnt;
-            wave_total += cnt;
+            if (lane >= kTileWords) mine = 0;
+            if (lane < kTileWords && w < a.n_words) a.bitmap[w] = mine;
+            lane_total += (uint32_t)__popcll(mine);
         }
     }
-    block_partial_store(a.block_partials, wave_total, lane, wave);
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) lane_total += __shfl_xor(lane_total, d); // lanes 0..15 -> lane 0
+    block_partial_store(a.block_partials, lane_total, lane, wave);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -242,7 +269,6 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
 //   uniform layout (word_row_base == null): word w covers rows [64w, min(64w+64, n_rows))
 //   ragged layout (arbitrary block sizes, e.g. the loader's trailing 1-row block): each
 //   batch's BitSet starts on a fresh word, word w covers rows [base[w], base[w] + nvalid[w]).
-// tile_counts must be zeroed before the launch.
 // ---------------------------------------------------------------------------------------------
 
 // SelectIteratorMatch (Select.scala:25-51): keep the row iff its `width` raw bytes equal one IN-list value.
@@ -301,10 +327,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_generic(const FilterAr
             acc &= ballot64(valid && eval_row(a.cols[ci], valid ? base + lane : base));
         acc &= low_mask(nv);
         const uint32_t cnt = (uint32_t)__popcll(acc);
-        if (lane == 0) {
-            a.bitmap[w] = acc;
-            if (cnt) atomicAdd(&a.tile_counts[w / kTileWords], cnt); // distinct addresses: no serialisation
-        }
+        if (lane == 0) a.bitmap[w] = acc;
         wave_total += cnt;
     }
     block_partial_store(a.block_partials, wave_total, lane, wave);
@@ -327,7 +350,9 @@ __global__ __launch_bounds__(64) void k_total(const TotalArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_scan: exclusive prefix of tile_counts within chunks of 1024 tiles + per-chunk sums.
+// k_scan: per-tile survivor counts straight from the bitmap (thread t popcounts the 16 words = one 128-B line
+// of tile t), exclusive prefix within chunks of 1024 tiles, per-chunk sums.  Reading the 12.5 MB bitmap here
+// is cheaper than making the hot filter kernel store a 4-byte count per tile.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kChunkTiles) void k_scan(const ScanArgs a) {
     __shared__ uint32_t s_wave[kChunkTiles / 64];
@@ -335,7 +360,15 @@ __global__ __launch_bounds__(kChunkTiles) void k_scan(const ScanArgs a) {
     const int lane = t & 63;
     const int wave = t >> 6;
     const int64_t tile = (int64_t)blockIdx.x * kChunkTiles + t;
-    const uint32_t c = tile < a.n_tiles ? a.tile_counts[tile] : 0u;
+    uint32_t c = 0;
+    if (tile < a.n_tiles) { // the bitmap is allocated in whole tiles; words past n_words are zero
+        const uint4 *p = (const uint4 *)(a.bitmap + tile * kTileWords);
+#pragma unroll
+        for (int i = 0; i < kTileWords / 2; ++i) {
+            const uint4 v = p[i];
+            c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+        }
+    }
     uint32_t incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -461,30 +494,31 @@ int filter_grid(int64_t units, bool generic, int grid_blocks) {
 #define IMM3_LAUNCH(kern, grid, block, s, ev0, ev1, args) \
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, s, ev0, ev1, 0, args)
 
-#define IMM3_TILE_CASE(k0, k1, k2)                                                              \
+#define IMM3_TILE_CASE(k0, k1, k2, T)                                                           \
     if (a.kinds[0] == k0 && a.kinds[1] == k1 && a.kinds[2] == k2) {                             \
-        IMM3_LAUNCH((k_filter_tile<k0, k1, k2>), grid, kBlockThreads, s, ev0, ev1, a);          \
+        IMM3_LAUNCH((k_filter_tile<k0, k1, k2, T>), grid, kBlockThreads, s, ev0, ev1, a);       \
         return true;                                                                            \
     }
 
-// kinds must be sorted ascending with TK_NONE (= 3) last; at most one TK_S2 column per launch
+// kinds must be sorted ascending with TK_NONE (= 3) last; at most one TK_S2 column per launch.
+// T (tiles per wave iteration) is chosen so a wave has >= 4 KiB in flight: bytes/row x 1024 x T.
 bool launch_filter_tile(const TileArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    IMM3_TILE_CASE(TK_NONE, TK_NONE, TK_NONE)
-    IMM3_TILE_CASE(TK_I32, TK_NONE, TK_NONE)
-    IMM3_TILE_CASE(TK_I8, TK_NONE, TK_NONE)
-    IMM3_TILE_CASE(TK_S2, TK_NONE, TK_NONE)
-    IMM3_TILE_CASE(TK_I32, TK_I32, TK_NONE)
-    IMM3_TILE_CASE(TK_I32, TK_I8, TK_NONE)
-    IMM3_TILE_CASE(TK_I8, TK_I8, TK_NONE)
-    IMM3_TILE_CASE(TK_I32, TK_S2, TK_NONE)
-    IMM3_TILE_CASE(TK_I8, TK_S2, TK_NONE)
-    IMM3_TILE_CASE(TK_I32, TK_I32, TK_I32)
-    IMM3_TILE_CASE(TK_I32, TK_I32, TK_I8)
-    IMM3_TILE_CASE(TK_I32, TK_I8, TK_I8)
-    IMM3_TILE_CASE(TK_I8, TK_I8, TK_I8)
-    IMM3_TILE_CASE(TK_I32, TK_I32, TK_S2)
-    IMM3_TILE_CASE(TK_I32, TK_I8, TK_S2)
-    IMM3_TILE_CASE(TK_I8, TK_I8, TK_S2)
+    IMM3_TILE_CASE(TK_NONE, TK_NONE, TK_NONE, 1)
+    IMM3_TILE_CASE(TK_I32, TK_NONE, TK_NONE, 1)
+    IMM3_TILE_CASE(TK_I8, TK_NONE, TK_NONE, 4)
+    IMM3_TILE_CASE(TK_S2, TK_NONE, TK_NONE, 2)
+    IMM3_TILE_CASE(TK_I32, TK_I32, TK_NONE, 1)
+    IMM3_TILE_CASE(TK_I32, TK_I8, TK_NONE, 1)
+    IMM3_TILE_CASE(TK_I8, TK_I8, TK_NONE, 2)
+    IMM3_TILE_CASE(TK_I32, TK_S2, TK_NONE, 1)
+    IMM3_TILE_CASE(TK_I8, TK_S2, TK_NONE, 2)
+    IMM3_TILE_CASE(TK_I32, TK_I32, TK_I32, 1)
+    IMM3_TILE_CASE(TK_I32, TK_I32, TK_I8, 1)
+    IMM3_TILE_CASE(TK_I32, TK_I8, TK_I8, 1)
+    IMM3_TILE_CASE(TK_I8, TK_I8, TK_I8, 2)
+    IMM3_TILE_CASE(TK_I32, TK_I32, TK_S2, 1)
+    IMM3_TILE_CASE(TK_I32, TK_I8, TK_S2, 1)
+    IMM3_TILE_CASE(TK_I8, TK_I8, TK_S2, 1)
     return false;
 }
 
