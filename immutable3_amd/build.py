@@ -1,4 +1,5 @@
-"""Builds lib/libimm3.so (hipcc, gfx950) from csrc/.  hipcc cross-compiles without a GPU."""
+"""Builds lib/libimm3.so (hipcc, gfx950) from csrc/ and the C++ host CLIs (bin/imm3_sql, bin/imm3_loader).
+hipcc cross-compiles without a GPU."""
 from __future__ import annotations
 
 import os
@@ -12,7 +13,11 @@ def build_native(force: bool = False) -> str:
     out = os.path.join(_PKG, "lib", "libimm3.so")
     srcs = [os.path.join(csrc, f) for f in ("imm3_kernels.hip", "imm3_api.cpp", "imm3_internal.h")]
     srcs.append(os.path.join(_PKG, "..", "include", "imm3.h"))
-    if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(s) for s in srcs):
+    host = os.path.join(_PKG, "host")
+    srcs += [os.path.join(host, f) for f in os.listdir(host) if f.endswith(".hpp")]
+    srcs += [os.path.join(host, "cli", f) for f in os.listdir(os.path.join(host, "cli"))]
+    outs = [out, os.path.join(_PKG, "bin", "imm3_sql"), os.path.join(_PKG, "bin", "imm3_loader")]
+    if force or not all(os.path.exists(o) for o in outs) or min(os.path.getmtime(o) for o in outs) < max(os.path.getmtime(s) for s in srcs):
         cmd = ["make", "-C", csrc, "-s"] + (["-B"] if force else [])
         subprocess.check_call(cmd)
     return out

@@ -1,0 +1,397 @@
+// operators.hpp -- GPU-backed Operator / ScanOp / SelectOp / ProjectOp / Engine: the C++ host-side mirror of the
+// reference's operator package above the C ABI (include/imm3.h).  Same names, argument meaning and error texts:
+//
+//   engine/src/main/scala/immutabledb/engine/operator/Operator.scala:14-28   Operator / ColumnVectorOperator / ProjectionOperator
+//   engine/src/main/scala/immutabledb/engine/operator/Scan.scala:10-73       ScanOp, mkScanOp
+//   engine/src/main/scala/immutabledb/engine/operator/Select.scala:5-165     SelectOp, mkSelectOp
+//   engine/src/main/scala/immutabledb/engine/operator/Project.scala:8-81     ProjectOp, mkProjectOp
+//   engine/src/main/scala/immutabledb/engine/Engine.scala:85-128,158-262     getColumns / resolveSelectOps / execute
+//   core/src/main/scala/immutabledb/DataVector.scala:15-48                   ColumnVectorBatch family
+//
+// Operators are plan builders: the first iterator() call fuses ScanOp -> SelectOp* (-> ProjectOp) of one segment
+// into one imm3_query.  Everything that touches data goes through the C ABI; there is no CPU evaluation path.
+#pragma once
+
+#include <functional>
+#include <memory>
+
+#include "../../include/imm3.h"
+#include "storage.hpp"
+
+namespace immutabledb {
+
+inline void imm3Check(int rc) {
+    if (rc != IMM3_OK) throw Exception(imm3_last_error());
+}
+
+// ---- vectors (DataVector.scala) ----
+struct BitSet { // scala.collection.mutable.BitSet over the GPU's words: bit i <-> word i>>6, bit i&63
+    std::vector<uint64_t> words;
+    bool contains(int i) const { return (size_t)(i >> 6) < words.size() && ((words[(size_t)(i >> 6)] >> (i & 63)) & 1ULL); }
+    int size() const { int c = 0; for (uint64_t w : words) c += __builtin_popcountll(w); return c; }
+    bool isEmpty() const { for (uint64_t w : words) if (w) return false; return true; }
+    std::vector<int> toList() const {
+        std::vector<int> out;
+        for (size_t k = 0; k < words.size(); ++k)
+            for (uint64_t w = words[k]; w; w &= w - 1) out.push_back((int)(k * 64 + (size_t)__builtin_ctzll(w)));
+        return out;
+    }
+};
+
+struct ColumnVector { // Int / TinyInt / String column vector: a typed VIEW of the block (DENSE decode is a reinterpretation)
+    ColumnType type = ColumnType::INT;
+    const uint8_t *data = nullptr;
+    int width = 4;
+    int n = 0;
+    Value value(int pos) const {
+        switch (type) {
+        case ColumnType::INT: { int32_t v; std::memcpy(&v, data + (size_t)pos * 4, 4); return Value::ofInt(v); }
+        case ColumnType::TINYINT: return Value::ofByte((int8_t)data[pos]);
+        default: return Value::ofString(std::string((const char *)data + (size_t)pos * (size_t)width, (size_t)width)); // new String(bytes)
+        }
+    }
+};
+
+struct ColumnVectorBatch { // FilledColumnVectorBatch (DataVector.scala:24-31)
+    int oid = 0;
+    int size = 0;
+    std::vector<ColumnVector> columnVectors;
+    std::vector<Column> columns;
+    BitSet selected;
+    bool selectedInUse = true;
+};
+
+// ---- pull iterators (scala Iterator) ----
+template <typename A>
+struct Iterator {
+    virtual ~Iterator() = default;
+    virtual bool hasNext() = 0;
+    virtual A next() = 0;
+};
+
+template <typename A>
+struct Operator { // Operator.scala:14-16
+    virtual ~Operator() = default;
+    virtual std::unique_ptr<Iterator<A>> iterator() = 0;
+};
+using ColumnVectorOperator = Operator<ColumnVectorBatch>; // Operator.scala:18-20
+using ProjectionOperator = Operator<Row>;                 // Operator.scala:26-28
+
+template <typename A>
+struct VectorIterator : Iterator<A> {
+    std::vector<A> items;
+    size_t pos = 0;
+    bool hasNext() override { return pos < items.size(); }
+    A next() override { return std::move(items[pos++]); }
+};
+
+// ---- device-resident SegmentManager ----
+class GpuSegmentManager {
+  public:
+    explicit GpuSegmentManager(const SegmentManager &sm, int device = 0) : sm(sm) { imm3Check(imm3_ctx_create(device, nullptr, &ctx_)); }
+    ~GpuSegmentManager() {
+        for (auto &kv : segs_) imm3_segment_destroy(kv.second);
+        imm3_ctx_destroy(ctx_);
+    }
+    GpuSegmentManager(const GpuSegmentManager &) = delete;
+    GpuSegmentManager &operator=(const GpuSegmentManager &) = delete;
+
+    imm3_ctx *ctx() const { return ctx_; }
+    // all columns of one segment id, staged into HBM once (SegmentManager keeps its mmaps the same way)
+    imm3_segment *deviceSegment(const std::string &tableName, int segIdx) {
+        const auto key = std::make_pair(tableName, segIdx);
+        auto it = segs_.find(key);
+        if (it != segs_.end()) return it->second;
+        const Table &t = sm.getTable(tableName);
+        std::vector<imm3_column> cols(t.columns.size());
+        for (size_t i = 0; i < t.columns.size(); ++i) {
+            const std::string k = tableName + "." + t.columns[i].name;
+            const MappedFile &f = sm.segments.at(k).at((size_t)segIdx);
+            const SegmentMeta &m = sm.segmentsMeta.at(k).at((size_t)segIdx);
+            cols[i].codec = (int32_t)t.columns[i].codec;
+            cols[i].width = t.columns[i].width();
+            cols[i].dat = f.data;
+            cols[i].dat_bytes = f.size;
+            cols[i].block_offsets = m.blockOffsets.data();
+            cols[i].n_offsets = (int32_t)m.blockOffsets.size();
+        }
+        imm3_segment *seg = nullptr;
+        imm3Check(imm3_segment_create(ctx_, cols.data(), (int32_t)cols.size(), &seg));
+        segs_[key] = seg;
+        return seg;
+    }
+    const SegmentManager &sm;
+
+  private:
+    imm3_ctx *ctx_ = nullptr;
+    std::map<std::pair<std::string, int>, imm3_segment *> segs_;
+};
+
+struct Leaf { std::string col; SelectCondition cond; };
+
+// RAII imm3_query
+struct QueryHandle {
+    imm3_query *q = nullptr;
+    ~QueryHandle() { if (q) imm3_query_destroy(q); }
+};
+
+// ---- ScanOp (Scan.scala:17) ----
+class ScanOp : public ColumnVectorOperator {
+  public:
+    ScanOp(GpuSegmentManager &sm, int segIdx, const std::string &tableName, std::vector<Column> cols)
+        : sm_(sm), segIdx_(segIdx), tableName_(tableName), cols_(std::move(cols)) {}
+    static std::function<std::shared_ptr<ScanOp>(const std::vector<Column> &, int)> mkScanOp(GpuSegmentManager &sm, const std::string &tableName) {
+        return [&sm, tableName](const std::vector<Column> &cols, int segIdx) { return std::make_shared<ScanOp>(sm, segIdx, tableName, cols); };
+    }
+    const Table &table() const { return sm_.sm.getTable(tableName_); }
+
+    // builds the fused query: leaves in application order, optional projection
+    void makeQuery(const std::vector<Leaf> &leaves, const std::vector<std::string> &projNames, int limit, QueryHandle &h) const {
+        const Table &t = table();
+        std::vector<int32_t> used;
+        for (const auto &c : cols_) used.push_back(t.columnIndex(c.name));
+        auto usedIndex = [&](const std::string &name) -> int32_t {
+            for (size_t i = 0; i < cols_.size(); ++i)
+                if (cols_[i].name == name) return (int32_t)i; // `.filter(_.name == col).head`, Select.scala:60
+            throw Exception("NoSuchElementException: next on empty iterator");
+        };
+        std::vector<imm3_select> sels(leaves.size());
+        std::vector<std::string> blobs(leaves.size());
+        std::vector<std::vector<int32_t>> lens(leaves.size());
+        for (size_t i = 0; i < leaves.size(); ++i) {
+            sels[i] = imm3_select{};
+            sels[i].column = usedIndex(leaves[i].col);
+            sels[i].cond = (int32_t)leaves[i].cond.kind;
+            sels[i].value = leaves[i].cond.value;
+            for (const auto &v : leaves[i].cond.values) { blobs[i] += v; lens[i].push_back((int32_t)v.size()); }
+            sels[i].match_bytes = (const uint8_t *)blobs[i].data();
+            sels[i].match_lens = lens[i].data();
+            sels[i].n_match = (int32_t)lens[i].size();
+        }
+        std::vector<int32_t> proj;
+        for (const auto &n : projNames) {
+            bool found = false;
+            for (size_t i = 0; i < cols_.size() && !found; ++i)
+                if (cols_[i].name == n) { proj.push_back((int32_t)i); found = true; }
+            if (!found) throw Exception("NoSuchElementException: key not found: " + n); // vecCols(col), Project.scala:56
+        }
+        imm3Check(imm3_query_create(sm_.ctx(), sm_.deviceSegment(tableName_, segIdx_), used.data(), (int32_t)used.size(),
+                                    sels.data(), (int32_t)sels.size(), proj.data(), (int32_t)proj.size(), limit, t.blockSize, &h.q));
+    }
+
+    std::unique_ptr<Iterator<ColumnVectorBatch>> batches(const std::vector<Leaf> &leaves) const {
+        QueryHandle h;
+        makeQuery(leaves, {}, 0, h);
+        imm3Check(imm3_query_run_select(h.q));
+        int32_t nb = 0;
+        int64_t nwords = 0, nrows = 0;
+        imm3Check(imm3_query_layout(h.q, &nb, &nwords, &nrows));
+        std::vector<int32_t> size((size_t)nb), oid((size_t)nb);
+        std::vector<int64_t> woff((size_t)nb);
+        imm3Check(imm3_query_batches(h.q, size.data(), oid.data(), woff.data()));
+        std::vector<uint64_t> words((size_t)nwords);
+        imm3Check(imm3_query_bitmap(h.q, words.data(), nwords));
+        auto it = std::make_unique<VectorIterator<ColumnVectorBatch>>();
+        int64_t row = 0;
+        for (int32_t k = 0; k < nb; ++k) {
+            ColumnVectorBatch b;
+            b.oid = oid[(size_t)k];
+            b.size = size[(size_t)k];
+            b.columns = cols_;
+            const int64_t nw = (b.size + 63) / 64;
+            b.selected.words.assign(words.begin() + woff[(size_t)k], words.begin() + woff[(size_t)k] + nw);
+            b.selectedInUse = leaves.empty() ? true : !b.selected.isEmpty(); // Select.scala:44-47
+            for (const auto &c : cols_) {
+                const MappedFile &f = sm_.sm.segments.at(tableName_ + "." + c.name).at((size_t)segIdx_);
+                ColumnVector v;
+                v.type = c.columnType;
+                v.width = c.width();
+                v.data = f.data + (size_t)row * (size_t)v.width;
+                v.n = b.size;
+                b.columnVectors.push_back(v);
+            }
+            row += b.size;
+            it->items.push_back(std::move(b));
+        }
+        return it;
+    }
+    std::unique_ptr<Iterator<ColumnVectorBatch>> iterator() override { return batches({}); }
+    const std::vector<Column> &cols() const { return cols_; }
+
+  private:
+    GpuSegmentManager &sm_;
+    int segIdx_;
+    std::string tableName_;
+    std::vector<Column> cols_;
+};
+
+// ---- SelectOp (Select.scala:14) ----
+class SelectOp : public ColumnVectorOperator {
+  public:
+    SelectOp(const std::string &col, SelectCondition cond, std::shared_ptr<ColumnVectorOperator> op) : col_(col), cond_(std::move(cond)), op_(std::move(op)) {}
+    static std::function<std::shared_ptr<ColumnVectorOperator>(std::shared_ptr<ColumnVectorOperator>)> mkSelectOp(const std::string &col, const SelectCondition &cond) {
+        return [col, cond](std::shared_ptr<ColumnVectorOperator> op) { return std::make_shared<SelectOp>(col, cond, op); };
+    }
+    // (ScanOp, leaves in application order: innermost SelectOp first)
+    std::shared_ptr<ScanOp> chain(std::vector<Leaf> &leaves) const {
+        std::shared_ptr<ScanOp> scan;
+        if (auto inner = std::dynamic_pointer_cast<SelectOp>(op_)) scan = inner->chain(leaves);
+        else if (auto s = std::dynamic_pointer_cast<ScanOp>(op_)) scan = s;
+        else throw Exception("SelectOp chain must end in a ScanOp for the fused GPU path");
+        leaves.push_back(Leaf{col_, cond_});
+        return scan;
+    }
+    static void checkConditions(const std::vector<Leaf> &leaves) {
+        for (const auto &l : leaves)
+            if (l.cond.kind == SelectCondition::NotMatch || l.cond.kind == SelectCondition::NoOp)
+                throw Exception("Unsupported condition: " + l.cond.toString()); // Select.scala:22
+    }
+    std::unique_ptr<Iterator<ColumnVectorBatch>> iterator() override {
+        std::vector<Leaf> leaves;
+        auto scan = chain(leaves);
+        checkConditions(leaves);
+        return scan->batches(leaves);
+    }
+
+  private:
+    std::string col_;
+    SelectCondition cond_;
+    std::shared_ptr<ColumnVectorOperator> op_;
+};
+
+// ---- ProjectOp (Project.scala:17) ----
+class ProjectOp : public ProjectionOperator {
+  public:
+    ProjectOp(std::vector<std::string> cols, std::shared_ptr<ColumnVectorOperator> op, int limit = 0) : cols_(std::move(cols)), op_(std::move(op)), limit_(limit) {}
+    static std::function<std::shared_ptr<ProjectOp>(std::shared_ptr<ColumnVectorOperator>)> mkProjectOp(const std::vector<std::string> &cols, int limit = 0) {
+        return [cols, limit](std::shared_ptr<ColumnVectorOperator> op) { return std::make_shared<ProjectOp>(cols, op, limit); };
+    }
+    std::unique_ptr<Iterator<Row>> iterator() override {
+        std::vector<Leaf> leaves;
+        std::shared_ptr<ScanOp> scan;
+        if (auto sel = std::dynamic_pointer_cast<SelectOp>(op_)) scan = sel->chain(leaves);
+        else scan = std::dynamic_pointer_cast<ScanOp>(op_);
+        if (!scan) return hostIterator();
+        SelectOp::checkConditions(leaves);
+        QueryHandle h;
+        scan->makeQuery(leaves, cols_, limit_, h);
+        imm3Check(imm3_query_run(h.q));
+        uint64_t n = 0;
+        imm3Check(imm3_query_row_count(h.q, &n));
+        std::vector<Column> pcols;
+        for (const auto &name : cols_)
+            for (const auto &c : scan->cols())
+                if (c.name == name) { pcols.push_back(c); break; }
+        std::vector<std::vector<uint8_t>> bufs(pcols.size());
+        std::vector<void *> ptrs(pcols.size());
+        for (size_t j = 0; j < pcols.size(); ++j) {
+            bufs[j].resize((size_t)std::max<uint64_t>(n, 1) * (size_t)pcols[j].width());
+            ptrs[j] = bufs[j].data();
+        }
+        imm3Check(imm3_query_fetch_rows(h.q, nullptr, ptrs.data(), n));
+        auto it = std::make_unique<VectorIterator<Row>>();
+        it->items.reserve((size_t)n);
+        for (uint64_t i = 0; i < n; ++i) {
+            std::vector<Value> xs;
+            for (size_t j = 0; j < pcols.size(); ++j) {
+                ColumnVector v;
+                v.type = pcols[j].columnType;
+                v.width = pcols[j].width();
+                v.data = bufs[j].data();
+                xs.push_back(v.value((int)i));
+            }
+            it->items.push_back(Row::fromSeq(std::move(xs)));
+        }
+        return it;
+    }
+
+  private:
+    // ProjectIterator over batches from a non-fusable upstream (Project.scala:37-80); empty batches are skipped
+    // (the reference faults on them).
+    std::unique_ptr<Iterator<Row>> hostIterator() {
+        auto it = std::make_unique<VectorIterator<Row>>();
+        auto in = op_->iterator();
+        int total = 0;
+        while (in->hasNext() && !(limit_ > 0 && total >= limit_)) {
+            ColumnVectorBatch vec = in->next();
+            std::vector<int> vecCols;
+            for (const auto &name : cols_) {
+                int idx = -1;
+                for (size_t i = 0; i < vec.columns.size(); ++i)
+                    if (vec.columns[i].name == name) { idx = (int)i; break; }
+                if (idx < 0) throw Exception("NoSuchElementException: key not found: " + name);
+                vecCols.push_back(idx);
+            }
+            for (int pos : vec.selected.toList()) {
+                if (limit_ > 0 && total >= limit_) break;
+                std::vector<Value> xs;
+                for (int ci : vecCols) xs.push_back(vec.columnVectors[(size_t)ci].value(pos));
+                it->items.push_back(Row::fromSeq(std::move(xs)));
+                ++total;
+            }
+        }
+        return it;
+    }
+    std::vector<std::string> cols_;
+    std::shared_ptr<ColumnVectorOperator> op_;
+    int limit_;
+};
+
+// ---- Engine (Engine.scala:81-197), Project queries ----
+class Engine {
+  public:
+    explicit Engine(GpuSegmentManager &sm) : sm_(sm) {}
+
+    // Engine.getColumns (:85-106): (selectColumnsSet.toList ++ projectColumns).toSet.toList.  Scala's Set1..Set4 keep
+    // insertion order, so for <= 4 distinct columns this is first-seen order (SURVEY A.1 rule 3).
+    static std::vector<Column> getColumns(const Query &q, const Table &table) {
+        std::vector<Column> out;
+        auto add = [&](const Column &c) { for (const auto &x : out) if (x == c) return; out.push_back(c); };
+        std::function<void(const SelectADT &)> rec = [&](const SelectADT &s) {
+            if (s.kind == SelectADT::And || s.kind == SelectADT::Or) { rec(*s.op1); rec(*s.op2); }
+            else if (s.kind == SelectADT::Select) add(table.getColumn(s.col));
+        };
+        rec(*q.select);
+        if (q.project.kind == ProjectADT::Project) for (const auto &c : q.project.cols) add(table.getColumn(c));
+        else if (q.project.kind == ProjectADT::ProjectAgg) {
+            for (const auto &a : q.project.aggs) add(table.getColumn(a.col));
+            for (const auto &g : q.project.groupBy) add(table.getColumn(g));
+        }
+        return out;
+    }
+    // resolveSelectOps + runOps (:108-128, :237-245): left-to-right fold, AND/OR tag ignored
+    static std::vector<Leaf> resolveSelectOps(const Query &q) {
+        std::vector<Leaf> out;
+        std::function<void(const SelectADT &)> rec = [&](const SelectADT &s) {
+            if (s.kind == SelectADT::And || s.kind == SelectADT::Or) { rec(*s.op1); rec(*s.op2); }
+            else if (s.kind == SelectADT::Select) out.push_back(Leaf{s.col, s.cond});
+        };
+        rec(*q.select);
+        return out;
+    }
+    // one fused pipeline per segment; rows in ascending segment order (the reference's order across segments is
+    // unspecified: queue interleaving, Engine.scala:255); `limit` is global, as the consumer-side ProjectOp's is.
+    std::vector<Row> execute(const Query &q) {
+        if (q.project.kind != ProjectADT::Project) throw Exception("Only Project queries are on the GPU path (ProjectAgg: SURVEY 8f)");
+        const Table &table = sm_.sm.getTable(q.table);
+        const std::vector<Column> used = getColumns(q, table);
+        const std::vector<Leaf> leaves = resolveSelectOps(q);
+        auto mkScan = ScanOp::mkScanOp(sm_, q.table);
+        auto mkProj = ProjectOp::mkProjectOp(q.project.cols, q.project.limit);
+        std::vector<Row> rows;
+        const int nseg = sm_.sm.getTableSegmentCount(table.name);
+        for (int seg = 0; seg < nseg; ++seg) {
+            if (q.project.limit > 0 && (int)rows.size() >= q.project.limit) break;
+            std::shared_ptr<ColumnVectorOperator> op = mkScan(used, seg);
+            for (const auto &l : leaves) op = SelectOp::mkSelectOp(l.col, l.cond)(op);
+            auto it = mkProj(op)->iterator();
+            while (it->hasNext() && !(q.project.limit > 0 && (int)rows.size() >= q.project.limit)) rows.push_back(it->next());
+        }
+        return rows;
+    }
+
+  private:
+    GpuSegmentManager &sm_;
+};
+
+} // namespace immutabledb
