@@ -431,7 +431,7 @@ extern "C" int imm3_query_create(imm3_ctx *ctx, const imm3_segment *seg,
             const int64_t len = (int64_t)first.offsets[(size_t)k + 1] - (int64_t)first.offsets[(size_t)k];
             if (len < 0) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": negative length (NegativeArraySizeException in the reference)");
             if (len % first.width) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": byte length is not a multiple of the value width (malformed segment)");
-            if (cursor + (uint64_t)len > first.bytes) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": runs past the segment data (BufferUnderflowException in the reference)");
+            if (cursor + (uint64_t)len > first.bytes) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": bytes [" + std::to_string(cursor) + ", " + std::to_string(cursor + (uint64_t)len) + ") run past the segment data of " + std::to_string(first.bytes) + " bytes (BufferUnderflowException in the reference)");
             const int64_t n = len / first.width;
             q->batch_size[(size_t)k] = (int32_t)n;
             q->batch_oid[(size_t)k] = (int32_t)((uint32_t)k * (uint32_t)table_block_size); // vecCounter * table.blockSize

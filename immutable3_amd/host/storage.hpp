@@ -52,7 +52,8 @@ struct SegmentMeta {
     std::vector<int32_t> blockOffsets;
     static SegmentMeta load(const std::string &path) {
         SegmentMeta m;
-        for (const auto &v : json::parse(readFile(path)).at("blockOffset").arr) m.blockOffsets.push_back((int32_t)v.num);
+        const json::Value j = json::parse(readFile(path)); // keep the document alive while iterating it
+        for (const auto &v : j.at("blockOffset").arr) m.blockOffsets.push_back((int32_t)v.num);
         return m;
     }
     static void store(const std::string &path, const SegmentMeta &m) {
