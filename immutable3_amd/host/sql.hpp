@@ -15,6 +15,7 @@
 
 #include <cctype>
 #include <cstdlib>
+#include <cstring>
 
 #include "schema.hpp"
 
