@@ -7,7 +7,8 @@ storage.py   the reference's on-disk format: SegmentManager (reader) and Segment
 schema.py, query.py   Column / Table / Row and the Query ADT
 synth.py     seeded synthetic tables of BASELINE.json's configs
 """
-from .query import EQ, GT, LT, And, Match, NoOp, NoSelect, NotMatch, Or, Project, Query, Select  # noqa: F401
+from .query import (EQ, GT, LT, And, Avg, Count, Match, Max, Min, NoOp, NoSelect, NotMatch, Or, Project,  # noqa: F401
+                    ProjectAgg, Query, Select, Sum)
 from .schema import CodecType, Column, ColumnType, Row, Table, TableIO  # noqa: F401
 
 __version__ = "0.1.0"

@@ -11,7 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 def build_native(force: bool = False) -> str:
     csrc = os.path.join(_PKG, "csrc")
     out = os.path.join(_PKG, "lib", "libimm3.so")
-    srcs = [os.path.join(csrc, f) for f in ("imm3_kernels.hip", "imm3_api.cpp", "imm3_internal.h")]
+    srcs = [os.path.join(csrc, f) for f in ("imm3_kernels.hip", "imm3_agg.hip", "imm3_api.cpp", "imm3_internal.h")]
     srcs.append(os.path.join(_PKG, "..", "include", "imm3.h"))
     host = os.path.join(_PKG, "host")
     srcs += [os.path.join(host, f) for f in os.listdir(host) if f.endswith(".hpp")]

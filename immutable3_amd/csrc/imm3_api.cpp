@@ -98,6 +98,16 @@ struct imm3_query {
     uint64_t cap_rows = 0;
     bool reserved = false;
     bool ran_select = false, ran_project = false;
+    // group-by aggregation
+    bool is_agg = false;
+    std::vector<int32_t> group_cols;           // index into `used`
+    std::vector<imm3_aggregate> aggs;
+    uint32_t agg_mask = 0;
+    unsigned long long *d_akeys = nullptr, *d_acounts = nullptr, *d_okeys = nullptr, *d_ocounts = nullptr;
+    uint32_t *d_afirst = nullptr, *d_ofirst = nullptr, *d_ameta = nullptr; // d_ameta: {n_groups, overflow}
+    long long *d_avals = nullptr, *d_ovals = nullptr;
+    uint32_t out_cap = 0;
+    bool ran_agg = false;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -336,6 +346,9 @@ static void query_free(imm3_query *q) {
     (void)hipFree(q->d_row_index);
     for (auto p : q->d_proj) (void)hipFree(p);
     for (auto &p : q->preds) (void)hipFree(p.d_blob);
+    (void)hipFree(q->d_akeys); (void)hipFree(q->d_acounts); (void)hipFree(q->d_okeys); (void)hipFree(q->d_ocounts);
+    (void)hipFree(q->d_afirst); (void)hipFree(q->d_ofirst); (void)hipFree(q->d_ameta);
+    (void)hipFree(q->d_avals); (void)hipFree(q->d_ovals);
     delete q;
 }
 
@@ -798,6 +811,8 @@ static int run_project(imm3_query *q) {
     return IMM3_OK;
 }
 
+static int run_agg(imm3_query *q);
+
 extern "C" int imm3_query_run_select(imm3_query *q) {
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
     q->ran_project = false;
@@ -810,6 +825,7 @@ extern "C" int imm3_query_run(imm3_query *q) {
     int rc = run_select(q);
     if (rc) return rc;
     if (!q->proj.empty()) rc = run_project(q);
+    if (!rc && q->is_agg) rc = run_agg(q);
     return rc;
 }
 
@@ -920,4 +936,174 @@ extern "C" int imm3_query_device_ptr(imm3_query *q, int32_t which, void **ptr) {
         }
         return fail(IMM3_ERR_ARG, "unknown device pointer id");
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// group-by aggregation (ProjectAggOp)
+// ---------------------------------------------------------------------------------------------
+extern "C" int imm3_query_create_agg(imm3_ctx *ctx, const imm3_segment *seg,
+                                     const int32_t *used_cols, int32_t n_used,
+                                     const imm3_select *sels, int32_t n_sels,
+                                     const int32_t *group_cols, int32_t n_group,
+                                     const imm3_aggregate *aggs, int32_t n_aggs,
+                                     int32_t table_block_size, imm3_query **out) {
+    if (!out) return fail(IMM3_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (n_group < 0 || n_group > kMaxGroupCols || (n_group > 0 && !group_cols)) return fail(IMM3_ERR_ARG, "0..4 group columns are supported on the GPU path");
+    if (n_aggs < 1 || n_aggs > kMaxAggs || !aggs) return fail(IMM3_ERR_ARG, "1..4 aggregates are supported on the GPU path");
+    imm3_query *q = nullptr;
+    int rc = imm3_query_create(ctx, seg, used_cols, n_used, sels, n_sels, nullptr, 0, 0, table_block_size, &q);
+    if (rc) return rc;
+    std::unique_ptr<imm3_query, void (*)(imm3_query *)> guard(q, query_free);
+    int key_bytes = 0;
+    for (int32_t g = 0; g < n_group; ++g) {
+        if (group_cols[g] < 0 || group_cols[g] >= n_used) return fail(IMM3_ERR_ARG, "group column is not among the used columns");
+        key_bytes += seg->cols[(size_t)q->used[(size_t)group_cols[g]]].width;
+    }
+    if (key_bytes > 8) return fail(IMM3_ERR_ARG, "group key wider than 8 bytes is not supported on the GPU path");
+    const bool has_batches = !q->batch_size.empty();
+    for (int32_t j = 0; j < n_aggs; ++j) {
+        if (aggs[j].column < 0 || aggs[j].column >= n_used) return fail(IMM3_ERR_ARG, "aggregate column is not among the used columns");
+        const SegCol &sc = seg->cols[(size_t)q->used[(size_t)aggs[j].column]];
+        const bool is_str = sc.codec == IMM3_DENSE_STRING;
+        if (aggs[j].kind != IMM3_AGG_COUNT && aggs[j].kind != IMM3_AGG_MIN && aggs[j].kind != IMM3_AGG_MAX) return fail(IMM3_ERR_ARG, "Unknown Aggregate type");
+        // ProjectAggregate.scala:176-220: a String vector only takes CountAggr / MaxStringAggr
+        if (has_batches && is_str && aggs[j].kind == IMM3_AGG_MIN) return fail(IMM3_ERR_UNSUPPORTED_VECTOR, "bad aggregator for this data type");
+        if (is_str && aggs[j].kind == IMM3_AGG_MAX && sc.width > 8) return fail(IMM3_ERR_ARG, "MAX over strings wider than 8 bytes is not supported on the GPU path");
+    }
+    q->is_agg = true;
+    q->group_cols.assign(group_cols, group_cols + n_group);
+    q->aggs.assign(aggs, aggs + n_aggs);
+    // table capacity: twice the number of possible groups, bounded by the rows and by 2^27 slots
+    double domain = 1.0;
+    for (int b = 0; b < key_bytes; ++b) domain *= 256.0;
+    const double bound = std::min<double>(domain, (double)std::max<int64_t>(q->n_rows, 1));
+    uint64_t slots = 1024;
+    while ((double)slots < 2.0 * bound && slots < (1ULL << 27)) slots <<= 1;
+    q->agg_mask = (uint32_t)(slots - 1);
+    HIPCHK(hipSetDevice(ctx->device));
+    void *p = nullptr;
+    const size_t n = (size_t)slots + 1;
+    HIPCHK(hipMalloc(&p, n * sizeof(unsigned long long))); q->d_akeys = (unsigned long long *)p;
+    HIPCHK(hipMalloc(&p, n * sizeof(uint32_t))); q->d_afirst = (uint32_t *)p;
+    HIPCHK(hipMalloc(&p, n * sizeof(unsigned long long))); q->d_acounts = (unsigned long long *)p;
+    HIPCHK(hipMalloc(&p, n * kMaxAggs * sizeof(long long))); q->d_avals = (long long *)p;
+    HIPCHK(hipMalloc(&p, 2 * sizeof(uint32_t))); q->d_ameta = (uint32_t *)p;
+    *out = guard.release();
+    return IMM3_OK;
+}
+
+static void fill_agg_args(const imm3_query *q, AggArgs &a) {
+    std::memset(&a, 0, sizeof(a));
+    a.bitmap = q->d_bitmap;
+    a.n_words = q->n_words;
+    a.n_tiles = q->n_tiles;
+    a.word_row_base = q->d_word_row_base;
+    int shift = 0;
+    for (size_t g = 0; g < q->group_cols.size(); ++g) {
+        const SegCol &sc = q->seg->cols[(size_t)q->used[(size_t)q->group_cols[g]]];
+        a.groups[g].data = sc.d_data;
+        a.groups[g].width = sc.width;
+        a.groups[g].shift = shift;
+        shift += sc.width;
+    }
+    a.n_group = (int32_t)q->group_cols.size();
+    for (size_t j = 0; j < q->aggs.size(); ++j) {
+        const SegCol &sc = q->seg->cols[(size_t)q->used[(size_t)q->aggs[j].column]];
+        a.aggs[j].data = sc.d_data;
+        a.aggs[j].width = sc.width;
+        a.aggs[j].kind = q->aggs[j].kind;
+        a.aggs[j].is_str = sc.codec == IMM3_DENSE_STRING;
+    }
+    a.n_agg = (int32_t)q->aggs.size();
+    a.keys = q->d_akeys;
+    a.first = q->d_afirst;
+    a.counts = q->d_acounts;
+    a.vals = q->d_avals;
+    a.mask = q->agg_mask;
+    a.n_groups = q->d_ameta;
+    a.overflow = q->d_ameta + 1;
+    a.out_cap = q->out_cap;
+    a.out_keys = q->d_okeys;
+    a.out_first = q->d_ofirst;
+    a.out_counts = q->d_ocounts;
+    a.out_vals = q->d_ovals;
+}
+
+static int run_agg(imm3_query *q) {
+    imm3_ctx *ctx = q->ctx;
+    AggArgs a;
+    fill_agg_args(q, a);
+    LaunchTimer t(ctx, 4);
+    launch_group_agg(a, ctx->stream, t.start, t.stop);
+    HIPCHK(hipGetLastError());
+    q->ran_agg = true;
+    return IMM3_OK;
+}
+
+// collect the occupied slots; grows the dense output and collects again if it was too small
+static int settle_groups(imm3_query *q, uint32_t *n_groups) {
+    if (!q->is_agg || !q->ran_agg) return fail(IMM3_ERR_STATE, "no aggregation has been run");
+    imm3_ctx *ctx = q->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        AggArgs a;
+        fill_agg_args(q, a);
+        HIPCHK(hipMemsetAsync(q->d_ameta, 0, sizeof(uint32_t), s)); // n_groups only; keep the overflow flag
+        launch_group_collect(a, s);
+        HIPCHK(hipGetLastError());
+        uint32_t meta[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(meta, q->d_ameta, sizeof(meta), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (meta[1]) return fail(IMM3_ERR_LAYOUT, "more distinct groups than the aggregation table holds (2^27)");
+        if (meta[0] <= q->out_cap) { *n_groups = meta[0]; return IMM3_OK; }
+        (void)hipFree(q->d_okeys); (void)hipFree(q->d_ofirst); (void)hipFree(q->d_ocounts); (void)hipFree(q->d_ovals);
+        q->d_okeys = nullptr; q->d_ofirst = nullptr; q->d_ocounts = nullptr; q->d_ovals = nullptr;
+        void *p = nullptr;
+        const size_t n = meta[0];
+        HIPCHK(hipMalloc(&p, n * sizeof(unsigned long long))); q->d_okeys = (unsigned long long *)p;
+        HIPCHK(hipMalloc(&p, n * sizeof(uint32_t))); q->d_ofirst = (uint32_t *)p;
+        HIPCHK(hipMalloc(&p, n * sizeof(unsigned long long))); q->d_ocounts = (unsigned long long *)p;
+        HIPCHK(hipMalloc(&p, n * kMaxAggs * sizeof(long long))); q->d_ovals = (long long *)p;
+        q->out_cap = meta[0];
+    }
+    return fail(IMM3_ERR_DEVICE, "group collection did not converge");
+}
+
+extern "C" int imm3_query_group_count(imm3_query *q, uint32_t *n_groups) {
+    if (!q || !n_groups) return fail(IMM3_ERR_ARG, "null argument");
+    return settle_groups(q, n_groups);
+}
+
+extern "C" int imm3_query_fetch_groups(imm3_query *q, uint64_t *keys, uint32_t *first_row, uint64_t *counts, int64_t *vals, uint32_t max_groups) {
+    if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    uint32_t n = 0;
+    const int rc = settle_groups(q, &n);
+    if (rc) return rc;
+    std::vector<unsigned long long> hk(n), hc(n);
+    std::vector<uint32_t> hf(n);
+    std::vector<long long> hv((size_t)n * kMaxAggs);
+    hipStream_t s = q->ctx->stream;
+    if (n) {
+        HIPCHK(hipMemcpyAsync(hk.data(), q->d_okeys, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hf.data(), q->d_ofirst, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hc.data(), q->d_ocounts, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hv.data(), q->d_ovals, (size_t)n * kMaxAggs * sizeof(long long), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return hf[x] < hf[y]; }); // first-seen order
+    const size_t na = q->aggs.size();
+    for (uint32_t o = 0; o < n && o < max_groups; ++o) {
+        const uint32_t i = order[o];
+        if (keys) keys[o] = hk[i];
+        if (first_row) first_row[o] = hf[i];
+        if (counts) counts[o] = hc[i];
+        if (vals)
+            for (size_t j = 0; j < na; ++j)
+                vals[(size_t)o * na + j] = q->aggs[j].kind == IMM3_AGG_COUNT ? (int64_t)hc[i] : (int64_t)hv[(size_t)i * kMaxAggs + j];
+    }
+    return IMM3_OK;
 }

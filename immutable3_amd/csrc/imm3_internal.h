@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 
 namespace imm3 {
 
@@ -114,6 +115,51 @@ struct GatherArgs {
 };
 
 // launchers (imm3_kernels.hip)
+// ---- group-by aggregation (imm3_agg.hip) ----
+constexpr int kMaxGroupCols = 4;
+constexpr int kMaxAggs = 4;
+enum AggKind : int32_t { AGG_COUNT = 0, AGG_MIN = 1, AGG_MAX = 2 };
+
+struct GroupCol {
+    const void *data;
+    int32_t width;
+    int32_t shift;               // byte position of this column inside the u64 group key
+};
+
+struct AggCol {
+    const void *data;
+    int32_t width;
+    int32_t kind;                // AggKind
+    int32_t is_str;              // AGG_MAX over a string column: values compared as big-endian-packed bytes
+    int32_t pad;
+};
+
+struct AggArgs {
+    const uint64_t *bitmap;
+    int64_t n_words, n_tiles;
+    const uint32_t *word_row_base; // ragged layout, else null
+    GroupCol groups[kMaxGroupCols];
+    AggCol aggs[kMaxAggs];
+    int32_t n_group, n_agg;
+    // global open-addressing table: mask + 1 slots, plus one for the all-ones key
+    unsigned long long *keys;
+    uint32_t *first;             // first (lowest) selected row of the group
+    unsigned long long *counts;
+    long long *vals;             // kMaxAggs per slot
+    uint32_t mask;
+    uint32_t out_cap;
+    uint32_t *n_groups;
+    uint32_t *overflow;
+    // dense output of k_group_collect
+    unsigned long long *out_keys;
+    uint32_t *out_first;
+    unsigned long long *out_counts;
+    long long *out_vals;
+};
+
+void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+void launch_group_collect(const AggArgs &a, hipStream_t s);
+
 constexpr int kMaxFilterGrid = 4096; // capacity of block_partials
 int filter_grid(int64_t units, bool generic, int grid_blocks);
 // ev0/ev1: optional events stamped with the kernel's own start/end (hipExtLaunchKernelGGL), else null

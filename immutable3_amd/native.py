@@ -27,7 +27,8 @@ EXPORTS = [
     "imm3_abi_version", "imm3_last_error", "imm3_device_count",
     "imm3_ctx_create", "imm3_ctx_destroy", "imm3_ctx_sync", "imm3_ctx_stream",
     "imm3_segment_create", "imm3_segment_wrap_device", "imm3_segment_destroy", "imm3_segment_bytes",
-    "imm3_query_create", "imm3_query_destroy", "imm3_query_reserve_rows",
+    "imm3_query_create", "imm3_query_create_agg", "imm3_query_group_count", "imm3_query_fetch_groups",
+    "imm3_query_destroy", "imm3_query_reserve_rows",
     "imm3_query_run", "imm3_query_run_select", "imm3_query_sync",
     "imm3_query_layout", "imm3_query_batches", "imm3_query_count", "imm3_query_bitmap",
     "imm3_query_row_count", "imm3_query_fetch_rows", "imm3_query_device_ptr",
@@ -95,6 +96,9 @@ def load() -> C.CDLL:
     L.imm3_segment_destroy.argtypes = [vp]
     L.imm3_segment_bytes.argtypes = [vp, P(u64)]
     L.imm3_query_create.argtypes = [vp, vp, vp, i32, P(CSelect), i32, vp, i32, i64, i32, P(vp)]
+    L.imm3_query_create_agg.argtypes = [vp, vp, vp, i32, P(CSelect), i32, vp, i32, vp, i32, i32, P(vp)]
+    L.imm3_query_group_count.argtypes = [vp, P(C.c_uint32)]
+    L.imm3_query_fetch_groups.argtypes = [vp, vp, vp, vp, vp, C.c_uint32]
     L.imm3_query_destroy.argtypes = [vp]
     L.imm3_query_reserve_rows.argtypes = [vp, u64]
     L.imm3_query_run.argtypes = [vp]
@@ -234,14 +238,20 @@ class DeviceSegment:
             pass
 
 
+AGG_COUNT, AGG_MIN, AGG_MAX = 0, 1, 2
+
+
 class DeviceQuery:
-    """imm3_query: ScanOp -> SelectOp* -> ProjectOp over one device segment."""
+    """imm3_query: ScanOp -> SelectOp* -> ProjectOp (or ProjectAggOp when `aggs` is given) over one device segment."""
 
     def __init__(self, ctx: Context, seg: DeviceSegment, used_cols: Sequence[int],
-                 sels: Sequence[tuple], proj: Sequence[int] = (), limit: int = 0, table_block_size: int = 1024):
+                 sels: Sequence[tuple], proj: Sequence[int] = (), limit: int = 0, table_block_size: int = 1024,
+                 group_cols: Optional[Sequence[int]] = None, aggs: Optional[Sequence[tuple]] = None):
         self.ctx, self.seg = ctx, seg
         self.used_cols = list(used_cols)
         self.proj = list(proj)
+        self.group_cols = list(group_cols or [])
+        self.aggs = list(aggs) if aggs is not None else None
         used = np.array(self.used_cols or [0], dtype=np.int32)
         pj = np.array(self.proj or [0], dtype=np.int32)
         cs = (CSelect * max(1, len(sels)))()
@@ -262,8 +272,15 @@ class DeviceQuery:
             elif operand is not None:
                 cs[i].value = float(operand)
         self._h = C.c_void_p()
-        _check(load().imm3_query_create(ctx._h, seg._h, used.ctypes.data, len(self.used_cols), cs, len(sels),
-                                        pj.ctypes.data, len(self.proj), limit, table_block_size, C.byref(self._h)))
+        if self.aggs is not None:
+            gc = np.array(self.group_cols or [0], dtype=np.int32)
+            ag = np.array([[k, c] for (k, c) in self.aggs] or [[0, 0]], dtype=np.int32)
+            _check(load().imm3_query_create_agg(ctx._h, seg._h, used.ctypes.data, len(self.used_cols), cs, len(sels),
+                                                gc.ctypes.data, len(self.group_cols), ag.ctypes.data, len(self.aggs),
+                                                table_block_size, C.byref(self._h)))
+        else:
+            _check(load().imm3_query_create(ctx._h, seg._h, used.ctypes.data, len(self.used_cols), cs, len(sels),
+                                            pj.ctypes.data, len(self.proj), limit, table_block_size, C.byref(self._h)))
         nb, tw, nr = C.c_int32(0), C.c_int64(0), C.c_int64(0)
         _check(load().imm3_query_layout(self._h, C.byref(nb), C.byref(tw), C.byref(nr)))
         self.n_batches, self.total_words, self.n_rows = nb.value, tw.value, nr.value
@@ -314,6 +331,19 @@ class DeviceQuery:
         ptrs = (C.c_void_p * max(1, len(cols)))(*[c.ctypes.data for c in cols])
         _check(load().imm3_query_fetch_rows(self._h, idx.ctypes.data, ptrs, n))
         return idx[:n], [c[:n] for c in cols]
+
+    def fetch_groups(self):
+        """(keys uint64[g], first_row uint32[g], counts uint64[g], vals int64[g, n_aggs]) in first-seen order."""
+        n = C.c_uint32(0)
+        _check(load().imm3_query_group_count(self._h, C.byref(n)))
+        g = n.value
+        na = max(1, len(self.aggs or []))
+        keys = np.zeros(max(g, 1), np.uint64)
+        first = np.zeros(max(g, 1), np.uint32)
+        counts = np.zeros(max(g, 1), np.uint64)
+        vals = np.zeros((max(g, 1), na), np.int64)
+        _check(load().imm3_query_fetch_groups(self._h, keys.ctypes.data, first.ctypes.data, counts.ctypes.data, vals.ctypes.data, g))
+        return keys[:g], first[:g], counts[:g], vals[:g, : len(self.aggs or [])]
 
     def device_ptr(self, which: int) -> int:
         p = C.c_void_p()

@@ -22,8 +22,8 @@ import numpy as np
 
 from . import native
 from .native import Imm3Error
-from .query import (EQ, GT, LT, And, Match, NoOp, NoSelect, NotMatch, Or, Project, Query, Select, SelectADT,
-                    SelectCondition)
+from .query import (EQ, GT, LT, And, Avg, Count, Match, Max, Min, NoOp, NoSelect, NotMatch, Or, Project, ProjectAgg,
+                    Query, Select, SelectADT, SelectCondition, Sum)
 from .schema import CodecType, Column, Row, Table
 from .storage import SegmentManager
 
@@ -342,6 +342,191 @@ class ProjectOp(ProjectionOperator):
                 return
 
 
+# ------------------------------------------------------------------------------------------
+# aggregation (engine/.../operator/ProjectAggregate.scala, ProjectAggregateQueue.scala)
+# ------------------------------------------------------------------------------------------
+def java_double_to_string(v: float) -> str:
+    """Double.toString for the integral values Max/MinDoubleAggr hold (value.toDouble of an Int / Byte)."""
+    iv = int(v)
+    if abs(iv) < 10 ** 7:
+        return f"{iv}.0"
+    digits = str(abs(iv))
+    return ("-" if iv < 0 else "") + digits[0] + "." + (digits[1:].rstrip("0") or "0") + "E" + str(len(digits) - 1)
+
+
+class Aggregator:                    # ProjectAggregate.scala:11-20
+    kind = native.AGG_COUNT
+
+    def __init__(self, col: str, alias: str):
+        self.col, self.alias = col, alias
+
+    def make(self):
+        return type(self)(self.col, self.alias)
+
+
+class CountAggr(Aggregator):         # :22-35
+    kind = native.AGG_COUNT
+
+    def __init__(self, col, alias):
+        super().__init__(col, alias)
+        self.counter = 0
+
+    def set(self, n):
+        self.counter = n
+
+    def get(self):
+        return self.counter
+
+    def combine(self, other):
+        self.counter += other.get()
+        return self
+
+    def repr(self):
+        return str(self.counter)
+
+
+class MaxDoubleAggr(Aggregator):     # :37-48
+    kind = native.AGG_MAX
+
+    def __init__(self, col, alias):
+        super().__init__(col, alias)
+        self.value = -1.7976931348623157e308
+
+    def add(self, v):
+        if v > self.value:
+            self.value = float(v)
+
+    def get(self):
+        return self.value
+
+    def combine(self, other):
+        self.add(other.get())
+        return self
+
+    def repr(self):
+        return java_double_to_string(self.value)
+
+
+class MinDoubleAggr(MaxDoubleAggr):  # :50-61
+    kind = native.AGG_MIN
+
+    def __init__(self, col, alias):
+        Aggregator.__init__(self, col, alias)
+        self.value = 1.7976931348623157e308
+
+    def add(self, v):
+        if v < self.value:
+            self.value = float(v)
+
+
+class MaxStringAggr(Aggregator):     # :79-91
+    kind = native.AGG_MAX
+
+    def __init__(self, col, alias):
+        super().__init__(col, alias)
+        self.value = ""
+
+    def add(self, v):
+        if self.value == "" or v > self.value:
+            self.value = v
+
+    def get(self):
+        return self.value
+
+    def combine(self, other):
+        self.add(other.get())
+        return self
+
+    def repr(self):
+        return self.value
+
+
+def resolveProjectOp(projectAgg: ProjectAgg, table: Table):
+    """Engine.resolveProjectOp (Engine.scala:130-156): Aggregate ADT -> Aggregators, default aliases
+    col_max / col_min / col_count; Min over a STRING column becomes MaxStringAggr (the reference's own mapping,
+    :145); Sum / Avg parse but are rejected (:152)."""
+    aggs = []
+    for a in projectAgg.aggs:
+        if isinstance(a, Max):
+            ct = table.getColumn(a.col).columnType
+            aggs.append((MaxStringAggr if ct == "STRING" else MaxDoubleAggr)(a.col, a.alias or a.col + "_max"))
+        elif isinstance(a, Min):
+            ct = table.getColumn(a.col).columnType
+            aggs.append((MaxStringAggr if ct == "STRING" else MinDoubleAggr)(a.col, a.alias or a.col + "_min"))
+        elif isinstance(a, Count):
+            aggs.append(CountAggr(a.col, a.alias or a.col + "_count"))
+        else:
+            raise Exception("Unknown Aggregate type")
+    return lambda op: ProjectAggOp(aggs, op, list(projectAgg.groupBy))
+
+
+class ProjectAggOp(Operator):
+    """ProjectAggOp(aggs, op, groupBy) (ProjectAggregate.scala:125): yields (groupKey, {alias: Aggregator}) in
+    first-seen order.  The whole chain of one segment runs fused on the GPU: scan+select kernel, then the LDS
+    hash-aggregation kernel; group keys and aggregates come back already reduced."""
+
+    def __init__(self, aggs: Sequence[Aggregator], op: ColumnVectorOperator, groupBy: Sequence[str]):
+        self.aggs, self.op, self.groupBy = list(aggs), op, list(groupBy)
+
+    @staticmethod
+    def make(aggs, groupBy):           # ProjectAggregate.scala:116-122
+        return lambda op: ProjectAggOp(aggs, op, groupBy)
+
+    def iterator(self):
+        if isinstance(self.op, ScanOp):
+            scan, leaves = self.op, []
+        else:
+            scan, leaves = self.op._chain()
+        for (_, cond) in leaves:
+            if not isinstance(cond, (Match, GT, LT, EQ)):
+                raise Exception(f"Unsupported condition: {cond}")
+        colnames = [c.name for c in scan.cols]
+        # groupCols filters the BATCH columns by membership in groupBy (:135-140): batch-column order
+        group_idx = [i for i, n in enumerate(colnames) if n in self.groupBy]
+        by_alias = {}
+        for a in self.aggs:              # aggsMap is a HashMap keyed by alias: a later duplicate replaces an earlier one
+            by_alias[a.alias] = a
+        aggs = list(by_alias.values())
+        t = scan._table()
+        sels = []
+        for (col, cond) in leaves:
+            code, operand = _cond_spec(cond)
+            sels.append((colnames.index(col), code, operand))
+        seg = scan.sm.device_segment(scan.tableName, scan.segIdx)
+        q = native.DeviceQuery(seg.ctx, seg, scan._used_indices(), sels, (), 0, t.blockSize,
+                               group_cols=group_idx, aggs=[(a.kind, colnames.index(a.col)) for a in aggs])
+        q.run()
+        keys, first, counts, vals = q.fetch_groups()
+        q.close()
+        widths = [scan.cols[i].width for i in group_idx]
+        for g in range(keys.shape[0]):
+            raw = int(keys[g]).to_bytes(8, "little")
+            parts, off = [], 0
+            for i, w in zip(group_idx, widths):
+                parts.append(_key_part(scan.cols[i], raw[off: off + w]))
+                off += w
+            out = {}
+            for j, a in enumerate(aggs):
+                na = a.make()
+                if isinstance(na, CountAggr):
+                    na.set(int(counts[g]))
+                elif isinstance(na, MaxStringAggr):
+                    w = scan.cols[colnames.index(a.col)].width
+                    na.value = int(vals[g, j]).to_bytes(8, "big", signed=True)[8 - w:].decode("utf-8", errors="replace")
+                else:
+                    na.value = float(int(vals[g, j]))
+                out[a.alias] = na
+            yield "_".join(parts), out
+
+
+def _key_part(col: Column, raw: bytes) -> str:
+    if col.codec == CodecType.DENSE_INT:
+        return str(int.from_bytes(raw, "little", signed=True))
+    if col.codec == CodecType.DENSE_TINYINT:
+        return str(int.from_bytes(raw, "little", signed=True))
+    return raw.decode("utf-8", errors="replace")
+
+
 def _value(x):
     if isinstance(x, np.ndarray):           # fixed-width string: new String(bytes) (DataType.scala:70)
         return bytes(x).decode("utf-8", errors="replace")
@@ -379,8 +564,15 @@ def getColumns(query: Query, table: Table) -> List[Column]:
             c = table.getColumn(name)
             if c not in cols:
                 cols.append(c)
-    else:
-        raise Exception("Only Project is on the GPU path (ProjectAgg is out of scope, SURVEY 8f)")
+    else:                                              # ProjectAgg: aggsCols ++ groupCols (Engine.scala:96-100)
+        for a in query.project.aggs:
+            c = table.getColumn(a.col)
+            if c not in cols:
+                cols.append(c)
+        for name in query.project.groupBy:
+            c = table.getColumn(name)
+            if c not in cols:
+                cols.append(c)
     return cols
 
 
@@ -418,7 +610,37 @@ class Engine:
                 op = leaf(op)
             yield segIdx, mk_proj(op)
 
+    def execute_agg(self, query: Query):
+        """ProjectAgg queries: per-segment ProjectAggOp, then ProjectAggregateQueueOp's combine by group key
+        (first arrival first; segments in ascending order).  Returns an ordered dict key -> {alias: Aggregator}."""
+        table = self.sm.getTable(query.table)
+        used = getColumns(query, table)
+        leaves = resolveSelectOps(query)
+        mk_scan = ScanOp.mkScanOp(self.sm, query.table)
+        mk_agg = resolveProjectOp(query.project, table)
+        result = {}
+        for segIdx in range(self.sm.getTableSegmentCount(table.name)):
+            if not self.sm.owns(table.name, segIdx):
+                continue
+            op = mk_scan(used, segIdx)
+            for leaf in leaves:
+                op = leaf(op)
+            for key, aggmap in mk_agg(op).iterator():
+                cur = result.get(key)
+                if cur is None:
+                    result[key] = aggmap
+                else:
+                    for alias, agg in aggmap.items():
+                        cur[alias] = cur[alias].combine(agg) if alias in cur else agg
+        return result
+
     def execute(self, query: Query) -> Iterator[Row]:
+        if isinstance(query.project, ProjectAgg):
+            # ProjectAggregateQueueOp.next: Row of the aggregators' repr.  The reference lists them in the iteration
+            # order of a mutable.HashMap keyed by alias (not reproduced); here: SELECT-list order.
+            for _, aggmap in self.execute_agg(query).items():
+                yield Row(*[a.repr() for a in aggmap.values()])
+            return
         limit = query.project.limit
         total = 0
         for _, proj in self.pipelines(query):

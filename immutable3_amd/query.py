@@ -93,6 +93,42 @@ class Project(ProjectADT):         # Query.scala:29
 
 
 @dataclass(frozen=True)
+class Aggregate:                   # Query.scala:17-20
+    col: str
+    alias: Optional[str] = None
+
+
+class Sum(Aggregate):              # Query.scala:21 (parsed, then rejected: Engine.scala:152)
+    pass
+
+
+class Avg(Aggregate):              # Query.scala:22
+    pass
+
+
+class Min(Aggregate):              # Query.scala:23
+    pass
+
+
+class Max(Aggregate):              # Query.scala:24
+    pass
+
+
+class Count(Aggregate):            # Query.scala:25
+    pass
+
+
+@dataclass(frozen=True)
+class ProjectAgg(ProjectADT):      # Query.scala:30
+    aggs: tuple
+    groupBy: tuple = ()
+
+    def __init__(self, aggs, groupBy=()):
+        object.__setattr__(self, "aggs", tuple(aggs))
+        object.__setattr__(self, "groupBy", tuple(groupBy))
+
+
+@dataclass(frozen=True)
 class Query:                       # Query.scala:42-46
     table: str
     select: SelectADT

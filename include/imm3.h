@@ -120,6 +120,30 @@ int imm3_query_create(imm3_ctx *ctx, const imm3_segment *seg,
                       int32_t table_block_size, imm3_query **out);
 int imm3_query_destroy(imm3_query *q);
 
+/* ---- group-by aggregation: ProjectAggOp (engine/.../operator/ProjectAggregate.scala:115-227) over the rows the
+ * SelectOps keep.  CountAggr / MinDoubleAggr / MaxDoubleAggr / MaxStringAggr (:22-112).
+ *   group_cols  indices into used_cols, in the order their values are joined into the group key (the reference
+ *               joins them in batch-column order with "_", :151-156); total width <= 8 bytes on this path
+ *   aggs        {kind, column (index into used_cols)}; MIN/MAX on INT/TINYINT, MAX on STRING (<= 8 bytes), COUNT on any
+ * Groups come back in first-seen order (the reference's LinkedHashMap order): ascending first selected row. ---- */
+enum { IMM3_AGG_COUNT = 0, IMM3_AGG_MIN = 1, IMM3_AGG_MAX = 2 };
+typedef struct {
+    int32_t kind;
+    int32_t column;
+} imm3_aggregate;
+int imm3_query_create_agg(imm3_ctx *ctx, const imm3_segment *seg,
+                          const int32_t *used_cols, int32_t n_used,
+                          const imm3_select *sels, int32_t n_sels,
+                          const int32_t *group_cols, int32_t n_group,
+                          const imm3_aggregate *aggs, int32_t n_aggs,
+                          int32_t table_block_size, imm3_query **out);
+int imm3_query_group_count(imm3_query *q, uint32_t *n_groups);
+/* keys: the group columns' raw bytes packed little-endian in group_cols order; first_row: lowest selected row of
+ * the group; counts: selected rows of the group; vals[g * n_aggs + j]: COUNT -> the count, MIN/MAX numeric -> the
+ * int32 value sign-extended, MAX string -> the value's bytes packed big-endian.  Sorted by first_row. */
+int imm3_query_fetch_groups(imm3_query *q, uint64_t *keys, uint32_t *first_row, uint64_t *counts, int64_t *vals,
+                            uint32_t max_groups);
+
 /* Pre-size the projected-row buffers so that imm3_query_run() never has to wait for the count
  * (fully asynchronous run).  Without it an unlimited projection synchronises once to size them. */
 int imm3_query_reserve_rows(imm3_query *q, uint64_t rows);

@@ -196,3 +196,106 @@ def project(cols, proj: Sequence[int], limit: int, masks: Sequence[np.ndarray]):
             rows.append(tuple(r))
             where.append((k, int(p)))
     return rows, where, would_throw
+
+
+# ------------------------------------------------------------------------------------------------------------
+# ProjectAggOp (engine/src/main/scala/immutabledb/engine/operator/ProjectAggregate.scala:115-227) and the
+# cross-segment combine of ProjectAggregateQueueOp (engine/.../operator/ProjectAggregateQueue.scala:9-55).
+# ------------------------------------------------------------------------------------------------------------
+def java_double_to_string(v: float) -> str:
+    """Double.toString for the integral values the aggregators hold (value.toDouble of an Int / Byte)."""
+    if v != v:
+        return "NaN"
+    iv = int(v)
+    if abs(iv) < 10 ** 7:
+        return f"{iv}.0" if iv != 0 or math.copysign(1.0, v) > 0 else "-0.0"
+    digits = str(abs(iv))
+    mant = digits[0] + "." + (digits[1:].rstrip("0") or "0")
+    return ("-" if iv < 0 else "") + mant + "E" + str(len(digits) - 1)
+
+
+DOUBLE_MIN_VALUE = 4.9e-324              # scala Double.MinValue is -Double.MaxValue; see below
+DOUBLE_MAX = 1.7976931348623157e308
+
+
+def project_agg(cols, group: Sequence[int], aggs: Sequence[Tuple[str, int]], masks: Sequence[np.ndarray]):
+    """One segment.  cols: used columns (dat, offsets, codec, width) in batch order; group: used indices of the
+    group-by columns IN BATCH-COLUMN ORDER (groupCols is built by filtering currVecBatch.columns, :135-140);
+    aggs: [(kind in {'count','min','max'}, used index)] in SELECT-list order; masks: per-batch keep masks.
+    Returns an insertion-ordered dict  groupKey -> [state per aggregate]  (LinkedHashMap, :126) where a state is
+    an int (CountAggr), a float (Max/MinDoubleAggr, started at -/+Double.MaxValue) or a str (MaxStringAggr)."""
+    bounds = [_block_bounds(c[1]) for c in cols]
+    result = {}
+    for k, keep in enumerate(masks):
+        idx = np.flatnonzero(keep)
+        if idx.size == 0:
+            continue
+        need = sorted(set(group) | {c for _, c in aggs})
+        vecs = {}
+        for j in need:
+            dat, _, codec, width = cols[j]
+            s, ln = bounds[j][k]
+            vecs[j] = decode_block(dat[s: s + ln], codec, width)
+
+        def val(j, p):
+            v = vecs[j][p]
+            return bytes(v).decode("utf-8", errors="replace") if cols[j][2] == DENSE_STRING else int(v)
+
+        for p in idx:
+            key = "_".join(str(val(j, p)) for j in group)          # getResultMapKey: mkString("_"), :144
+            st = result.get(key)
+            if st is None:
+                st = []
+                for kind, j in aggs:                                # getNewAggs: fresh aggregators, :146-150
+                    is_str = cols[j][2] == DENSE_STRING
+                    if kind == "count":
+                        st.append(0)
+                    elif is_str:
+                        st.append("")                              # MaxStringAggr.max = "", :80 (also what Min maps to, Engine.scala:145)
+                    elif kind == "max":
+                        st.append(-DOUBLE_MAX)                     # Double.MinValue, :38
+                    else:
+                        st.append(DOUBLE_MAX)                      # Double.MaxValue, :51
+                result[key] = st
+            for a, (kind, j) in enumerate(aggs):
+                v = val(j, p)
+                if kind == "count":
+                    st[a] += 1                                     # CountAggr.add, :24
+                elif isinstance(v, str):
+                    if kind == "min":
+                        raise RefException("bad aggregator for this data type")
+                    st[a] = v if st[a] == "" or v > st[a] else st[a]   # MaxStringAggr.add, :81-83
+                elif kind == "max":
+                    st[a] = float(v) if float(v) > st[a] else st[a]    # MaxDoubleAggr.add, :39
+                else:
+                    st[a] = float(v) if float(v) < st[a] else st[a]    # MinDoubleAggr.add, :52
+    return result
+
+
+def combine_agg(per_segment, aggs: Sequence[Tuple[str, int]]):
+    """ProjectAggregateQueueOp.init: merge the per-segment maps by key, first arrival first (segments in
+    ascending order here; the reference's arrival order is a race).  Returns ordered dict key -> states."""
+    out = {}
+    for seg in per_segment:
+        for key, st in seg.items():
+            cur = out.get(key)
+            if cur is None:
+                out[key] = list(st)
+                continue
+            for a, (kind, _) in enumerate(aggs):
+                if kind == "count":
+                    cur[a] += st[a]
+                elif isinstance(st[a], str):
+                    cur[a] = st[a] if cur[a] == "" or st[a] > cur[a] else cur[a]
+                elif kind == "max":
+                    cur[a] = max(cur[a], st[a])
+                else:
+                    cur[a] = min(cur[a], st[a])
+    return out
+
+
+def agg_repr(state) -> str:
+    """Aggregator.repr: Long.toString / Double.toString / the String."""
+    if isinstance(state, float):
+        return java_double_to_string(state)
+    return str(state)

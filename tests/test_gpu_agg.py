@@ -1,0 +1,179 @@
+"""GPU suite: group-by aggregation (ProjectAggOp / ProjectAggregateQueueOp) through the C ABI and
+the operator mirror, against the oracle's restatement (oracle_np.project_agg / combine_agg)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DENSE_INT, DENSE_STRING, DENSE_TINYINT, EQ, GT, LT, MATCH, RawColumn, blocks_of
+from immutable3_amd import Count, GT as QGT, LT as QLT, And, Match, Max, Min, NoSelect, ProjectAgg, Query, Select, Sum
+from immutable3_amd import native, synth
+from oracle import oracle_np
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KIND = {"count": native.AGG_COUNT, "min": native.AGG_MIN, "max": native.AGG_MAX}
+CODES = [b"CA", b"NY", b"TX", b"WA", b"VA", b"DC", b"CT"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = native.Context(0)
+    yield c
+    c.close()
+
+
+def gpu_groups(ctx, cols, used, sels, group, aggs, block_size=1024):
+    seg = native.DeviceSegment(ctx, [c.native() for c in cols])
+    q = native.DeviceQuery(ctx, seg, used, sels, (), 0, block_size, group_cols=group, aggs=[(KIND[k], c) for k, c in aggs])
+    q.run()
+    keys, first, counts, vals = q.fetch_groups()
+    q.close()
+    seg.close()
+    return keys, first, counts, vals
+
+
+def check(ctx, cols, used, sels, group, aggs, block_size=1024):
+    ucols = [cols[i] for i in used]
+    _, _, masks = oracle_np.scan_select([c.npcol() for c in ucols], sels, block_size)
+    expect = oracle_np.project_agg([c.npcol() for c in ucols], group, aggs, masks)
+    keys, first, counts, vals = gpu_groups(ctx, cols, used, sels, group, aggs, block_size)
+    assert keys.shape[0] == len(expect)
+    got = []
+    for g in range(keys.shape[0]):
+        raw = int(keys[g]).to_bytes(8, "little")
+        parts, off = [], 0
+        for gi in group:
+            c = ucols[gi]
+            chunk = raw[off: off + c.width]
+            parts.append(chunk.decode() if c.codec == DENSE_STRING else str(int.from_bytes(chunk, "little", signed=True)))
+            off += c.width
+        st = []
+        for j, (kind, ci) in enumerate(aggs):
+            c = ucols[ci]
+            if kind == "count":
+                st.append(int(counts[g]))
+            elif c.codec == DENSE_STRING:
+                st.append(int(vals[g, j]).to_bytes(8, "big", signed=True)[8 - c.width:].decode())
+            else:
+                st.append(float(int(vals[g, j])))
+        got.append(("_".join(parts), st))
+    assert got == [(k, v) for k, v in expect.items()]          # same groups, same first-seen order, same values
+    assert (np.diff(first.astype(np.int64)) > 0).all()
+    assert int(counts.sum()) == sum(int(m.sum()) for m in masks)
+    return got
+
+
+def make_cols(rng, n, block_rows, id_range=50):
+    ids = rng.integers(-id_range, id_range, size=n).astype(np.int32)
+    age = rng.integers(-128, 128, size=n).astype(np.int8)
+    st = np.array([list(CODES[i]) for i in rng.integers(0, len(CODES), size=n)], dtype=np.uint8).reshape(n, 2)
+    return [RawColumn(DENSE_INT, 4, ids, block_rows), RawColumn(DENSE_TINYINT, 1, age, block_rows), RawColumn(DENSE_STRING, 2, st, block_rows)]
+
+
+def test_test100_group_by_state_kat(ctx):
+    """Closed form on the C1 table: state = CODES7[i % 7] -> 15,15,14,14,14,14,14 rows; first-seen order CA..CT."""
+    t = synth.test_100()
+    cols = [RawColumn(DENSE_INT, 4, t["id"], [100]), RawColumn(DENSE_STRING, 2, t["state"], [100]), RawColumn(DENSE_TINYINT, 1, t["age"], [100])]
+    got = check(ctx, cols, [0, 1, 2], [], [1], [("count", 0), ("max", 2), ("min", 2), ("max", 0)])
+    assert [k for k, _ in got] == synth.CODES7
+    assert [v[0] for _, v in got] == [15, 15, 14, 14, 14, 14, 14]
+    age = t["age"].astype(int)
+    assert [v[1] for _, v in got] == [float(age[k::7].max()) for k in range(7)]
+    assert [v[3] for _, v in got] == [float(99 - ((99 - k) % 7)) for k in range(7)]
+    # select max(age) from test_100 where (age > 18 and age < 30) -> single group "" (no group by)
+    got = check(ctx, cols, [2], [(0, GT, 18.0), (0, LT, 30.0)], [], [("max", 0), ("count", 0)])
+    assert got == [("", [29.0, 11])]
+
+
+LAYOUTS = [(0, []), (1, [1]), (100, [100]), (1025, [1024, 1]), (25, [4, 4, 1, 4, 4, 1, 4, 3]), (5000, blocks_of(5000, 1024)),
+           (70000, blocks_of(70000, 1024)), (130, [64, 0, 66])]
+
+
+@pytest.mark.parametrize("n,block_rows", LAYOUTS)
+def test_random_group_queries(ctx, n, block_rows):
+    rng = np.random.default_rng(77 + n)
+    for trial in range(4):
+        cols = make_cols(rng, n, block_rows)
+        used = [0, 1, 2]
+        sels = [[], [(1, GT, 0.0)], [(2, MATCH, [b"CA", b"NY", b"TX"])], [(0, GT, -10.0), (0, LT, 10.0)]][trial]
+        group = [[2], [1, 2], [], [0]][trial]
+        aggs = [[("count", 0), ("max", 1)], [("min", 0), ("max", 2), ("count", 2)], [("max", 0), ("min", 1)], [("count", 0), ("min", 1), ("max", 1), ("max", 2)]][trial]
+        check(ctx, cols, used, sels, group, aggs)
+
+
+def test_high_cardinality_groups_spill_past_lds(ctx):
+    """200k rows, ~100k distinct int keys: the per-work-group LDS tables overflow and rows go to the global table."""
+    rng = np.random.default_rng(5)
+    n = 200_000
+    ids = rng.integers(0, 100_000, size=n).astype(np.int32)
+    age = rng.integers(0, 100, size=n).astype(np.int8)
+    cols = [RawColumn(DENSE_INT, 4, ids, blocks_of(n, 1024)), RawColumn(DENSE_TINYINT, 1, age, blocks_of(n, 1024))]
+    check(ctx, cols, [0, 1], [], [0], [("count", 0), ("max", 1), ("min", 1)])
+    # two-column key of 5 bytes incl. negative ints
+    ids2 = rng.integers(-2**31, 2**31, size=3000, dtype=np.int64).astype(np.int32)
+    ids2[::3] = -1
+    cols = [RawColumn(DENSE_INT, 4, ids2, blocks_of(3000, 1024)), RawColumn(DENSE_TINYINT, 1, age[:3000], blocks_of(3000, 1024))]
+    check(ctx, cols, [0, 1], [(1, GT, 10.0)], [0, 1], [("count", 0)])
+
+
+def test_all_ones_key_and_extremes(ctx):
+    """An 8-byte key of all 0xFF bytes (two int columns both -1) uses the table's reserved slot."""
+    a = np.array([-1, -1, 5, -1, 5, -2**31, 2**31 - 1] * 50, dtype=np.int64).astype(np.int32)
+    b = np.array([-1, 7, -1, -1, -1, 0, 0] * 50, dtype=np.int64).astype(np.int32)
+    cols = [RawColumn(DENSE_INT, 4, a, blocks_of(a.size, 64)), RawColumn(DENSE_INT, 4, b, blocks_of(a.size, 64))]
+    got = check(ctx, cols, [0, 1], [], [0, 1], [("count", 0), ("min", 0), ("max", 1)], block_size=64)
+    assert got[0] == ("-1_-1", [100, -1.0, -1.0])
+
+
+def test_agg_errors(ctx):
+    rng = np.random.default_rng(1)
+    cols = make_cols(rng, 100, [100])
+    seg = native.DeviceSegment(ctx, [c.native() for c in cols])
+    with pytest.raises(native.Imm3Error) as e:      # MIN over a String vector: "bad aggregator for this data type"
+        native.DeviceQuery(ctx, seg, [2], [], (), 0, 1024, group_cols=[], aggs=[(native.AGG_MIN, 0)])
+    assert e.value.code == native.ERR_UNSUPPORTED_VECTOR and "bad aggregator" in e.value.msg
+    with pytest.raises(native.Imm3Error):           # unknown aggregate kind
+        native.DeviceQuery(ctx, seg, [0], [], (), 0, 1024, group_cols=[], aggs=[(9, 0)])
+    wide = [RawColumn(DENSE_INT, 4, np.arange(10, dtype=np.int32), [10]) for _ in range(3)]
+    seg2 = native.DeviceSegment(ctx, [c.native() for c in wide])
+    with pytest.raises(native.Imm3Error) as e:      # 12-byte key
+        native.DeviceQuery(ctx, seg2, [0, 1, 2], [], (), 0, 1024, group_cols=[0, 1, 2], aggs=[(native.AGG_COUNT, 0)])
+    assert e.value.code == native.ERR_ARG
+    seg.close(); seg2.close()
+
+
+def test_engine_agg_over_segments_and_double_repr():
+    """Engine.execute on ProjectAgg over the 3-segment quirk_25 table: per-segment ProjectAggOp + combine by key."""
+    from immutable3_amd.operators import Engine, GpuSegmentManager
+    from immutable3_amd.storage import SegmentManager
+    g = GpuSegmentManager(SegmentManager(GOLDEN))
+    q = Query("quirk_25", Select("id", QGT(2)), ProjectAgg([Count("id"), Max("id"), Min("age"), Max("state")], ["state"]))
+    res = Engine(g).execute_agg(q)
+    ids = np.arange(25)
+    states = [synth.CODES7[i % 7] for i in range(25)]
+    ages = (ids * 5) % 11 - 5
+    keep = ids > 2
+    order = []
+    for i in np.flatnonzero(keep):
+        if states[i] not in order:
+            order.append(states[i])
+    assert list(res) == order
+    for s in order:
+        sel = [i for i in np.flatnonzero(keep) if states[i] == s]
+        a = res[s]
+        assert a["id_count"].repr() == str(len(sel))
+        assert a["id_max"].repr() == f"{max(sel)}.0"
+        assert a["age_min"].repr() == f"{int(min(ages[sel]))}.0"
+        assert a["state_max"].repr() == s
+    rows = [tuple(r) for r in Engine(g).execute(q)]
+    assert rows[0] == (res[order[0]]["id_count"].repr(), res[order[0]]["id_max"].repr(), res[order[0]]["age_min"].repr(), order[0])
+    with pytest.raises(Exception, match="Unknown Aggregate type"):
+        list(Engine(g).execute(Query("quirk_25", NoSelect, ProjectAgg([Sum("id")], []))))
+    # Min over a STRING column is mapped to MaxStringAggr by the reference's planner (Engine.scala:145)
+    res = Engine(g).execute_agg(Query("quirk_25", NoSelect, ProjectAgg([Min("state")], [])))
+    assert res[""]["state_min"].repr() == max(states)
+    g.close()
+    from immutable3_amd.operators import java_double_to_string
+    assert [java_double_to_string(v) for v in (0.0, 89.0, -5.0, 9999999.0, 1e7, 12345678.0, 2147483647.0, -2147483648.0)] == \
+        ["0.0", "89.0", "-5.0", "9999999.0", "1.0E7", "1.2345678E7", "2.147483647E9", "-2.147483648E9"]
