@@ -179,6 +179,30 @@ class ScanOp : public ColumnVectorOperator {
                                     sels.data(), (int32_t)sels.size(), proj.data(), (int32_t)proj.size(), limit, t.blockSize, &h.q));
     }
 
+    void makeAggQuery(const std::vector<Leaf> &leaves, const std::vector<int32_t> &group, const std::vector<imm3_aggregate> &aggs, QueryHandle &h) const {
+        const Table &t = table();
+        std::vector<int32_t> used;
+        for (const auto &c : cols_) used.push_back(t.columnIndex(c.name));
+        std::vector<imm3_select> sels(leaves.size());
+        std::vector<std::string> blobs(leaves.size());
+        std::vector<std::vector<int32_t>> lens(leaves.size());
+        for (size_t i = 0; i < leaves.size(); ++i) {
+            sels[i] = imm3_select{};
+            sels[i].column = -1;
+            for (size_t k = 0; k < cols_.size(); ++k) if (cols_[k].name == leaves[i].col) { sels[i].column = (int32_t)k; break; }
+            if (sels[i].column < 0) throw Exception("NoSuchElementException: next on empty iterator");
+            sels[i].cond = (int32_t)leaves[i].cond.kind;
+            sels[i].value = leaves[i].cond.value;
+            for (const auto &v : leaves[i].cond.values) { blobs[i] += v; lens[i].push_back((int32_t)v.size()); }
+            sels[i].match_bytes = (const uint8_t *)blobs[i].data();
+            sels[i].match_lens = lens[i].data();
+            sels[i].n_match = (int32_t)lens[i].size();
+        }
+        imm3Check(imm3_query_create_agg(sm_.ctx(), sm_.deviceSegment(tableName_, segIdx_), used.data(), (int32_t)used.size(),
+                                        sels.data(), (int32_t)sels.size(), group.data(), (int32_t)group.size(),
+                                        aggs.data(), (int32_t)aggs.size(), t.blockSize, &h.q));
+    }
+
     std::unique_ptr<Iterator<ColumnVectorBatch>> batches(const std::vector<Leaf> &leaves) const {
         QueryHandle h;
         makeQuery(leaves, {}, 0, h);
@@ -337,7 +361,136 @@ class ProjectOp : public ProjectionOperator {
     int limit_;
 };
 
-// ---- Engine (Engine.scala:81-197), Project queries ----
+
+// ---- aggregation (engine/.../operator/ProjectAggregate.scala:11-227, ProjectAggregateQueue.scala:9-55) ----
+inline std::string javaDoubleToString(double v) { // Double.toString for the integral values the aggregators hold
+    const long long iv = (long long)v;
+    if (iv > -10000000LL && iv < 10000000LL) return std::to_string(iv) + ".0";
+    std::string digits = std::to_string(iv < 0 ? -iv : iv);
+    std::string frac = digits.substr(1);
+    while (!frac.empty() && frac.back() == '0') frac.pop_back();
+    if (frac.empty()) frac = "0";
+    return std::string(iv < 0 ? "-" : "") + digits[0] + "." + frac + "E" + std::to_string(digits.size() - 1);
+}
+
+struct Aggregator { // CountAggr / MaxDoubleAggr / MinDoubleAggr / MaxStringAggr, folded into one tagged value
+    enum Kind { CountAggr, MaxDoubleAggr, MinDoubleAggr, MaxStringAggr } kind = CountAggr;
+    std::string col, alias;
+    long long counter = 0;
+    double dvalue = 0;
+    std::string svalue;
+    static Aggregator make(Kind k, const std::string &col, const std::string &alias) {
+        Aggregator a;
+        a.kind = k;
+        a.col = col;
+        a.alias = alias;
+        a.dvalue = k == MaxDoubleAggr ? -1.7976931348623157e308 : 1.7976931348623157e308; // Double.MinValue / MaxValue
+        return a;
+    }
+    int abiKind() const { return kind == CountAggr ? IMM3_AGG_COUNT : (kind == MinDoubleAggr ? IMM3_AGG_MIN : IMM3_AGG_MAX); }
+    void combine(const Aggregator &o) { // ProjectAggregateQueue.scala:27-34
+        switch (kind) {
+        case CountAggr: counter += o.counter; break;
+        case MaxDoubleAggr: if (o.dvalue > dvalue) dvalue = o.dvalue; break;
+        case MinDoubleAggr: if (o.dvalue < dvalue) dvalue = o.dvalue; break;
+        case MaxStringAggr: if (svalue.empty() || o.svalue > svalue) svalue = o.svalue; break;
+        }
+    }
+    std::string repr() const {
+        switch (kind) {
+        case CountAggr: return std::to_string(counter);
+        case MaxStringAggr: return svalue;
+        default: return javaDoubleToString(dvalue);
+        }
+    }
+};
+
+using AggMap = std::vector<Aggregator>;                       // alias order = SELECT-list order (see Engine::executeAgg)
+using AggMapTuple = std::pair<std::string, AggMap>;           // (groupKey, aggregators)
+
+// ProjectAggOp(aggs, op, groupBy): one segment, fused on the GPU (scan+select kernel, LDS hash aggregation kernel)
+class ProjectAggOp : public Operator<AggMapTuple> {
+  public:
+    ProjectAggOp(std::vector<Aggregator> aggs, std::shared_ptr<ColumnVectorOperator> op, std::vector<std::string> groupBy)
+        : aggs_(std::move(aggs)), op_(std::move(op)), groupBy_(std::move(groupBy)) {}
+    std::unique_ptr<Iterator<AggMapTuple>> iterator() override {
+        std::vector<Leaf> leaves;
+        std::shared_ptr<ScanOp> scan;
+        if (auto sel = std::dynamic_pointer_cast<SelectOp>(op_)) scan = sel->chain(leaves);
+        else scan = std::dynamic_pointer_cast<ScanOp>(op_);
+        if (!scan) throw Exception("ProjectAggOp must sit on a ScanOp / SelectOp chain for the fused GPU path");
+        SelectOp::checkConditions(leaves);
+        const std::vector<Column> &cols = scan->cols();
+        auto usedIndex = [&](const std::string &n) -> int32_t {
+            for (size_t i = 0; i < cols.size(); ++i) if (cols[i].name == n) return (int32_t)i;
+            throw Exception("NoSuchElementException: key not found: " + n);
+        };
+        // groupCols filters the BATCH columns by membership in groupBy (ProjectAggregate.scala:135-140)
+        std::vector<int32_t> group;
+        for (size_t i = 0; i < cols.size(); ++i)
+            for (const auto &g : groupBy_) if (cols[i].name == g) { group.push_back((int32_t)i); break; }
+        // aggsMap is keyed by alias: a later duplicate replaces an earlier one
+        std::vector<Aggregator> aggs;
+        for (const auto &a : aggs_) {
+            bool replaced = false;
+            for (auto &b : aggs) if (b.alias == a.alias) { b = a; replaced = true; }
+            if (!replaced) aggs.push_back(a);
+        }
+        std::vector<imm3_aggregate> abi(aggs.size());
+        for (size_t j = 0; j < aggs.size(); ++j) { abi[j].kind = aggs[j].abiKind(); abi[j].column = usedIndex(aggs[j].col); }
+        QueryHandle h;
+        scan->makeAggQuery(leaves, group, abi, h);
+        imm3Check(imm3_query_run(h.q));
+        uint32_t n = 0;
+        imm3Check(imm3_query_group_count(h.q, &n));
+        std::vector<uint64_t> keys(n), counts(n);
+        std::vector<uint32_t> first(n);
+        std::vector<int64_t> vals((size_t)n * aggs.size());
+        imm3Check(imm3_query_fetch_groups(h.q, keys.data(), first.data(), counts.data(), vals.data(), n));
+        auto it = std::make_unique<VectorIterator<AggMapTuple>>();
+        for (uint32_t g = 0; g < n; ++g) {
+            std::string key;
+            int off = 0;
+            for (size_t k = 0; k < group.size(); ++k) {
+                const Column &c = cols[(size_t)group[k]];
+                const int w = c.width();
+                uint8_t raw[8] = {0};
+                for (int b = 0; b < w; ++b) raw[b] = (uint8_t)(keys[g] >> (8 * (off + b)));
+                ColumnVector v;
+                v.type = c.columnType;
+                v.width = w;
+                v.data = raw;
+                if (k) key += "_";
+                key += v.value(0).toString(); // mkString("_"), ProjectAggregate.scala:144
+                off += w;
+            }
+            AggMap m = aggs;
+            for (size_t j = 0; j < aggs.size(); ++j) {
+                const int64_t x = vals[(size_t)g * aggs.size() + j];
+                switch (m[j].kind) {
+                case Aggregator::CountAggr: m[j].counter = (long long)counts[g]; break;
+                case Aggregator::MaxStringAggr: {
+                    const int w = cols[(size_t)abi[j].column].width();
+                    std::string sv((size_t)w, '\0');
+                    for (int b = 0; b < w; ++b) sv[(size_t)b] = (char)((uint64_t)x >> (8 * (w - 1 - b)));
+                    m[j].svalue = sv;
+                    break;
+                }
+                default: m[j].dvalue = (double)x;
+                }
+            }
+            it->items.emplace_back(key, std::move(m));
+        }
+        return it;
+    }
+
+  private:
+    std::vector<Aggregator> aggs_;
+    std::shared_ptr<ColumnVectorOperator> op_;
+    std::vector<std::string> groupBy_;
+};
+
+// ---- Engine (Engine.scala:81-197) ----
 class Engine {
   public:
     explicit Engine(GpuSegmentManager &sm) : sm_(sm) {}
@@ -371,8 +524,62 @@ class Engine {
     }
     // one fused pipeline per segment; rows in ascending segment order (the reference's order across segments is
     // unspecified: queue interleaving, Engine.scala:255); `limit` is global, as the consumer-side ProjectOp's is.
+    // Engine.resolveProjectOp (:130-156): default aliases col_max / col_min / col_count; Min over a STRING column
+    // becomes MaxStringAggr (the reference's own mapping, :145); Sum / Avg parse but are rejected (:152).
+    static std::vector<Aggregator> resolveProjectOp(const ProjectADT &p, const Table &table) {
+        std::vector<Aggregator> out;
+        for (const auto &a : p.aggs) {
+            const bool isStr = table.getColumn(a.col).columnType == ColumnType::STRING;
+            switch (a.kind) {
+            case Aggregate::Max: out.push_back(Aggregator::make(isStr ? Aggregator::MaxStringAggr : Aggregator::MaxDoubleAggr, a.col, a.alias.empty() ? a.col + "_max" : a.alias)); break;
+            case Aggregate::Min: out.push_back(Aggregator::make(isStr ? Aggregator::MaxStringAggr : Aggregator::MinDoubleAggr, a.col, a.alias.empty() ? a.col + "_min" : a.alias)); break;
+            case Aggregate::Count: out.push_back(Aggregator::make(Aggregator::CountAggr, a.col, a.alias.empty() ? a.col + "_count" : a.alias)); break;
+            default: throw Exception("Unknown Aggregate type");
+            }
+        }
+        return out;
+    }
+    // ProjectAgg: per-segment ProjectAggOp + ProjectAggregateQueueOp's combine by key (first arrival first; segments
+    // ascending).  Rows list the aggregators' repr in SELECT-list order (the reference iterates a mutable.HashMap
+    // keyed by alias, whose order is not reproduced).
+    std::vector<AggMapTuple> executeAgg(const Query &q) {
+        const Table &table = sm_.sm.getTable(q.table);
+        const std::vector<Column> used = getColumns(q, table);
+        const std::vector<Leaf> leaves = resolveSelectOps(q);
+        const std::vector<Aggregator> aggs = resolveProjectOp(q.project, table);
+        auto mkScan = ScanOp::mkScanOp(sm_, q.table);
+        std::vector<AggMapTuple> result;
+        const int nseg = sm_.sm.getTableSegmentCount(table.name);
+        for (int seg = 0; seg < nseg; ++seg) {
+            std::shared_ptr<ColumnVectorOperator> op = mkScan(used, seg);
+            for (const auto &l : leaves) op = SelectOp::mkSelectOp(l.col, l.cond)(op);
+            ProjectAggOp agg(aggs, op, q.project.groupBy);
+            auto it = agg.iterator();
+            while (it->hasNext()) {
+                AggMapTuple t = it->next();
+                bool merged = false;
+                for (auto &r : result)
+                    if (r.first == t.first) {
+                        for (size_t j = 0; j < r.second.size() && j < t.second.size(); ++j) r.second[j].combine(t.second[j]);
+                        merged = true;
+                        break;
+                    }
+                if (!merged) result.push_back(std::move(t));
+            }
+        }
+        return result;
+    }
     std::vector<Row> execute(const Query &q) {
-        if (q.project.kind != ProjectADT::Project) throw Exception("Only Project queries are on the GPU path (ProjectAgg: SURVEY 8f)");
+        if (q.project.kind == ProjectADT::ProjectAgg) {
+            std::vector<Row> rows;
+            for (const auto &t : executeAgg(q)) {
+                std::vector<Value> xs;
+                for (const auto &a : t.second) xs.push_back(Value::ofString(a.repr()));
+                rows.push_back(Row::fromSeq(std::move(xs)));
+            }
+            return rows;
+        }
+        if (q.project.kind != ProjectADT::Project) throw Exception("NoProject");
         const Table &table = sm_.sm.getTable(q.table);
         const std::vector<Column> used = getColumns(q, table);
         const std::vector<Leaf> leaves = resolveSelectOps(q);

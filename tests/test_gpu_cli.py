@@ -51,3 +51,20 @@ def test_sql_cli_errors():
     assert rc == 1 and "does not exist" in out[0]
     rc, out = run("select id from missing")
     assert rc == 1 and "does not exist in SegmentManager" in out[0]
+
+
+def test_sql_cli_aggregates():
+    """select ... group by through the C++ Engine: per-segment GPU aggregation + combine by key."""
+    rc, out = run("select count(id), max(age) from test_100 group by state")
+    assert rc == 0
+    import numpy as np
+    from immutable3_amd import synth
+    t = synth.test_100()
+    age = t["age"].astype(int)
+    assert out == [f"Row({len(range(k, 100, 7))},{age[k::7].max()}.0)" for k in range(7)]
+    rc, out = run("select max(id), min(id), count(age) from quirk_25 where id > 2")
+    assert rc == 0 and out == ["Row(24.0,3.0,22)"]
+    rc, out = run("select min(state) from quirk_25")          # Min over STRING -> MaxStringAggr (Engine.scala:145)
+    assert rc == 0 and out == ["Row(WA)"]
+    rc, out = run("select sum(id) from quirk_25")
+    assert rc == 1 and out == ["Unknown Aggregate type"]
