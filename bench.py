@@ -310,7 +310,34 @@ def extra_workloads(ctx, native, synth, n, steps: int = 30):
                           "compact_gather": float(np.mean(k[2])) if k[2].size else None},
         }
         q.close()
+    # group-by aggregation: select count(id), max(age) from t [where age > 18 and age < 30] group by state
+    for name, sels in (("agg_group_by_state_all_rows", []),
+                       ("agg_group_by_state_range_age", [(1, native.GT, 18.0), (1, native.LT, 30.0)])):
+        q = native.DeviceQuery(ctx, seg, [1, 2, 0], sels, (), 0, 1024, group_cols=[0], aggs=[(native.AGG_COUNT, 2), (native.AGG_MAX, 1)])
+        for _ in range(2):
+            q.run()
+        torch.cuda.synchronize()
+        ctx.timing_enable(8 * 10 + 8)
+        ctx.timing_mask(0xFFFFFFFF)
+        ctx.timing_reset()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            q.run()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        k0, k4 = ctx.timing_collect(0), ctx.timing_collect(4)
+        ctx.timing_enable(0)
+        keys, first, counts, vals = q.fetch_groups()
+        out[name] = {"rows_per_s": n / dt, "ms_per_query": dt * 1e3, "groups": int(keys.shape[0]), "selected_rows": int(counts.sum()),
+                     "kernel_ms": {"scan_select": float(np.mean(k0)) if k0.size else None, "group_agg": float(np.mean(k4)) if k4.size else None}}
+        q.close()
     seg.close()
+    # host -> HBM staging of one 400 MB column from pageable memory (the step before the path)
+    t0 = time.perf_counter()
+    s2 = native.DeviceSegment(ctx, [(native.DENSE_INT, 4, ids.view(np.uint8), n * 4, synth.block_offsets(n, 4))])
+    dt = time.perf_counter() - t0
+    out["staging_400MB_pageable"] = {"seconds": dt, "GBps": n * 4 / dt / 1e9}
+    s2.close()
     return out
 
 

@@ -6,7 +6,7 @@
 //              in a LinkedHashMap and update one Aggregator per alias (CountAggr.add, Max/MinDoubleAggr.add,
 //              MaxStringAggr.add, :11-112).
 //   here     : the group key is the concatenation of the group columns' raw bytes (<= 8 bytes, u64).  Every
-//              work-group aggregates its spans into an LDS hash table (LDS atomics: no global contention on hot
+//              work-group aggregates its share of the selection bitmap into an LDS hash table (LDS atomics: no global contention on hot
 //              groups), then flushes the table into a global open-addressing table with one atomic set per
 //              (work-group, group).  k_group_collect compacts the occupied entries; the host orders them by
 //              first_row, which IS the LinkedHashMap's first-seen order.
@@ -85,18 +85,130 @@ __device__ __forceinline__ uint32_t global_slot(const AggArgs &a, unsigned long 
     return 0xFFFFFFFFu;
 }
 
-__global__ __launch_bounds__(kBlockThreads) void k_group_agg(const AggArgs a) {
-    __shared__ uint16_t s_list[kSpanWords * 64];              // 32 KiB: in-span positions of the survivors
+// Where a selected row's group lives: slot >= 0 in the work-group's LDS table, or (slot < 0) index gslot of the
+// global table when the LDS table is crowded (many distinct keys).
+struct LdsTable {
+    unsigned long long *keys;
+    uint32_t *first;
+    uint32_t *count;
+    long long *vals;
+};
+
+struct GroupRef {
+    int slot;
+    uint32_t gslot;
+};
+
+// find / insert the key, and account the row itself (first-seen row, count)
+__device__ __forceinline__ GroupRef agg_locate(const AggArgs &a, const LdsTable &t, uint32_t row, unsigned long long key) {
+    GroupRef r{-1, 0xFFFFFFFFu};
+    if (key == kEmptyKey) r.slot = kLdsSlots;
+    else {
+        uint32_t s = hash_key(key) & (kLdsSlots - 1);
+        for (int probes = 0; probes < kMaxProbes; ++probes) {
+            unsigned long long cur = t.keys[s]; // plain read first: after warm-up the key is there and no CAS is needed
+            if (cur == kEmptyKey) cur = atomicCAS(&t.keys[s], kEmptyKey, key);
+            if (cur == kEmptyKey || cur == key) { r.slot = (int)s; break; }
+            s = (s + 1) & (kLdsSlots - 1);
+        }
+    }
+    if (r.slot >= 0) {
+        if (row < t.first[r.slot]) atomicMin(&t.first[r.slot], row);
+        atomicAdd(&t.count[r.slot], 1u);
+    } else {
+        r.gslot = global_slot(a, key);
+        if (r.gslot != 0xFFFFFFFFu) {
+            atomicMin(&a.first[r.gslot], row);
+            atomicAdd(&a.counts[r.gslot], 1ULL);
+        }
+    }
+    return r;
+}
+
+// fold value v of aggregate j into the row's group
+__device__ __forceinline__ void agg_fold(const AggArgs &a, const LdsTable &t, const GroupRef &r, int j, long long v) {
+    const int kind = a.aggs[j].kind;
+    if (kind == AGG_COUNT) return;
+    const bool str = a.aggs[j].is_str;
+    if (r.slot >= 0) {
+        long long *p = &t.vals[r.slot * kMaxAggs + j];
+        // read before the atomic: once a group's extreme is established almost every row is a no-op
+        if (kind == AGG_MIN) { if (v < *p) atomicMin(p, v); }
+        else if (str) { if ((unsigned long long)v > (unsigned long long)*p) atomicMax((unsigned long long *)p, (unsigned long long)v); }
+        else if (v > *p) atomicMax(p, v);
+    } else if (r.gslot != 0xFFFFFFFFu) {
+        long long *p = &a.vals[(size_t)r.gslot * kMaxAggs + j];
+        if (kind == AGG_MIN) atomicMin(p, v);
+        else if (str) atomicMax((unsigned long long *)p, (unsigned long long)v);
+        else atomicMax(p, v);
+    }
+}
+
+__device__ __forceinline__ unsigned long long row_key(const AggArgs &a, int64_t row) {
+    unsigned long long key = 0;
+    for (int g = 0; g < a.n_group; ++g) key |= load_le(a.groups[g].data, row, a.groups[g].width) << (8 * a.groups[g].shift);
+    return key;
+}
+
+constexpr int kAggThreads = 1024;                 // 16 waves share one LDS table
+constexpr int kAggWaves = kAggThreads / 64;
+
+// raw little-endian values of 4 consecutive rows (row0 % 4 == 0) with ONE load of >= 4 bytes per lane.
+// Sub-dword gathers are slow on this chip (measured: 0.49 ms just to load a 2-byte and a 1-byte column of 100 M rows
+// with ushort / sbyte loads); dword / dwordx2 / dwordx4 loads of lane-contiguous rows stream at HBM rate.
+__device__ __forceinline__ void load4_raw(const void *base, int64_t row0, int width, unsigned long long (&out)[4]) {
+    const uint8_t *p = (const uint8_t *)base + row0 * (int64_t)width;
+    switch (width) {
+    case 1: {
+        const uint32_t v = __builtin_nontemporal_load((const uint32_t *)p);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = (v >> (8 * k)) & 0xFFu;
+        break;
+    }
+    case 2: {
+        const uint2 v = *(const uint2 *)p;
+        out[0] = v.x & 0xFFFFu; out[1] = v.x >> 16; out[2] = v.y & 0xFFFFu; out[3] = v.y >> 16;
+        break;
+    }
+    case 4: {
+        const uint4 v = *(const uint4 *)p;
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+        break;
+    }
+    case 8: {
+        const uint4 v0 = *(const uint4 *)p, v1 = *((const uint4 *)p + 1);
+        out[0] = ((unsigned long long)v0.y << 32) | v0.x; out[1] = ((unsigned long long)v0.w << 32) | v0.z;
+        out[2] = ((unsigned long long)v1.y << 32) | v1.x; out[3] = ((unsigned long long)v1.w << 32) | v1.z;
+        break;
+    }
+    default:
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = load_le(base, row0 + k, width);
+    }
+}
+
+// raw little-endian value -> the i64 the tables hold (see agg_value)
+__device__ __forceinline__ long long agg_from_raw(const AggCol &a, unsigned long long raw) {
+    if (a.kind == AGG_COUNT) return 0;
+    if (a.is_str) return (long long)(__builtin_bswap64(raw) >> (8 * (8 - a.width))); // big-endian pack
+    if (a.width == 4) return (long long)(int32_t)(uint32_t)raw;
+    return (long long)(int8_t)(uint8_t)raw;
+}
+
+// Uniform layout: one wave step = 4 consecutive bitmap words = 256 rows; lane l owns rows 4l .. 4l+3 of the step
+// (bits = nibble l&15 of word l>>4) and loads them with one >= 4-byte load per column.  Steps without a survivor are
+// skipped before any column load.  Ragged layout: lane l <-> row base(word) + l, one word per step.
+__global__ __launch_bounds__(kAggThreads) void k_group_agg(const AggArgs a) {
     __shared__ unsigned long long s_keys[kLdsSlots + 1];      // 8 KiB
     __shared__ uint32_t s_first[kLdsSlots + 1];               // 4 KiB
     __shared__ uint32_t s_count[kLdsSlots + 1];               // 4 KiB
     __shared__ long long s_vals[(kLdsSlots + 1) * kMaxAggs];  // 32 KiB
-    __shared__ uint32_t s_wave[kWavesPerBlock];
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = t >> 6;
+    const LdsTable tab{s_keys, s_first, s_count, s_vals};
 
-    for (int i = t; i <= kLdsSlots; i += kBlockThreads) {
+    for (int i = t; i <= kLdsSlots; i += kAggThreads) {
         s_keys[i] = kEmptyKey;
         s_first[i] = 0xFFFFFFFFu;
         s_count[i] = 0;
@@ -108,72 +220,58 @@ __global__ __launch_bounds__(kBlockThreads) void k_group_agg(const AggArgs a) {
     }
     __syncthreads();
 
-    const int64_t n_spans = (a.n_tiles + kSpanTiles - 1) / kSpanTiles;
-    for (int64_t span = blockIdx.x; span < n_spans; span += gridDim.x) {
-        // survivors of the span -> ascending list in LDS (same scheme as k_gather)
-        const int64_t w = span * kSpanWords + t;
-        uint64_t word = w < a.n_words ? a.bitmap[w] : 0ULL;
-        const uint32_t pc = (uint32_t)__popcll(word);
-        uint32_t incl = pc;
+    const int64_t stride = (int64_t)gridDim.x * kAggWaves;
+    if (!a.word_row_base) {
+        const int64_t n_steps = (a.n_words + 3) / 4;
+        for (int64_t st = (int64_t)blockIdx.x * kAggWaves + wave; st < n_steps; st += stride) {
+            const int64_t w = st * 4 + (lane >> 4);
+            const uint64_t word = w < a.n_words ? a.bitmap[w] : 0ULL; // 16 lanes share an address: 4 x 8 B per wave
+            const uint32_t nib = (uint32_t)(word >> (4 * (lane & 15))) & 0xFu;
+            if (!__ballot(nib != 0)) continue; // wave-uniform: nothing selected in these 256 rows
+            const int64_t row0 = st * 256 + 4 * lane;
+            // group key of the lane's 4 rows, one column at a time (keeps few registers live)
+            unsigned long long key[4] = {0, 0, 0, 0};
+            for (int g = 0; g < a.n_group; ++g) {
+                unsigned long long raw[4];
+                load4_raw(a.groups[g].data, row0, a.groups[g].width, raw);
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d);
-            if (lane >= d) incl += up;
-        }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        uint32_t off = incl - pc, total = 0;
-#pragma unroll
-        for (int i = 0; i < kWavesPerBlock; ++i) {
-            if (i < wave) off += s_wave[i];
-            total += s_wave[i];
-        }
-        while (word) {
-            const int b = __builtin_ctzll(word);
-            s_list[off++] = (uint16_t)(t * 64 + b);
-            word &= word - 1;
-        }
-        __syncthreads();
-        for (uint32_t i = t; i < total; i += kBlockThreads) {
-            const uint32_t r = s_list[i];
-            const int64_t row = a.word_row_base ? (int64_t)a.word_row_base[span * kSpanWords + (r >> 6)] + (r & 63)
-                                                : span * (int64_t)(kSpanWords * 64) + r;
-            unsigned long long key = 0;
-            for (int g = 0; g < a.n_group; ++g) key |= load_le(a.groups[g].data, row, a.groups[g].width) << (8 * a.groups[g].shift);
-            long long vals[kMaxAggs];
-            for (int j = 0; j < a.n_agg; ++j) vals[j] = agg_value(a.aggs[j], row);
-            // LDS table
-            int slot = -1;
-            if (key == kEmptyKey) slot = kLdsSlots;
-            else {
-                uint32_t s = hash_key(key) & (kLdsSlots - 1);
-                for (int probes = 0; probes < kMaxProbes; ++probes) {
-                    const unsigned long long prev = atomicCAS(&s_keys[s], kEmptyKey, key);
-                    if (prev == kEmptyKey || prev == key) { slot = (int)s; break; }
-                    s = (s + 1) & (kLdsSlots - 1);
-                }
+                for (int k = 0; k < 4; ++k) key[k] |= raw[k] << (8 * a.groups[g].shift);
             }
-            if (slot >= 0) {
-                atomicMin(&s_first[slot], (uint32_t)row);
-                atomicAdd(&s_count[slot], 1u);
-                for (int j = 0; j < a.n_agg; ++j) {
-                    long long *v = &s_vals[slot * kMaxAggs + j];
-                    if (a.aggs[j].kind == AGG_MIN) atomicMin(v, vals[j]);
-                    else if (a.aggs[j].kind == AGG_MAX) {
-                        if (a.aggs[j].is_str) atomicMax((unsigned long long *)v, (unsigned long long)vals[j]);
-                        else atomicMax(v, vals[j]);
-                    }
-                }
-            } else { // the work-group's table is crowded (many distinct keys): straight to the global table
-                const uint32_t g = global_slot(a, key);
-                if (g != 0xFFFFFFFFu) agg_update_global(a, g, (uint32_t)row, 1ULL, vals);
+            if (a.debug == 1) { // ablation: key loads only
+                asm volatile("" ::"v"((uint32_t)key[0]), "v"((uint32_t)key[3]));
+                continue;
+            }
+            GroupRef ref[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ref[k] = GroupRef{-1, 0xFFFFFFFFu};
+                if ((nib >> k) & 1u) ref[k] = agg_locate(a, tab, (uint32_t)(row0 + k), key[k]);
+            }
+            // then every aggregate column: one load for the 4 rows, fold, next column
+            for (int q = 0; q < a.n_agg; ++q) {
+                if (a.aggs[q].kind == AGG_COUNT) continue;
+                unsigned long long raw[4];
+                load4_raw(a.aggs[q].data, row0, a.aggs[q].width, raw);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if ((nib >> k) & 1u) agg_fold(a, tab, ref[k], q, agg_from_raw(a.aggs[q], raw[k]));
             }
         }
-        __syncthreads(); // s_list / s_wave are reused by the next span
+    } else {
+        for (int64_t w = (int64_t)blockIdx.x * kAggWaves + wave; w < a.n_words; w += stride) {
+            const uint64_t word = a.bitmap[w];
+            if (word == 0) continue; // wave-uniform
+            if ((word >> lane) & 1ULL) {
+                const int64_t row = (int64_t)a.word_row_base[w] + lane;
+                const GroupRef ref = agg_locate(a, tab, (uint32_t)row, row_key(a, row));
+                for (int q = 0; q < a.n_agg; ++q) agg_fold(a, tab, ref, q, agg_value(a.aggs[q], row));
+            }
+        }
     }
+    __syncthreads();
 
     // flush: one atomic set per (work-group, group)
-    for (int i = t; i <= kLdsSlots; i += kBlockThreads) {
+    for (int i = t; i <= kLdsSlots; i += kAggThreads) {
         if (s_count[i] == 0) continue;
         const unsigned long long key = i == kLdsSlots ? kEmptyKey : s_keys[i];
         const uint32_t g = global_slot(a, key);
@@ -228,9 +326,9 @@ void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_
     const int64_t n = (int64_t)a.mask + 2;
     const int init_grid = (int)std::min<int64_t>((n + kBlockThreads - 1) / kBlockThreads, 2048);
     hipLaunchKernelGGL(k_group_init, dim3(init_grid), dim3(kBlockThreads), 0, s, a);
-    const int64_t n_spans = (a.n_tiles + kSpanTiles - 1) / kSpanTiles;
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_spans, 512)); // 80 KiB of LDS per work-group: 2 per CU
-    hipExtLaunchKernelGGL(k_group_agg, dim3(grid), dim3(kBlockThreads), 0, s, ev0, ev1, 0, a);
+    const int64_t want = ((a.n_words + 3) / 4 + kAggWaves - 1) / kAggWaves;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, 512)); // 1024-thread work-groups, 48 KiB LDS: 2 per CU
+    hipExtLaunchKernelGGL(k_group_agg, dim3(grid), dim3(kAggThreads), 0, s, ev0, ev1, 0, a);
 }
 
 void launch_group_collect(const AggArgs &a, hipStream_t s) {

@@ -998,6 +998,7 @@ static void fill_agg_args(const imm3_query *q, AggArgs &a) {
     a.bitmap = q->d_bitmap;
     a.n_words = q->n_words;
     a.n_tiles = q->n_tiles;
+    a.n_rows = q->n_rows;
     a.word_row_base = q->d_word_row_base;
     int shift = 0;
     for (size_t g = 0; g < q->group_cols.size(); ++g) {
@@ -1034,6 +1035,7 @@ static int run_agg(imm3_query *q) {
     imm3_ctx *ctx = q->ctx;
     AggArgs a;
     fill_agg_args(q, a);
+    a.debug = ctx->filter_variant >= 100 ? ctx->filter_variant - 100 : 0;
     LaunchTimer t(ctx, 4);
     launch_group_agg(a, ctx->stream, t.start, t.stop);
     HIPCHK(hipGetLastError());

@@ -136,11 +136,12 @@ struct AggCol {
 
 struct AggArgs {
     const uint64_t *bitmap;
-    int64_t n_words, n_tiles;
+    int64_t n_words, n_tiles, n_rows;
     const uint32_t *word_row_base; // ragged layout, else null
     GroupCol groups[kMaxGroupCols];
     AggCol aggs[kMaxAggs];
     int32_t n_group, n_agg;
+    int32_t debug, pad;          // ablation switch for experiments (0 in production)
     // global open-addressing table: mask + 1 slots, plus one for the all-ones key
     unsigned long long *keys;
     uint32_t *first;             // first (lowest) selected row of the group
