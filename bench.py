@@ -95,11 +95,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the immutable3 hot path has no CPU fallback")
+    # Rehearsal knobs (not used by the driver): IMM3_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # IMM3_BENCH_BACKEND=gloo swaps RCCL for gloo, so the N > 1 code path can be exercised on a 1-GPU box.
+    if os.environ.get("IMM3_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("IMM3_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # "nccl" IS RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
 
     from immutable3_amd import native, synth
 
@@ -142,6 +150,7 @@ def main():
         q = queries[i % len(queries)]
         q.run_select()                                   # fused ScanOp -> SelectOp(GT) -> SelectOp(LT) kernel
         if world > 1:                                    # final selected-row-count reduction over RCCL / xGMI
+            q.join_count()                               # the count is reduced on the library's aux stream
             counts[i:i + 1].copy_(views[i % len(queries)])
             works.append(dist.all_reduce(counts[i:i + 1], op=dist.ReduceOp.SUM, async_op=True))
 

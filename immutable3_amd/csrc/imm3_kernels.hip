@@ -395,6 +395,18 @@ template <typename T>
 __device__ __forceinline__ void copy_elem(const void *src, void *dst, int64_t row, uint64_t out) {
     ((T *)dst)[out] = ((const T *)src)[row];
 }
+// 1- and 2-byte values are fetched as the aligned dword that contains them: sub-dword global loads are several
+// times slower per instruction on this chip (see imm3_agg.hip), and neighbouring survivors share the dword anyway.
+template <>
+__device__ __forceinline__ void copy_elem<uint8_t>(const void *src, void *dst, int64_t row, uint64_t out) {
+    const uint32_t v = ((const uint32_t *)src)[row >> 2];
+    ((uint8_t *)dst)[out] = (uint8_t)(v >> (8 * (row & 3)));
+}
+template <>
+__device__ __forceinline__ void copy_elem<uint16_t>(const void *src, void *dst, int64_t row, uint64_t out) {
+    const uint32_t v = ((const uint32_t *)src)[row >> 1];
+    ((uint16_t *)dst)[out] = (uint16_t)(v >> (16 * (row & 1)));
+}
 
 __global__ __launch_bounds__(kBlockThreads) void k_gather(const GatherArgs a) {
     __shared__ uint16_t s_list[kSpanWords * 64]; // 32 KiB

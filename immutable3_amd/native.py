@@ -29,7 +29,7 @@ EXPORTS = [
     "imm3_segment_create", "imm3_segment_wrap_device", "imm3_segment_destroy", "imm3_segment_bytes",
     "imm3_query_create", "imm3_query_create_agg", "imm3_query_group_count", "imm3_query_fetch_groups",
     "imm3_query_destroy", "imm3_query_reserve_rows",
-    "imm3_query_run", "imm3_query_run_select", "imm3_query_sync",
+    "imm3_query_run", "imm3_query_run_select", "imm3_query_sync", "imm3_query_join_count",
     "imm3_query_layout", "imm3_query_batches", "imm3_query_count", "imm3_query_bitmap",
     "imm3_query_row_count", "imm3_query_fetch_rows", "imm3_query_device_ptr",
     "imm3_ctx_timing_enable", "imm3_ctx_timing_reset", "imm3_ctx_timing_mask", "imm3_ctx_timing_collect", "imm3_ctx_set_tuning",
@@ -104,6 +104,7 @@ def load() -> C.CDLL:
     L.imm3_query_run.argtypes = [vp]
     L.imm3_query_run_select.argtypes = [vp]
     L.imm3_query_sync.argtypes = [vp]
+    L.imm3_query_join_count.argtypes = [vp]
     L.imm3_query_layout.argtypes = [vp, P(i32), P(i64), P(i64)]
     L.imm3_query_batches.argtypes = [vp, vp, vp, vp]
     L.imm3_query_count.argtypes = [vp, P(u64)]
@@ -306,6 +307,9 @@ class DeviceQuery:
 
     def sync(self):
         _check(load().imm3_query_sync(self._h))
+
+    def join_count(self):
+        _check(load().imm3_query_join_count(self._h))
 
     def count(self) -> int:
         n = C.c_uint64(0)

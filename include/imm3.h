@@ -155,6 +155,10 @@ int imm3_query_run(imm3_query *q);
 /* Only the ScanOp -> SelectOp* part (selection bitmap + count). */
 int imm3_query_run_select(imm3_query *q);
 int imm3_query_sync(imm3_query *q);
+/* The selected-row count of a select-only run is reduced on the context's auxiliary stream so that it overlaps the
+ * next scan.  Host getters wait for it by themselves; a DEVICE consumer of imm3_query_device_ptr(q, 1) that runs on
+ * the context's main stream calls this first: it makes the main stream wait (stream-side, no host block). */
+int imm3_query_join_count(imm3_query *q);
 
 /* ---- results ---- */
 /* Batches as ScanOp yields them (FilledColumnVectorBatch, core/DataVector.scala:24-31): */
