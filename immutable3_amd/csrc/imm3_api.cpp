@@ -713,7 +713,9 @@ static int run_select(imm3_query *q, bool overlap_total) {
         a.n_tiles = q->n_tiles;
         a.bitmap = q->d_bitmap;
         a.block_partials = q->d_block_partials;
-        grid = filter_grid(q->n_tiles, false, ctx->grid_blocks);
+        bool any_i32 = false;
+        for (int k = 0; k < kMaxTileCols; ++k) any_i32 |= (a.kinds[k] == TK_I32);
+        grid = filter_grid(q->n_tiles, false, any_i32 || n == 0, ctx->grid_blocks);
         LaunchTimer t(ctx, 0);
         if (!launch_filter_tile(a, grid, s, t.start, t.stop)) return fail(IMM3_ERR_ARG, "internal: no tile kernel for this column combination");
         HIPCHK(hipGetLastError());
@@ -736,7 +738,7 @@ static int run_select(imm3_query *q, bool overlap_total) {
         a.block_partials = q->d_block_partials;
         a.word_row_base = q->d_word_row_base;
         a.word_nvalid = q->d_word_nvalid;
-        grid = filter_grid(q->n_words, true, ctx->grid_blocks);
+        grid = filter_grid(q->n_words, true, false, ctx->grid_blocks);
         {
             LaunchTimer t(ctx, 0);
             launch_filter_generic(a, grid, s, t.start, t.stop);

@@ -162,7 +162,7 @@ void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_
 void launch_group_collect(const AggArgs &a, hipStream_t s);
 
 constexpr int kMaxFilterGrid = 4096; // capacity of block_partials
-int filter_grid(int64_t units, bool generic, int grid_blocks);
+int filter_grid(int64_t units, bool generic, bool any_i32, int grid_blocks);
 // ev0/ev1: optional events stamped with the kernel's own start/end (hipExtLaunchKernelGGL), else null
 bool launch_filter_tile(const TileArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 void launch_filter_generic(const FilterArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
