@@ -59,6 +59,7 @@ struct TileArgs {
     int64_t n_rows, n_words, n_tiles;
     uint64_t *bitmap;
     uint32_t *block_partials;
+    void *stage[kMaxTileCols];      // per column: dense per-tile staging of the survivors' values, or null
 };
 
 struct FilterArgs {
@@ -95,6 +96,7 @@ struct ScanArgs {
 struct ProjCol {
     const void *src;             // flat column
     void *dst;                   // packed output, width bytes per emitted row
+    const void *staged;          // survivors' values staged per tile by the filter kernel (width 4 or 1), or null
     int32_t width;
     int32_t pad;
 };
@@ -111,6 +113,7 @@ struct GatherArgs {
     ProjCol proj[kMaxProj];
     int32_t n_proj;
     int32_t pad;
+    int64_t n_staged_tiles;        // tiles [0, n) have staged values (the full tiles)
     const uint32_t *word_row_base; // ragged layout, else null
 };
 

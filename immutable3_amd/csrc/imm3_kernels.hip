@@ -180,11 +180,72 @@ struct ColRegs<TK_S2> {
     __device__ __forceinline__ bool row(const TileCol &c, int64_t r) { return hit(c, ((const uint16_t *)c.data)[r]); }
 };
 
-// AND the per-kind results of one FULL tile (registers already loaded), store its bitmap line, return in
-// lanes 0..15 the popcount of the words they own.
+// ---- survivor staging -------------------------------------------------------------------------------------
+// When a SELECT-list column is also a predicate column its values are already in registers here.  Instead of
+// letting k_gather re-read the whole column (at 10 % selectivity nearly every 64-byte sector is touched again),
+// the survivors' values of the tile are compacted -- rank = number of set bits below the row -- through a small
+// per-wave LDS buffer and stored DENSELY at stage[tile * 1024 + rank].  k_gather then copies from there.
+template <int KIND>
+struct StageBytes { static constexpr int value = 0; };
+template <> struct StageBytes<TK_I32> { static constexpr int value = kTileRows * 4; };
+template <> struct StageBytes<TK_I8> { static constexpr int value = kTileRows; };
+
+// LDS hand-off between the lanes of ONE wave: LDS operations of a wave complete in order, so draining lgkmcnt is
+// enough (a workgroup-scope fence would also wait for every outstanding global load/store: vmcnt(0)); the asm
+// memory clobber keeps the compiler from moving LDS accesses across it.
+__device__ __forceinline__ void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <int KIND>
+__device__ __forceinline__ void stage_col(ColRegs<KIND> &, void *, int64_t, int, uint64_t, uint32_t, uint32_t, uint8_t *) {}
+
+template <>
+__device__ __forceinline__ void stage_col<TK_I32>(ColRegs<TK_I32> &c, void *stage, int64_t tile, int lane, uint64_t mine,
+                                                  uint32_t wprefix, uint32_t cnt, uint8_t *lds) {
+    if (!stage) return; // wave-uniform
+    uint32_t *l = (uint32_t *)lds;
+#pragma unroll
+    for (int j = 0; j < kTileWords; ++j) { // lane l holds row 64j + l of the tile
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, j);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), j);
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)wprefix, j);
+        const uint64_t m = ((uint64_t)hi << 32) | lo;
+        if ((m >> lane) & 1ULL) l[base + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u))] = (uint32_t)c.v[j];
+    }
+    lds_wave_sync();
+    uint32_t *out = (uint32_t *)stage + tile * kTileRows;
+    for (uint32_t i = lane; i < cnt; i += 64) out[i] = l[i];
+    lds_wave_sync();
+}
+
+template <>
+__device__ __forceinline__ void stage_col<TK_I8>(ColRegs<TK_I8> &c, void *stage, int64_t tile, int lane, uint64_t mine,
+                                                 uint32_t wprefix, uint32_t cnt, uint8_t *lds) {
+    if (!stage) return;
+    // lane l holds rows 16l .. 16l+15 = bits [16(l&3), +16) of word l>>2
+    const int wi = lane >> 2, bo = 16 * (lane & 3);
+    const uint32_t wlo = lane_read((uint32_t)mine, wi), whi = lane_read((uint32_t)(mine >> 32), wi);
+    const uint64_t word = ((uint64_t)whi << 32) | wlo;
+    const uint32_t base = lane_read(wprefix, wi) + (uint32_t)__popcll(word & ((1ULL << bo) - 1ULL));
+    const uint32_t bits = (uint32_t)(word >> bo) & 0xFFFFu;
+    // walk the lane's set bits only (popcount iterations instead of 16 predicated steps)
+    const uint64_t blo = ((uint64_t)(uint32_t)c.v[1] << 32) | (uint32_t)c.v[0], bhi = ((uint64_t)(uint32_t)c.v[3] << 32) | (uint32_t)c.v[2];
+    uint32_t pos = base;
+    for (uint32_t b = bits; b; b &= b - 1u) {
+        const int k = __builtin_ctz(b);
+        lds[pos++] = (uint8_t)((k < 8 ? blo : bhi) >> (8 * (k & 7)));
+    }
+    lds_wave_sync();
+    uint32_t *out = (uint32_t *)((uint8_t *)stage + tile * kTileRows);
+    const uint32_t ndw = (cnt + 3) >> 2; // whole dwords; the tile's staging slot is 1024 bytes, so over-copy is harmless
+    for (uint32_t i = lane; i < ndw; i += 64) out[i] = ((const uint32_t *)lds)[i];
+    lds_wave_sync();
+}
+
+// AND the per-kind results of one FULL tile (registers already loaded), store its bitmap line, stage survivors'
+// values where asked, return in lanes 0..15 the popcount of the words they own.
 template <int K0, int K1, int K2>
 __device__ __forceinline__ uint32_t finish_full_tile(const TileArgs &a, int64_t tile, int lane, ColRegs<K0> &c0,
-                                                     ColRegs<K1> &c1, ColRegs<K2> &c2) {
+                                                     ColRegs<K1> &c1, ColRegs<K2> &c2, uint8_t *lds) {
     constexpr bool any_i32 = (K0 == TK_I32) || (K1 == TK_I32) || (K2 == TK_I32);
     const int64_t w = tile * kTileWords + lane; // lane j < 16 owns bitmap word j of the tile
     uint64_t mine = ~0ULL;
@@ -198,15 +259,32 @@ __device__ __forceinline__ uint32_t finish_full_tile(const TileArgs &a, int64_t 
     if (any_i32) mine &= words_to_lanes(acc);
     if (lane >= kTileWords) mine = 0;
     if (lane < kTileWords) __builtin_nontemporal_store(mine, a.bitmap + w); // 16 lanes x 8 B = one 128-B line
-    return (uint32_t)__popcll(mine);
+    const uint32_t pc = (uint32_t)__popcll(mine);
+    if (a.stage[0] || a.stage[1] || a.stage[2]) { // wave-uniform
+        uint32_t incl = pc; // exclusive prefix of the word popcounts over lanes 0..15
+#pragma unroll
+        for (int d = 1; d < kTileWords; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        const uint32_t wprefix = incl - pc;
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)incl, kTileWords - 1);
+        stage_col<K0>(c0, a.stage[0], tile, lane, mine, wprefix, cnt, lds);
+        stage_col<K1>(c1, a.stage[1], tile, lane, mine, wprefix, cnt, lds + StageBytes<K0>::value);
+        stage_col<K2>(c2, a.stage[2], tile, lane, mine, wprefix, cnt, lds + StageBytes<K0>::value + StageBytes<K1>::value);
+    }
+    return pc;
 }
 
 // T = tiles per wave iteration: narrow columns take several tiles at once so that every wave keeps >= 4 KiB of
 // loads in flight (8 waves/CU x 4 KiB is what saturates HBM, see the header comment).
 template <int K0, int K1, int K2, int T>
 __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a) {
+    constexpr int kStage = StageBytes<K0>::value + StageBytes<K1>::value + StageBytes<K2>::value;
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerBlock][kStage > 0 ? kStage : 16];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    uint8_t *lds = s_stage[wave];
     uint32_t lane_total = 0; // lanes 0..15: survivors in the words they stored
     const int64_t n_full = a.n_rows / kTileRows;
     const int64_t n_groups = n_full / T;
@@ -225,7 +303,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
             c2[t].load(a.cols[2], row0, lane);
         }
 #pragma unroll
-        for (int t = 0; t < T; ++t) lane_total += finish_full_tile<K0, K1, K2>(a, grp * T + t, lane, c0[t], c1[t], c2[t]);
+        for (int t = 0; t < T; ++t) lane_total += finish_full_tile<K0, K1, K2>(a, grp * T + t, lane, c0[t], c1[t], c2[t], lds);
     }
     // leftovers: fewer than T full tiles, then the one partial tile at the end of the segment
     for (int64_t tile = n_groups * T + wave_id; tile < a.n_tiles; tile += n_waves) {
@@ -237,7 +315,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
             c0.load(a.cols[0], row0, lane);
             c1.load(a.cols[1], row0, lane);
             c2.load(a.cols[2], row0, lane);
-            lane_total += finish_full_tile<K0, K1, K2>(a, tile, lane, c0, c1, c2);
+            lane_total += finish_full_tile<K0, K1, K2>(a, tile, lane, c0, c1, c2, lds);
         } else { // rolled, bounds-checked
             const int64_t w = tile * kTileWords + lane;
             uint64_t mine = ~0ULL;
@@ -411,6 +489,7 @@ __device__ __forceinline__ void copy_elem<uint16_t>(const void *src, void *dst, 
 __global__ __launch_bounds__(kBlockThreads) void k_gather(const GatherArgs a) {
     __shared__ uint16_t s_list[kSpanWords * 64]; // 32 KiB
     __shared__ uint32_t s_wave[kWavesPerBlock];
+    __shared__ uint32_t s_toff[kSpanTiles];       // survivors of the span before each of its tiles
     __shared__ unsigned long long s_base;
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -436,6 +515,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_gather(const GatherArgs a) {
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
             if (lane == 0) s_base = part + a.tile_offsets[tile0];
+            if (lane < kSpanTiles) s_toff[lane] = tile0 + lane < a.n_tiles ? a.tile_offsets[tile0 + lane] - a.tile_offsets[tile0] : 0xFFFFFFFFu;
         }
         __syncthreads();
         uint32_t off = incl - pc;
@@ -467,8 +547,15 @@ __global__ __launch_bounds__(kBlockThreads) void k_gather(const GatherArgs a) {
                                     ? (int64_t)a.word_row_base[span * kSpanWords + (r >> 6)] + (r & 63)
                                     : span * (int64_t)(kSpanWords * 64) + r;
             if (a.row_index) a.row_index[out] = (uint32_t)row;
+            const int64_t tile = tile0 + (r >> 10);
             for (int pj = 0; pj < a.n_proj; ++pj) {
                 const ProjCol &pc2 = a.proj[pj];
+                if (pc2.staged && tile < a.n_staged_tiles) { // survivors' values were compacted per tile by the filter kernel
+                    const int64_t sidx = tile * kTileRows + (i - s_toff[r >> 10]);
+                    if (pc2.width == 4) ((uint32_t *)pc2.dst)[out] = ((const uint32_t *)pc2.staged)[sidx];
+                    else copy_elem<uint8_t>(pc2.staged, pc2.dst, sidx, out);
+                    continue;
+                }
                 switch (pc2.width) {
                 case 4: copy_elem<uint32_t>(pc2.src, pc2.dst, row, out); break;
                 case 1: copy_elem<uint8_t>(pc2.src, pc2.dst, row, out); break;

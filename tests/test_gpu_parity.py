@@ -242,3 +242,19 @@ def test_rerun_and_two_queries(ctx, oracle):
     assert q2.count() == c2 and q2.bitmap().tolist() == w2.tolist()
     assert q1.row_count() == c1 and q2.row_count() == min(5, c2)
     q1.close(); q2.close(); seg.close()
+
+
+# ---- survivor staging (projected column == predicate column): every selectivity incl. 0 % and 100 % ----------
+@pytest.mark.parametrize("lo,hi", [(-1.0, 1e9), (1e9, 2e9), (0.0, 2.0), (49.0, 51.0), (10.0, 90.0)])
+def test_staged_projection_selectivities(ctx, oracle, lo, hi):
+    rng = np.random.default_rng(int(lo) + 7)
+    n = 300_000 + 37
+    ids = rng.integers(0, 100, size=n).astype(np.int32)
+    age = rng.integers(0, 100, size=n).astype(np.int8)
+    other = rng.integers(-5, 5, size=n).astype(np.int32)
+    br = blocks_of(n, 1024)
+    cols = [RawColumn(DENSE_INT, 4, ids, br), RawColumn(DENSE_TINYINT, 1, age, br), RawColumn(DENSE_INT, 4, other, br)]
+    # both projected columns are predicate columns (staged); `other` is gathered the ordinary way
+    check(ctx, oracle, cols, [1, 0, 2], [(0, GT, lo), (0, LT, hi), (1, GT, lo), (1, LT, hi)], proj=[1, 0, 2, 1])
+    check(ctx, oracle, cols, [0], [(0, GT, lo), (0, LT, hi)], proj=[0])
+    check(ctx, oracle, cols, [1], [(0, GT, lo), (0, LT, hi)], proj=[0])
