@@ -55,3 +55,56 @@ class ShardedCount:
         mine = owned_segments(self.n_segments, self.rank, self.world)
         local = sum(int(self.local_count(s)) for s in mine)
         return local, allreduce_count(local, self.device)
+
+
+def allgather_groups(local_groups):
+    """Group-by partial aggregates of every rank -> every rank.  `local_groups` is a picklable list of
+    (segIdx, position_in_segment, groupKey, [state per aggregate]) for the segments this rank owns.  The tables are
+    tiny (one row per group per segment), so one all_gather_object is the whole exchange -- the second and last
+    collective of the path (after the count all-reduce)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return list(local_groups)
+    gathered = [None] * dist.get_world_size()
+    dist.all_gather_object(gathered, list(local_groups))
+    return [g for part in gathered for g in part]
+
+
+def merge_groups(groups, kinds):
+    """ProjectAggregateQueueOp's combine (engine/.../operator/ProjectAggregateQueue.scala:17-49) over the gathered
+    partials, first arrival first with arrival order DEFINED as (segment index, first-seen position) -- the same
+    result on every rank and the same as a single process visiting the segments in ascending order.
+    kinds: per aggregate 'count' | 'min' | 'max' | 'maxstr'.  Returns an ordered dict key -> [states]."""
+    out = {}
+    for segIdx, pos, key, states in sorted(groups, key=lambda g: (g[0], g[1])):
+        cur = out.get(key)
+        if cur is None:
+            out[key] = list(states)
+            continue
+        for j, kind in enumerate(kinds):
+            if kind == "count":
+                cur[j] += states[j]
+            elif kind == "min":
+                cur[j] = min(cur[j], states[j])
+            elif kind == "max":
+                cur[j] = max(cur[j], states[j])
+            else:  # MaxStringAggr: "" means unset
+                cur[j] = states[j] if cur[j] == "" or states[j] > cur[j] else cur[j]
+    return out
+
+
+class ShardedAggregate:
+    """`select agg(..) .. group by ..` over segments sharded s mod G: every rank aggregates its own segments with
+    `local_agg(seg) -> ordered [(groupKey, [states])]` (the GPU hash-aggregation kernel through the C ABI), the
+    per-segment group tables are all-gathered and merged."""
+
+    def __init__(self, n_segments: int, rank: int, world: int, local_agg, kinds):
+        self.n_segments, self.rank, self.world, self.local_agg, self.kinds = n_segments, rank, world, local_agg, list(kinds)
+
+    def run(self):
+        local = []
+        for seg in owned_segments(self.n_segments, self.rank, self.world):
+            for pos, (key, states) in enumerate(self.local_agg(seg)):
+                local.append((seg, pos, key, list(states)))
+        return merge_groups(allgather_groups(local), self.kinds)

@@ -76,3 +76,52 @@ def test_single_process_identity():
     assert [owner_of(s, 8) for s in range(10)] == [0, 1, 2, 3, 4, 5, 6, 7, 0, 1]
     local, total = ShardedCount(3, 0, 1, lambda s: s + 1).run()
     assert local == total == 6
+
+
+def _agg_worker(rank, world, port, n_segments, out):
+    import torch.distributed as dist
+    from immutable3_amd.distributed import ShardedAggregate
+    from oracle import oracle_np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def local_agg(seg):
+        cols, masks = _agg_segment(seg)
+        res = oracle_np.project_agg(cols, [1], AGGS, masks)
+        return list(res.items())
+
+    merged = ShardedAggregate(n_segments, rank, world, local_agg, ["count", "max", "min"]).run()
+    out[rank] = list(merged.items())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+AGGS = [("count", 0), ("max", 0), ("min", 0)]
+
+
+def _agg_segment(seg, n=3000):
+    from immutable3_amd import synth
+    from oracle import oracle_np
+    ids = synth.uniform_below(300 + seg, n, 1000, np.int32)
+    grp = synth.uniform_below(400 + seg, n, 5 + seg, np.int8)          # later segments introduce new groups
+    br = blocks_of(n, 1024)
+    a = RawColumn(DENSE_INT, 4, ids, br)
+    b = RawColumn(2, 1, grp, br)
+    cols = [a.npcol(), b.npcol()]
+    _, _, masks = oracle_np.scan_select(cols, [(0, GT, 100.0)], 1024)
+    return cols, masks
+
+
+def test_world2_sharded_aggregate():
+    from oracle import oracle_np
+    world, n_segments = 2, 5
+    port = _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_agg_worker, args=(world, port, n_segments, out), nprocs=world, join=True)
+    per_seg = []
+    for seg in range(n_segments):
+        cols, masks = _agg_segment(seg)
+        per_seg.append(oracle_np.project_agg(cols, [1], AGGS, masks))
+    expect = oracle_np.combine_agg(per_seg, AGGS)
+    assert out[0] == out[1] == [(k, v) for k, v in expect.items()]
