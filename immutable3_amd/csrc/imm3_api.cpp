@@ -212,6 +212,41 @@ extern "C" int imm3_ctx_set_tuning(imm3_ctx *ctx, int32_t filter_variant, int32_
     return IMM3_OK;
 }
 
+extern "C" int imm3_ctx_measure_read_gbps(imm3_ctx *ctx, uint64_t bytes, int32_t iters, double *gbps) {
+    if (!ctx || !gbps) return fail(IMM3_ERR_ARG, "null argument");
+    if (iters < 1) iters = 1;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n_tiles = (int64_t)(bytes / (kTileRows * 4));
+    if (n_tiles < 1) return fail(IMM3_ERR_ARG, "bytes too small");
+    const size_t sz = (size_t)n_tiles * kTileRows * 4;
+    void *buf[3] = {nullptr, nullptr, nullptr};
+    void *sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    for (auto &b : buf) {
+        HIPCHK(hipMalloc(&b, sz));
+        HIPCHK(hipMemsetAsync(b, 0x11, sz, ctx->stream));
+    }
+    HIPCHK(hipMalloc(&sink, 64));
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    std::vector<float> ms;
+    for (int i = 0; i < iters + 3; ++i) {
+        launch_read_stream((const int32_t *)buf[i % 3], n_tiles, (int32_t *)sink, ctx->stream, e0, e1);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventSynchronize(e1));
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, e0, e1));
+        if (i >= 3) ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    *gbps = (double)sz / (ms[ms.size() / 2] * 1e-3) / 1e9;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    for (auto &b : buf) (void)hipFree(b);
+    (void)hipFree(sink);
+    return IMM3_OK;
+}
+
 extern "C" int imm3_ctx_timing_enable(imm3_ctx *ctx, int32_t max_records) {
     if (!ctx) return fail(IMM3_ERR_ARG, "ctx is null");
     HIPCHK(hipSetDevice(ctx->device));

@@ -170,6 +170,7 @@ int filter_grid(int64_t units, bool generic, bool any_i32, int grid_blocks);
 bool launch_filter_tile(const TileArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 void launch_filter_generic(const FilterArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 void launch_total(const TotalArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+void launch_read_stream(const int32_t *data, int64_t n_tiles, int32_t *sink, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 void launch_scan(const ScanArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 void launch_gather(const GatherArgs &a, int grid_blocks, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 

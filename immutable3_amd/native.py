@@ -32,7 +32,7 @@ EXPORTS = [
     "imm3_query_run", "imm3_query_run_select", "imm3_query_sync", "imm3_query_join_count",
     "imm3_query_layout", "imm3_query_batches", "imm3_query_count", "imm3_query_bitmap",
     "imm3_query_row_count", "imm3_query_fetch_rows", "imm3_query_device_ptr",
-    "imm3_ctx_timing_enable", "imm3_ctx_timing_reset", "imm3_ctx_timing_mask", "imm3_ctx_timing_collect", "imm3_ctx_set_tuning",
+    "imm3_ctx_timing_enable", "imm3_ctx_timing_reset", "imm3_ctx_timing_mask", "imm3_ctx_timing_collect", "imm3_ctx_set_tuning", "imm3_ctx_measure_read_gbps",
 ]
 
 
@@ -117,6 +117,7 @@ def load() -> C.CDLL:
     L.imm3_ctx_timing_mask.argtypes = [vp, C.c_uint32]
     L.imm3_ctx_timing_collect.argtypes = [vp, i32, vp, i32, P(i32)]
     L.imm3_ctx_set_tuning.argtypes = [vp, i32, i32]
+    L.imm3_ctx_measure_read_gbps.argtypes = [vp, u64, i32, P(C.c_double)]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ("imm3_last_error",):
@@ -158,6 +159,11 @@ class Context:
 
     def set_tuning(self, filter_variant: int = 0, grid_blocks: int = 0):
         _check(load().imm3_ctx_set_tuning(self._h, filter_variant, grid_blocks))
+
+    def measure_read_gbps(self, nbytes: int = 400_000_000, iters: int = 30) -> float:
+        g = C.c_double(0.0)
+        _check(load().imm3_ctx_measure_read_gbps(self._h, nbytes, iters, C.byref(g)))
+        return g.value
 
     def timing_enable(self, max_records: int):
         _check(load().imm3_ctx_timing_enable(self._h, max_records))

@@ -189,6 +189,10 @@ int imm3_ctx_timing_mask(imm3_ctx *ctx, uint32_t kernel_mask);
 /* Synchronises, then writes up to cap durations (ms) of launches of `kernel_id`, oldest first. */
 int imm3_ctx_timing_collect(imm3_ctx *ctx, int32_t kernel_id, float *ms_out, int32_t cap, int32_t *n_out);
 
+/* Empirical read-only streaming ceiling of this GPU: times a kernel that only reads `bytes` (non-temporal dword loads,
+ * same tiling and grid as the scan+select kernel, three rotated buffers) and returns the median GB/s over `iters`. */
+int imm3_ctx_measure_read_gbps(imm3_ctx *ctx, uint64_t bytes, int32_t iters, double *gbps);
+
 /* Tuning knobs (0 = default): filter variant, grid size in workgroups.  For experiments/bench. */
 int imm3_ctx_set_tuning(imm3_ctx *ctx, int32_t filter_variant, int32_t grid_blocks);
 
