@@ -207,6 +207,7 @@ def main():
     ctx.timing_enable(args.steps + 8)
     ctx.timing_mask(1 << 0)
     ctx.timing_reset()
+    ctx.devclock_enable(args.steps + 8)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for i in range(args.steps):
@@ -216,7 +217,9 @@ def main():
     torch.cuda.synchronize()
     elapsed_events = time.perf_counter() - t1
     kernel_ms = ctx.timing_collect(0)
+    devclock_ms = ctx.devclock_collect()
     ctx.timing_enable(0)
+    ctx.devclock_enable(0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -271,8 +274,10 @@ def main():
                 "kernel_ms_mean": mean_ms,
                 "kernel_ms_min": float(np.min(kernel_ms)) if kernel_ms.size else None,
                 "kernel_launches_timed": int(kernel_ms.size),
+                "kernel_ms_mean_device_clock": float(np.mean(devclock_ms)) if devclock_ms.size else None,
                 "timing": "HIP events stamped by hipExtLaunchKernelGGL on the launching stream, second pass of the same K steps; "
-                          "reads ~4 us above rocprofv3's kernel-only duration (start stamp precedes dispatch), see DESIGN.md section 6",
+                          "reads ~4 us above rocprofv3's kernel-only duration (start stamp precedes dispatch), see DESIGN.md section 6; "
+                          "kernel_ms_mean_device_clock = first work-group entry to last work-group exit on the 100 MHz device clock, same launches",
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ROW * n,
                 "empirical_read_ceiling_GBps": read_ceiling,
                 "frac_of_empirical_read_ceiling": (achieved / read_ceiling) if read_ceiling else None,

@@ -51,6 +51,10 @@ struct imm3_ctx {
     uint32_t timing_mask = 0xFFFFFFFFu;
     std::vector<TimingRecord> pool; // pre-created event pairs
     size_t used = 0;
+    // device-clock stamps (diagnostics): slot i = kMaxFilterGrid {start, end} pairs for the i-th tile launch
+    unsigned long long *d_stamps = nullptr;
+    int32_t stamp_slots = 0, stamp_used = 0;
+    std::vector<int32_t> stamp_grids;
 };
 
 struct SegCol {
@@ -186,6 +190,7 @@ extern "C" int imm3_ctx_destroy(imm3_ctx *ctx) {
         (void)hipEventDestroy(r.stop);
     }
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+    (void)hipFree(ctx->d_stamps);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return IMM3_OK;
@@ -209,6 +214,41 @@ extern "C" int imm3_ctx_set_tuning(imm3_ctx *ctx, int32_t filter_variant, int32_
     if (!ctx) return fail(IMM3_ERR_ARG, "ctx is null");
     ctx->filter_variant = filter_variant;
     ctx->grid_blocks = grid_blocks;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_ctx_devclock_enable(imm3_ctx *ctx, int32_t max_launches) {
+    if (!ctx) return fail(IMM3_ERR_ARG, "ctx is null");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->d_stamps);
+    ctx->d_stamps = nullptr;
+    ctx->stamp_slots = 0;
+    ctx->stamp_used = 0;
+    ctx->stamp_grids.clear();
+    if (max_launches > 0) {
+        void *p = nullptr;
+        HIPCHK(hipMalloc(&p, (size_t)max_launches * kMaxFilterGrid * 2 * sizeof(unsigned long long)));
+        ctx->d_stamps = (unsigned long long *)p;
+        ctx->stamp_slots = max_launches;
+    }
+    return IMM3_OK;
+}
+
+extern "C" int imm3_ctx_devclock_collect(imm3_ctx *ctx, float *ms_out, int32_t cap, int32_t *n_out) {
+    if (!ctx || !n_out) return fail(IMM3_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const int32_t n = ctx->stamp_used;
+    std::vector<unsigned long long> h((size_t)kMaxFilterGrid * 2);
+    for (int32_t i = 0; i < n && i < cap; ++i) {
+        const int32_t g = ctx->stamp_grids[(size_t)i];
+        HIPCHK(hipMemcpy(h.data(), ctx->d_stamps + (size_t)i * kMaxFilterGrid * 2, (size_t)g * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long lo = ~0ULL, hi = 0;
+        for (int32_t b = 0; b < g; ++b) { lo = std::min(lo, h[(size_t)2 * b]); hi = std::max(hi, h[(size_t)2 * b + 1]); }
+        if (ms_out) ms_out[i] = (float)((double)(hi - lo) / 100000.0); // 100 MHz ticks -> ms
+    }
+    *n_out = n;
     return IMM3_OK;
 }
 
@@ -781,10 +821,12 @@ static int run_select(imm3_query *q, bool overlap_total) {
         a.block_partials = q->d_block_partials;
         bool any_i32 = false;
         for (int k = 0; k < kMaxTileCols; ++k) any_i32 |= (a.kinds[k] == TK_I32);
+        if (ctx->d_stamps && ctx->stamp_used < ctx->stamp_slots) a.stamps = ctx->d_stamps + (size_t)ctx->stamp_used * kMaxFilterGrid * 2;
         grid = filter_grid(q->n_tiles, false, any_i32 || n == 0, ctx->grid_blocks);
         // staging adds ~2x the VALU work per tile: 8 work-groups per CU overlap it with the loads (measured on C3:
         // filter+stage 135 us at 512 WGs, 102 us at 2048; whole query 198 us unstaged -> 169 us)
         if (q->stage_written && ctx->grid_blocks <= 0) grid = filter_grid(q->n_tiles, true, false, 0);
+        if (a.stamps) { ctx->stamp_grids.push_back(grid); ++ctx->stamp_used; }
         LaunchTimer t(ctx, 0);
         if (!launch_filter_tile(a, grid, s, t.start, t.stop)) return fail(IMM3_ERR_ARG, "internal: no tile kernel for this column combination");
         HIPCHK(hipGetLastError());

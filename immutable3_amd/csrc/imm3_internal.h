@@ -60,6 +60,7 @@ struct TileArgs {
     uint64_t *bitmap;
     uint32_t *block_partials;
     void *stage[kMaxTileCols];      // per column: dense per-tile staging of the survivors' values, or null
+    unsigned long long *stamps;     // diagnostics only: per work-group {start, end} of the 100 MHz device clock, or null
 };
 
 struct FilterArgs {

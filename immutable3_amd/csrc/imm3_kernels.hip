@@ -285,6 +285,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint8_t *lds = s_stage[wave];
+    if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x] = wall_clock64(); // instrumented pass of bench.py only
     uint32_t lane_total = 0; // lanes 0..15: survivors in the words they stored
     const int64_t n_full = a.n_rows / kTileRows;
     const int64_t n_groups = n_full / T;
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) lane_total += __shfl_xor(lane_total, d); // lanes 0..15 -> lane 0
     block_partial_store(a.block_partials, lane_total, lane, wave);
+    if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x + 1] = wall_clock64(); // after the barrier in the store above
 }
 
 // ---------------------------------------------------------------------------------------------

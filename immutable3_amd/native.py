@@ -32,7 +32,7 @@ EXPORTS = [
     "imm3_query_run", "imm3_query_run_select", "imm3_query_sync", "imm3_query_join_count",
     "imm3_query_layout", "imm3_query_batches", "imm3_query_count", "imm3_query_bitmap",
     "imm3_query_row_count", "imm3_query_fetch_rows", "imm3_query_device_ptr",
-    "imm3_ctx_timing_enable", "imm3_ctx_timing_reset", "imm3_ctx_timing_mask", "imm3_ctx_timing_collect", "imm3_ctx_set_tuning", "imm3_ctx_measure_read_gbps",
+    "imm3_ctx_timing_enable", "imm3_ctx_timing_reset", "imm3_ctx_timing_mask", "imm3_ctx_timing_collect", "imm3_ctx_set_tuning", "imm3_ctx_measure_read_gbps", "imm3_ctx_devclock_enable", "imm3_ctx_devclock_collect",
 ]
 
 
@@ -118,6 +118,8 @@ def load() -> C.CDLL:
     L.imm3_ctx_timing_collect.argtypes = [vp, i32, vp, i32, P(i32)]
     L.imm3_ctx_set_tuning.argtypes = [vp, i32, i32]
     L.imm3_ctx_measure_read_gbps.argtypes = [vp, u64, i32, P(C.c_double)]
+    L.imm3_ctx_devclock_enable.argtypes = [vp, i32]
+    L.imm3_ctx_devclock_collect.argtypes = [vp, vp, i32, P(i32)]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ("imm3_last_error",):
@@ -164,6 +166,15 @@ class Context:
         g = C.c_double(0.0)
         _check(load().imm3_ctx_measure_read_gbps(self._h, nbytes, iters, C.byref(g)))
         return g.value
+
+    def devclock_enable(self, max_launches: int):
+        _check(load().imm3_ctx_devclock_enable(self._h, max_launches))
+
+    def devclock_collect(self, cap: int = 65536) -> np.ndarray:
+        out = np.zeros(cap, dtype=np.float32)
+        n = C.c_int32(0)
+        _check(load().imm3_ctx_devclock_collect(self._h, out.ctypes.data, cap, C.byref(n)))
+        return out[: min(n.value, cap)]
 
     def timing_enable(self, max_records: int):
         _check(load().imm3_ctx_timing_enable(self._h, max_records))

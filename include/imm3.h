@@ -189,6 +189,12 @@ int imm3_ctx_timing_mask(imm3_ctx *ctx, uint32_t kernel_mask);
 /* Synchronises, then writes up to cap durations (ms) of launches of `kernel_id`, oldest first. */
 int imm3_ctx_timing_collect(imm3_ctx *ctx, int32_t kernel_id, float *ms_out, int32_t cap, int32_t *n_out);
 
+/* Cross-check of the event timing: when enabled, every tile-kernel launch also records, per work-group, the 100 MHz
+ * device clock at entry and exit; collect() returns per launch (last work-group's exit - first work-group's entry) in
+ * ms, oldest first.  Diagnostics only (bench.py's instrumented pass); costs two stores per work-group. */
+int imm3_ctx_devclock_enable(imm3_ctx *ctx, int32_t max_launches);
+int imm3_ctx_devclock_collect(imm3_ctx *ctx, float *ms_out, int32_t cap, int32_t *n_out);
+
 /* Empirical read-only streaming ceiling of this GPU: times a kernel that only reads `bytes` (non-temporal dword loads,
  * same tiling and grid as the scan+select kernel, three rotated buffers) and returns the median GB/s over `iters`. */
 int imm3_ctx_measure_read_gbps(imm3_ctx *ctx, uint64_t bytes, int32_t iters, double *gbps);
