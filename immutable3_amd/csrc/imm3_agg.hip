@@ -228,12 +228,15 @@ __global__ __launch_bounds__(kAggThreads) void k_group_agg(const AggArgs a) {
             const uint64_t word = w < a.n_words ? a.bitmap[w] : 0ULL; // 16 lanes share an address: 4 x 8 B per wave
             const uint32_t nib = (uint32_t)(word >> (4 * (lane & 15))) & 0xFu;
             if (!__ballot(nib != 0)) continue; // wave-uniform: nothing selected in these 256 rows
-            const int64_t row0 = st * 256 + 4 * lane;
+            const int64_t row0 = st * 256 + 4 * lane;                 // (virtual) row of the lane's first row
+            const int64_t tile = st >> 2;                              // table queries address columns through the tile table
+            const int64_t in_tile = (st & 3) * 256 + 4 * lane;
             // group key of the lane's 4 rows, one column at a time (keeps few registers live)
             unsigned long long key[4] = {0, 0, 0, 0};
             for (int g = 0; g < a.n_group; ++g) {
                 unsigned long long raw[4];
-                load4_raw(a.groups[g].data, row0, a.groups[g].width, raw);
+                if (a.groups[g].tile_ptrs) load4_raw(a.groups[g].tile_ptrs[tile], in_tile, a.groups[g].width, raw);
+                else load4_raw(a.groups[g].data, row0, a.groups[g].width, raw);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) key[k] |= raw[k] << (8 * a.groups[g].shift);
             }
@@ -251,7 +254,8 @@ __global__ __launch_bounds__(kAggThreads) void k_group_agg(const AggArgs a) {
             for (int q = 0; q < a.n_agg; ++q) {
                 if (a.aggs[q].kind == AGG_COUNT) continue;
                 unsigned long long raw[4];
-                load4_raw(a.aggs[q].data, row0, a.aggs[q].width, raw);
+                if (a.aggs[q].tile_ptrs) load4_raw(a.aggs[q].tile_ptrs[tile], in_tile, a.aggs[q].width, raw);
+                else load4_raw(a.aggs[q].data, row0, a.aggs[q].width, raw);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if ((nib >> k) & 1u) agg_fold(a, tab, ref[k], q, agg_from_raw(a.aggs[q], raw[k]));

@@ -71,6 +71,16 @@ struct imm3_segment {
     uint64_t device_bytes = 0;
 };
 
+struct imm3_table { // all segments of one table as one scan unit: the tile table
+    imm3_ctx *ctx = nullptr;
+    std::vector<const imm3_segment *> segs;
+    std::vector<int64_t> seg_rows;     // rows per segment
+    std::vector<int64_t> tile_start;   // n_segs + 1: first (virtual) tile of each segment
+    int64_t n_tiles = 0, n_rows = 0;
+    uint32_t *d_tile_rows = nullptr;   // valid rows per tile
+    std::vector<void **> d_tile_ptrs;  // per column: device array of per-tile pointers
+};
+
 struct FoldedPred { // all SelectOp leaves on one segment column, folded
     int32_t seg_col = 0;
     int32_t kind = 0, width = 0;
@@ -82,7 +92,10 @@ struct FoldedPred { // all SelectOp leaves on one segment column, folded
 
 struct imm3_query {
     imm3_ctx *ctx = nullptr;
-    const imm3_segment *seg = nullptr;
+    const imm3_segment *seg = nullptr;   // the segment (table queries: the first one, for the schema)
+    const imm3_table *table = nullptr;   // table query: columns are addressed through the tile table
+    std::vector<int32_t> seg_first_batch; // table query: n_segs + 1
+    std::vector<int64_t> seg_first_word;  // table query: n_segs + 1
     std::vector<int32_t> used;     // segment column index of each used column
     std::vector<int32_t> proj;     // index into `used`
     int64_t limit = 0;
@@ -351,7 +364,7 @@ struct LaunchTimer {
 // ---------------------------------------------------------------------------------------------
 // segment
 // ---------------------------------------------------------------------------------------------
-static constexpr uint64_t kPad = 4096; // readable slack past every column so wide loads never fault
+static constexpr uint64_t kPad = 16384; // readable slack past every column: a partial last tile is read as a whole (1024 rows x <= 16 B)
 
 static int segment_build(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, bool wrap, imm3_segment **out) {
     if (!ctx || !out) return fail(IMM3_ERR_ARG, "null argument");
@@ -462,7 +475,57 @@ static int ensure_row_capacity(imm3_query *q, uint64_t rows) {
     return IMM3_OK;
 }
 
-extern "C" int imm3_query_create(imm3_ctx *ctx, const imm3_segment *seg,
+
+// Batches of ONE segment as ScanOp yields them: the FIRST used column defines them (Scan.scala:55,72); BlockIterator
+// takes each block by a relative get from a rewound buffer (Segment.scala:159-168), i.e. from a running cursor.
+// Every other used column must hold the same rows in the same blocks, otherwise the reference either throws
+// ArrayIndexOutOfBounds (shorter) or silently joins the wrong rows (longer): refused.
+struct SegLayout {
+    std::vector<int32_t> size, oid;
+    std::vector<int64_t> word_off; // within the segment's own bitmap
+    int64_t rows = 0, words = 0;
+    bool ragged = false;
+};
+
+static int segment_layout(const imm3_segment *seg, const std::vector<int32_t> &used, int32_t table_block_size, SegLayout &L) {
+    const SegCol &first = seg->cols[(size_t)used[0]];
+    const int32_t nb = first.offsets.empty() ? 0 : (int32_t)first.offsets.size() - 1;
+    L.size.resize((size_t)nb);
+    L.oid.resize((size_t)nb);
+    L.word_off.resize((size_t)nb);
+    uint64_t cursor = 0;
+    for (int32_t k = 0; k < nb; ++k) {
+        const int64_t len = (int64_t)first.offsets[(size_t)k + 1] - (int64_t)first.offsets[(size_t)k];
+        if (len < 0) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": negative length (NegativeArraySizeException in the reference)");
+        if (len % first.width) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": byte length is not a multiple of the value width (malformed segment)");
+        if (cursor + (uint64_t)len > first.bytes) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": bytes [" + std::to_string(cursor) + ", " + std::to_string(cursor + (uint64_t)len) + ") run past the segment data of " + std::to_string(first.bytes) + " bytes (BufferUnderflowException in the reference)");
+        const int64_t n = len / first.width;
+        L.size[(size_t)k] = (int32_t)n;
+        L.oid[(size_t)k] = (int32_t)((uint32_t)k * (uint32_t)table_block_size); // vecCounter * table.blockSize
+        L.word_off[(size_t)k] = L.words;
+        if (k < nb - 1 && (n % 64)) L.ragged = true;
+        L.words += (n + 63) / 64;
+        L.rows += n;
+        cursor += (uint64_t)len;
+    }
+    if (L.rows > 0xFFFFFFFFLL) return fail(IMM3_ERR_LAYOUT, "segment too large");
+    for (size_t i = 1; i < used.size(); ++i) {
+        const SegCol &sc = seg->cols[(size_t)used[i]];
+        const int32_t nbc = sc.offsets.empty() ? 0 : (int32_t)sc.offsets.size() - 1;
+        if (nbc < nb) return fail(IMM3_ERR_LAYOUT, "used column " + std::to_string(i) + " has fewer blocks than the first used column (ArrayIndexOutOfBounds in the reference)");
+        uint64_t cur = 0;
+        for (int32_t k = 0; k < nb; ++k) {
+            const int64_t len = (int64_t)sc.offsets[(size_t)k + 1] - (int64_t)sc.offsets[(size_t)k];
+            if (len < 0 || len % sc.width || len / sc.width != L.size[(size_t)k])
+                return fail(IMM3_ERR_LAYOUT, "used column " + std::to_string(i) + " block " + std::to_string(k) + " does not hold the same rows as the first used column");
+            if (cur + (uint64_t)len > sc.bytes) return fail(IMM3_ERR_LAYOUT, "used column " + std::to_string(i) + " block " + std::to_string(k) + " runs past the segment data");
+            cur += (uint64_t)len;
+        }
+    }
+    return IMM3_OK;
+}
+
+static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_table *table,
                                  const int32_t *used_cols, int32_t n_used,
                                  const imm3_select *sels, int32_t n_sels,
                                  const int32_t *proj, int32_t n_proj, int64_t limit,
@@ -495,14 +558,48 @@ extern "C" int imm3_query_create(imm3_ctx *ctx, const imm3_segment *seg,
     std::unique_ptr<imm3_query, void (*)(imm3_query *)> q(new imm3_query(), query_free);
     q->ctx = ctx;
     q->seg = seg;
+    q->table = table;
     q->used.assign(used_cols, used_cols + n_used);
     q->proj.assign(proj, proj + n_proj);
     q->limit = limit;
 
-    // (2) batches: the FIRST used column defines them (Scan.scala:55,72); BlockIterator takes each block
-    //     by a relative get from a rewound buffer (Segment.scala:159-168), i.e. from a running cursor.
-    const SegCol &first = seg->cols[(size_t)q->used[0]];
-    const int32_t nb = first.offsets.empty() ? 0 : (int32_t)first.offsets.size() - 1;
+    // (2) batches (segment_layout); a table query concatenates the segments' batches, each segment's bitmap starting
+    //     on a fresh tile of the virtual row space
+    int32_t nb = 0;
+    if (!table) {
+        SegLayout L;
+        const int lrc = segment_layout(seg, q->used, table_block_size, L);
+        if (lrc) return lrc;
+        nb = (int32_t)L.size.size();
+        q->batch_size = L.size;
+        q->batch_oid = L.oid;
+        q->batch_word_off = L.word_off;
+        q->n_rows = L.rows;
+        q->n_words = L.words;
+        q->ragged = L.ragged;
+        q->n_tiles = (q->n_words + kTileWords - 1) / kTileWords;
+    } else {
+        for (size_t si = 0; si < table->segs.size(); ++si) {
+            SegLayout L;
+            const int lrc = segment_layout(table->segs[si], q->used, table_block_size, L);
+            if (lrc) return lrc;
+            if (L.ragged || L.rows != table->seg_rows[si]) return fail(IMM3_ERR_LAYOUT, "segment " + std::to_string(si) + " does not have the uniform layout a table query needs");
+            q->seg_first_batch.push_back((int32_t)q->batch_size.size());
+            q->seg_first_word.push_back(table->tile_start[si] * kTileWords);
+            for (size_t k = 0; k < L.size.size(); ++k) {
+                q->batch_size.push_back(L.size[k]);
+                q->batch_oid.push_back(L.oid[k]);
+                q->batch_word_off.push_back(table->tile_start[si] * kTileWords + L.word_off[k]);
+            }
+        }
+        q->seg_first_batch.push_back((int32_t)q->batch_size.size());
+        q->seg_first_word.push_back(table->n_tiles * kTileWords);
+        nb = (int32_t)q->batch_size.size();
+        q->n_rows = table->n_rows;
+        q->n_tiles = table->n_tiles;
+        q->n_words = table->n_tiles * kTileWords; // virtual: every segment padded to whole tiles
+    }
+    q->n_chunks = (q->n_tiles + kChunkTiles - 1) / kChunkTiles;
 
     if (nb >= 1) {
         // ScanOp.next dispatches on the codec of every used column (Scan.scala:37-50) ...
@@ -520,48 +617,6 @@ extern "C" int imm3_query_create(imm3_ctx *ctx, const imm3_segment *seg,
             if ((sels[i].cond == IMM3_MATCH) != is_str) return fail(IMM3_ERR_UNSUPPORTED_VECTOR, "Unsupported column vector");
         }
     }
-
-    q->batch_size.resize((size_t)nb);
-    q->batch_oid.resize((size_t)nb);
-    q->batch_word_off.resize((size_t)nb);
-    {
-        uint64_t cursor = 0;
-        int64_t words = 0, rows = 0;
-        for (int32_t k = 0; k < nb; ++k) {
-            const int64_t len = (int64_t)first.offsets[(size_t)k + 1] - (int64_t)first.offsets[(size_t)k];
-            if (len < 0) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": negative length (NegativeArraySizeException in the reference)");
-            if (len % first.width) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": byte length is not a multiple of the value width (malformed segment)");
-            if (cursor + (uint64_t)len > first.bytes) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": bytes [" + std::to_string(cursor) + ", " + std::to_string(cursor + (uint64_t)len) + ") run past the segment data of " + std::to_string(first.bytes) + " bytes (BufferUnderflowException in the reference)");
-            const int64_t n = len / first.width;
-            q->batch_size[(size_t)k] = (int32_t)n;
-            q->batch_oid[(size_t)k] = (int32_t)((uint32_t)k * (uint32_t)table_block_size); // vecCounter * table.blockSize
-            q->batch_word_off[(size_t)k] = words;
-            if (k < nb - 1 && (n % 64)) q->ragged = true;
-            words += (n + 63) / 64;
-            rows += n;
-            cursor += (uint64_t)len;
-        }
-        q->n_rows = rows;
-        q->n_words = words;
-    }
-    if (q->n_rows > 0xFFFFFFFFLL) return fail(IMM3_ERR_LAYOUT, "segment too large");
-    // every other used column must hold the same rows in the same blocks, otherwise the reference either
-    // throws ArrayIndexOutOfBounds (shorter) or silently joins the wrong rows (longer): refused here.
-    for (int32_t i = 1; i < n_used; ++i) {
-        const SegCol &sc = seg->cols[(size_t)q->used[(size_t)i]];
-        const int32_t nbc = sc.offsets.empty() ? 0 : (int32_t)sc.offsets.size() - 1;
-        if (nbc < nb) return fail(IMM3_ERR_LAYOUT, "used column " + std::to_string(i) + " has fewer blocks than the first used column (ArrayIndexOutOfBounds in the reference)");
-        uint64_t cursor = 0;
-        for (int32_t k = 0; k < nb; ++k) {
-            const int64_t len = (int64_t)sc.offsets[(size_t)k + 1] - (int64_t)sc.offsets[(size_t)k];
-            if (len < 0 || len % sc.width || len / sc.width != q->batch_size[(size_t)k])
-                return fail(IMM3_ERR_LAYOUT, "used column " + std::to_string(i) + " block " + std::to_string(k) + " does not hold the same rows as the first used column");
-            if (cursor + (uint64_t)len > sc.bytes) return fail(IMM3_ERR_LAYOUT, "used column " + std::to_string(i) + " block " + std::to_string(k) + " runs past the segment data");
-            cursor += (uint64_t)len;
-        }
-    }
-    q->n_tiles = (q->n_words + kTileWords - 1) / kTileWords;
-    q->n_chunks = (q->n_tiles + kChunkTiles - 1) / kChunkTiles;
 
     // (3) fold the SelectOp leaves per column.  Every leaf only clears bits (Select.scala:37,68,106,144) and
     //     runOps ignores AND/OR (Engine.scala:240), so the chain is a conjunction and order is irrelevant.
@@ -679,7 +734,7 @@ extern "C" int imm3_query_create(imm3_ctx *ctx, const imm3_segment *seg,
             n_s2 += s2;
         }
         if (all_tile && n_s2 <= 1) {
-            const int64_t n_full = q->n_rows / kTileRows;
+            const int64_t n_full = table ? q->n_tiles : q->n_rows / kTileRows; // staging slots (table: one per virtual tile)
             for (auto &fp : q->preds) {
                 if (fp.kind == KIND_STR || n_full == 0) continue;
                 if (fp.kind == KIND_I8 && ctx->filter_variant == 4) continue; // experiment: stage int32 columns only
@@ -694,6 +749,122 @@ extern "C" int imm3_query_create(imm3_ctx *ctx, const imm3_segment *seg,
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *out = q.release();
+    return IMM3_OK;
+}
+
+extern "C" int imm3_query_create(imm3_ctx *ctx, const imm3_segment *seg,
+                                 const int32_t *used_cols, int32_t n_used,
+                                 const imm3_select *sels, int32_t n_sels,
+                                 const int32_t *proj, int32_t n_proj, int64_t limit,
+                                 int32_t table_block_size, imm3_query **out) {
+    return query_create_impl(ctx, seg, nullptr, used_cols, n_used, sels, n_sels, proj, n_proj, limit, table_block_size, out);
+}
+
+extern "C" int imm3_query_create_table(imm3_ctx *ctx, const imm3_table *table,
+                                       const int32_t *used_cols, int32_t n_used,
+                                       const imm3_select *sels, int32_t n_sels,
+                                       const int32_t *proj, int32_t n_proj, int64_t limit,
+                                       int32_t table_block_size, imm3_query **out) {
+    if (!table || table->segs.empty()) return fail(IMM3_ERR_ARG, "table is null or empty");
+    return query_create_impl(ctx, table->segs[0], table, used_cols, n_used, sels, n_sels, proj, n_proj, limit, table_block_size, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// table: the tile table over all segments
+// ---------------------------------------------------------------------------------------------
+extern "C" int imm3_table_create(imm3_ctx *ctx, const imm3_segment *const *segs, int32_t n_segs, imm3_table **out) {
+    if (!ctx || !out) return fail(IMM3_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (n_segs <= 0 || !segs) return fail(IMM3_ERR_ARG, "a table needs at least one segment");
+    HIPCHK(hipSetDevice(ctx->device));
+    std::unique_ptr<imm3_table> t(new imm3_table());
+    t->ctx = ctx;
+    const size_t ncols = segs[0]->cols.size();
+    std::vector<int32_t> all_cols(ncols);
+    for (size_t c = 0; c < ncols; ++c) all_cols[c] = (int32_t)c;
+    t->tile_start.push_back(0);
+    for (int32_t si = 0; si < n_segs; ++si) {
+        const imm3_segment *sg = segs[si];
+        if (!sg || sg->ctx->device != ctx->device) return fail(IMM3_ERR_ARG, "segment is null or lives on another device");
+        if (sg->cols.size() != ncols) return fail(IMM3_ERR_ARG, "segments of one table must have the same columns");
+        for (size_t c = 0; c < ncols; ++c)
+            if (sg->cols[c].codec != segs[0]->cols[c].codec || sg->cols[c].width != segs[0]->cols[c].width)
+                return fail(IMM3_ERR_ARG, "segments of one table must have the same column types");
+        SegLayout L;
+        const int rc = segment_layout(sg, all_cols, 0, L);
+        if (rc) return rc;
+        if (L.ragged) return fail(IMM3_ERR_LAYOUT, "segment " + std::to_string(si) + ": a non-final block is not a multiple of 64 rows (ragged layout); use per-segment queries");
+        t->segs.push_back(sg);
+        t->seg_rows.push_back(L.rows);
+        t->tile_start.push_back(t->tile_start.back() + (L.rows + kTileRows - 1) / kTileRows);
+        t->n_rows += L.rows;
+    }
+    t->n_tiles = t->tile_start.back();
+    if (t->n_tiles * (int64_t)kTileRows > 0xFFFFFFFFLL) return fail(IMM3_ERR_LAYOUT, "table too large for 32-bit virtual row ids on one device");
+    std::vector<uint32_t> rows((size_t)std::max<int64_t>(t->n_tiles, 1), 0);
+    std::vector<std::vector<const void *>> ptrs(ncols, std::vector<const void *>((size_t)std::max<int64_t>(t->n_tiles, 1), nullptr));
+    for (size_t si = 0; si < t->segs.size(); ++si) {
+        const int64_t nt = t->tile_start[si + 1] - t->tile_start[si];
+        for (int64_t k = 0; k < nt; ++k) {
+            const size_t tile = (size_t)(t->tile_start[si] + k);
+            rows[tile] = (uint32_t)std::min<int64_t>(kTileRows, t->seg_rows[si] - k * kTileRows);
+            for (size_t c = 0; c < ncols; ++c) ptrs[c][tile] = t->segs[si]->cols[c].d_data + (size_t)k * kTileRows * (size_t)t->segs[si]->cols[c].width;
+        }
+    }
+    void *p = nullptr;
+    HIPCHK(hipMalloc(&p, rows.size() * sizeof(uint32_t)));
+    t->d_tile_rows = (uint32_t *)p;
+    HIPCHK(hipMemcpyAsync(t->d_tile_rows, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    t->d_tile_ptrs.assign(ncols, nullptr);
+    for (size_t c = 0; c < ncols; ++c) {
+        HIPCHK(hipMalloc(&p, ptrs[c].size() * sizeof(void *)));
+        t->d_tile_ptrs[c] = (void **)p;
+        HIPCHK(hipMemcpyAsync(t->d_tile_ptrs[c], ptrs[c].data(), ptrs[c].size() * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *out = t.release();
+    return IMM3_OK;
+}
+
+extern "C" int imm3_table_destroy(imm3_table *t) {
+    if (!t) return IMM3_OK;
+    (void)hipSetDevice(t->ctx->device);
+    (void)hipStreamSynchronize(t->ctx->stream);
+    (void)hipFree(t->d_tile_rows);
+    for (auto p : t->d_tile_ptrs) (void)hipFree(p);
+    delete t;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_query_segment_starts(const imm3_query *q, int32_t *n_segments, int32_t *first_batch, int64_t *first_word) {
+    if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    if (!q->table) { // one segment
+        if (n_segments) *n_segments = 1;
+        if (first_batch) { first_batch[0] = 0; first_batch[1] = (int32_t)q->batch_size.size(); }
+        if (first_word) { first_word[0] = 0; first_word[1] = q->n_words; }
+        return IMM3_OK;
+    }
+    const size_t n = q->table->segs.size();
+    if (n_segments) *n_segments = (int32_t)n;
+    if (first_batch) std::memcpy(first_batch, q->seg_first_batch.data(), (n + 1) * sizeof(int32_t));
+    if (first_word) std::memcpy(first_word, q->seg_first_word.data(), (n + 1) * sizeof(int64_t));
+    return IMM3_OK;
+}
+
+extern "C" int imm3_query_locate_rows(const imm3_query *q, const uint32_t *row_index, uint64_t n, uint32_t *segment_out, uint32_t *row_out) {
+    if (!q || (n && !row_index)) return fail(IMM3_ERR_ARG, "null argument");
+    for (uint64_t i = 0; i < n; ++i) {
+        if (!q->table) {
+            if (segment_out) segment_out[i] = 0;
+            if (row_out) row_out[i] = row_index[i];
+            continue;
+        }
+        const int64_t tile = row_index[i] >> 10;
+        const auto &ts = q->table->tile_start;
+        const size_t si = (size_t)(std::upper_bound(ts.begin(), ts.end(), tile) - ts.begin()) - 1;
+        if (segment_out) segment_out[i] = (uint32_t)si;
+        if (row_out) row_out[i] = (uint32_t)((tile - ts[si]) * kTileRows + (row_index[i] & (kTileRows - 1)));
+    }
     return IMM3_OK;
 }
 
@@ -773,6 +944,7 @@ static int run_select(imm3_query *q, bool overlap_total) {
         if (!q->ragged && ctx->filter_variant != 1 && tile_kind(p) != TK_NONE) tile_preds.push_back(&p);
         else generic_preds.push_back(&p);
     }
+    if (q->table && !generic_preds.empty()) return fail(IMM3_ERR_ARG, "table queries support int32 / int8 / 2-byte string predicates (<= 8 IN-list values); use per-segment queries");
     std::stable_sort(tile_preds.begin(), tile_preds.end(),
                      [](const FoldedPred *x, const FoldedPred *y) { return tile_kind(*x) < tile_kind(*y); });
     int pass = 0;
@@ -802,6 +974,7 @@ static int run_select(imm3_query *q, bool overlap_total) {
             const FoldedPred &fp = *take[(size_t)k];
             TileCol &c = a.cols[k];
             c.data = q->seg->cols[(size_t)fp.seg_col].d_data;
+            if (q->table) a.tile_ptrs[k] = (const void *const *)q->table->d_tile_ptrs[(size_t)fp.seg_col];
             c.lo = (int32_t)fp.lo;
             c.hi = (int32_t)fp.hi;
             a.kinds[k] = tile_kind(fp);
@@ -819,6 +992,7 @@ static int run_select(imm3_query *q, bool overlap_total) {
         a.n_tiles = q->n_tiles;
         a.bitmap = q->d_bitmap;
         a.block_partials = q->d_block_partials;
+        a.tile_rows = q->table ? q->table->d_tile_rows : nullptr; // table query: address the columns through the tile table
         bool any_i32 = false;
         for (int k = 0; k < kMaxTileCols; ++k) any_i32 |= (a.kinds[k] == TK_I32);
         if (ctx->d_stamps && ctx->stamp_used < ctx->stamp_slots) a.stamps = ctx->d_stamps + (size_t)ctx->stamp_used * kMaxFilterGrid * 2;
@@ -907,6 +1081,7 @@ static int launch_project(imm3_query *q) {
     g.cap_rows = q->cap_rows;
     g.n_staged_tiles = q->n_rows / kTileRows;
     g.word_row_base = q->d_word_row_base;
+    g.tile_rows = q->table ? q->table->d_tile_rows : nullptr;
     // more SELECT-list columns than one launch carries: gather in groups (row indices written by the first)
     size_t done = 0;
     const size_t np = q->proj.size();
@@ -917,6 +1092,7 @@ static int launch_project(imm3_query *q) {
         for (size_t j = 0; j < take; ++j) {
             const SegCol &sc = q->seg->cols[(size_t)q->used[(size_t)q->proj[done + j]]];
             g.proj[j].src = sc.d_data;
+            g.proj[j].tile_ptrs = q->table ? (const void *const *)q->table->d_tile_ptrs[(size_t)q->used[(size_t)q->proj[done + j]]] : nullptr;
             g.proj[j].dst = q->d_proj[done + j];
             g.proj[j].width = sc.width;
             g.proj[j].staged = nullptr;
@@ -1113,18 +1289,18 @@ extern "C" int imm3_query_device_ptr(imm3_query *q, int32_t which, void **ptr) {
 // ---------------------------------------------------------------------------------------------
 // group-by aggregation (ProjectAggOp)
 // ---------------------------------------------------------------------------------------------
-extern "C" int imm3_query_create_agg(imm3_ctx *ctx, const imm3_segment *seg,
-                                     const int32_t *used_cols, int32_t n_used,
-                                     const imm3_select *sels, int32_t n_sels,
-                                     const int32_t *group_cols, int32_t n_group,
-                                     const imm3_aggregate *aggs, int32_t n_aggs,
-                                     int32_t table_block_size, imm3_query **out) {
+static int query_create_agg_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_table *table,
+                                 const int32_t *used_cols, int32_t n_used,
+                                 const imm3_select *sels, int32_t n_sels,
+                                 const int32_t *group_cols, int32_t n_group,
+                                 const imm3_aggregate *aggs, int32_t n_aggs,
+                                 int32_t table_block_size, imm3_query **out) {
     if (!out) return fail(IMM3_ERR_ARG, "out is null");
     *out = nullptr;
     if (n_group < 0 || n_group > kMaxGroupCols || (n_group > 0 && !group_cols)) return fail(IMM3_ERR_ARG, "0..4 group columns are supported on the GPU path");
     if (n_aggs < 1 || n_aggs > kMaxAggs || !aggs) return fail(IMM3_ERR_ARG, "1..4 aggregates are supported on the GPU path");
     imm3_query *q = nullptr;
-    int rc = imm3_query_create(ctx, seg, used_cols, n_used, sels, n_sels, nullptr, 0, 0, table_block_size, &q);
+    int rc = query_create_impl(ctx, seg, table, used_cols, n_used, sels, n_sels, nullptr, 0, 0, table_block_size, &q);
     if (rc) return rc;
     std::unique_ptr<imm3_query, void (*)(imm3_query *)> guard(q, query_free);
     int key_bytes = 0;
@@ -1165,6 +1341,25 @@ extern "C" int imm3_query_create_agg(imm3_ctx *ctx, const imm3_segment *seg,
     return IMM3_OK;
 }
 
+extern "C" int imm3_query_create_agg(imm3_ctx *ctx, const imm3_segment *seg,
+                                     const int32_t *used_cols, int32_t n_used,
+                                     const imm3_select *sels, int32_t n_sels,
+                                     const int32_t *group_cols, int32_t n_group,
+                                     const imm3_aggregate *aggs, int32_t n_aggs,
+                                     int32_t table_block_size, imm3_query **out) {
+    return query_create_agg_impl(ctx, seg, nullptr, used_cols, n_used, sels, n_sels, group_cols, n_group, aggs, n_aggs, table_block_size, out);
+}
+
+extern "C" int imm3_query_create_table_agg(imm3_ctx *ctx, const imm3_table *table,
+                                           const int32_t *used_cols, int32_t n_used,
+                                           const imm3_select *sels, int32_t n_sels,
+                                           const int32_t *group_cols, int32_t n_group,
+                                           const imm3_aggregate *aggs, int32_t n_aggs,
+                                           int32_t table_block_size, imm3_query **out) {
+    if (!table || table->segs.empty()) return fail(IMM3_ERR_ARG, "table is null or empty");
+    return query_create_agg_impl(ctx, table->segs[0], table, used_cols, n_used, sels, n_sels, group_cols, n_group, aggs, n_aggs, table_block_size, out);
+}
+
 static void fill_agg_args(const imm3_query *q, AggArgs &a) {
     std::memset(&a, 0, sizeof(a));
     a.bitmap = q->d_bitmap;
@@ -1176,6 +1371,7 @@ static void fill_agg_args(const imm3_query *q, AggArgs &a) {
     for (size_t g = 0; g < q->group_cols.size(); ++g) {
         const SegCol &sc = q->seg->cols[(size_t)q->used[(size_t)q->group_cols[g]]];
         a.groups[g].data = sc.d_data;
+        a.groups[g].tile_ptrs = q->table ? (const void *const *)q->table->d_tile_ptrs[(size_t)q->used[(size_t)q->group_cols[g]]] : nullptr;
         a.groups[g].width = sc.width;
         a.groups[g].shift = shift;
         shift += sc.width;
@@ -1184,6 +1380,7 @@ static void fill_agg_args(const imm3_query *q, AggArgs &a) {
     for (size_t j = 0; j < q->aggs.size(); ++j) {
         const SegCol &sc = q->seg->cols[(size_t)q->used[(size_t)q->aggs[j].column]];
         a.aggs[j].data = sc.d_data;
+        a.aggs[j].tile_ptrs = q->table ? (const void *const *)q->table->d_tile_ptrs[(size_t)q->used[(size_t)q->aggs[j].column]] : nullptr;
         a.aggs[j].width = sc.width;
         a.aggs[j].kind = q->aggs[j].kind;
         a.aggs[j].is_str = sc.codec == IMM3_DENSE_STRING;

@@ -61,6 +61,10 @@ struct TileArgs {
     uint32_t *block_partials;
     void *stage[kMaxTileCols];      // per column: dense per-tile staging of the survivors' values, or null
     unsigned long long *stamps;     // diagnostics only: per work-group {start, end} of the 100 MHz device clock, or null
+    // table queries (imm3_table): the tile table replaces cols[k].data / n_rows.  Tile t holds tile_rows[t] valid rows
+    // (1024 except the last tile of each segment) starting at tile_ptrs[k][t] in column k.  Null for one segment.
+    const uint32_t *tile_rows;
+    const void *const *tile_ptrs[kMaxTileCols];
 };
 
 struct FilterArgs {
@@ -98,6 +102,7 @@ struct ProjCol {
     const void *src;             // flat column
     void *dst;                   // packed output, width bytes per emitted row
     const void *staged;          // survivors' values staged per tile by the filter kernel (width 4 or 1), or null
+    const void *const *tile_ptrs; // table queries: per-tile pointer into this column (src unused), else null
     int32_t width;
     int32_t pad;
 };
@@ -116,6 +121,7 @@ struct GatherArgs {
     int32_t pad;
     int64_t n_staged_tiles;        // tiles [0, n) have staged values (the full tiles)
     const uint32_t *word_row_base; // ragged layout, else null
+    const uint32_t *tile_rows;     // table queries: valid rows per tile (staged iff 1024), else null
 };
 
 // launchers (imm3_kernels.hip)
@@ -126,12 +132,14 @@ enum AggKind : int32_t { AGG_COUNT = 0, AGG_MIN = 1, AGG_MAX = 2 };
 
 struct GroupCol {
     const void *data;
+    const void *const *tile_ptrs; // table queries: per-tile pointer, else null
     int32_t width;
     int32_t shift;               // byte position of this column inside the u64 group key
 };
 
 struct AggCol {
     const void *data;
+    const void *const *tile_ptrs; // table queries: per-tile pointer, else null
     int32_t width;
     int32_t kind;                // AggKind
     int32_t is_str;              // AGG_MAX over a string column: values compared as big-endian-packed bytes

@@ -93,16 +93,16 @@ __device__ __forceinline__ void block_partial_store(uint32_t *block_partials, ui
 // ---------------------------------------------------------------------------------------------
 template <int KIND>
 struct ColRegs { // TK_NONE: no column
-    __device__ __forceinline__ void load(const TileCol &, int64_t, int) {}
+    __device__ __forceinline__ void load(const void *, int64_t, int) {}
     __device__ __forceinline__ void eval(const TileCol &, uint64_t (&)[kTileWords], uint64_t &, int) {}
-    __device__ __forceinline__ bool row(const TileCol &, int64_t) { return true; }
+    __device__ __forceinline__ bool row(const void *, const TileCol &, int64_t) { return true; }
 };
 
 template <>
 struct ColRegs<TK_I32> {
     int32_t v[kTileWords];
-    __device__ __forceinline__ void load(const TileCol &c, int64_t row0, int lane) {
-        const int32_t *p = (const int32_t *)c.data + row0 + lane;
+    __device__ __forceinline__ void load(const void *data, int64_t row0, int lane) {
+        const int32_t *p = (const int32_t *)data + row0 + lane;
 #pragma unroll
         for (int j = 0; j < kTileWords; ++j) v[j] = __builtin_nontemporal_load(p + 64 * j);
     }
@@ -110,14 +110,14 @@ struct ColRegs<TK_I32> {
 #pragma unroll
         for (int j = 0; j < kTileWords; ++j) acc[j] &= ballot64(in_closed(v[j], c.lo, c.hi));
     }
-    __device__ __forceinline__ bool row(const TileCol &c, int64_t r) { return in_closed(((const int32_t *)c.data)[r], c.lo, c.hi); }
+    __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return in_closed(((const int32_t *)data)[r], c.lo, c.hi); }
 };
 
 template <>
 struct ColRegs<TK_I8> {
     v4i v;
-    __device__ __forceinline__ void load(const TileCol &c, int64_t row0, int lane) {
-        v = __builtin_nontemporal_load((const v4i *)((const int8_t *)c.data + row0) + lane);
+    __device__ __forceinline__ void load(const void *data, int64_t row0, int lane) {
+        v = __builtin_nontemporal_load((const v4i *)((const int8_t *)data + row0) + lane);
     }
     __device__ __forceinline__ void eval(const TileCol &c, uint64_t (&)[kTileWords], uint64_t &mine, int lane) {
         uint32_t bits = 0;
@@ -131,14 +131,14 @@ struct ColRegs<TK_I8> {
         const uint32_t hi = lane_read(bits, src + 2) | (lane_read(bits, src + 3) << 16);
         mine &= ((uint64_t)hi << 32) | lo;
     }
-    __device__ __forceinline__ bool row(const TileCol &c, int64_t r) { return in_closed((int32_t)((const int8_t *)c.data)[r], c.lo, c.hi); }
+    __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return in_closed((int32_t)((const int8_t *)data)[r], c.lo, c.hi); }
 };
 
 template <>
 struct ColRegs<TK_S2> {
     v4i v[2];
-    __device__ __forceinline__ void load(const TileCol &c, int64_t row0, int lane) {
-        const v4i *p = (const v4i *)((const uint16_t *)c.data + row0) + lane;
+    __device__ __forceinline__ void load(const void *data, int64_t row0, int lane) {
+        const v4i *p = (const v4i *)((const uint16_t *)data + row0) + lane;
         v[0] = __builtin_nontemporal_load(p);
         v[1] = __builtin_nontemporal_load(p + 64);
     }
@@ -177,7 +177,7 @@ struct ColRegs<TK_S2> {
         const bool second = (lane & 8) != 0;
         mine &= ((uint64_t)(second ? hi1 : hi0) << 32) | (second ? lo1 : lo0);
     }
-    __device__ __forceinline__ bool row(const TileCol &c, int64_t r) { return hit(c, ((const uint16_t *)c.data)[r]); }
+    __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return hit(c, ((const uint16_t *)data)[r]); }
 };
 
 // ---- survivor staging -------------------------------------------------------------------------------------
@@ -276,6 +276,30 @@ __device__ __forceinline__ uint32_t finish_full_tile(const TileArgs &a, int64_t 
     return pc;
 }
 
+// A tile with fewer than 1024 valid rows (the end of a segment): rolled, bounds-checked, row-at-a-time.
+// `valid_rows` rows starting at element `row0` of each column pointer.
+template <int K0, int K1, int K2>
+__device__ __forceinline__ uint32_t partial_tile(const TileArgs &a, int64_t tile, int lane, const void *d0, const void *d1, const void *d2,
+                                                 int64_t row0, int64_t valid_rows, ColRegs<K0> &c0, ColRegs<K1> &c1, ColRegs<K2> &c2) {
+    const int64_t w = tile * kTileWords + lane;
+    uint64_t mine = ~0ULL;
+    if (a.and_existing) mine = (lane < kTileWords && w < a.n_words) ? a.bitmap[w] : 0ULL;
+#pragma unroll 1
+    for (int j = 0; j < kTileWords; ++j) {
+        const int64_t i = 64 * j + lane;
+        const bool valid = i < valid_rows;
+        const int64_t r = row0 + (valid ? i : 0);
+        bool keep = valid;
+        if (valid) keep = c0.row(d0, a.cols[0], r) && c1.row(d1, a.cols[1], r) && c2.row(d2, a.cols[2], r);
+        const uint64_t m = ballot64(keep);
+        if (lane == j) mine &= m;
+    }
+    mine &= low_mask(valid_rows - 64 * (int64_t)lane); // rows past the end are not rows
+    if (lane >= kTileWords) mine = 0;
+    if (lane < kTileWords && w < a.n_words) a.bitmap[w] = mine;
+    return (uint32_t)__popcll(mine);
+}
+
 // T = tiles per wave iteration: narrow columns take several tiles at once so that every wave keeps >= 4 KiB of
 // loads in flight (8 waves/CU x 4 KiB is what saturates HBM, see the header comment).
 template <int K0, int K1, int K2, int T>
@@ -287,10 +311,36 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
     uint8_t *lds = s_stage[wave];
     if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x] = wall_clock64(); // instrumented pass of bench.py only
     uint32_t lane_total = 0; // lanes 0..15: survivors in the words they stored
-    const int64_t n_full = a.n_rows / kTileRows;
-    const int64_t n_groups = n_full / T;
     const int64_t wave_id = (int64_t)blockIdx.x * kWavesPerBlock + wave;
     const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
+
+    if (a.tile_rows) { // table query: tiles come from the tile table (one partial tile per segment), one tile per step
+        for (int64_t tile = wave_id; tile < a.n_tiles; tile += n_waves) {
+            const uint32_t rows_here = a.tile_rows[tile];
+            const void *d0 = K0 != TK_NONE ? a.tile_ptrs[0][tile] : nullptr;
+            const void *d1 = K1 != TK_NONE ? a.tile_ptrs[1][tile] : nullptr;
+            const void *d2 = K2 != TK_NONE ? a.tile_ptrs[2][tile] : nullptr;
+            ColRegs<K0> c0;
+            ColRegs<K1> c1;
+            ColRegs<K2> c2;
+            if (rows_here == kTileRows) {
+                c0.load(d0, 0, lane);
+                c1.load(d1, 0, lane);
+                c2.load(d2, 0, lane);
+                lane_total += finish_full_tile<K0, K1, K2>(a, tile, lane, c0, c1, c2, lds);
+            } else {
+                lane_total += partial_tile<K0, K1, K2>(a, tile, lane, d0, d1, d2, 0, rows_here, c0, c1, c2);
+            }
+        }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) lane_total += __shfl_xor(lane_total, d);
+        block_partial_store(a.block_partials, lane_total, lane, wave);
+        if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x + 1] = wall_clock64();
+        return;
+    }
+
+    const int64_t n_full = a.n_rows / kTileRows;
+    const int64_t n_groups = n_full / T;
 
     for (int64_t grp = wave_id; grp < n_groups; grp += n_waves) {
         ColRegs<K0> c0[T];
@@ -299,9 +349,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int64_t row0 = (grp * T + t) * kTileRows;
-            c0[t].load(a.cols[0], row0, lane);
-            c1[t].load(a.cols[1], row0, lane);
-            c2[t].load(a.cols[2], row0, lane);
+            c0[t].load(a.cols[0].data, row0, lane);
+            c1[t].load(a.cols[1].data, row0, lane);
+            c2[t].load(a.cols[2].data, row0, lane);
         }
 #pragma unroll
         for (int t = 0; t < T; ++t) lane_total += finish_full_tile<K0, K1, K2>(a, grp * T + t, lane, c0[t], c1[t], c2[t], lds);
@@ -313,28 +363,12 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
         ColRegs<K1> c1;
         ColRegs<K2> c2;
         if (tile < n_full) {
-            c0.load(a.cols[0], row0, lane);
-            c1.load(a.cols[1], row0, lane);
-            c2.load(a.cols[2], row0, lane);
+            c0.load(a.cols[0].data, row0, lane);
+            c1.load(a.cols[1].data, row0, lane);
+            c2.load(a.cols[2].data, row0, lane);
             lane_total += finish_full_tile<K0, K1, K2>(a, tile, lane, c0, c1, c2, lds);
         } else { // rolled, bounds-checked
-            const int64_t w = tile * kTileWords + lane;
-            uint64_t mine = ~0ULL;
-            if (a.and_existing) mine = (lane < kTileWords && w < a.n_words) ? a.bitmap[w] : 0ULL;
-#pragma unroll 1
-            for (int j = 0; j < kTileWords; ++j) {
-                const int64_t row = row0 + 64 * j + lane;
-                const bool valid = row < a.n_rows;
-                const int64_t r = valid ? row : 0;
-                bool keep = valid;
-                if (valid) keep = c0.row(a.cols[0], r) && c1.row(a.cols[1], r) && c2.row(a.cols[2], r);
-                const uint64_t m = ballot64(keep);
-                if (lane == j) mine &= m;
-            }
-            mine &= low_mask(a.n_rows - (row0 + 64 * (int64_t)lane)); // rows past the end are not rows
-            if (lane >= kTileWords) mine = 0;
-            if (lane < kTileWords && w < a.n_words) a.bitmap[w] = mine;
-            lane_total += (uint32_t)__popcll(mine);
+            lane_total += partial_tile<K0, K1, K2>(a, tile, lane, a.cols[0].data, a.cols[1].data, a.cols[2].data, row0, a.n_rows - row0, c0, c1, c2);
         }
     }
 #pragma unroll
@@ -545,14 +579,19 @@ __global__ __launch_bounds__(kBlockThreads) void k_gather(const GatherArgs a) {
             const uint32_t r = s_list[i];
             const unsigned long long out = base + i;
             if (out >= a.cap_rows) continue;
-            const int64_t row = a.word_row_base
-                                    ? (int64_t)a.word_row_base[span * kSpanWords + (r >> 6)] + (r & 63)
-                                    : span * (int64_t)(kSpanWords * 64) + r;
-            if (a.row_index) a.row_index[out] = (uint32_t)row;
+            int64_t row = a.word_row_base
+                              ? (int64_t)a.word_row_base[span * kSpanWords + (r >> 6)] + (r & 63)
+                              : span * (int64_t)(kSpanWords * 64) + r;
+            if (a.row_index) a.row_index[out] = (uint32_t)row; // table queries: virtual row = tile * 1024 + position
             const int64_t tile = tile0 + (r >> 10);
+            const bool staged_tile = a.tile_rows ? a.tile_rows[tile] == (uint32_t)kTileRows : tile < a.n_staged_tiles;
             for (int pj = 0; pj < a.n_proj; ++pj) {
-                const ProjCol &pc2 = a.proj[pj];
-                if (pc2.staged && tile < a.n_staged_tiles) { // survivors' values were compacted per tile by the filter kernel
+                ProjCol pc2 = a.proj[pj];
+                if (pc2.tile_ptrs) { // table query: the column of this tile's segment, position within the tile
+                    pc2.src = pc2.tile_ptrs[tile];
+                    row = r & (kTileRows - 1);
+                }
+                if (pc2.staged && staged_tile) { // survivors' values were compacted per tile by the filter kernel
                     const int64_t sidx = tile * kTileRows + (i - s_toff[r >> 10]);
                     if (pc2.width == 4) ((uint32_t *)pc2.dst)[out] = ((const uint32_t *)pc2.staged)[sidx];
                     else copy_elem<uint8_t>(pc2.staged, pc2.dst, sidx, out);

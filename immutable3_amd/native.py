@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -27,6 +28,8 @@ EXPORTS = [
     "imm3_abi_version", "imm3_last_error", "imm3_device_count",
     "imm3_ctx_create", "imm3_ctx_destroy", "imm3_ctx_sync", "imm3_ctx_stream",
     "imm3_segment_create", "imm3_segment_wrap_device", "imm3_segment_destroy", "imm3_segment_bytes",
+    "imm3_table_create", "imm3_table_destroy", "imm3_query_create_table", "imm3_query_create_table_agg",
+    "imm3_query_segment_starts", "imm3_query_locate_rows",
     "imm3_query_create", "imm3_query_create_agg", "imm3_query_group_count", "imm3_query_fetch_groups",
     "imm3_query_destroy", "imm3_query_reserve_rows",
     "imm3_query_run", "imm3_query_run_select", "imm3_query_sync", "imm3_query_join_count",
@@ -97,6 +100,12 @@ def load() -> C.CDLL:
     L.imm3_segment_bytes.argtypes = [vp, P(u64)]
     L.imm3_query_create.argtypes = [vp, vp, vp, i32, P(CSelect), i32, vp, i32, i64, i32, P(vp)]
     L.imm3_query_create_agg.argtypes = [vp, vp, vp, i32, P(CSelect), i32, vp, i32, vp, i32, i32, P(vp)]
+    L.imm3_table_create.argtypes = [vp, P(vp), i32, P(vp)]
+    L.imm3_table_destroy.argtypes = [vp]
+    L.imm3_query_create_table.argtypes = [vp, vp, vp, i32, P(CSelect), i32, vp, i32, i64, i32, P(vp)]
+    L.imm3_query_create_table_agg.argtypes = [vp, vp, vp, i32, P(CSelect), i32, vp, i32, vp, i32, i32, P(vp)]
+    L.imm3_query_segment_starts.argtypes = [vp, P(i32), vp, vp]
+    L.imm3_query_locate_rows.argtypes = [vp, vp, u64, vp, vp]
     L.imm3_query_group_count.argtypes = [vp, P(C.c_uint32)]
     L.imm3_query_fetch_groups.argtypes = [vp, vp, vp, vp, vp, C.c_uint32]
     L.imm3_query_destroy.argtypes = [vp]
@@ -149,6 +158,11 @@ class Context:
         self._h = C.c_void_p()
         _check(load().imm3_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
         self.device = device
+        # handles created on this context; closed before the context itself (they hold raw pointers into it)
+        self._children = weakref.WeakSet()
+
+    def _adopt(self, child):
+        self._children.add(child)
 
     def sync(self):
         _check(load().imm3_ctx_sync(self._h))
@@ -193,6 +207,11 @@ class Context:
 
     def close(self):
         if self._h:
+            kids = list(self._children)
+            for kind in (DeviceQuery, DeviceTable, DeviceSegment):   # queries -> tables -> segments
+                for k in kids:
+                    if isinstance(k, kind):
+                        k.close()
             load().imm3_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -234,6 +253,7 @@ class DeviceSegment:
         self._h = C.c_void_p()
         fn = load().imm3_segment_wrap_device if wrap_device else load().imm3_segment_create
         _check(fn(ctx._h, arr, len(cols), C.byref(self._h)))
+        ctx._adopt(self)
         self._keep = keep if wrap_device else None
         self.widths = [c[1] for c in cols]
         self.codecs = [c[0] for c in cols]
@@ -257,6 +277,29 @@ class DeviceSegment:
 
 
 AGG_COUNT, AGG_MIN, AGG_MAX = 0, 1, 2
+
+
+class DeviceTable:
+    """imm3_table: all segments of one table as one scan unit (one launch over the tile table)."""
+
+    def __init__(self, ctx: Context, segs: Sequence[DeviceSegment]):
+        self.ctx, self.segs = ctx, list(segs)
+        arr = (C.c_void_p * len(self.segs))(*[s._h for s in self.segs])
+        self._h = C.c_void_p()
+        _check(load().imm3_table_create(ctx._h, arr, len(self.segs), C.byref(self._h)))
+        ctx._adopt(self)
+        self.widths, self.codecs = self.segs[0].widths, self.segs[0].codecs
+
+    def close(self):
+        if self._h:
+            load().imm3_table_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DeviceQuery:
@@ -290,15 +333,19 @@ class DeviceQuery:
             elif operand is not None:
                 cs[i].value = float(operand)
         self._h = C.c_void_p()
+        self.is_table = isinstance(seg, DeviceTable)
+        create = load().imm3_query_create_table if self.is_table else load().imm3_query_create
+        create_agg = load().imm3_query_create_table_agg if self.is_table else load().imm3_query_create_agg
         if self.aggs is not None:
             gc = np.array(self.group_cols or [0], dtype=np.int32)
             ag = np.array([[k, c] for (k, c) in self.aggs] or [[0, 0]], dtype=np.int32)
-            _check(load().imm3_query_create_agg(ctx._h, seg._h, used.ctypes.data, len(self.used_cols), cs, len(sels),
+            _check(create_agg(ctx._h, seg._h, used.ctypes.data, len(self.used_cols), cs, len(sels),
                                                 gc.ctypes.data, len(self.group_cols), ag.ctypes.data, len(self.aggs),
                                                 table_block_size, C.byref(self._h)))
         else:
-            _check(load().imm3_query_create(ctx._h, seg._h, used.ctypes.data, len(self.used_cols), cs, len(sels),
-                                            pj.ctypes.data, len(self.proj), limit, table_block_size, C.byref(self._h)))
+            _check(create(ctx._h, seg._h, used.ctypes.data, len(self.used_cols), cs, len(sels),
+                          pj.ctypes.data, len(self.proj), limit, table_block_size, C.byref(self._h)))
+        ctx._adopt(self)
         nb, tw, nr = C.c_int32(0), C.c_int64(0), C.c_int64(0)
         _check(load().imm3_query_layout(self._h, C.byref(nb), C.byref(tw), C.byref(nr)))
         self.n_batches, self.total_words, self.n_rows = nb.value, tw.value, nr.value
@@ -312,6 +359,23 @@ class DeviceQuery:
         woff = np.zeros(nb, np.int64)
         _check(load().imm3_query_batches(self._h, size.ctypes.data, oid.ctypes.data, woff.ctypes.data))
         return size[: self.n_batches], oid[: self.n_batches], woff[: self.n_batches]
+
+    def segment_starts(self):
+        """(first_batch int32[n_seg+1], first_word int64[n_seg+1])"""
+        n = C.c_int32(0)
+        _check(load().imm3_query_segment_starts(self._h, C.byref(n), None, None))
+        fb = np.zeros(n.value + 1, np.int32)
+        fw = np.zeros(n.value + 1, np.int64)
+        _check(load().imm3_query_segment_starts(self._h, C.byref(n), fb.ctypes.data, fw.ctypes.data))
+        return fb, fw
+
+    def locate_rows(self, row_index: np.ndarray):
+        """virtual row ids of a table query -> (segment uint32[n], row-in-segment uint32[n])"""
+        row_index = np.ascontiguousarray(row_index, dtype=np.uint32)
+        seg = np.zeros(max(row_index.size, 1), np.uint32)
+        row = np.zeros(max(row_index.size, 1), np.uint32)
+        _check(load().imm3_query_locate_rows(self._h, row_index.ctypes.data, row_index.size, seg.ctypes.data, row.ctypes.data))
+        return seg[: row_index.size], row[: row_index.size]
 
     def reserve_rows(self, rows: int):
         _check(load().imm3_query_reserve_rows(self._h, rows))

@@ -52,6 +52,7 @@ enum {
 
 typedef struct imm3_ctx imm3_ctx;         /* device + stream + scratch                                   */
 typedef struct imm3_segment imm3_segment; /* one segment's columns resident in HBM (SegmentManager role) */
+typedef struct imm3_table imm3_table;     /* all resident segments of one table: scanned by ONE launch    */
 typedef struct imm3_query imm3_query;     /* one PipelineThread: ScanOp -> SelectOp* -> ProjectOp        */
 
 /* One column of one segment as the reference stores it: `<col>_<id>.dat` bytes + the
@@ -103,6 +104,42 @@ int imm3_segment_wrap_device(imm3_ctx *ctx, const imm3_column *cols, int32_t nco
 int imm3_segment_destroy(imm3_segment *seg);
 int imm3_segment_bytes(const imm3_segment *seg, uint64_t *device_bytes);
 
+enum { IMM3_AGG_COUNT = 0, IMM3_AGG_MIN = 1, IMM3_AGG_MAX = 2 };
+typedef struct {
+    int32_t kind;
+    int32_t column;
+} imm3_aggregate;
+
+/* ---- table: every segment of one table (SegmentManager.getSegments, SegmentManager.scala:108-111) as ONE scan unit.
+ * The reference fans out one PipelineThread per segment (Engine.scala:176-180) and merges on the consumer thread;
+ * a README-style table (block 1024 x segment 1000) has ~1 M rows per segment, so 100 M rows are ~98 segments and a
+ * per-segment launch sequence is launch-bound.  A table query runs the same fused kernels over a TILE TABLE (per
+ * 1024-row tile: valid rows + one pointer per column) that spans all segments: one scan+select launch, one
+ * compaction, rows / groups in ascending (segment, row) order -- exactly what Engine.execute returns.
+ * Requires every segment to have the uniform layout (all columns cut into the same blocks, every non-final block
+ * a multiple of 64 rows); otherwise IMM3_ERR_LAYOUT and the caller falls back to per-segment queries.
+ * The segments stay owned by the caller and must outlive the table. ---- */
+int imm3_table_create(imm3_ctx *ctx, const imm3_segment *const *segs, int32_t n_segs, imm3_table **out);
+int imm3_table_destroy(imm3_table *t);
+/* Table flavours of imm3_query_create / imm3_query_create_agg (same arguments, `seg` replaced by `table`).
+ * Layout getters cover all segments in order (batches of segment 0, then segment 1, ...; oid restarts per segment);
+ * imm3_query_segment_starts gives, per segment, its first batch and its first word in the bitmap. */
+int imm3_query_create_table(imm3_ctx *ctx, const imm3_table *table,
+                            const int32_t *used_cols, int32_t n_used,
+                            const imm3_select *sels, int32_t n_sels,
+                            const int32_t *proj, int32_t n_proj, int64_t limit,
+                            int32_t table_block_size, imm3_query **out);
+int imm3_query_create_table_agg(imm3_ctx *ctx, const imm3_table *table,
+                                const int32_t *used_cols, int32_t n_used,
+                                const imm3_select *sels, int32_t n_sels,
+                                const int32_t *group_cols, int32_t n_group,
+                                const imm3_aggregate *aggs, int32_t n_aggs,
+                                int32_t table_block_size, imm3_query **out);
+/* n_segments + 1 entries each (last = totals); any pointer may be NULL */
+int imm3_query_segment_starts(const imm3_query *q, int32_t *n_segments, int32_t *first_batch, int64_t *first_word);
+/* Row indices of a TABLE query are virtual (tile * 1024 + position); this maps them to (segment, row in segment). */
+int imm3_query_locate_rows(const imm3_query *q, const uint32_t *row_index, uint64_t n, uint32_t *segment_out, uint32_t *row_out);
+
 /* ---- query: one PipelineThread (Engine.scala:235-262) over one segment ----
  *   used_cols   indices into the segment's columns, in Engine.getColumns order (Engine.scala:85-106);
  *               the FIRST one defines the batches (Scan.scala:55,72)
@@ -126,11 +163,6 @@ int imm3_query_destroy(imm3_query *q);
  *               joins them in batch-column order with "_", :151-156); total width <= 8 bytes on this path
  *   aggs        {kind, column (index into used_cols)}; MIN/MAX on INT/TINYINT, MAX on STRING (<= 8 bytes), COUNT on any
  * Groups come back in first-seen order (the reference's LinkedHashMap order): ascending first selected row. ---- */
-enum { IMM3_AGG_COUNT = 0, IMM3_AGG_MIN = 1, IMM3_AGG_MAX = 2 };
-typedef struct {
-    int32_t kind;
-    int32_t column;
-} imm3_aggregate;
 int imm3_query_create_agg(imm3_ctx *ctx, const imm3_segment *seg,
                           const int32_t *used_cols, int32_t n_used,
                           const imm3_select *sels, int32_t n_sels,
