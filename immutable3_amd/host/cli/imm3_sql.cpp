@@ -2,6 +2,7 @@
 //   imm3_sql -q "select id, age from test_100 where (age > 18 and age < 30) limit 10" -d <dataDir> [--device n]
 // Prints one `Row(...)` per line, like `println(it.next)` (SqlCli.scala:72).
 //   --parse-only   print the parsed Query ADT and the planner's column order / leaves; no GPU needed.
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <iostream>
@@ -35,7 +36,7 @@ static std::string showQuery(const Query &q) {
 
 int main(int argc, char **argv) {
     std::string query, dataDir;
-    int device = 0;
+    int device = 0, repeat = 0;
     bool parseOnly = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -44,6 +45,7 @@ int main(int argc, char **argv) {
         else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
         else if (a == "--cpu-count" && i + 1 < argc) ++i; // accepted for SqlCli compatibility; segments run on the GPU
         else if (a == "--parse-only") parseOnly = true;
+        else if (a == "--repeat" && i + 1 < argc) repeat = std::atoi(argv[++i]); // re-run the query N times on the resident table, time to stderr
         else { std::fprintf(stderr, "Error parsing arguments: %s\n", a.c_str()); return 2; }
     }
     if (query.empty() || (dataDir.empty() && !parseOnly)) {
@@ -69,6 +71,12 @@ int main(int argc, char **argv) {
         GpuSegmentManager gsm(sm, device);
         Engine engine(gsm);
         for (const Row &r : engine.execute(q)) std::cout << r.toString() << "\n";
+        for (int k = 0; k < repeat; ++k) { // segments are resident now: this is the steady-state query time
+            const auto t0 = std::chrono::steady_clock::now();
+            const size_t n = engine.execute(q).size();
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            std::fprintf(stderr, "repeat %d: %.3f ms (%zu rows)\n", k, ms, n);
+        }
     } catch (const std::exception &e) {
         std::cout << e.what() << "\n"; // res.fold(err => println(err), ...)
         return 1;

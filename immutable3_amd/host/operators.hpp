@@ -90,8 +90,26 @@ class GpuSegmentManager {
   public:
     explicit GpuSegmentManager(const SegmentManager &sm, int device = 0) : sm(sm) { imm3Check(imm3_ctx_create(device, nullptr, &ctx_)); }
     ~GpuSegmentManager() {
+        for (auto &kv : tables_) imm3_table_destroy(kv.second);
         for (auto &kv : segs_) imm3_segment_destroy(kv.second);
         imm3_ctx_destroy(ctx_);
+    }
+    // every segment of the table as ONE scan unit (imm3_table), or nullptr when the table cannot take the
+    // single-launch path (ragged segments): callers then fall back to one pipeline per segment
+    imm3_table *deviceTable(const std::string &tableName) {
+        auto it = tables_.find(tableName);
+        if (it != tables_.end()) return it->second;
+        std::vector<const imm3_segment *> segs;
+        const int n = sm.getTableSegmentCount(tableName);
+        for (int s = 0; s < n; ++s) segs.push_back(deviceSegment(tableName, s));
+        imm3_table *t = nullptr;
+        if (!segs.empty()) {
+            const int rc = imm3_table_create(ctx_, segs.data(), (int32_t)segs.size(), &t);
+            if (rc != IMM3_OK && rc != IMM3_ERR_LAYOUT) throw Exception(imm3_last_error());
+            if (rc != IMM3_OK) t = nullptr;
+        }
+        tables_[tableName] = t;
+        return t;
     }
     GpuSegmentManager(const GpuSegmentManager &) = delete;
     GpuSegmentManager &operator=(const GpuSegmentManager &) = delete;
@@ -125,6 +143,7 @@ class GpuSegmentManager {
   private:
     imm3_ctx *ctx_ = nullptr;
     std::map<std::pair<std::string, int>, imm3_segment *> segs_;
+    std::map<std::string, imm3_table *> tables_;
 };
 
 struct Leaf { std::string col; SelectCondition cond; };
@@ -144,6 +163,7 @@ class ScanOp : public ColumnVectorOperator {
         return [&sm, tableName](const std::vector<Column> &cols, int segIdx) { return std::make_shared<ScanOp>(sm, segIdx, tableName, cols); };
     }
     const Table &table() const { return sm_.sm.getTable(tableName_); }
+    GpuSegmentManager &manager() const { return sm_; }
 
     // builds the fused query: leaves in application order, optional projection
     void makeQuery(const std::vector<Leaf> &leaves, const std::vector<std::string> &projNames, int limit, QueryHandle &h) const {
@@ -440,6 +460,39 @@ class ProjectAggOp : public Operator<AggMapTuple> {
         for (size_t j = 0; j < aggs.size(); ++j) { abi[j].kind = aggs[j].abiKind(); abi[j].column = usedIndex(aggs[j].col); }
         QueryHandle h;
         scan->makeAggQuery(leaves, group, abi, h);
+        auto it = std::make_unique<VectorIterator<AggMapTuple>>();
+        it->items = decode(h, cols, group, aggs, abi);
+        return it;
+    }
+
+    // the same aggregation as ONE table-level query (imm3_table): groups merged across segments on the GPU
+    std::vector<AggMapTuple> runOn(imm3_table *table, const std::vector<Column> &cols, const std::vector<int32_t> &usedIdx, const std::vector<imm3_select> &sels) {
+        std::vector<int32_t> group;
+        for (size_t i = 0; i < cols.size(); ++i)
+            for (const auto &g : groupBy_) if (cols[i].name == g) { group.push_back((int32_t)i); break; }
+        std::vector<Aggregator> aggs;
+        for (const auto &a : aggs_) {
+            bool replaced = false;
+            for (auto &b : aggs) if (b.alias == a.alias) { b = a; replaced = true; }
+            if (!replaced) aggs.push_back(a);
+        }
+        std::vector<imm3_aggregate> abi(aggs.size());
+        for (size_t j = 0; j < aggs.size(); ++j) {
+            abi[j].kind = aggs[j].abiKind();
+            abi[j].column = -1;
+            for (size_t i = 0; i < cols.size(); ++i) if (cols[i].name == aggs[j].col) abi[j].column = (int32_t)i;
+            if (abi[j].column < 0) throw Exception("NoSuchElementException: key not found: " + aggs[j].col);
+        }
+        auto scanOp = std::dynamic_pointer_cast<ScanOp>(op_);
+        QueryHandle h;
+        imm3Check(imm3_query_create_table_agg(scanOp->manager().ctx(), table, usedIdx.data(), (int32_t)usedIdx.size(), sels.data(), (int32_t)sels.size(),
+                                              group.data(), (int32_t)group.size(), abi.data(), (int32_t)abi.size(), scanOp->table().blockSize, &h.q));
+        return decode(h, cols, group, aggs, abi);
+    }
+
+  private:
+    static std::vector<AggMapTuple> decode(QueryHandle &h, const std::vector<Column> &cols, const std::vector<int32_t> &group,
+                                           const std::vector<Aggregator> &aggs, const std::vector<imm3_aggregate> &abi) {
         imm3Check(imm3_query_run(h.q));
         uint32_t n = 0;
         imm3Check(imm3_query_group_count(h.q, &n));
@@ -447,7 +500,7 @@ class ProjectAggOp : public Operator<AggMapTuple> {
         std::vector<uint32_t> first(n);
         std::vector<int64_t> vals((size_t)n * aggs.size());
         imm3Check(imm3_query_fetch_groups(h.q, keys.data(), first.data(), counts.data(), vals.data(), n));
-        auto it = std::make_unique<VectorIterator<AggMapTuple>>();
+        std::vector<AggMapTuple> items;
         for (uint32_t g = 0; g < n; ++g) {
             std::string key;
             int off = 0;
@@ -479,12 +532,11 @@ class ProjectAggOp : public Operator<AggMapTuple> {
                 default: m[j].dvalue = (double)x;
                 }
             }
-            it->items.emplace_back(key, std::move(m));
+            items.emplace_back(key, std::move(m));
         }
-        return it;
+        return items;
     }
 
-  private:
     std::vector<Aggregator> aggs_;
     std::shared_ptr<ColumnVectorOperator> op_;
     std::vector<std::string> groupBy_;
@@ -522,6 +574,47 @@ class Engine {
         rec(*q.select);
         return out;
     }
+    // ---- single-launch table path (imm3_table) ----
+    struct TablePlan {
+        imm3_table *table = nullptr;
+        std::vector<Column> used;
+        std::vector<int32_t> usedIdx;
+        std::vector<imm3_select> sels;
+        std::vector<std::string> blobs;
+        std::vector<std::vector<int32_t>> lens;
+    };
+    // fills `p` and returns true when the whole table can run as one fused launch
+    bool tablePlan(const Query &q, TablePlan &p) {
+        const Table &table = sm_.sm.getTable(q.table);
+        p.table = sm_.deviceTable(q.table);
+        if (!p.table) return false;
+        p.used = getColumns(q, table);
+        for (const auto &c : p.used) p.usedIdx.push_back(table.columnIndex(c.name));
+        const std::vector<Leaf> leaves = resolveSelectOps(q);
+        SelectOp::checkConditions(leaves);
+        p.sels.resize(leaves.size());
+        p.blobs.resize(leaves.size());
+        p.lens.resize(leaves.size());
+        for (size_t i = 0; i < leaves.size(); ++i) {
+            int32_t ci = -1;
+            for (size_t k = 0; k < p.used.size(); ++k) if (p.used[k].name == leaves[i].col) { ci = (int32_t)k; break; }
+            if (ci < 0) throw Exception("NoSuchElementException: next on empty iterator");
+            const Column &c = p.used[(size_t)ci];
+            if (leaves[i].cond.kind == SelectCondition::Match &&
+                (c.codec != CodecType::DENSE_STRING || c.width() != 2 || leaves[i].cond.values.empty() || leaves[i].cond.values.size() > 8))
+                return false; // the tile kernels take 2-byte strings with <= 8 IN-list values
+            p.sels[i] = imm3_select{};
+            p.sels[i].column = ci;
+            p.sels[i].cond = (int32_t)leaves[i].cond.kind;
+            p.sels[i].value = leaves[i].cond.value;
+            for (const auto &v : leaves[i].cond.values) { p.blobs[i] += v; p.lens[i].push_back((int32_t)v.size()); }
+            p.sels[i].match_bytes = (const uint8_t *)p.blobs[i].data();
+            p.sels[i].match_lens = p.lens[i].data();
+            p.sels[i].n_match = (int32_t)p.lens[i].size();
+        }
+        return true;
+    }
+
     // one fused pipeline per segment; rows in ascending segment order (the reference's order across segments is
     // unspecified: queue interleaving, Engine.scala:255); `limit` is global, as the consumer-side ProjectOp's is.
     // Engine.resolveProjectOp (:130-156): default aliases col_max / col_min / col_count; Min over a STRING column
@@ -547,6 +640,14 @@ class Engine {
         const std::vector<Column> used = getColumns(q, table);
         const std::vector<Leaf> leaves = resolveSelectOps(q);
         const std::vector<Aggregator> aggs = resolveProjectOp(q.project, table);
+        {   // one table-level aggregation query: groups come back already merged in (segment, row) first-seen order
+            TablePlan p;
+            if (tablePlan(q, p)) {
+                auto scan = std::make_shared<ScanOp>(sm_, 0, q.table, p.used);
+                ProjectAggOp op(aggs, scan, q.project.groupBy);
+                return op.runOn(p.table, p.used, p.usedIdx, p.sels);
+            }
+        }
         auto mkScan = ScanOp::mkScanOp(sm_, q.table);
         std::vector<AggMapTuple> result;
         const int nseg = sm_.sm.getTableSegmentCount(table.name);
@@ -580,6 +681,46 @@ class Engine {
             return rows;
         }
         if (q.project.kind != ProjectADT::Project) throw Exception("NoProject");
+        {   // the whole table in ONE fused launch when it qualifies
+            TablePlan p;
+            if (tablePlan(q, p)) {
+                std::vector<int32_t> proj;
+                std::vector<Column> pcols;
+                for (const auto &name : q.project.cols) {
+                    bool found = false;
+                    for (size_t k = 0; k < p.used.size() && !found; ++k)
+                        if (p.used[k].name == name) { proj.push_back((int32_t)k); pcols.push_back(p.used[k]); found = true; }
+                    if (!found) throw Exception("NoSuchElementException: key not found: " + name);
+                }
+                QueryHandle h;
+                imm3Check(imm3_query_create_table(sm_.ctx(), p.table, p.usedIdx.data(), (int32_t)p.usedIdx.size(), p.sels.data(), (int32_t)p.sels.size(),
+                                                  proj.data(), (int32_t)proj.size(), q.project.limit, sm_.sm.getTable(q.table).blockSize, &h.q));
+                imm3Check(imm3_query_run(h.q));
+                uint64_t n = 0;
+                imm3Check(imm3_query_row_count(h.q, &n));
+                std::vector<std::vector<uint8_t>> bufs(pcols.size());
+                std::vector<void *> ptrs(pcols.size());
+                for (size_t j = 0; j < pcols.size(); ++j) {
+                    bufs[j].resize((size_t)std::max<uint64_t>(n, 1) * (size_t)pcols[j].width());
+                    ptrs[j] = bufs[j].data();
+                }
+                imm3Check(imm3_query_fetch_rows(h.q, nullptr, ptrs.data(), n));
+                std::vector<Row> rows;
+                rows.reserve((size_t)n);
+                for (uint64_t i = 0; i < n; ++i) {
+                    std::vector<Value> xs;
+                    for (size_t j = 0; j < pcols.size(); ++j) {
+                        ColumnVector v;
+                        v.type = pcols[j].columnType;
+                        v.width = pcols[j].width();
+                        v.data = bufs[j].data();
+                        xs.push_back(v.value((int)i));
+                    }
+                    rows.push_back(Row::fromSeq(std::move(xs)));
+                }
+                return rows;
+            }
+        }
         const Table &table = sm_.sm.getTable(q.table);
         const std::vector<Column> used = getColumns(q, table);
         const std::vector<Leaf> leaves = resolveSelectOps(q);

@@ -121,6 +121,7 @@ class GpuSegmentManager:
         self.ctxs = list(ctxs)
         self.tables = sm.tables
         self._segs: Dict[Tuple[str, int], native.DeviceSegment] = {}
+        self._tables: Dict[str, Optional[native.DeviceTable]] = {}
         self._filter = segment_filter
 
     def getTable(self, tableName: str) -> Table:
@@ -148,7 +149,29 @@ class GpuSegmentManager:
             self._segs[key] = native.DeviceSegment(self.ctx_of(segIdx), cols)
         return self._segs[key]
 
+    def device_table(self, tableName: str) -> Optional[native.DeviceTable]:
+        """All owned segments of the table as one scan unit (imm3_table), or None when the table cannot take the
+        single-launch path (ragged segments, several contexts): callers then fall back to per-segment pipelines."""
+        if tableName in self._tables:
+            return self._tables[tableName]
+        table = None
+        if len(self.ctxs) == 1:
+            segs = [s for s in range(self.getTableSegmentCount(tableName)) if self.owns(tableName, s)]
+            if segs:
+                try:
+                    table = native.DeviceTable(self.ctxs[0], [self.device_segment(tableName, s) for s in segs])
+                    table.segment_ids = segs
+                except Imm3Error as e:
+                    if e.code != native.ERR_LAYOUT:
+                        raise
+        self._tables[tableName] = table
+        return table
+
     def close(self):
+        for t in self._tables.values():
+            if t is not None:
+                t.close()
+        self._tables.clear()
         for s in self._segs.values():
             s.close()
         self._segs.clear()
@@ -493,7 +516,22 @@ class ProjectAggOp(Operator):
             code, operand = _cond_spec(cond)
             sels.append((colnames.index(col), code, operand))
         seg = scan.sm.device_segment(scan.tableName, scan.segIdx)
-        q = native.DeviceQuery(seg.ctx, seg, scan._used_indices(), sels, (), 0, t.blockSize,
+        yield from self._run(seg, scan.cols, scan._used_indices(), sels, t.blockSize)
+
+    def _run(self, seg, cols, used_idx, sels, block_size):
+        """seg: a DeviceSegment or a DeviceTable (then the groups are already merged across segments)."""
+        colnames = [c.name for c in cols]
+        group_idx = [i for i, n in enumerate(colnames) if n in self.groupBy]
+        by_alias = {}
+        for a in self.aggs:
+            by_alias[a.alias] = a
+        aggs = list(by_alias.values())
+
+        class _S:                             # the per-row decoding below only needs `cols`
+            pass
+        scan = _S()
+        scan.cols = list(cols)
+        q = native.DeviceQuery(seg.ctx, seg, used_idx, sels, (), 0, block_size,
                                group_cols=group_idx, aggs=[(a.kind, colnames.index(a.col)) for a in aggs])
         q.run()
         keys, first, counts, vals = q.fetch_groups()
@@ -610,10 +648,37 @@ class Engine:
                 op = leaf(op)
             yield segIdx, mk_proj(op)
 
+    def _table_plan(self, query: Query):
+        """(DeviceTable, used columns, select specs) when the whole table can run as ONE fused launch, else None."""
+        table = self.sm.getTable(query.table)
+        dt = self.sm.device_table(query.table)
+        if dt is None:
+            return None
+        used = getColumns(query, table)
+        names = [c.name for c in used]
+        sels = []
+        for leaf in resolveSelectOps(query):
+            op = leaf(None)
+            if not isinstance(op.cond, (Match, GT, LT, EQ)):
+                raise Exception(f"Unsupported condition: {op.cond}")
+            code, operand = _cond_spec(op.cond)
+            col = used[names.index(op.col)]
+            if code == native.MATCH and (col.codec != CodecType.DENSE_STRING or col.width != 2 or not (0 < len(operand) <= 8)):
+                return None                      # the tile kernels take 2-byte strings with <= 8 IN-list values
+            sels.append((names.index(op.col), code, operand))
+        tnames = [c.name for c in table.columns]
+        return dt, used, [tnames.index(n) for n in names], sels
+
     def execute_agg(self, query: Query):
         """ProjectAgg queries: per-segment ProjectAggOp, then ProjectAggregateQueueOp's combine by group key
-        (first arrival first; segments in ascending order).  Returns an ordered dict key -> {alias: Aggregator}."""
+        (first arrival first; segments in ascending order).  Returns an ordered dict key -> {alias: Aggregator}.
+        When the table qualifies, the whole thing is one imm3 table query (groups already merged on the GPU)."""
         table = self.sm.getTable(query.table)
+        plan = self._table_plan(query)
+        if plan is not None:
+            dt, used, used_idx, sels = plan
+            agg_op = resolveProjectOp(query.project, table)(ScanOp(self.sm, 0, query.table, used))
+            return dict(agg_op._run(dt, used, used_idx, sels, table.blockSize))
         used = getColumns(query, table)
         leaves = resolveSelectOps(query)
         mk_scan = ScanOp.mkScanOp(self.sm, query.table)
@@ -634,12 +699,37 @@ class Engine:
                         cur[alias] = cur[alias].combine(agg) if alias in cur else agg
         return result
 
+    def execute_table_columns(self, query: Query):
+        """Project query over the whole table as ONE fused launch: (segment uint32[n], row uint32[n], [column arrays])
+        in ascending (segment, row) order with the global limit applied -- or None when the table does not qualify."""
+        plan = self._table_plan(query)
+        if plan is None:
+            return None
+        dt, used, used_idx, sels = plan
+        names = [c.name for c in used]
+        proj = [names.index(n) for n in query.project.cols]
+        q = native.DeviceQuery(dt.ctx, dt, used_idx, sels, proj, query.project.limit, self.sm.getTable(query.table).blockSize)
+        q.run()
+        idx, cols = q.fetch_rows()
+        seg, row = q.locate_rows(idx)
+        out = []
+        for raw, codec in zip(cols, q.proj_codecs):
+            out.append(raw.reshape(-1).view("<i4") if codec == native.DENSE_INT else
+                       raw.reshape(-1).view(np.int8) if codec == native.DENSE_TINYINT else raw)
+        q.close()
+        seg_ids = np.asarray(getattr(dt, "segment_ids", list(range(len(dt.segs)))), dtype=np.uint32)
+        return seg_ids[seg] if seg.size else seg, row, out
+
     def execute(self, query: Query) -> Iterator[Row]:
         if isinstance(query.project, ProjectAgg):
             # ProjectAggregateQueueOp.next: Row of the aggregators' repr.  The reference lists them in the iteration
             # order of a mutable.HashMap keyed by alias (not reproduced); here: SELECT-list order.
             for _, aggmap in self.execute_agg(query).items():
                 yield Row(*[a.repr() for a in aggmap.values()])
+            return
+        fused = self.execute_table_columns(query)
+        if fused is not None:
+            yield from _rows_from_columns(fused[2])
             return
         limit = query.project.limit
         total = 0

@@ -134,3 +134,45 @@ def test_multi_segment_table_on_disk(tmp_path):
         assert idx.tolist() == rows.tolist()
         assert (cols[0] == c["id"][rows]).all() and (cols[1] == st[rows]).all() and (cols[2] == c["age"][rows]).all()
     g.close()
+
+
+def test_engine_uses_single_launch_table_path(tmp_path):
+    """README-style table (loader-quirk segments: S*B + 1 rows, trailing 1-row block): Engine answers Project and
+    ProjectAgg queries with ONE fused table query; results equal numpy over the concatenated segments."""
+    from immutable3_amd import Count, Max, ProjectAgg
+    from immutable3_amd.operators import Engine, GpuSegmentManager
+    t = synth.table_schema("tq", 1024)
+    TableIO.store(str(tmp_path), t)
+    allc = []
+    for s in range(5):
+        n = 4 * 1024 + 1 if s < 4 else 1500
+        cols = {"id": (np.arange(n, dtype=np.int64) + s * 10 ** 5).astype(np.int32),
+                "age": synth.uniform_below(300 + s, n, 100, np.int8), "state": synth.state_codes(400 + s, n)}
+        write_segment_arrays(str(tmp_path), t, s, cols, block_rows=([1024] * 4 + [1]) if s < 4 else [1024, 476])
+        allc.append(cols)
+    g = GpuSegmentManager(SegmentManager(str(tmp_path)))
+    assert g.device_table("tq") is not None
+    q = Query("tq", And(And(Select("age", GT(18)), Select("age", LT(30))), Select("state", Match(["CA", "NY"]))), Project(["id", "state", "age"], 40))
+    seg, row, cols = Engine(g).execute_table_columns(q)
+    exp = []
+    for s, c in enumerate(allc):
+        st = c["state"]
+        keep = (c["age"] > 18) & (c["age"] < 30) & (((st[:, 0] == 67) & (st[:, 1] == 65)) | ((st[:, 0] == 78) & (st[:, 1] == 89)))
+        for r in np.flatnonzero(keep):
+            exp.append((s, int(r), int(c["id"][r]), bytes(st[r]), int(c["age"][r])))
+    exp = exp[:40]
+    assert seg.tolist() == [e[0] for e in exp] and row.tolist() == [e[1] for e in exp]
+    assert cols[0].tolist() == [e[2] for e in exp] and [bytes(v) for v in cols[1]] == [e[3] for e in exp] and cols[2].tolist() == [e[4] for e in exp]
+    rows = list(Engine(g).execute(q))
+    assert rows == [Row(e[2], e[3].decode(), e[4]) for e in exp]
+    res = Engine(g).execute_agg(Query("tq", Select("age", GT(50)), ProjectAgg([Count("id"), Max("age")], ["state"])))
+    order, cnt, mx = [], {}, {}
+    for c in allc:
+        for r in np.flatnonzero(c["age"] > 50):
+            k = bytes(c["state"][r]).decode()
+            if k not in cnt:
+                order.append(k); cnt[k] = 0; mx[k] = -1
+            cnt[k] += 1; mx[k] = max(mx[k], int(c["age"][r]))
+    assert list(res) == order
+    assert all(res[k]["id_count"].repr() == str(cnt[k]) and res[k]["age_max"].repr() == f"{mx[k]}.0" for k in order)
+    g.close()

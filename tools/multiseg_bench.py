@@ -24,8 +24,8 @@ binp = os.path.join(__file__.rsplit("/tools/", 1)[0], "immutable3_amd", "bin", "
 for sql in ("select count(id) from t100m where (age > 18 and age < 30)",
             "select id, age from t100m where (age > 18 and age < 30) limit 10",
             "select count(id), max(age) from t100m group by state"):
-    for rep in range(2):
-        t0 = time.perf_counter()
-        p = subprocess.run([binp, "-q", sql, "-d", root], capture_output=True, text=True)
-        dt = time.perf_counter() - t0
-        print(f"{dt*1e3:8.1f} ms  rc={p.returncode}  {sql}  -> {p.stdout.splitlines()[:2]}")
+    t0 = time.perf_counter()
+    p = subprocess.run([binp, "-q", sql, "-d", root, "--repeat", "5"], capture_output=True, text=True)
+    dt = time.perf_counter() - t0
+    rep = [l.split(":")[1].split("ms")[0].strip() for l in p.stderr.splitlines() if l.startswith("repeat")]
+    print(f"{dt*1e3:8.1f} ms process  rc={p.returncode}  resident repeats (ms): {rep}  {sql}  -> {p.stdout.splitlines()[:2]}")
