@@ -7,6 +7,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <map>
+#include <mutex>
+#include <unordered_map>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -51,6 +54,13 @@ struct imm3_ctx {
     uint32_t timing_mask = 0xFFFFFFFFu;
     std::vector<TimingRecord> pool; // pre-created event pairs
     size_t used = 0;
+    // Caching allocator for per-query buffers.  Every user of such a buffer runs on `stream`, so a block freed by one
+    // query and handed to the next is reused in stream order: no synchronisation, no hipMalloc/hipFree (each ~50-100 us)
+    // on the query path once the pool is warm.
+    std::mutex pool_mu;
+    std::multimap<size_t, void *> pool_free;
+    std::unordered_map<void *, size_t> pool_size;
+    size_t pool_cached = 0;
     // device-clock stamps (diagnostics): slot i = kMaxFilterGrid {start, end} pairs for the i-th tile launch
     unsigned long long *d_stamps = nullptr;
     int32_t stamp_slots = 0, stamp_used = 0;
@@ -134,6 +144,68 @@ struct imm3_query {
 };
 
 // ---------------------------------------------------------------------------------------------
+// context-level caching allocator (see imm3_ctx::pool_*)
+// ---------------------------------------------------------------------------------------------
+static size_t pool_bucket(size_t bytes) {
+    if (bytes < 256) bytes = 256;
+    if (bytes <= (1u << 20)) { size_t b = 256; while (b < bytes) b <<= 1; return b; }
+    return (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+}
+
+static hipError_t pool_alloc(imm3_ctx *ctx, void **out, size_t bytes) {
+    const size_t b = pool_bucket(bytes);
+    {
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
+        auto it = ctx->pool_free.find(b);
+        if (it != ctx->pool_free.end()) {
+            *out = it->second;
+            ctx->pool_free.erase(it);
+            ctx->pool_cached -= b;
+            return hipSuccess;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, b);
+    if (e != hipSuccess) { // give cached blocks back to the driver and retry once
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
+        for (auto &kv : ctx->pool_free) { ctx->pool_size.erase(kv.second); (void)hipFree(kv.second); }
+        ctx->pool_free.clear();
+        ctx->pool_cached = 0;
+        e = hipMalloc(&p, b);
+        if (e != hipSuccess) return e;
+    }
+    {
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
+        ctx->pool_size[p] = b;
+    }
+    *out = p;
+    return hipSuccess;
+}
+
+static void pool_release(imm3_ctx *ctx, void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    auto it = ctx->pool_size.find(p);
+    if (it == ctx->pool_size.end()) { (void)hipFree(p); return; }
+    constexpr size_t kMaxCached = (size_t)16 << 30; // keep at most 16 GiB parked
+    if (ctx->pool_cached + it->second > kMaxCached) {
+        ctx->pool_size.erase(it);
+        (void)hipFree(p);
+        return;
+    }
+    ctx->pool_free.emplace(it->second, p);
+    ctx->pool_cached += it->second;
+}
+
+static void pool_drain(imm3_ctx *ctx) {
+    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    for (auto &kv : ctx->pool_free) (void)hipFree(kv.second);
+    ctx->pool_free.clear();
+    ctx->pool_size.clear();
+    ctx->pool_cached = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // scalar rules shared with the reference (JVM d2i / i2b): Select.scala:65,73; SURVEY Appendix A.1 rule 5
 // ---------------------------------------------------------------------------------------------
 static int32_t jvm_d2i(double d) {
@@ -204,6 +276,7 @@ extern "C" int imm3_ctx_destroy(imm3_ctx *ctx) {
     }
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
     (void)hipFree(ctx->d_stamps);
+    pool_drain(ctx);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return IMM3_OK;
@@ -235,6 +308,7 @@ extern "C" int imm3_ctx_devclock_enable(imm3_ctx *ctx, int32_t max_launches) {
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     (void)hipFree(ctx->d_stamps);
+    pool_drain(ctx);
     ctx->d_stamps = nullptr;
     ctx->stamp_slots = 0;
     ctx->stamp_used = 0;
@@ -431,22 +505,23 @@ extern "C" int imm3_segment_bytes(const imm3_segment *seg, uint64_t *device_byte
 // ---------------------------------------------------------------------------------------------
 static void query_free(imm3_query *q) {
     if (!q) return;
-    (void)hipSetDevice(q->ctx->device);
-    (void)hipStreamSynchronize(q->ctx->stream);
-    (void)hipFree(q->d_bitmap);
-    (void)hipFree(q->d_tile_offsets);
-    (void)hipFree(q->d_chunk_sums);
-    (void)hipFree(q->d_block_partials);
-    (void)hipFree(q->d_total);
-    (void)hipFree(q->d_word_row_base);
-    (void)hipFree(q->d_word_nvalid);
-    (void)hipFree(q->d_row_index);
-    for (auto p : q->d_proj) (void)hipFree(p);
-    for (auto &p : q->preds) { (void)hipFree(p.d_blob); (void)hipFree(p.d_stage); }
-    (void)hipFree(q->d_akeys); (void)hipFree(q->d_acounts); (void)hipFree(q->d_okeys); (void)hipFree(q->d_ocounts);
-    (void)hipFree(q->d_afirst); (void)hipFree(q->d_ofirst); (void)hipFree(q->d_ameta);
-    (void)hipFree(q->d_avals); (void)hipFree(q->d_ovals);
-    if (q->ctx->aux) (void)hipStreamSynchronize(q->ctx->aux);
+    imm3_ctx *ctx = q->ctx;
+    (void)hipSetDevice(ctx->device);
+    // no synchronisation: every buffer goes back to the context's pool and is only ever reused in stream order
+    if (ctx->aux && q->total_on_aux) (void)hipStreamSynchronize(ctx->aux);
+    pool_release(ctx, q->d_bitmap);
+    pool_release(ctx, q->d_tile_offsets);
+    pool_release(ctx, q->d_chunk_sums);
+    pool_release(ctx, q->d_block_partials);
+    pool_release(ctx, q->d_total);
+    pool_release(ctx, q->d_word_row_base);
+    pool_release(ctx, q->d_word_nvalid);
+    pool_release(ctx, q->d_row_index);
+    for (auto p : q->d_proj) pool_release(ctx, p);
+    for (auto &p : q->preds) { pool_release(ctx, p.d_blob); pool_release(ctx, p.d_stage); }
+    pool_release(ctx, q->d_akeys); pool_release(ctx, q->d_acounts); pool_release(ctx, q->d_okeys); pool_release(ctx, q->d_ocounts);
+    pool_release(ctx, q->d_afirst); pool_release(ctx, q->d_ofirst); pool_release(ctx, q->d_ameta);
+    pool_release(ctx, q->d_avals); pool_release(ctx, q->d_ovals);
     if (q->ev_filter_done) (void)hipEventDestroy(q->ev_filter_done);
     if (q->ev_total_done) (void)hipEventDestroy(q->ev_total_done);
     delete q;
@@ -455,26 +530,25 @@ static void query_free(imm3_query *q) {
 static int ensure_row_capacity(imm3_query *q, uint64_t rows) {
     if (rows <= q->cap_rows && q->d_row_index) return IMM3_OK;
     if (rows < 1) rows = 1;
-    HIPCHK(hipStreamSynchronize(q->ctx->stream));
-    (void)hipFree(q->d_row_index);
+    imm3_ctx *ctx = q->ctx;
+    pool_release(ctx, q->d_row_index); // stream-ordered: a gather still in flight finishes before any reuse
     q->d_row_index = nullptr;
     for (auto &p : q->d_proj) {
-        (void)hipFree(p);
+        pool_release(ctx, p);
         p = nullptr;
     }
     void *p = nullptr;
-    HIPCHK(hipMalloc(&p, rows * sizeof(uint32_t)));
+    HIPCHK(pool_alloc(ctx, &p, rows * sizeof(uint32_t)));
     q->d_row_index = (uint32_t *)p;
     q->d_proj.assign(q->proj.size(), nullptr);
     for (size_t j = 0; j < q->proj.size(); ++j) {
         const SegCol &sc = q->seg->cols[(size_t)q->used[(size_t)q->proj[j]]];
-        HIPCHK(hipMalloc(&p, rows * (uint64_t)sc.width));
+        HIPCHK(pool_alloc(ctx, &p, rows * (uint64_t)sc.width));
         q->d_proj[j] = (uint8_t *)p;
     }
     q->cap_rows = rows;
     return IMM3_OK;
 }
-
 
 // Batches of ONE segment as ScanOp yields them: the FIRST used column defines them (Scan.scala:55,72); BlockIterator
 // takes each block by a relative get from a rewound buffer (Segment.scala:159-168), i.e. from a running cursor.
@@ -670,7 +744,7 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
                 std::string blob;
                 for (auto &v : p.match) blob += v;
                 void *d = nullptr;
-                HIPCHK(hipMalloc(&d, blob.size()));
+                HIPCHK(pool_alloc(ctx, &d, blob.size()));
                 p.d_blob = (uint8_t *)d;
                 HIPCHK(hipMemcpyAsync(d, blob.data(), blob.size(), hipMemcpyHostToDevice, ctx->stream));
                 HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -681,15 +755,15 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
     // (4) device buffers
     void *p = nullptr;
     const size_t words_alloc = (size_t)std::max<int64_t>(q->n_tiles * kTileWords, 1);
-    HIPCHK(hipMalloc(&p, words_alloc * sizeof(uint64_t)));
+    HIPCHK(pool_alloc(ctx, &p, words_alloc * sizeof(uint64_t)));
     q->d_bitmap = (uint64_t *)p;
-    HIPCHK(hipMalloc(&p, (size_t)std::max<int64_t>(q->n_tiles, 1) * sizeof(uint32_t)));
+    HIPCHK(pool_alloc(ctx, &p, (size_t)std::max<int64_t>(q->n_tiles, 1) * sizeof(uint32_t)));
     q->d_tile_offsets = (uint32_t *)p;
-    HIPCHK(hipMalloc(&p, (size_t)std::max<int64_t>(q->n_chunks, 1) * sizeof(uint32_t)));
+    HIPCHK(pool_alloc(ctx, &p, (size_t)std::max<int64_t>(q->n_chunks, 1) * sizeof(uint32_t)));
     q->d_chunk_sums = (uint32_t *)p;
-    HIPCHK(hipMalloc(&p, kMaxFilterGrid * sizeof(uint32_t)));
+    HIPCHK(pool_alloc(ctx, &p, kMaxFilterGrid * sizeof(uint32_t)));
     q->d_block_partials = (uint32_t *)p;
-    HIPCHK(hipMalloc(&p, 2 * sizeof(unsigned long long)));
+    HIPCHK(pool_alloc(ctx, &p, 2 * sizeof(unsigned long long)));
     q->d_total = (unsigned long long *)p;
     q->d_n_emit = q->d_total + 1;
     HIPCHK(hipMemsetAsync(q->d_total, 0, 2 * sizeof(unsigned long long), ctx->stream));
@@ -708,9 +782,9 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
             }
             row += n;
         }
-        HIPCHK(hipMalloc(&p, base.size() * sizeof(uint32_t) + 4));
+        HIPCHK(pool_alloc(ctx, &p, base.size() * sizeof(uint32_t) + 4));
         q->d_word_row_base = (uint32_t *)p;
-        HIPCHK(hipMalloc(&p, nvalid.size() + 4));
+        HIPCHK(pool_alloc(ctx, &p, nvalid.size() + 4));
         q->d_word_nvalid = (uint8_t *)p;
         if (!base.empty()) {
             HIPCHK(hipMemcpyAsync(q->d_word_row_base, base.data(), base.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -742,7 +816,7 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
                 for (int32_t pj : q->proj) projected |= (q->used[(size_t)pj] == fp.seg_col);
                 if (!projected) continue;
                 void *d = nullptr;
-                HIPCHK(hipMalloc(&d, (size_t)n_full * kTileRows * (size_t)fp.width + 256));
+                HIPCHK(pool_alloc(ctx, &d, (size_t)n_full * kTileRows * (size_t)fp.width + 256));
                 fp.d_stage = (uint8_t *)d;
             }
         }
@@ -1332,11 +1406,11 @@ static int query_create_agg_impl(imm3_ctx *ctx, const imm3_segment *seg, const i
     HIPCHK(hipSetDevice(ctx->device));
     void *p = nullptr;
     const size_t n = (size_t)slots + 1;
-    HIPCHK(hipMalloc(&p, n * sizeof(unsigned long long))); q->d_akeys = (unsigned long long *)p;
-    HIPCHK(hipMalloc(&p, n * sizeof(uint32_t))); q->d_afirst = (uint32_t *)p;
-    HIPCHK(hipMalloc(&p, n * sizeof(unsigned long long))); q->d_acounts = (unsigned long long *)p;
-    HIPCHK(hipMalloc(&p, n * kMaxAggs * sizeof(long long))); q->d_avals = (long long *)p;
-    HIPCHK(hipMalloc(&p, 2 * sizeof(uint32_t))); q->d_ameta = (uint32_t *)p;
+    HIPCHK(pool_alloc(ctx, &p, n * sizeof(unsigned long long))); q->d_akeys = (unsigned long long *)p;
+    HIPCHK(pool_alloc(ctx, &p, n * sizeof(uint32_t))); q->d_afirst = (uint32_t *)p;
+    HIPCHK(pool_alloc(ctx, &p, n * sizeof(unsigned long long))); q->d_acounts = (unsigned long long *)p;
+    HIPCHK(pool_alloc(ctx, &p, n * kMaxAggs * sizeof(long long))); q->d_avals = (long long *)p;
+    HIPCHK(pool_alloc(ctx, &p, 2 * sizeof(uint32_t))); q->d_ameta = (uint32_t *)p;
     *out = guard.release();
     return IMM3_OK;
 }
@@ -1429,14 +1503,14 @@ static int settle_groups(imm3_query *q, uint32_t *n_groups) {
         HIPCHK(hipStreamSynchronize(s));
         if (meta[1]) return fail(IMM3_ERR_LAYOUT, "more distinct groups than the aggregation table holds (2^27)");
         if (meta[0] <= q->out_cap) { *n_groups = meta[0]; return IMM3_OK; }
-        (void)hipFree(q->d_okeys); (void)hipFree(q->d_ofirst); (void)hipFree(q->d_ocounts); (void)hipFree(q->d_ovals);
+        pool_release(ctx, q->d_okeys); pool_release(ctx, q->d_ofirst); pool_release(ctx, q->d_ocounts); pool_release(ctx, q->d_ovals);
         q->d_okeys = nullptr; q->d_ofirst = nullptr; q->d_ocounts = nullptr; q->d_ovals = nullptr;
         void *p = nullptr;
         const size_t n = meta[0];
-        HIPCHK(hipMalloc(&p, n * sizeof(unsigned long long))); q->d_okeys = (unsigned long long *)p;
-        HIPCHK(hipMalloc(&p, n * sizeof(uint32_t))); q->d_ofirst = (uint32_t *)p;
-        HIPCHK(hipMalloc(&p, n * sizeof(unsigned long long))); q->d_ocounts = (unsigned long long *)p;
-        HIPCHK(hipMalloc(&p, n * kMaxAggs * sizeof(long long))); q->d_ovals = (long long *)p;
+        HIPCHK(pool_alloc(ctx, &p, n * sizeof(unsigned long long))); q->d_okeys = (unsigned long long *)p;
+        HIPCHK(pool_alloc(ctx, &p, n * sizeof(uint32_t))); q->d_ofirst = (uint32_t *)p;
+        HIPCHK(pool_alloc(ctx, &p, n * sizeof(unsigned long long))); q->d_ocounts = (unsigned long long *)p;
+        HIPCHK(pool_alloc(ctx, &p, n * kMaxAggs * sizeof(long long))); q->d_ovals = (long long *)p;
         q->out_cap = meta[0];
     }
     return fail(IMM3_ERR_DEVICE, "group collection did not converge");

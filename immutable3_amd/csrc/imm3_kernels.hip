@@ -302,7 +302,8 @@ __device__ __forceinline__ uint32_t partial_tile(const TileArgs &a, int64_t tile
 
 // T = tiles per wave iteration: narrow columns take several tiles at once so that every wave keeps >= 4 KiB of
 // loads in flight (8 waves/CU x 4 KiB is what saturates HBM, see the header comment).
-template <int K0, int K1, int K2, int T>
+// TABLE selects the tile-table walk (table queries) at compile time, so the single-segment kernel carries none of it.
+template <int K0, int K1, int K2, int T, bool TABLE>
 __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a) {
     constexpr int kStage = StageBytes<K0>::value + StageBytes<K1>::value + StageBytes<K2>::value;
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerBlock][kStage > 0 ? kStage : 16];
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
     const int64_t wave_id = (int64_t)blockIdx.x * kWavesPerBlock + wave;
     const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
 
-    if (a.tile_rows) { // table query: tiles come from the tile table (one partial tile per segment), one tile per step
+    if constexpr (TABLE) { // table query: tiles come from the tile table (one partial tile per segment), one tile per step
         for (int64_t tile = wave_id; tile < a.n_tiles; tile += n_waves) {
             const uint32_t rows_here = a.tile_rows[tile];
             const void *d0 = K0 != TK_NONE ? a.tile_ptrs[0][tile] : nullptr;
@@ -337,8 +338,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
         block_partial_store(a.block_partials, lane_total, lane, wave);
         if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x + 1] = wall_clock64();
         return;
-    }
-
+    } else {
     const int64_t n_full = a.n_rows / kTileRows;
     const int64_t n_groups = n_full / T;
 
@@ -375,6 +375,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
     for (int d = 8; d >= 1; d >>= 1) lane_total += __shfl_xor(lane_total, d); // lanes 0..15 -> lane 0
     block_partial_store(a.block_partials, lane_total, lane, wave);
     if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x + 1] = wall_clock64(); // after the barrier in the store above
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -661,7 +662,8 @@ int filter_grid(int64_t units, bool generic, bool any_i32, int grid_blocks) {
 
 #define IMM3_TILE_CASE(k0, k1, k2, T)                                                           \
     if (a.kinds[0] == k0 && a.kinds[1] == k1 && a.kinds[2] == k2) {                             \
-        IMM3_LAUNCH((k_filter_tile<k0, k1, k2, T>), grid, kBlockThreads, s, ev0, ev1, a);       \
+        if (a.tile_rows) IMM3_LAUNCH((k_filter_tile<k0, k1, k2, 1, true>), grid, kBlockThreads, s, ev0, ev1, a); \
+        else IMM3_LAUNCH((k_filter_tile<k0, k1, k2, T, false>), grid, kBlockThreads, s, ev0, ev1, a);             \
         return true;                                                                            \
     }
 
