@@ -4,6 +4,7 @@
 // touches data fails with IMM3_ERR_DEVICE.
 #include "../../include/imm3.h"
 #include "imm3_internal.h"
+#include "../host/codec.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -73,13 +74,24 @@ struct SegCol {
     bool owned = false;
     uint64_t bytes = 0;
     std::vector<int32_t> offsets;
+    // PFOR_INT (imm3_codec.hip): the blocks stay compressed in d_data
+    std::vector<int32_t> block_rows;   // the value count each block declares (its first word)
+    int64_t rows = 0;
+    bool tile_aligned = false;         // every block but the last holds exactly 1024 rows: block k == bitmap tile k
+    uint32_t *d_block_off = nullptr;   // n_blocks + 1 byte offsets
+    uint32_t *d_row_base = nullptr;    // n_blocks + 1 first rows
+    uint8_t *d_dense = nullptr;        // decoded int32 column, made on first need (Project, aggregation, ragged, table)
 };
 
 struct imm3_segment {
     imm3_ctx *ctx = nullptr;
     std::vector<SegCol> cols;
     uint64_t device_bytes = 0;
+    std::mutex decode_mu;              // guards the lazy d_dense of PFOR_INT columns
 };
+
+// the flat, fixed-width form of a column (what every kernel but k_filter_pfor reads)
+static inline const uint8_t *col_flat(const SegCol &sc) { return sc.codec == IMM3_PFOR_INT ? sc.d_dense : sc.d_data; }
 
 struct imm3_table { // all segments of one table as one scan unit: the tile table
     imm3_ctx *ctx = nullptr;
@@ -98,6 +110,7 @@ struct FoldedPred { // all SelectOp leaves on one segment column, folded
     std::vector<std::string> match;        // string: surviving IN-list values (each exactly width bytes)
     uint8_t *d_blob = nullptr;             // device copy when it does not fit the kernel arguments
     uint8_t *d_stage = nullptr;            // survivors' values staged per tile (column is also projected)
+    bool pfor = false;                     // PFOR_INT column evaluated on its compressed blocks (k_filter_pfor)
 };
 
 struct imm3_query {
@@ -119,7 +132,8 @@ struct imm3_query {
     // device buffers
     uint64_t *d_bitmap = nullptr;
     uint32_t *d_tile_offsets = nullptr, *d_chunk_sums = nullptr, *d_block_partials = nullptr;
-    unsigned long long *d_total = nullptr, *d_n_emit = nullptr; // adjacent: d_n_emit = d_total + 1
+    unsigned long long *d_total = nullptr, *d_n_emit = nullptr; // adjacent: d_n_emit = d_total + 1; d_total + 2 = status word
+    bool has_pfor_pass = false;   // a k_filter_pfor pass may flag malformed blocks in the status word
     uint32_t *d_word_row_base = nullptr;
     uint8_t *d_word_nvalid = nullptr;
     uint32_t *d_row_index = nullptr;
@@ -440,12 +454,122 @@ struct LaunchTimer {
 // ---------------------------------------------------------------------------------------------
 static constexpr uint64_t kPad = 16384; // readable slack past every column: a partial last tile is read as a whole (1024 rows x <= 16 B)
 
+static void segment_free(imm3_segment *seg) {
+    if (!seg) return;
+    for (auto &c : seg->cols) {
+        if (c.owned && c.d_data) (void)hipFree(c.d_data);
+        if (c.d_block_off) (void)hipFree(c.d_block_off);
+        if (c.d_row_base) (void)hipFree(c.d_row_base);
+        if (c.d_dense) (void)hipFree(c.d_dense);
+    }
+    delete seg;
+}
+
+// PFOR_INT column: the rows of a block are not implied by its byte length; read the count word of every block
+// (PFORCodec.scala:19-31 -> compressed(0) = input.length) and index the blocks for the kernels.
+static int pfor_index(imm3_ctx *ctx, imm3_segment *seg, SegCol &sc) {
+    if (sc.width != 4) return fail(IMM3_ERR_ARG, "width does not match codec");
+    const size_t nb = sc.offsets.empty() ? 0 : sc.offsets.size() - 1;
+    std::vector<uint32_t> off(nb + 1, 0u);
+    for (size_t k = 0; k <= nb && !sc.offsets.empty(); ++k) {
+        const int64_t o = sc.offsets[k];
+        if (o < 0 || (uint64_t)o > sc.bytes || (o & 3) || (k > 0 && o < sc.offsets[k - 1]))
+            return fail(IMM3_ERR_LAYOUT, "PFOR_INT block " + std::to_string(k) + ": offsets must ascend in whole 4-byte words within the segment data");
+        off[k] = (uint32_t)o;
+    }
+    void *p = nullptr;
+    HIPCHK(hipMalloc(&p, (nb + 1) * sizeof(uint32_t)));
+    sc.d_block_off = (uint32_t *)p;
+    HIPCHK(hipMalloc(&p, (nb + 1) * sizeof(uint32_t)));
+    sc.d_row_base = (uint32_t *)p;
+    seg->device_bytes += 2 * (nb + 1) * sizeof(uint32_t);
+    HIPCHK(hipMemcpyAsync(sc.d_block_off, off.data(), (nb + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    sc.block_rows.assign(nb, 0);
+    if (nb) {
+        int32_t *d_counts = nullptr;
+        HIPCHK(hipMalloc(&p, nb * sizeof(int32_t)));
+        d_counts = (int32_t *)p;
+        launch_pfor_counts(sc.d_data, sc.d_block_off, (int64_t)nb, d_counts, ctx->stream);
+        const hipError_t e1 = hipGetLastError();
+        const hipError_t e2 = hipMemcpyAsync(sc.block_rows.data(), d_counts, nb * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+        const hipError_t e3 = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_counts);
+        HIPCHK(e1);
+        HIPCHK(e2);
+        HIPCHK(e3);
+    }
+    std::vector<uint32_t> base(nb + 1, 0u);
+    int64_t rows = 0;
+    sc.tile_aligned = true;
+    for (size_t k = 0; k < nb; ++k) {
+        const int64_t n = sc.block_rows[k];
+        const int64_t words = ((int64_t)off[k + 1] - (int64_t)off[k]) / 4;
+        // a block of n values needs at least the count word (+ n / 32 mini-blocks may all have width 0)
+        if (n < 0 || words < 1) return fail(IMM3_ERR_LAYOUT, "PFOR_INT block " + std::to_string(k) + " is malformed (no count word)");
+        if (k + 1 < nb && n != kTileRows) sc.tile_aligned = false;
+        if (n > kTileRows) sc.tile_aligned = false;
+        base[k] = (uint32_t)rows;
+        rows += n;
+        if (rows > 0xFFFFFFFFLL) return fail(IMM3_ERR_LAYOUT, "segment too large");
+    }
+    base[nb] = (uint32_t)rows;
+    sc.rows = rows;
+    HIPCHK(hipMemcpyAsync(sc.d_row_base, base.data(), (nb + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return IMM3_OK;
+}
+
+// The decoded (dense int32) form of a PFOR_INT column, made once per segment on first need.
+static int ensure_dense(imm3_ctx *ctx, const imm3_segment *cseg, int32_t col) {
+    imm3_segment *seg = const_cast<imm3_segment *>(cseg);
+    SegCol &sc = seg->cols[(size_t)col];
+    if (sc.codec != IMM3_PFOR_INT) return IMM3_OK;
+    std::lock_guard<std::mutex> g(seg->decode_mu);
+    if (sc.d_dense) return IMM3_OK;
+    void *p = nullptr;
+    const size_t bytes = (size_t)sc.rows * 4 + kPad;
+    HIPCHK(hipMalloc(&p, bytes));
+    uint32_t *d_status = nullptr;
+    void *ps = nullptr;
+    hipError_t e = hipMalloc(&ps, sizeof(uint32_t));
+    if (e != hipSuccess) { (void)hipFree(p); HIPCHK(e); }
+    d_status = (uint32_t *)ps;
+    uint32_t status = 0;
+    PforArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.data = sc.d_data;
+    a.block_off = sc.d_block_off;
+    a.row_base = sc.d_row_base;
+    a.n_blocks = (int64_t)sc.block_rows.size();
+    a.out = (int32_t *)p;
+    a.status = d_status;
+    e = hipMemsetAsync(d_status, 0, sizeof(uint32_t), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync((uint8_t *)p + (size_t)sc.rows * 4, 0, kPad, ctx->stream);
+    if (e == hipSuccess && a.n_blocks > 0) {
+        LaunchTimer t(ctx, 5);
+        const int64_t want = (a.n_blocks + kWavesPerBlock - 1) / kWavesPerBlock;
+        launch_pfor_decode(a, (int)std::min<int64_t>(want, 2048), ctx->stream, t.start, t.stop);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&status, d_status, sizeof(status), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_status);
+    if (e != hipSuccess || status) {
+        (void)hipFree(p);
+        HIPCHK(e);
+        return fail(IMM3_ERR_LAYOUT, "malformed PFOR_INT block (width above 32, data past the block end, or count mismatch)");
+    }
+    sc.d_dense = (uint8_t *)p;
+    seg->device_bytes += bytes;
+    return IMM3_OK;
+}
+
 static int segment_build(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, bool wrap, imm3_segment **out) {
     if (!ctx || !out) return fail(IMM3_ERR_ARG, "null argument");
     *out = nullptr;
     if (ncols <= 0 || !cols) return fail(IMM3_ERR_ARG, "a segment needs at least one column");
     HIPCHK(hipSetDevice(ctx->device));
-    std::unique_ptr<imm3_segment> seg(new imm3_segment());
+    std::unique_ptr<imm3_segment, void (*)(imm3_segment *)> seg(new imm3_segment(), segment_free);
     seg->ctx = ctx;
     seg->cols.resize((size_t)ncols);
     for (int32_t i = 0; i < ncols; ++i) {
@@ -473,6 +597,11 @@ static int segment_build(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, 
         }
     }
     HIPCHK(hipStreamSynchronize(ctx->stream)); // host buffers may be unmapped after we return
+    for (auto &sc : seg->cols) {
+        if (sc.codec != IMM3_PFOR_INT) continue;
+        const int rc = pfor_index(ctx, seg.get(), sc);
+        if (rc) return rc;
+    }
     *out = seg.release();
     return IMM3_OK;
 }
@@ -488,9 +617,7 @@ extern "C" int imm3_segment_destroy(imm3_segment *seg) {
     if (!seg) return IMM3_OK;
     (void)hipSetDevice(seg->ctx->device);
     (void)hipStreamSynchronize(seg->ctx->stream);
-    for (auto &c : seg->cols)
-        if (c.owned && c.d_data) (void)hipFree(c.d_data);
-    delete seg;
+    segment_free(seg);
     return IMM3_OK;
 }
 
@@ -561,6 +688,11 @@ struct SegLayout {
     bool ragged = false;
 };
 
+// rows of block k of a column: DENSE_* = bytes / width; PFOR_INT = the count the block declares
+static inline int64_t block_rows_of(const SegCol &sc, int32_t k, int64_t len) {
+    return sc.codec == IMM3_PFOR_INT ? (int64_t)sc.block_rows[(size_t)k] : len / sc.width;
+}
+
 static int segment_layout(const imm3_segment *seg, const std::vector<int32_t> &used, int32_t table_block_size, SegLayout &L) {
     const SegCol &first = seg->cols[(size_t)used[0]];
     const int32_t nb = first.offsets.empty() ? 0 : (int32_t)first.offsets.size() - 1;
@@ -573,7 +705,7 @@ static int segment_layout(const imm3_segment *seg, const std::vector<int32_t> &u
         if (len < 0) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": negative length (NegativeArraySizeException in the reference)");
         if (len % first.width) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": byte length is not a multiple of the value width (malformed segment)");
         if (cursor + (uint64_t)len > first.bytes) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": bytes [" + std::to_string(cursor) + ", " + std::to_string(cursor + (uint64_t)len) + ") run past the segment data of " + std::to_string(first.bytes) + " bytes (BufferUnderflowException in the reference)");
-        const int64_t n = len / first.width;
+        const int64_t n = block_rows_of(first, k, len);
         L.size[(size_t)k] = (int32_t)n;
         L.oid[(size_t)k] = (int32_t)((uint32_t)k * (uint32_t)table_block_size); // vecCounter * table.blockSize
         L.word_off[(size_t)k] = L.words;
@@ -590,7 +722,7 @@ static int segment_layout(const imm3_segment *seg, const std::vector<int32_t> &u
         uint64_t cur = 0;
         for (int32_t k = 0; k < nb; ++k) {
             const int64_t len = (int64_t)sc.offsets[(size_t)k + 1] - (int64_t)sc.offsets[(size_t)k];
-            if (len < 0 || len % sc.width || len / sc.width != L.size[(size_t)k])
+            if (len < 0 || len % sc.width || block_rows_of(sc, k, len) != L.size[(size_t)k])
                 return fail(IMM3_ERR_LAYOUT, "used column " + std::to_string(i) + " block " + std::to_string(k) + " does not hold the same rows as the first used column");
             if (cur + (uint64_t)len > sc.bytes) return fail(IMM3_ERR_LAYOUT, "used column " + std::to_string(i) + " block " + std::to_string(k) + " runs past the segment data");
             cur += (uint64_t)len;
@@ -679,9 +811,11 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
         // ScanOp.next dispatches on the codec of every used column (Scan.scala:37-50) ...
         for (int32_t i = 0; i < n_used; ++i) {
             const SegCol &sc = seg->cols[(size_t)q->used[(size_t)i]];
-            if (sc.codec != IMM3_DENSE_INT && sc.codec != IMM3_DENSE_TINYINT && sc.codec != IMM3_DENSE_STRING)
+            // PFOR_INT: the reference dispatches it too (Scan.scala:37-39) but its decode throws on every block
+            // (PFORCodec.scala:43-50); here the blocks its encoder writes are decoded (imm3_codec.hip).
+            if (sc.codec != IMM3_DENSE_INT && sc.codec != IMM3_DENSE_TINYINT && sc.codec != IMM3_DENSE_STRING && sc.codec != IMM3_PFOR_INT)
                 return fail(IMM3_ERR_NO_CODEC, "No implementation for codec " + std::to_string(sc.codec));
-            if ((sc.codec == IMM3_DENSE_INT && sc.width != 4) || (sc.codec == IMM3_DENSE_TINYINT && sc.width != 1))
+            if (((sc.codec == IMM3_DENSE_INT || sc.codec == IMM3_PFOR_INT) && sc.width != 4) || (sc.codec == IMM3_DENSE_TINYINT && sc.width != 1))
                 return fail(IMM3_ERR_ARG, "width does not match codec");
         }
         // ... and each SelectIterator dispatches on the vector type (Select.scala:41,80,118,156).
@@ -707,7 +841,7 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
                 fp = &q->preds.back();
                 fp->seg_col = sci;
                 fp->width = sc.width;
-                if (sc.codec == IMM3_DENSE_INT) { fp->kind = KIND_I32; fp->lo = INT32_MIN; fp->hi = INT32_MAX; }
+                if (sc.codec == IMM3_DENSE_INT || sc.codec == IMM3_PFOR_INT) { fp->kind = KIND_I32; fp->lo = INT32_MIN; fp->hi = INT32_MAX; }
                 else if (sc.codec == IMM3_DENSE_TINYINT) { fp->kind = KIND_I8; fp->lo = -128; fp->hi = 127; }
                 else fp->kind = KIND_STR;
             }
@@ -738,6 +872,24 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
                 else { fp->lo = std::max(fp->lo, t); fp->hi = std::min(fp->hi, t); } // ==, Select.scala:144,152
             }
         }
+        // PFOR_INT columns: a predicate-only column of a tile-aligned segment is evaluated on its compressed blocks
+        // (k_filter_pfor); anything else reads the decoded column, made once per segment.
+        for (int32_t i = 0; i < n_used; ++i) {
+            const int32_t sci = q->used[(size_t)i];
+            const SegCol &sc = seg->cols[(size_t)sci];
+            if (sc.codec != IMM3_PFOR_INT) continue;
+            bool projected = false;
+            for (int32_t pj : q->proj) projected |= (pj == i);
+            FoldedPred *fp = nullptr;
+            for (auto &p : q->preds)
+                if (p.seg_col == sci) fp = &p;
+            const bool fused = fp && !table && !q->ragged && sc.tile_aligned && !projected && ctx->filter_variant != 1 && ctx->filter_variant != 5;
+            if (fused) fp->pfor = true;
+            else if (!table) { // a table decodes its PFOR_INT columns when it is created
+                const int drc = ensure_dense(ctx, seg, sci);
+                if (drc) return drc;
+            }
+        }
         for (auto &p : q->preds) {
             if (p.kind == KIND_STR ? p.match.empty() : p.lo > p.hi) q->always_false = true;
             if (p.kind == KIND_STR && (p.width > 8 || p.match.size() > (size_t)kMaxMatch) && !p.match.empty()) {
@@ -763,10 +915,10 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
     q->d_chunk_sums = (uint32_t *)p;
     HIPCHK(pool_alloc(ctx, &p, kMaxFilterGrid * sizeof(uint32_t)));
     q->d_block_partials = (uint32_t *)p;
-    HIPCHK(pool_alloc(ctx, &p, 2 * sizeof(unsigned long long)));
+    HIPCHK(pool_alloc(ctx, &p, 3 * sizeof(unsigned long long)));
     q->d_total = (unsigned long long *)p;
     q->d_n_emit = q->d_total + 1;
-    HIPCHK(hipMemsetAsync(q->d_total, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(q->d_total, 0, 3 * sizeof(unsigned long long), ctx->stream));
     HIPCHK(hipMemsetAsync(q->d_bitmap, 0, words_alloc * sizeof(uint64_t), ctx->stream));
     if (q->ragged) {
         std::vector<uint32_t> base((size_t)q->n_tiles * kTileWords, 0u);
@@ -804,7 +956,7 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
         bool all_tile = true;
         for (const auto &fp : q->preds) {
             const bool s2 = fp.kind == KIND_STR && fp.width == 2 && !fp.match.empty() && fp.match.size() <= (size_t)kMaxTileMatch;
-            if (fp.kind == KIND_STR && !s2) all_tile = false;
+            if ((fp.kind == KIND_STR && !s2) || fp.pfor) all_tile = false;
             n_s2 += s2;
         }
         if (all_tile && n_s2 <= 1) {
@@ -868,6 +1020,10 @@ extern "C" int imm3_table_create(imm3_ctx *ctx, const imm3_segment *const *segs,
         const int rc = segment_layout(sg, all_cols, 0, L);
         if (rc) return rc;
         if (L.ragged) return fail(IMM3_ERR_LAYOUT, "segment " + std::to_string(si) + ": a non-final block is not a multiple of 64 rows (ragged layout); use per-segment queries");
+        for (size_t c = 0; c < ncols; ++c) { // the tile table addresses flat columns: decode PFOR_INT ones now
+            const int drc = ensure_dense(ctx, sg, (int32_t)c);
+            if (drc) return drc;
+        }
         t->segs.push_back(sg);
         t->seg_rows.push_back(L.rows);
         t->tile_start.push_back(t->tile_start.back() + (L.rows + kTileRows - 1) / kTileRows);
@@ -882,7 +1038,7 @@ extern "C" int imm3_table_create(imm3_ctx *ctx, const imm3_segment *const *segs,
         for (int64_t k = 0; k < nt; ++k) {
             const size_t tile = (size_t)(t->tile_start[si] + k);
             rows[tile] = (uint32_t)std::min<int64_t>(kTileRows, t->seg_rows[si] - k * kTileRows);
-            for (size_t c = 0; c < ncols; ++c) ptrs[c][tile] = t->segs[si]->cols[c].d_data + (size_t)k * kTileRows * (size_t)t->segs[si]->cols[c].width;
+            for (size_t c = 0; c < ncols; ++c) ptrs[c][tile] = col_flat(t->segs[si]->cols[c]) + (size_t)k * kTileRows * (size_t)t->segs[si]->cols[c].width;
         }
     }
     void *p = nullptr;
@@ -962,7 +1118,7 @@ extern "C" int imm3_query_reserve_rows(imm3_query *q, uint64_t rows) {
 static void fill_colpred(const imm3_query *q, const FoldedPred &fp, ColPred &cp) {
     std::memset(&cp, 0, sizeof(cp));
     const SegCol &sc = q->seg->cols[(size_t)fp.seg_col];
-    cp.data = sc.d_data;
+    cp.data = col_flat(sc);
     cp.kind = fp.kind;
     cp.width = fp.width;
     cp.lo = (int32_t)fp.lo;
@@ -1013,9 +1169,10 @@ static int run_select(imm3_query *q, bool overlap_total) {
     // to 3 columns (at most one string) per launch; everything else -- other string widths, long IN-lists,
     // ragged layouts -- through the word-at-a-time kernel, up to 4 columns per launch.  Every pass after the
     // first ANDs into the bitmap in memory.
-    std::vector<const FoldedPred *> tile_preds, generic_preds;
+    std::vector<const FoldedPred *> tile_preds, generic_preds, pfor_preds;
     for (const auto &p : q->preds) {
-        if (!q->ragged && ctx->filter_variant != 1 && tile_kind(p) != TK_NONE) tile_preds.push_back(&p);
+        if (p.pfor) pfor_preds.push_back(&p);
+        else if (!q->ragged && ctx->filter_variant != 1 && tile_kind(p) != TK_NONE) tile_preds.push_back(&p);
         else generic_preds.push_back(&p);
     }
     if (q->table && !generic_preds.empty()) return fail(IMM3_ERR_ARG, "table queries support int32 / int8 / 2-byte string predicates (<= 8 IN-list values); use per-segment queries");
@@ -1024,7 +1181,7 @@ static int run_select(imm3_query *q, bool overlap_total) {
     int pass = 0;
     int grid = 1;
     q->stage_written = false;
-    const bool single_tile_pass = generic_preds.empty() && tile_preds.size() <= (size_t)kMaxTileCols;
+    const bool single_tile_pass = generic_preds.empty() && pfor_preds.empty() && tile_preds.size() <= (size_t)kMaxTileCols;
     // tile passes (a query without predicates is one tile pass with zero columns)
     size_t ti = 0;
     const bool need_empty_pass = q->preds.empty() && !q->ragged && ctx->filter_variant != 1;
@@ -1047,7 +1204,7 @@ static int run_select(imm3_query *q, bool overlap_total) {
         for (int k = 0; k < n; ++k) {
             const FoldedPred &fp = *take[(size_t)k];
             TileCol &c = a.cols[k];
-            c.data = q->seg->cols[(size_t)fp.seg_col].d_data;
+            c.data = col_flat(q->seg->cols[(size_t)fp.seg_col]);
             if (q->table) a.tile_ptrs[k] = (const void *const *)q->table->d_tile_ptrs[(size_t)fp.seg_col];
             c.lo = (int32_t)fp.lo;
             c.hi = (int32_t)fp.hi;
@@ -1077,6 +1234,32 @@ static int run_select(imm3_query *q, bool overlap_total) {
         if (a.stamps) { ctx->stamp_grids.push_back(grid); ++ctx->stamp_used; }
         LaunchTimer t(ctx, 0);
         if (!launch_filter_tile(a, grid, s, t.start, t.stop)) return fail(IMM3_ERR_ARG, "internal: no tile kernel for this column combination");
+        HIPCHK(hipGetLastError());
+        ++pass;
+    }
+    // PFOR_INT passes: one compressed column per launch, decoded in LDS and compared in registers
+    q->has_pfor_pass = !pfor_preds.empty();
+    for (const FoldedPred *fp : pfor_preds) {
+        const SegCol &sc = q->seg->cols[(size_t)fp->seg_col];
+        PforArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.data = sc.d_data;
+        a.block_off = sc.d_block_off;
+        a.n_blocks = (int64_t)sc.block_rows.size();
+        a.lo = (int32_t)fp->lo;
+        a.hi = (int32_t)fp->hi;
+        a.and_existing = pass > 0;
+        a.n_rows = q->n_rows;
+        a.n_words = q->n_words;
+        a.n_tiles = q->n_tiles;
+        a.bitmap = q->d_bitmap;
+        a.block_partials = q->d_block_partials;
+        a.status = (uint32_t *)(q->d_total + 2);
+        grid = filter_grid(q->n_tiles, true, false, ctx->grid_blocks);
+        {
+            LaunchTimer t(ctx, 0);
+            launch_filter_pfor(a, grid, s, t.start, t.stop);
+        }
         HIPCHK(hipGetLastError());
         ++pass;
     }
@@ -1165,7 +1348,7 @@ static int launch_project(imm3_query *q) {
         g.n_proj = (int32_t)take;
         for (size_t j = 0; j < take; ++j) {
             const SegCol &sc = q->seg->cols[(size_t)q->used[(size_t)q->proj[done + j]]];
-            g.proj[j].src = sc.d_data;
+            g.proj[j].src = col_flat(sc);
             g.proj[j].tile_ptrs = q->table ? (const void *const *)q->table->d_tile_ptrs[(size_t)q->used[(size_t)q->proj[done + j]]] : nullptr;
             g.proj[j].dst = q->d_proj[done + j];
             g.proj[j].width = sc.width;
@@ -1283,8 +1466,11 @@ extern "C" int imm3_query_count(imm3_query *q, uint64_t *selected_rows) {
         const int jrc = join_total(q, q->ctx->stream);
         if (jrc) return jrc;
     }
+    unsigned long long status = 0;
     HIPCHK(hipMemcpyAsync(&total, q->d_total, sizeof(total), hipMemcpyDeviceToHost, q->ctx->stream));
+    if (q->has_pfor_pass) HIPCHK(hipMemcpyAsync(&status, q->d_total + 2, sizeof(status), hipMemcpyDeviceToHost, q->ctx->stream));
     HIPCHK(hipStreamSynchronize(q->ctx->stream));
+    if (status) return fail(IMM3_ERR_LAYOUT, "malformed PFOR_INT block (width above 32, data past the block end, or count mismatch)");
     *selected_rows = total;
     return IMM3_OK;
 }
@@ -1393,6 +1579,18 @@ static int query_create_agg_impl(imm3_ctx *ctx, const imm3_segment *seg, const i
         if (has_batches && is_str && aggs[j].kind == IMM3_AGG_MIN) return fail(IMM3_ERR_UNSUPPORTED_VECTOR, "bad aggregator for this data type");
         if (is_str && aggs[j].kind == IMM3_AGG_MAX && sc.width > 8) return fail(IMM3_ERR_ARG, "MAX over strings wider than 8 bytes is not supported on the GPU path");
     }
+    // group / aggregate columns are read row by row: PFOR_INT ones through their decoded form
+    if (!table) {
+        auto need_dense = [&](int32_t used_idx) -> int {
+            const int32_t sci = q->used[(size_t)used_idx];
+            if (seg->cols[(size_t)sci].codec != IMM3_PFOR_INT) return IMM3_OK;
+            for (auto &fp : q->preds)
+                if (fp.seg_col == sci) fp.pfor = false;
+            return ensure_dense(ctx, seg, sci);
+        };
+        for (int32_t g = 0; g < n_group; ++g) { rc = need_dense(group_cols[g]); if (rc) return rc; }
+        for (int32_t j = 0; j < n_aggs; ++j) { rc = need_dense(aggs[j].column); if (rc) return rc; }
+    }
     q->is_agg = true;
     q->group_cols.assign(group_cols, group_cols + n_group);
     q->aggs.assign(aggs, aggs + n_aggs);
@@ -1444,7 +1642,7 @@ static void fill_agg_args(const imm3_query *q, AggArgs &a) {
     int shift = 0;
     for (size_t g = 0; g < q->group_cols.size(); ++g) {
         const SegCol &sc = q->seg->cols[(size_t)q->used[(size_t)q->group_cols[g]]];
-        a.groups[g].data = sc.d_data;
+        a.groups[g].data = col_flat(sc);
         a.groups[g].tile_ptrs = q->table ? (const void *const *)q->table->d_tile_ptrs[(size_t)q->used[(size_t)q->group_cols[g]]] : nullptr;
         a.groups[g].width = sc.width;
         a.groups[g].shift = shift;
@@ -1453,7 +1651,7 @@ static void fill_agg_args(const imm3_query *q, AggArgs &a) {
     a.n_group = (int32_t)q->group_cols.size();
     for (size_t j = 0; j < q->aggs.size(); ++j) {
         const SegCol &sc = q->seg->cols[(size_t)q->used[(size_t)q->aggs[j].column]];
-        a.aggs[j].data = sc.d_data;
+        a.aggs[j].data = col_flat(sc);
         a.aggs[j].tile_ptrs = q->table ? (const void *const *)q->table->d_tile_ptrs[(size_t)q->used[(size_t)q->aggs[j].column]] : nullptr;
         a.aggs[j].width = sc.width;
         a.aggs[j].kind = q->aggs[j].kind;
@@ -1550,5 +1748,40 @@ extern "C" int imm3_query_fetch_groups(imm3_query *q, uint64_t *keys, uint32_t *
             for (size_t j = 0; j < na; ++j)
                 vals[(size_t)o * na + j] = q->aggs[j].kind == IMM3_AGG_COUNT ? (int64_t)hc[i] : (int64_t)hv[(size_t)i * kMaxAggs + j];
     }
+    return IMM3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// write side of the PFOR_INT codec (host only; host/codec.hpp)
+// ---------------------------------------------------------------------------------------------
+extern "C" uint64_t imm3_pfor_encode_bound(int32_t n_values) {
+    return n_values < 0 ? 0 : (uint64_t)immutabledb::codec::pforEncodeBound(n_values);
+}
+
+extern "C" int imm3_pfor_encode_block(const int32_t *values, int32_t n_values, void *out, uint64_t cap, uint64_t *bytes_out) {
+    if (n_values < 0 || (n_values > 0 && !values) || !out || !bytes_out) return fail(IMM3_ERR_ARG, "bad argument");
+    const std::vector<uint8_t> blk = immutabledb::codec::pforEncodeBlock(values, n_values);
+    if (blk.size() > cap) return fail(IMM3_ERR_ARG, "output buffer too small (see imm3_pfor_encode_bound)");
+    std::memcpy(out, blk.data(), blk.size());
+    *bytes_out = blk.size();
+    return IMM3_OK;
+}
+
+extern "C" int imm3_pfor_encode_column(const int32_t *values, uint64_t n_values, int32_t block_rows, void *out, uint64_t cap,
+                                       int32_t *offsets_out, uint64_t *bytes_out) {
+    if ((n_values > 0 && !values) || block_rows <= 0 || !out || !offsets_out || !bytes_out) return fail(IMM3_ERR_ARG, "bad argument");
+    uint64_t pos = 0;
+    size_t k = 0;
+    offsets_out[0] = 0;
+    for (uint64_t r = 0; r < n_values; r += (uint64_t)block_rows) {
+        const int32_t n = (int32_t)std::min<uint64_t>((uint64_t)block_rows, n_values - r);
+        const std::vector<uint8_t> blk = immutabledb::codec::pforEncodeBlock(values + r, n);
+        if (pos + blk.size() > cap) return fail(IMM3_ERR_ARG, "output buffer too small");
+        if (pos + blk.size() > 0x7FFFFFFFULL) return fail(IMM3_ERR_LAYOUT, "segment data above 2 GiB (blockOffset is an Int, Segment.scala:33)");
+        std::memcpy((uint8_t *)out + pos, blk.data(), blk.size());
+        pos += blk.size();
+        offsets_out[++k] = (int32_t)pos;
+    }
+    *bytes_out = pos;
     return IMM3_OK;
 }

@@ -176,6 +176,25 @@ void launch_group_collect(const AggArgs &a, hipStream_t s);
 constexpr int kMaxFilterGrid = 4096; // capacity of block_partials
 int filter_grid(int64_t units, bool generic, bool any_i32, int grid_blocks);
 // ev0/ev1: optional events stamped with the kernel's own start/end (hipExtLaunchKernelGGL), else null
+// ---- PFOR_INT blocks (imm3_codec.hip) ----
+struct PforArgs {
+    const uint8_t *data;          // the column's .dat bytes in HBM (blocks start on 4-byte boundaries)
+    const uint32_t *block_off;    // n_blocks + 1 byte offsets
+    const uint32_t *row_base;     // decode: n_blocks + 1 first rows (prefix sum of the blocks' value counts)
+    int64_t n_blocks;
+    int32_t lo, hi;               // filter: closed interval
+    int32_t and_existing;
+    int32_t pad;
+    int64_t n_rows, n_words, n_tiles;
+    uint64_t *bitmap;
+    uint32_t *block_partials;
+    int32_t *out;                 // decode: dense int32 column
+    uint32_t *status;             // bit 0 set when a block is malformed
+};
+void launch_pfor_counts(const uint8_t *data, const uint32_t *block_off, int64_t n_blocks, int32_t *counts, hipStream_t s);
+void launch_filter_pfor(const PforArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+void launch_pfor_decode(const PforArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+
 bool launch_filter_tile(const TileArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 void launch_filter_generic(const FilterArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 void launch_total(const TotalArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);

@@ -18,60 +18,10 @@
 //                row indices and gather the projected columns with dense, coalesced stores
 // All of it is HBM-bound integer/byte work: no MFMA anywhere.
 #include "imm3_internal.h"
+#include "imm3_device.h"
 #include <hip/hip_ext.h>
 
 namespace imm3 {
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-
-// ---------------------------------------------------------------------------------------------
-// small helpers
-// ---------------------------------------------------------------------------------------------
-
-// x in [lo, hi] (lo <= hi guaranteed by the host) with one subtract and one unsigned compare.
-__device__ __forceinline__ bool in_closed(int32_t x, int32_t lo, int32_t hi) {
-    return ((uint32_t)x - (uint32_t)lo) <= ((uint32_t)hi - (uint32_t)lo);
-}
-
-__device__ __forceinline__ uint64_t ballot64(bool p) { return (uint64_t)__ballot(p); }
-
-// clang has no __builtin_amdgcn_writelane; bind the LLVM intrinsic directly (emits v_writelane_b32).
-extern "C" __device__ int imm3_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
-
-// mask of the first `rem` bits (rem may be <= 0 or >= 64)
-__device__ __forceinline__ uint64_t low_mask(int64_t rem) {
-    return rem >= 64 ? ~0ULL : (rem <= 0 ? 0ULL : ((1ULL << rem) - 1ULL));
-}
-
-// value of `v` in lane `src_lane` (any lane -> any lane, through the LDS crossbar, no memory)
-__device__ __forceinline__ uint32_t lane_read(uint32_t v, int src_lane) {
-    return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
-}
-
-// Move 16 wave-uniform words into lanes 0..15 (lane j receives word j) with v_writelane.
-__device__ __forceinline__ uint64_t words_to_lanes(const uint64_t (&acc)[kTileWords]) {
-    int lo = 0, hi = 0;
-#pragma unroll
-    for (int j = 0; j < kTileWords; ++j) {
-        lo = imm3_writelane_i32((int)(uint32_t)acc[j], j, lo);
-        hi = imm3_writelane_i32((int)(uint32_t)(acc[j] >> 32), j, hi);
-    }
-    return ((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo;
-}
-
-// Per-workgroup survivor count -> block_partials[blockIdx.x]; k_total sums them.  (One same-address
-// atomicAdd per wave costs ~12 ns serialised: 4096 of them were 40 % of the kernel.)
-__device__ __forceinline__ void block_partial_store(uint32_t *block_partials, uint32_t wave_total, int lane, int wave) {
-    __shared__ uint32_t s_part[kWavesPerBlock];
-    if (lane == 0) s_part[wave] = wave_total;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-#pragma unroll
-        for (int i = 0; i < kWavesPerBlock; ++i) t += s_part[i];
-        block_partials[blockIdx.x] = t;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // k_filter_tile<K0, K1, K2>: the hot kernel.  Uniform layout (every non-final block has rows % 64 == 0,
@@ -189,11 +139,6 @@ template <int KIND>
 struct StageBytes { static constexpr int value = 0; };
 template <> struct StageBytes<TK_I32> { static constexpr int value = kTileRows * 4; };
 template <> struct StageBytes<TK_I8> { static constexpr int value = kTileRows; };
-
-// LDS hand-off between the lanes of ONE wave: LDS operations of a wave complete in order, so draining lgkmcnt is
-// enough (a workgroup-scope fence would also wait for every outstanding global load/store: vmcnt(0)); the asm
-// memory clobber keeps the compiler from moving LDS accesses across it.
-__device__ __forceinline__ void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <int KIND>
 __device__ __forceinline__ void stage_col(ColRegs<KIND> &, void *, int64_t, int, uint64_t, uint32_t, uint32_t, uint8_t *) {}

@@ -36,6 +36,7 @@ EXPORTS = [
     "imm3_query_layout", "imm3_query_batches", "imm3_query_count", "imm3_query_bitmap",
     "imm3_query_row_count", "imm3_query_fetch_rows", "imm3_query_device_ptr",
     "imm3_ctx_timing_enable", "imm3_ctx_timing_reset", "imm3_ctx_timing_mask", "imm3_ctx_timing_collect", "imm3_ctx_set_tuning", "imm3_ctx_measure_read_gbps", "imm3_ctx_devclock_enable", "imm3_ctx_devclock_collect",
+    "imm3_pfor_encode_bound", "imm3_pfor_encode_block", "imm3_pfor_encode_column",
 ]
 
 
@@ -131,8 +132,12 @@ def load() -> C.CDLL:
     L.imm3_ctx_devclock_collect.argtypes = [vp, vp, i32, P(i32)]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name not in ("imm3_last_error",):
+        if name not in ("imm3_last_error", "imm3_pfor_encode_bound"):
             fn.restype = C.c_int
+    L.imm3_pfor_encode_bound.restype = C.c_uint64
+    L.imm3_pfor_encode_bound.argtypes = [C.c_int32]
+    L.imm3_pfor_encode_block.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.imm3_pfor_encode_column.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -141,6 +146,28 @@ def _check(rc: int):
     if rc != OK:
         msg = load().imm3_last_error()
         raise Imm3Error(rc, msg.decode() if msg else f"imm3 error {rc}")
+
+
+def pfor_encode_block(values) -> bytes:
+    """PFORCodecInt.encode (core/codec/PFORCodec.scala:19-31) of one block of int32 values (host code)."""
+    v = np.ascontiguousarray(values, dtype=np.int32)
+    cap = load().imm3_pfor_encode_bound(v.size)
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_uint64(0)
+    _check(load().imm3_pfor_encode_block(v.ctypes.data, v.size, out.ctypes.data, cap, C.byref(n)))
+    return out[:n.value].tobytes()
+
+
+def pfor_encode_column(values, block_rows: int):
+    """A whole int32 column as SegmentWriter would write it with a PFOR_INT codec: (.dat bytes, blockOffset table)."""
+    v = np.ascontiguousarray(values, dtype=np.int32)
+    nb = (v.size + block_rows - 1) // block_rows
+    cap = v.size * 4 + nb * (load().imm3_pfor_encode_bound(0) + 4 * (block_rows // 32 + 4)) + 64
+    out = np.empty(cap, dtype=np.uint8)
+    offs = np.zeros(nb + 1, dtype=np.int32)
+    n = C.c_uint64(0)
+    _check(load().imm3_pfor_encode_column(v.ctypes.data, v.size, block_rows, out.ctypes.data, cap, offs.ctypes.data, C.byref(n)))
+    return out[:n.value].copy(), offs
 
 
 def device_count() -> int:

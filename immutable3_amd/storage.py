@@ -92,7 +92,11 @@ class SegmentWriter:
             self._put(x)
 
     def flush(self):
-        encoded = bytes(self._buf)                               # DenseCodec.encode(bytes) is the identity (DenseCodec.scala:18-22)
+        if self.column.codec == CodecType.PFOR_INT:              # PFORCodecInt.encode (PFORCodec.scala:19-31), host code of libimm3
+            from . import native
+            encoded = native.pfor_encode_block(np.frombuffer(bytes(self._buf), dtype="<i4"))
+        else:
+            encoded = bytes(self._buf)                           # DenseCodec.encode(bytes) is the identity (DenseCodec.scala:18-22)
         self._file.write(encoded)
         self.blockBufferOffsets.append(self.blockBufferOffsets[-1] + len(encoded))
         self._buf = bytearray()

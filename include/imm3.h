@@ -32,7 +32,11 @@ extern "C" {
 
 #define IMM3_ABI_VERSION 1
 
-/* CodecType (core/codec/Codec.scala:21-24), in enumeration order */
+/* CodecType (core/codec/Codec.scala:21-24), in enumeration order.
+ * IMM3_PFOR_INT: blocks as PFORCodecInt.encode writes them (core/codec/PFORCodec.scala:19-31: big-endian words of
+ * JavaFastPFOR 0.1.10's IntegratedIntCompressor.compress + 8 zero bytes).  The reference dispatches the codec
+ * (Column.scala:61, Scan.scala:37-39) but its decode throws on every block (PFORCodec.scala:43-50); this library
+ * decodes the blocks on the GPU (csrc/imm3_codec.hip), a documented departure from the reference's failure. */
 enum { IMM3_PFOR_INT = 0, IMM3_DENSE_INT = 1, IMM3_DENSE_TINYINT = 2, IMM3_DENSE_STRING = 3 };
 
 /* SelectCondition (core/Query.scala:3-9) */
@@ -59,7 +63,7 @@ typedef struct imm3_query imm3_query;     /* one PipelineThread: ScanOp -> Selec
  * `blockOffset` array of `<col>_<id>.meta` (core/storage/Segment.scala:33-58, 154-181;
  * core/storage/SegmentManager.scala:81-111) + the codec of core/Column.scala:18,57-63. */
 typedef struct {
-    int32_t codec;                /* IMM3_DENSE_INT / _TINYINT / _STRING                         */
+    int32_t codec;                /* IMM3_DENSE_INT / _TINYINT / _STRING / IMM3_PFOR_INT           */
     int32_t width;                /* bytes per value: 4, 1, or dtypeAttrs("size") for strings      */
     const void *dat;              /* host pointer to the (mmap'd) .dat bytes                       */
     uint64_t dat_bytes;
@@ -213,7 +217,8 @@ int imm3_query_device_ptr(imm3_query *q, int32_t which, void **ptr);
 
 /* ---- live kernel timing (HIP events on the context's stream) ----
  * When enabled, every kernel launch of this context is bracketed by an event pair.
- * kernel ids: 0 = scan+select, 1 = offsets scan, 2 = compact+gather, 3 = count reduce. */
+ * kernel ids: 0 = scan+select, 1 = offsets scan, 2 = compact+gather, 3 = count reduce, 4 = group-by aggregation,
+ *             5 = PFOR_INT column decode. */
 int imm3_ctx_timing_enable(imm3_ctx *ctx, int32_t max_records);
 int imm3_ctx_timing_reset(imm3_ctx *ctx);
 /* Only launches whose kernel id has its bit set in `kernel_mask` are bracketed (default: all). */
@@ -231,7 +236,19 @@ int imm3_ctx_devclock_collect(imm3_ctx *ctx, float *ms_out, int32_t cap, int32_t
  * same tiling and grid as the scan+select kernel, three rotated buffers) and returns the median GB/s over `iters`. */
 int imm3_ctx_measure_read_gbps(imm3_ctx *ctx, uint64_t bytes, int32_t iters, double *gbps);
 
-/* Tuning knobs (0 = default): filter variant, grid size in workgroups.  For experiments/bench. */
+/* ---- write side of the PFOR_INT codec (host code, no device involved) ----
+ * PFORCodecInt.encode (core/codec/PFORCodec.scala:19-31), which SegmentWriter.flush applies to each block of a PFOR_INT
+ * column (core/storage/Segment.scala:115-122).  imm3_pfor_encode_block: one block of n_values little-endian int32 ->
+ * the bytes appended to the .dat.  imm3_pfor_encode_column: a whole column cut into blocks of block_rows values (the
+ * last one shorter); offsets_out receives the n_blocks + 1 byte offsets of the .meta blockOffset table. */
+uint64_t imm3_pfor_encode_bound(int32_t n_values);
+int imm3_pfor_encode_block(const int32_t *values, int32_t n_values, void *out, uint64_t cap, uint64_t *bytes_out);
+int imm3_pfor_encode_column(const int32_t *values, uint64_t n_values, int32_t block_rows, void *out, uint64_t cap,
+                            int32_t *offsets_out, uint64_t *bytes_out);
+
+/* Tuning knobs (0 = default): filter variant, grid size in workgroups.  For experiments/bench.
+ * variant 1 = word-at-a-time kernel only, 2 = count reduce on the aux stream, 3 = no survivor staging,
+ * 4 = stage int32 columns only, 5 = PFOR_INT predicates read the decoded column instead of the compressed blocks. */
 int imm3_ctx_set_tuning(imm3_ctx *ctx, int32_t filter_variant, int32_t grid_blocks);
 
 #ifdef __cplusplus

@@ -116,6 +116,14 @@ int64_t imm3o_project(const imm3o_column *cols, int32_t ncols,
                       int32_t *out_batch, int32_t *out_pos, uint8_t *const *out_vals,
                       int64_t cap_rows, int32_t *would_throw);
 
+/* ---- PFOR_INT block codec (imm3_oracle_pfor.c; core/codec/PFORCodec.scala:19-31 + JavaFastPFOR 0.1.10) ----
+ * The block format is defined by the reference's ENCODER; the reference's decoder is broken (PFORCodec.scala:43-50),
+ * so decode is the inverse the encoder implies.  Parity unpinned (third-party library, no vectors offline). */
+int64_t imm3o_pfor_encode_bound(int32_t n);
+int64_t imm3o_pfor_encode_block(const int32_t *vals, int32_t n, uint8_t *out, int64_t cap);
+int32_t imm3o_pfor_block_count(const uint8_t *blk, int64_t len);
+int32_t imm3o_pfor_decode_block(const uint8_t *blk, int64_t len, int32_t *out, int32_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,10 +55,8 @@ class _CSelect(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the oracle with its own Makefile (gcc -O2).  Building the checker is not using it."""
-    src = os.path.join(_HERE, "imm3_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
-        os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "imm3_oracle.h"))
-    ):
+    srcs = [os.path.join(_HERE, f) for f in ("imm3_oracle.c", "imm3_oracle_pfor.c", "imm3_oracle.h")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return _LIB_PATH
 
@@ -93,6 +91,14 @@ def lib():
             C.POINTER(_CColumn), C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p,
             C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int64, C.POINTER(C.c_int32),
         ]
+        L.imm3o_pfor_encode_bound.restype = C.c_int64
+        L.imm3o_pfor_encode_bound.argtypes = [C.c_int32]
+        L.imm3o_pfor_encode_block.restype = C.c_int64
+        L.imm3o_pfor_encode_block.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+        L.imm3o_pfor_block_count.restype = C.c_int32
+        L.imm3o_pfor_block_count.argtypes = [C.c_void_p, C.c_int64]
+        L.imm3o_pfor_decode_block.restype = C.c_int32
+        L.imm3o_pfor_decode_block.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
         _lib = L
     return _lib
 
@@ -218,3 +224,44 @@ def project(cols: Sequence[OColumn], proj: Sequence[int], limit: int, block_size
         raise OracleError(int(-n), "project failed")
     n = int(n)
     return n, batch[:n], pos[:n], [v[:n] for v in vals], bool(wt.value)
+
+
+# ---- PFOR_INT block codec (imm3_oracle_pfor.c) ----------------------------------------------------------------
+def pfor_encode_block(vals: np.ndarray) -> bytes:
+    """PFORCodecInt.encode of one block of int32 values (PFORCodec.scala:19-31)."""
+    v = np.ascontiguousarray(vals, dtype=np.int32)
+    cap = lib().imm3o_pfor_encode_bound(v.size)
+    out = np.zeros(cap, dtype=np.uint8)
+    n = lib().imm3o_pfor_encode_block(v.ctypes.data, v.size, out.ctypes.data, cap)
+    if n < 0:
+        raise OracleError(ERR_ARG, "pfor encode failed")
+    return out[:n].tobytes()
+
+
+def pfor_decode_block(blk: bytes) -> np.ndarray:
+    """The decode the encoder implies (IntegratedIntCompressor.uncompress of the block's big-endian words)."""
+    b = np.frombuffer(blk, dtype=np.uint8)
+    n = lib().imm3o_pfor_block_count(b.ctypes.data, b.size)
+    if n < 0:
+        raise OracleError(ERR_INDEX, "pfor block too short")
+    out = np.zeros(max(n, 1), dtype=np.int32)
+    got = lib().imm3o_pfor_decode_block(b.ctypes.data, b.size, out.ctypes.data, out.size)
+    if got < 0:
+        raise OracleError(ERR_INDEX, "malformed pfor block")
+    return out[:got]
+
+
+def pfor_encode_column(vals: np.ndarray, block_rows: int):
+    """Whole column -> (.dat bytes, blockOffset table), one encoded block per block_rows values (SegmentWriter.flush)."""
+    v = np.ascontiguousarray(vals, dtype=np.int32)
+    parts, offs = [], [0]
+    for s in range(0, v.size, block_rows):
+        parts.append(pfor_encode_block(v[s:s + block_rows]))
+        offs.append(offs[-1] + len(parts[-1]))
+    return np.frombuffer(b"".join(parts), dtype=np.uint8).copy(), np.array(offs, dtype=np.int32)
+
+
+def pfor_decode_column(dat: np.ndarray, offs: np.ndarray) -> np.ndarray:
+    d = np.ascontiguousarray(dat, dtype=np.uint8)
+    out = [pfor_decode_block(d[int(offs[k]):int(offs[k + 1])].tobytes()) for k in range(len(offs) - 1)]
+    return np.concatenate(out) if out else np.zeros(0, dtype=np.int32)

@@ -299,3 +299,110 @@ def agg_repr(state) -> str:
     if isinstance(state, float):
         return java_double_to_string(state)
     return str(state)
+
+
+# ------------------------------------------------------------------------------------------
+# PFOR_INT block codec -- second, independent restatement (bit-stream formulation; the C oracle works word by word).
+# Format: core/codec/PFORCodec.scala:19-31 over JavaFastPFOR 0.1.10's IntegratedIntCompressor (see
+# imm3_oracle_pfor.c for the statement of the library's algorithm).  TEST INFRASTRUCTURE ONLY; parity unpinned.
+# ------------------------------------------------------------------------------------------
+def _pfor_width(deltas_u32: np.ndarray) -> int:
+    m = int(np.bitwise_or.reduce(deltas_u32.astype(np.uint64)))
+    return m.bit_length()
+
+
+def _pfor_pack(values_u32: np.ndarray, init: int, b: int) -> np.ndarray:
+    """32 values -> b little-endian words (b == 32: the values themselves)."""
+    if b == 32:
+        return values_u32.astype(np.uint32)
+    if b == 0:
+        return np.zeros(0, dtype=np.uint32)
+    prev = np.concatenate([[np.uint32(init & 0xFFFFFFFF)], values_u32[:-1]]).astype(np.uint32)
+    d = (values_u32 - prev).astype(np.uint32)  # wrapping
+    bits = ((d[:, None] >> np.arange(b, dtype=np.uint32)[None, :]) & 1).astype(np.uint8).reshape(-1)  # LSB-first stream
+    return np.packbits(bits, bitorder="little").view("<u4").astype(np.uint32)
+
+
+def pfor_encode_block(vals: np.ndarray) -> bytes:
+    v = np.ascontiguousarray(vals, dtype=np.int32).view(np.uint32)
+    n = v.size
+    words = [np.array([n], dtype=np.uint32)]
+    init = 0
+    n_mini = n // 32
+    widths, packed = [], []
+    for m in range(n_mini):
+        blk = v[32 * m:32 * m + 32]
+        prev = np.concatenate([[np.uint32(init)], blk[:-1]]).astype(np.uint32)
+        b = _pfor_width((blk - prev).astype(np.uint32))
+        widths.append(b)
+        packed.append(_pfor_pack(blk, init, b))
+        init = int(blk[-1])
+    g = 0
+    while g + 4 <= n_mini:
+        words.append(np.array([(widths[g] << 24) | (widths[g + 1] << 16) | (widths[g + 2] << 8) | widths[g + 3]], dtype=np.uint32))
+        words += packed[g:g + 4]
+        g += 4
+    for m in range(g, n_mini):
+        words.append(np.array([widths[m]], dtype=np.uint32))
+        words.append(packed[m])
+    tail = v[32 * n_mini:]
+    if tail.size:
+        out = bytearray()
+        for x in tail:
+            d = (int(x) - init) & 0xFFFFFFFF
+            init = int(x)
+            while d >= 128:
+                out.append(d & 127)
+                d >>= 7
+            out.append(d | 128)
+        while len(out) % 4:
+            out.append(0)
+        words.append(np.frombuffer(bytes(out), dtype="<u4").astype(np.uint32))
+    w = np.concatenate(words).astype(">u4")  # ByteBuffer.putInt: big-endian
+    return w.tobytes() + b"\0" * 8           # result.array(): the 8 spare bytes of allocate(len * 4 + 8)
+
+
+def pfor_decode_block(blk: bytes) -> np.ndarray:
+    w = np.frombuffer(blk, dtype=">u4").astype(np.uint32)
+    n = int(w[0])
+    out = np.zeros(n, dtype=np.uint32)
+    pos, init, n_mini = 1, 0, n // 32
+
+    def unpack(pos, b, init):
+        if b == 32:
+            return w[pos:pos + 32].copy()
+        if b == 0:
+            return np.full(32, init, dtype=np.uint32)
+        bits = np.unpackbits(w[pos:pos + b].astype("<u4").view(np.uint8), bitorder="little").reshape(32, b)
+        d = (bits.astype(np.uint64) << np.arange(b, dtype=np.uint64)[None, :]).sum(axis=1)
+        return ((np.cumsum(d) + init) & 0xFFFFFFFF).astype(np.uint32)
+
+    m = 0
+    while m + 4 <= n_mini:
+        h = int(w[pos]); pos += 1
+        for k in range(4):
+            b = (h >> (24 - 8 * k)) & 255
+            out[32 * (m + k):32 * (m + k) + 32] = unpack(pos, b, init)
+            pos += b
+            init = int(out[32 * (m + k) + 31])
+        m += 4
+    while m < n_mini:
+        b = int(w[pos]); pos += 1
+        out[32 * m:32 * m + 32] = unpack(pos, b, init)
+        pos += b
+        init = int(out[32 * m + 31])
+        m += 1
+    if n > 32 * n_mini:
+        by = w[pos:].astype("<u4").view(np.uint8)
+        i = 0
+        for k in range(32 * n_mini, n):
+            val, shift = 0, 0
+            while True:
+                c = int(by[i]); i += 1
+                val += (c & 127) << shift
+                if c & 128:
+                    break
+                shift += 7
+            init = (init + val) & 0xFFFFFFFF
+            out[k] = init
+    return out.view(np.int32)

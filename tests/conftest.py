@@ -14,7 +14,7 @@ def pytest_configure(config):
 
 
 # ---- helpers shared by the oracle tests and the GPU parity tests --------------------------------
-DENSE_INT, DENSE_TINYINT, DENSE_STRING = 1, 2, 3
+PFOR_INT, DENSE_INT, DENSE_TINYINT, DENSE_STRING = 0, 1, 2, 3
 MATCH, NOTMATCH, EQ, GT, LT, NOOP = 0, 1, 2, 3, 4, 5
 
 
@@ -47,6 +47,35 @@ class RawColumn:
 
     def npcol(self):
         return (self.dat, self.offsets, self.codec, self.width)
+
+    def native(self):
+        return (self.codec, self.width, self.dat, self.dat.size, self.offsets)
+
+
+class PforColumn:
+    """A PFOR_INT column: blocks as PFORCodecInt.encode writes them (oracle encoder).  The oracle side sees the
+    DENSE_INT column holding the same values in the same blocks -- the decode the encoder implies."""
+
+    def __init__(self, values, block_rows):
+        from oracle import oracle_c
+        self.codec, self.width = PFOR_INT, 4
+        self.values = np.ascontiguousarray(values, dtype=np.int32)
+        self.block_rows = list(block_rows)
+        parts, offs, pos = [], [0], 0
+        for n in self.block_rows:
+            blk = oracle_c.pfor_encode_block(self.values[pos:pos + n]) if n > 0 else b""
+            parts.append(blk)
+            offs.append(offs[-1] + len(blk))
+            pos += n
+        self.dat = np.frombuffer(b"".join(parts) or b"", dtype=np.uint8).copy()
+        self.offsets = np.array(offs, dtype=np.int32)
+        self._dense = RawColumn(DENSE_INT, 4, self.values, self.block_rows)
+
+    def ocol(self):
+        return self._dense.ocol()
+
+    def npcol(self):
+        return self._dense.npcol()
 
     def native(self):
         return (self.codec, self.width, self.dat, self.dat.size, self.offsets)
