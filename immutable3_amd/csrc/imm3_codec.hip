@@ -48,25 +48,43 @@ __device__ __forceinline__ int pw(int w) { return w + (w >> 6); }
 // whole rounds are written (the window has room), which keeps exec-mask bookkeeping off the shared scalar unit.
 struct PforRegs {
     uint32_t r[kPforRounds];
+    // rounds go in batches of four behind one wave-uniform test (a compressed block is usually 1-2 batches)
     __device__ __forceinline__ void load(const uint32_t *src, int n, int lane) { // n >= 1, wave-uniform
 #pragma unroll
-        for (int k = 0; k < kPforRounds; ++k) {
-            if (64 * k < n) {
-                const int i = 64 * k + lane;
-                r[k] = __builtin_nontemporal_load(src + (i < n ? i : n - 1));
+        for (int q = 0; q < kPforRounds; q += 4) {
+            if (64 * q < n) {
+#pragma unroll
+                for (int k = q; k < q + 4 && k < kPforRounds; ++k) {
+                    const int i = 64 * k + lane;
+                    r[k] = __builtin_nontemporal_load(src + (i < n ? i : n - 1));
+                }
             }
         }
     }
     __device__ __forceinline__ void store(uint32_t *win, int n, int lane) const {
 #pragma unroll
-        for (int k = 0; k < kPforRounds; ++k)
-            if (64 * k < n) win[65 * k + lane] = __builtin_bswap32(r[k]); // pw(64 k + lane)
+        for (int q = 0; q < kPforRounds; q += 4) {
+            if (64 * q < n) {
+#pragma unroll
+                for (int k = q; k < q + 4 && k < kPforRounds; ++k) win[65 * k + lane] = __builtin_bswap32(r[k]); // pw(64 k + lane)
+            }
+        }
         lds_wave_sync();
         // the pad slot after word 64 k - 1 repeats word 64 k, so every (w, w + 1) pair is adjacent
         if (lane >= 1 && lane < kPforRounds && 64 * lane < n) win[65 * lane - 1] = win[65 * lane];
         lds_wave_sync();
     }
 };
+
+// One step of the segmented inclusive wave scan: (tot, flag) of the DPP source lane is folded in; lanes without a
+// source (or in a masked row) fold in (0, 0).  flag is 0 or ~0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void seg_step(uint32_t &tot, uint32_t &flag) {
+    const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tot, CTRL, ROW_MASK, 0xF, true);
+    const uint32_t fup = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)flag, CTRL, ROW_MASK, 0xF, true);
+    tot += up & ~flag;
+    flag |= fup;
+}
 
 // Decode `count` (<= 1024, wave-uniform) values whose encoding starts at window word `pos`; `init` is the running
 // delta base.  Value 16 * lane + i of the chunk = base + d[i] (garbage where 16 * lane + i >= count).  Returns the
@@ -124,18 +142,15 @@ __device__ __forceinline__ int pfor_chunk(const uint32_t *win, int avail, int po
     }
     // (4) segmented inclusive scan of the lane totals: a raw lane restarts the chain with its last value
     uint32_t tot = d[15];
-    uint32_t flag = raw ? 1u : 0u;
+    uint32_t flag = raw ? ~0u : 0u; // all-ones once a raw lane has been seen at or below this lane
     if (lane == 0 && !raw) tot += (uint32_t)init;
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)tot, s);
-        const uint32_t fup = (uint32_t)__shfl_up((int)flag, s);
-        const bool take = lane >= s;
-        tot += (take && !flag) ? up : 0u;
-        flag |= take ? fup : 0u;
-    }
-    base = (uint32_t)__shfl_up((int)tot, 1);
-    if (lane == 0) base = (uint32_t)init;
+    seg_step<0x111, 0xF>(tot, flag); // row_shr:1
+    seg_step<0x112, 0xF>(tot, flag); // row_shr:2
+    seg_step<0x114, 0xF>(tot, flag); // row_shr:4
+    seg_step<0x118, 0xF>(tot, flag); // row_shr:8
+    seg_step<0x142, 0xA>(tot, flag); // row_bcast:15 -> rows 1, 3
+    seg_step<0x143, 0xC>(tot, flag); // row_bcast:31 -> rows 2, 3
+    base = (uint32_t)__builtin_amdgcn_update_dpp(init, (int)tot, 0x138, 0xF, 0xF, false); // wave_shr:1; lane 0 keeps init
     if (raw) base = 0;
     uint32_t chain = (uint32_t)init; // the last value decoded so far
     if (n_mini > 0) chain = (uint32_t)__shfl((int)tot, 2 * n_mini - 1);

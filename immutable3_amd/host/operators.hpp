@@ -43,6 +43,7 @@ struct ColumnVector { // Int / TinyInt / String column vector: a typed VIEW of t
     const uint8_t *data = nullptr;
     int width = 4;
     int n = 0;
+    std::shared_ptr<std::vector<uint8_t>> owner; // PFOR_INT: the column decoded by the GPU (data points into it)
     Value value(int pos) const {
         switch (type) {
         case ColumnType::INT: { int32_t v; std::memcpy(&v, data + (size_t)pos * 4, 4); return Value::ofInt(v); }
@@ -236,6 +237,21 @@ class ScanOp : public ColumnVectorOperator {
         std::vector<uint64_t> words((size_t)nwords);
         imm3Check(imm3_query_bitmap(h.q, words.data(), nwords));
         auto it = std::make_unique<VectorIterator<ColumnVectorBatch>>();
+        // PFOR_INT columns: the vectors of the batches are the GPU's decode of the segment (one projection, no predicate)
+        std::vector<std::shared_ptr<std::vector<uint8_t>>> decoded(cols_.size());
+        for (size_t ci = 0; ci < cols_.size(); ++ci) {
+            if (cols_[ci].codec != CodecType::PFOR_INT || nrows == 0) continue;
+            QueryHandle d;
+            const Table &t = table();
+            const int32_t used = t.columnIndex(cols_[ci].name), proj = 0;
+            imm3Check(imm3_query_create(sm_.ctx(), sm_.deviceSegment(tableName_, segIdx_), &used, 1, nullptr, 0, &proj, 1, 0, t.blockSize, &d.q));
+            imm3Check(imm3_query_run(d.q));
+            uint64_t n = 0;
+            imm3Check(imm3_query_row_count(d.q, &n));
+            decoded[ci] = std::make_shared<std::vector<uint8_t>>((size_t)n * 4);
+            void *outp = decoded[ci]->data();
+            imm3Check(imm3_query_fetch_rows(d.q, nullptr, &outp, n));
+        }
         int64_t row = 0;
         for (int32_t k = 0; k < nb; ++k) {
             ColumnVectorBatch b;
@@ -245,12 +261,14 @@ class ScanOp : public ColumnVectorOperator {
             const int64_t nw = (b.size + 63) / 64;
             b.selected.words.assign(words.begin() + woff[(size_t)k], words.begin() + woff[(size_t)k] + nw);
             b.selectedInUse = leaves.empty() ? true : !b.selected.isEmpty(); // Select.scala:44-47
-            for (const auto &c : cols_) {
+            for (size_t ci = 0; ci < cols_.size(); ++ci) {
+                const Column &c = cols_[ci];
                 const MappedFile &f = sm_.sm.segments.at(tableName_ + "." + c.name).at((size_t)segIdx_);
                 ColumnVector v;
                 v.type = c.columnType;
                 v.width = c.width();
-                v.data = f.data + (size_t)row * (size_t)v.width;
+                v.owner = decoded[ci];
+                v.data = (decoded[ci] ? decoded[ci]->data() : f.data) + (size_t)row * (size_t)v.width;
                 v.n = b.size;
                 b.columnVectors.push_back(v);
             }

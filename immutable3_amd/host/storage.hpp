@@ -11,6 +11,7 @@
 #include <cstring>
 #include <functional>
 
+#include "codec.hpp"
 #include "schema.hpp"
 
 namespace immutabledb {
@@ -88,7 +89,13 @@ class SegmentWriter {
         buf_ += b;
         ++recordsWritten_;
     }
-    void flush() { // DenseCodec.encode is the identity (codec/DenseCodec.scala:18-22)
+    void flush() { // codec.encode(bytes) (Segment.scala:115-122): identity for DENSE_* (codec/DenseCodec.scala:18-22)
+        if (column_.codec == CodecType::PFOR_INT) { // PFORCodecInt.encode (codec/PFORCodec.scala:19-31)
+            std::vector<int32_t> vals(buf_.size() / 4);
+            std::memcpy(vals.data(), buf_.data(), vals.size() * 4);
+            const std::vector<uint8_t> enc = codec::pforEncodeBlock(vals.data(), (int32_t)vals.size());
+            buf_.assign((const char *)enc.data(), enc.size());
+        }
         file_.write(buf_.data(), (std::streamsize)buf_.size());
         blockBufferOffsets.push_back(blockBufferOffsets.back() + (int32_t)buf_.size());
         buf_.clear();

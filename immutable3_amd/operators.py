@@ -248,9 +248,25 @@ class ScanOp(ColumnVectorOperator):
         seg = self.sm.device_segment(self.tableName, self.segIdx)
         return native.DeviceQuery(seg.ctx, seg, self._used_indices(), sels, proj, limit, t.blockSize)
 
+    def _pfor_decoded(self, c: Column) -> np.ndarray:
+        """PFOR_INT column of this segment as the GPU decodes it (one projection without predicates), cached."""
+        cache = self.__dict__.setdefault("_pfor_cache", {})
+        if c.name not in cache:
+            seg = self.sm.device_segment(self.tableName, self.segIdx)
+            t = self._table()
+            q = native.DeviceQuery(seg.ctx, seg, [[x.name for x in t.columns].index(c.name)], [], [0], 0, t.blockSize)
+            q.run()
+            _, cols = q.fetch_rows()
+            q.close()
+            cache[c.name] = cols[0].reshape(-1).view("<i4").copy()
+        return cache[c.name]
+
     def _host_vectors(self, k: int, start_row: int, size: int) -> List[ColumnVector]:
         out = []
         for c in self.cols:
+            if c.codec == CodecType.PFOR_INT:
+                out.append(IntColumnVector(self._pfor_decoded(c)[start_row:start_row + size]))
+                continue
             dat = self.sm.sm.segments[f"{self.tableName}.{c.name}"][self.segIdx]
             out.append(_decode_view(c, np.asarray(dat[start_row * c.width: (start_row + size) * c.width])))
         return out
@@ -333,7 +349,7 @@ class ProjectOp(ProjectionOperator):
         idx, cols = q.fetch_rows()
         out = []
         for raw, codec in zip(cols, q.proj_codecs):
-            if codec == native.DENSE_INT:
+            if codec in (native.DENSE_INT, native.PFOR_INT):
                 out.append(raw.reshape(-1).view("<i4"))
             elif codec == native.DENSE_TINYINT:
                 out.append(raw.reshape(-1).view(np.int8))
@@ -558,7 +574,7 @@ class ProjectAggOp(Operator):
 
 
 def _key_part(col: Column, raw: bytes) -> str:
-    if col.codec == CodecType.DENSE_INT:
+    if col.codec in (CodecType.DENSE_INT, CodecType.PFOR_INT):
         return str(int.from_bytes(raw, "little", signed=True))
     if col.codec == CodecType.DENSE_TINYINT:
         return str(int.from_bytes(raw, "little", signed=True))
@@ -714,7 +730,7 @@ class Engine:
         seg, row = q.locate_rows(idx)
         out = []
         for raw, codec in zip(cols, q.proj_codecs):
-            out.append(raw.reshape(-1).view("<i4") if codec == native.DENSE_INT else
+            out.append(raw.reshape(-1).view("<i4") if codec in (native.DENSE_INT, native.PFOR_INT) else
                        raw.reshape(-1).view(np.int8) if codec == native.DENSE_TINYINT else raw)
         q.close()
         seg_ids = np.asarray(getattr(dt, "segment_ids", list(range(len(dt.segs)))), dtype=np.uint32)

@@ -153,7 +153,7 @@ def write_segment_arrays(dataDir: str, table: Table, seg_id: int, arrays: Dict[s
     for c in table.columns:
         a = arrays[c.name]
         n = a.shape[0]
-        if c.codec == CodecType.DENSE_INT:
+        if c.codec in (CodecType.DENSE_INT, CodecType.PFOR_INT):
             raw = np.ascontiguousarray(a, dtype="<i4").view(np.uint8)
         elif c.codec == CodecType.DENSE_TINYINT:
             raw = np.ascontiguousarray(a, dtype=np.int8).view(np.uint8)
@@ -165,6 +165,21 @@ def write_segment_arrays(dataDir: str, table: Table, seg_id: int, arrays: Dict[s
         else:
             br = list(block_rows)
             assert sum(br) == n
+        if c.codec == CodecType.PFOR_INT:   # each block through PFORCodecInt.encode, as SegmentWriter.flush does
+            from . import native
+            vals = np.ascontiguousarray(a, dtype="<i4")
+            if block_rows is None:
+                raw, offs = native.pfor_encode_column(vals, table.blockSize)
+            else:
+                parts, offs, pos = [], [0], 0
+                for r in br:
+                    parts.append(native.pfor_encode_block(vals[pos:pos + r]))
+                    offs.append(offs[-1] + len(parts[-1]))
+                    pos += r
+                raw, offs = np.frombuffer(b"".join(parts), dtype=np.uint8), np.array(offs, dtype=np.int32)
+            raw.tofile(os.path.join(base, f"{c.name}_{seg_id}.dat"))
+            SegmentMeta.store(os.path.join(base, f"{c.name}_{seg_id}.meta"), SegmentMeta(offs))
+            continue
         offs = np.concatenate([[0], np.cumsum(np.array(br, dtype=np.int64) * c.width)]).astype(np.int32)
         raw.tofile(os.path.join(base, f"{c.name}_{seg_id}.dat"))
         SegmentMeta.store(os.path.join(base, f"{c.name}_{seg_id}.meta"), SegmentMeta(offs))

@@ -201,8 +201,8 @@ def test_errors(ctx):
     assert q.count() == 0 and q.n_batches == 0
     q.close()
     empty.close()
-    # unknown codec (PFOR_INT is not on the path)
-    bad = native.DeviceSegment(ctx, [(0, 4, np.zeros(16, np.uint8), 16, np.array([0, 16], np.int32))])
+    # unknown codec id (CodecType has four values, Codec.scala:21-24)
+    bad = native.DeviceSegment(ctx, [(7, 4, np.zeros(16, np.uint8), 16, np.array([0, 16], np.int32))])
     with pytest.raises(native.Imm3Error) as e:
         native.DeviceQuery(ctx, bad, [0], [])
     assert e.value.code == native.ERR_NO_CODEC

@@ -3,6 +3,8 @@ ENCODER writes (oracle restatement of PFORCodec.scala:19-31), the oracle runs th
 holding the same values in the same blocks.  Bit-exact bitmap, count, row order and projected values.
 Two device paths are covered: k_filter_pfor (predicate on the compressed blocks; tile-aligned segments, the column not
 projected) and k_pfor_decode (decoded column; projection, aggregation, ragged or odd block sizes, table queries)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,6 +12,7 @@ from conftest import DENSE_INT, DENSE_STRING, DENSE_TINYINT, EQ, GT, LT, MATCH, 
 from test_gpu_parity import check, ctx  # noqa: F401  (ctx is a fixture)
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def value_cases(rng, n):
@@ -128,3 +131,65 @@ def test_malformed_block_is_an_error(ctx, oracle):
     with pytest.raises(native.Imm3Error):
         q = native.DeviceQuery(ctx, seg, [0], [(0, GT, 5.0)], [0])
     seg.close()
+
+
+def _two_tables(tmp_path, n_segs=3):
+    """The same rows twice: table `tp` stores id as PFOR_INT, table `td` as DENSE_INT."""
+    from immutable3_amd import synth
+    from immutable3_amd.schema import CodecType, Column, Table, TableIO
+    from immutable3_amd.storage import write_segment_arrays
+    tabs = {}
+    for name, codec in (("tp", CodecType.PFOR_INT), ("td", CodecType.DENSE_INT)):
+        t = Table(name, [Column.make("id", codec), Column.make("state", CodecType.DENSE_STRING, {"size": "2"}),
+                         Column.make("age", CodecType.DENSE_TINYINT)], 1024)
+        TableIO.store(str(tmp_path), t)
+        for s in range(n_segs):
+            n = 5000 + 300 * s
+            cols = {"id": (np.arange(n, dtype=np.int64) * 3 + s * 10 ** 6).astype(np.int32),
+                    "age": synth.uniform_below(70 + s, n, 100, np.int8), "state": synth.state_codes(80 + s, n)}
+            write_segment_arrays(str(tmp_path), t, s, cols)
+        tabs[name] = t
+    return tabs
+
+
+def test_python_engine_over_pfor_table(tmp_path):
+    from immutable3_amd import GT, LT, And, Match, Project, Query, Select
+    from immutable3_amd.operators import Engine, GpuSegmentManager, ProjectOp, ScanOp, SelectOp
+    from immutable3_amd.storage import SegmentManager
+    _two_tables(tmp_path)
+    g = GpuSegmentManager(SegmentManager(str(tmp_path)))
+    e = Engine(g)
+    sel = And(And(Select("id", GT(2000)), Select("id", LT(1_009_000))), Select("age", LT(30)))
+    for proj in (Project(["id", "age"]), Project(["age", "state"], 50), Project(["id"], 7)):
+        rows = {}
+        for tn in ("tp", "td"):
+            rows[tn] = [tuple(r) for r in e.execute(Query(tn, sel, proj))]
+        assert rows["tp"] == rows["td"] and len(rows["tp"]) > 0
+    # operator level: the batches' vectors of a PFOR_INT column are the GPU's decode
+    for seg in range(2):
+        ba = list(SelectOp("id", GT(6000), ScanOp(g, seg, "tp", [g.sm.getTable("tp").getColumn("id")])).iterator())
+        bb = list(SelectOp("id", GT(6000), ScanOp(g, seg, "td", [g.sm.getTable("td").getColumn("id")])).iterator())
+        assert len(ba) == len(bb)
+        for x, y in zip(ba, bb):
+            assert x.size == y.size and x.selected.words.tolist() == y.selected.words.tolist()
+            assert np.asarray(x.columnVectors[0].data).tolist() == np.asarray(y.columnVectors[0].data).tolist()
+    g.close()
+
+
+def test_sql_cli_over_pfor_table(tmp_path):
+    import subprocess
+    _two_tables(tmp_path)
+    exe = os.path.join(ROOT, "immutable3_amd", "bin", "imm3_sql")
+
+    def run(sql):
+        p = subprocess.run([exe, "-q", sql, "-d", str(tmp_path)], capture_output=True, text=True)
+        assert p.returncode == 0, p.stdout + p.stderr
+        return p.stdout.splitlines()
+
+    for sql in ("select id, age from {t} where (id > 2000 and id < 1009000 and age < 30)",
+                "select state, id from {t} where (id > 14000 and state = 'CA') limit 25",
+                "select id from {t} limit 3",
+                "select count(id), max(id), min(age) from {t} where id > 9000 group by state",
+                "select count(age) from {t} where age > 50 group by id"):
+        a, b = run(sql.format(t="tp")), run(sql.format(t="td"))
+        assert a == b and len(a) > 0, sql

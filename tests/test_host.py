@@ -10,7 +10,7 @@ from immutable3_amd import EQ, GT, LT, And, Match, NoSelect, Or, Project, Query,
 from immutable3_amd import native, synth
 from immutable3_amd.operators import getColumns, resolveSelectOps, SelectOp
 from immutable3_amd.schema import CodecType, Column, Table, TableIO
-from immutable3_amd.storage import SegmentManager, SegmentWriter, load_csv, load_rows, write_segment_arrays
+from immutable3_amd.storage import SegmentManager, SegmentMeta, SegmentWriter, load_csv, load_rows, write_segment_arrays
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -111,3 +111,26 @@ def test_splitmix64_reference_values():
     v = synth.uniform_int30(1, 1000)
     assert v.min() >= 0 and v.max() < 2 ** 30
     assert synth.block_offsets(100_000_000, 4, 1024).size == 97657 + 1 and int(synth.block_offsets(2500, 4)[-1]) == 10000
+
+
+def test_pfor_segment_writer_matches_oracle_encoder(tmp_path):
+    """A PFOR_INT column goes through codec.encode per block (Segment.scala:115-122 -> PFORCodec.scala:19-31): the
+    row-at-a-time SegmentWriter, the bulk writer and the C++ loader CLI all write the oracle encoder's bytes."""
+    import subprocess
+    from oracle import oracle_c
+    from immutable3_amd.build import build_native
+    build_native()
+    vals = [(i * 37) % 1000 - 300 if i % 50 else -7 for i in range(150)]
+    t = Table("pf", [Column.make("v", CodecType.PFOR_INT)], 64)
+    load_rows(str(tmp_path / "a"), t, [[str(v)] for v in vals], segmentSize=100)
+    write_segment_arrays(str(tmp_path / "b"), t, 0, {"v": np.array(vals, dtype=np.int32)})
+    csv = tmp_path / "in.csv"
+    csv.write_text("v\n" + "\n".join(str(v) for v in vals) + "\n")
+    subprocess.check_call([os.path.join(ROOT, "immutable3_amd", "bin", "imm3_loader"), "-t", "pf", "-c", "v:PFOR_INT", "-d", str(tmp_path / "c"),
+                           "-i", str(csv), "--block-size", "64", "--segment-size", "100"])
+    want = b"".join(oracle_c.pfor_encode_block(np.array(vals[s:s + 64], dtype=np.int32)) for s in range(0, 150, 64))
+    for d in "abc":
+        assert open(tmp_path / d / "pf" / "v_0.dat", "rb").read() == want, d
+    offs = SegmentMeta.load(str(tmp_path / "a" / "pf" / "v_0.meta")).blockOffsets
+    assert len(offs) == 4 and offs[-1] == len(want)
+    assert open(tmp_path / "a" / "pf" / "v_0.meta").read() == open(tmp_path / "c" / "pf" / "v_0.meta").read()
