@@ -382,6 +382,33 @@ def extra_workloads(ctx, native, synth, n, steps: int = 30):
     dt = time.perf_counter() - t0
     out["staging_400MB_pageable"] = {"seconds": dt, "GBps": n * 4 / dt / 1e9}
     s2.close()
+    # PFOR_INT: the id column as PFORCodecInt.encode writes it; the range predicate is evaluated on the
+    # compressed blocks (k_filter_pfor), HBM traffic = compressed bytes.  VALU-bound, not HBM-bound.
+    dat, offs = native.pfor_encode_column(ids, 1024)
+    t0 = time.perf_counter()
+    sp = native.DeviceSegment(ctx, [(native.PFOR_INT, 4, dat, dat.size, offs)])
+    stage_s = time.perf_counter() - t0
+    q = native.DeviceQuery(ctx, sp, [0], [(0, native.GT, 1e6), (0, native.LT, 9e7)])
+    for _ in range(3):
+        q.run_select()
+    cnt = q.count()
+    torch.cuda.synchronize()
+    ctx.timing_enable(steps + 8)
+    ctx.timing_mask(1)
+    ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        q.run_select()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    k0 = ctx.timing_collect(0)
+    ctx.timing_enable(0)
+    out["pfor_range_id"] = {"rows_per_s": n / dt, "ms_per_query": dt * 1e3, "selected_rows": int(cnt), "compressed_bytes": int(dat.size),
+                            "compression_ratio": n * 4 / dat.size, "kernel_ms": {"scan_select": float(np.mean(k0)) if k0.size else None},
+                            "hbm_GBps": (dat.size + n / 8) / (float(np.mean(k0)) * 1e-3) / 1e9 if k0.size else None,
+                            "staging_seconds": stage_s, "bound": "valu"}
+    q.close()
+    sp.close()
     return out
 
 
