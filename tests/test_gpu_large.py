@@ -101,3 +101,36 @@ def test_c4_match_project_100m(big):
     idx10, v10 = q.fetch_rows()
     assert (idx10 == rows[:10]).all() and (v10[0].view("<i4").reshape(-1) == ids[rows[:10]]).all()
     q.close()
+
+
+def test_maximum_segment_size():
+    """The largest DENSE_INT segment the reference format can describe: blockOffset is an Array[Int]
+    (core/storage/Segment.scala:33), so a column holds < 2 GiB = 536 870 911 int32 rows.  Closed-form counts, the tail
+    of the segment (partial last tile, row indices near 2^29) and a mid-segment window."""
+    from immutable3_amd import native, synth
+    n = (2 ** 31 - 1) // 4
+    ctx = native.Context(0)
+    ids = np.arange(n, dtype=np.int32)
+    offs = synth.block_offsets(n, 4)
+    assert int(offs[-1]) == n * 4 and offs.dtype == np.int32
+    seg = native.DeviceSegment(ctx, [(DENSE_INT, 4, ids.view(np.uint8), n * 4, offs)])
+    del ids
+    q = native.DeviceQuery(ctx, seg, [0], [(0, GT, 1000.0), (0, LT, float(n - 1000))])
+    q.run()
+    assert q.count() == n - 2001
+    w = q.bitmap()
+    assert w.size == (n + 63) // 64 and popcount(w) == n - 2001
+    assert int(w[0]) == 0 and int(w[-1]) == 0 and int(w[w.size // 2]) == 2 ** 64 - 1
+    q.close()
+    q = native.DeviceQuery(ctx, seg, [0], [(0, GT, float(n - 70))], [0], 0)
+    q.run()
+    idx, vals = q.fetch_rows()
+    assert idx.tolist() == list(range(n - 69, n)) and vals[0].view("<i4").reshape(-1).tolist() == list(range(n - 69, n))
+    q.close()
+    q = native.DeviceQuery(ctx, seg, [0], [(0, GT, 2.0 ** 28 - 3), (0, LT, 2.0 ** 28 + 3)], [0], 3)
+    q.run()
+    idx, vals = q.fetch_rows()
+    assert idx.tolist() == [2 ** 28 - 2, 2 ** 28 - 1, 2 ** 28]
+    q.close()
+    seg.close()
+    ctx.close()
