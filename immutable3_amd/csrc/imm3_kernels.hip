@@ -400,7 +400,16 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_generic(const FilterAr
 __global__ __launch_bounds__(64) void k_total(const TotalArgs a) {
     const int lane = threadIdx.x;
     unsigned long long v = 0;
-    for (int i = lane; i < a.n_partials; i += 64) v += a.block_partials[i];
+    // 16-byte loads, several in flight: with 4096 partials (k_filter_pfor's grid) a dword-per-lane loop was 64 dependent
+    // round trips (10-18 us)
+    const uint4 *p4 = (const uint4 *)a.block_partials;
+    const int n4 = a.n_partials >> 2;
+#pragma unroll 4
+    for (int i = lane; i < n4; i += 64) {
+        const uint4 x = p4[i];
+        v += (unsigned long long)x.x + x.y + x.z + x.w;
+    }
+    for (int i = (n4 << 2) + lane; i < a.n_partials; i += 64) v += a.block_partials[i];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
     if (lane == 0) {
