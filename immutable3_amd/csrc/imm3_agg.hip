@@ -155,8 +155,8 @@ __device__ __forceinline__ unsigned long long row_key(const AggArgs &a, int64_t 
 
 // 8 waves share one LDS table: 3 work-groups per CU by LDS (48 KiB each) = 6 waves per SIMD.  (1024-thread groups
 // were held to ONE per CU by their 72 VGPRs: 0.41 ms -> 0.355 ms for 100 M rows.)  Counters for the same run
-// (rocprofv3 --pmc, per 256-row step): 351 vector, 376 scalar, 36 LDS instructions -- the kernel is instruction-bound
-// on both issue ports; a wave-synchronous variant (idle lanes steered to a dummy slot, rare paths behind ballots)
+// (rocprofv3 --pmc, per 256-row step): 251 vector, 238 scalar, 40 LDS instructions (LDS busy 0.15 ms, vector issue
+// 0.16 ms, scalar issue 0.15 ms of the 0.34 ms) -- instruction-bound on all three ports; a wave-synchronous variant (idle lanes steered to a dummy slot, rare paths behind ballots)
 // measured slower (0.47 ms) and was dropped.
 constexpr int kAggThreads = 512;
 constexpr int kAggWaves = kAggThreads / 64;
