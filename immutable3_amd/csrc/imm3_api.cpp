@@ -66,16 +66,29 @@ struct imm3_ctx {
     unsigned long long *d_stamps = nullptr;
     int32_t stamp_slots = 0, stamp_used = 0;
     std::vector<int32_t> stamp_grids;
+    uint32_t *d_xpow8 = nullptr;    // snappy CRC-32C check: x^(8 n) mod P for n = 0 .. 32768
 };
+
+static inline bool is_snappy(int32_t c) { return c == IMM3_SNAPPY_INT || c == IMM3_SNAPPY_TINYINT || c == IMM3_SNAPPY_STRING; }
+static inline bool is_compressed(int32_t c) { return c == IMM3_PFOR_INT || is_snappy(c); }
+// the DENSE_* codec whose decoded vectors a column's values are (type dispatch of ScanOp / SelectOp / ProjectAggOp)
+static inline int32_t value_codec(int32_t c) {
+    if (c == IMM3_PFOR_INT || c == IMM3_SNAPPY_INT) return IMM3_DENSE_INT;
+    if (c == IMM3_SNAPPY_TINYINT) return IMM3_DENSE_TINYINT;
+    if (c == IMM3_SNAPPY_STRING) return IMM3_DENSE_STRING;
+    return c;
+}
 
 struct SegCol {
     int32_t codec = 0, width = 0;
+    int32_t vcodec = 0;                // value_codec(codec)
     uint8_t *d_data = nullptr;
     bool owned = false;
     uint64_t bytes = 0;
     std::vector<int32_t> offsets;
-    // PFOR_INT (imm3_codec.hip): the blocks stay compressed in d_data
-    std::vector<int32_t> block_rows;   // the value count each block declares (its first word)
+    // PFOR_INT (imm3_codec.hip) / snappy (imm3_snappy.hip): the blocks stay compressed in d_data
+    std::vector<int32_t> block_rows;   // the rows each block declares (PFOR: its count word; snappy: uncompressed bytes / width)
+    int32_t in_cap = 0, out_cap = 0;   // snappy: LDS bytes k_snappy_decode needs for the largest block / chunk
     int64_t rows = 0;
     bool tile_aligned = false;         // every block but the last holds exactly 1024 rows: block k == bitmap tile k
     uint32_t *d_block_off = nullptr;   // n_blocks + 1 byte offsets
@@ -91,7 +104,7 @@ struct imm3_segment {
 };
 
 // the flat, fixed-width form of a column (what every kernel but k_filter_pfor reads)
-static inline const uint8_t *col_flat(const SegCol &sc) { return sc.codec == IMM3_PFOR_INT ? sc.d_dense : sc.d_data; }
+static inline const uint8_t *col_flat(const SegCol &sc) { return is_compressed(sc.codec) ? sc.d_dense : sc.d_data; }
 
 struct imm3_table { // all segments of one table as one scan unit: the tile table
     imm3_ctx *ctx = nullptr;
@@ -290,6 +303,7 @@ extern "C" int imm3_ctx_destroy(imm3_ctx *ctx) {
     }
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
     (void)hipFree(ctx->d_stamps);
+    (void)hipFree(ctx->d_xpow8);
     pool_drain(ctx);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -322,6 +336,7 @@ extern "C" int imm3_ctx_devclock_enable(imm3_ctx *ctx, int32_t max_launches) {
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     (void)hipFree(ctx->d_stamps);
+    (void)hipFree(ctx->d_xpow8);
     pool_drain(ctx);
     ctx->d_stamps = nullptr;
     ctx->stamp_slots = 0;
@@ -519,15 +534,98 @@ static int pfor_index(imm3_ctx *ctx, imm3_segment *seg, SegCol &sc) {
     return IMM3_OK;
 }
 
-// The decoded (dense int32) form of a PFOR_INT column, made once per segment on first need.
+// Snappy-coded column: a block's rows = the uncompressed bytes its chunks declare / width (k_snappy_sizes walks the
+// chunk headers); also sizes the LDS windows k_snappy_decode needs.
+static constexpr int32_t kSnappyLdsBudget = 64 * 1024 - 1024; // staged block + one chunk (the CRC table takes 1 KiB)
+
+static int snappy_index(imm3_ctx *ctx, imm3_segment *seg, SegCol &sc) {
+    const size_t nb = sc.offsets.empty() ? 0 : sc.offsets.size() - 1;
+    std::vector<uint32_t> off(nb + 1, 0u);
+    uint32_t biggest_block = 0;
+    for (size_t k = 0; k <= nb && !sc.offsets.empty(); ++k) {
+        const int64_t o = sc.offsets[k];
+        if (o < 0 || (uint64_t)o > sc.bytes || (k > 0 && o < sc.offsets[k - 1]))
+            return fail(IMM3_ERR_LAYOUT, "snappy block " + std::to_string(k) + ": offsets must ascend within the segment data");
+        off[k] = (uint32_t)o;
+        if (k > 0) biggest_block = std::max(biggest_block, off[k] - off[k - 1]);
+    }
+    void *p = nullptr;
+    HIPCHK(hipMalloc(&p, (nb + 1) * sizeof(uint32_t)));
+    sc.d_block_off = (uint32_t *)p;
+    HIPCHK(hipMalloc(&p, (nb + 1) * sizeof(uint32_t)));
+    sc.d_row_base = (uint32_t *)p;
+    seg->device_bytes += 2 * (nb + 1) * sizeof(uint32_t);
+    HIPCHK(hipMemcpyAsync(sc.d_block_off, off.data(), (nb + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<uint32_t> sizes(nb, 0u);
+    uint32_t max_chunk = 0;
+    if (nb) {
+        HIPCHK(hipMalloc(&p, (nb + 1) * sizeof(uint32_t)));
+        uint32_t *d_sizes = (uint32_t *)p; // [nb] = the largest chunk
+        hipError_t e = hipMemsetAsync(d_sizes + nb, 0, sizeof(uint32_t), ctx->stream);
+        if (e == hipSuccess) {
+            launch_snappy_sizes(sc.d_data, sc.d_block_off, (int64_t)nb, d_sizes, d_sizes + nb, ctx->stream);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(sizes.data(), d_sizes, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&max_chunk, d_sizes + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_sizes);
+        HIPCHK(e);
+    }
+    std::vector<uint32_t> base(nb + 1, 0u);
+    sc.block_rows.assign(nb, 0);
+    int64_t rows = 0;
+    for (size_t k = 0; k < nb; ++k) {
+        if (sizes[k] == 0xFFFFFFFFu) return fail(IMM3_ERR_LAYOUT, "snappy block " + std::to_string(k) + " is malformed (stream header, chunk header or length preamble)");
+        if (sizes[k] % (uint32_t)sc.width) return fail(IMM3_ERR_LAYOUT, "snappy block " + std::to_string(k) + ": uncompressed length is not a multiple of the value width");
+        sc.block_rows[k] = (int32_t)(sizes[k] / (uint32_t)sc.width);
+        base[k] = (uint32_t)rows;
+        rows += sc.block_rows[k];
+        if (rows > 0xFFFFFFFFLL) return fail(IMM3_ERR_LAYOUT, "segment too large");
+    }
+    base[nb] = (uint32_t)rows;
+    sc.rows = rows;
+    sc.tile_aligned = false;
+    sc.in_cap = (int32_t)((biggest_block + 3 + 8 + 15) & ~15u);
+    sc.out_cap = (int32_t)((std::max<uint32_t>(max_chunk, 16) + 15) & ~15u);
+    if (sc.in_cap + sc.out_cap > kSnappyLdsBudget)
+        return fail(IMM3_ERR_LAYOUT, "snappy block of " + std::to_string(biggest_block) + " stored bytes does not fit the GPU decoder's LDS window (stored block + largest chunk <= 63 KiB)");
+    HIPCHK(hipMemcpyAsync(sc.d_row_base, base.data(), (nb + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return IMM3_OK;
+}
+
+// x^(8 n) mod the CRC-32C polynomial (reflected) for n = 0 .. 32768: moves a slice's CRC past the bytes after it
+static int ensure_xpow8(imm3_ctx *ctx) {
+    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    if (ctx->d_xpow8) return IMM3_OK;
+    std::vector<uint32_t> t(32769);
+    uint32_t c = 0x80000000u; // x^0
+    for (size_t n = 0; n < t.size(); ++n) {
+        t[n] = c;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0x82F63B78u & (0u - (c & 1u))); // times x^8 = one zero byte
+    }
+    void *p = nullptr;
+    HIPCHK(hipMalloc(&p, t.size() * sizeof(uint32_t)));
+    const hipError_t e = hipMemcpy(p, t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(p); HIPCHK(e); }
+    ctx->d_xpow8 = (uint32_t *)p;
+    return IMM3_OK;
+}
+
+// The decoded (dense, fixed-width) form of a PFOR_INT / snappy column, made once per segment on first need.
 static int ensure_dense(imm3_ctx *ctx, const imm3_segment *cseg, int32_t col) {
     imm3_segment *seg = const_cast<imm3_segment *>(cseg);
     SegCol &sc = seg->cols[(size_t)col];
-    if (sc.codec != IMM3_PFOR_INT) return IMM3_OK;
+    if (!is_compressed(sc.codec)) return IMM3_OK;
+    if (is_snappy(sc.codec)) {
+        const int xrc = ensure_xpow8(ctx);
+        if (xrc) return xrc;
+    }
     std::lock_guard<std::mutex> g(seg->decode_mu);
     if (sc.d_dense) return IMM3_OK;
     void *p = nullptr;
-    const size_t bytes = (size_t)sc.rows * 4 + kPad;
+    const size_t bytes = (size_t)sc.rows * (size_t)sc.width + kPad;
     HIPCHK(hipMalloc(&p, bytes));
     uint32_t *d_status = nullptr;
     void *ps = nullptr;
@@ -544,11 +642,28 @@ static int ensure_dense(imm3_ctx *ctx, const imm3_segment *cseg, int32_t col) {
     a.out = (int32_t *)p;
     a.status = d_status;
     e = hipMemsetAsync(d_status, 0, sizeof(uint32_t), ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync((uint8_t *)p + (size_t)sc.rows * 4, 0, kPad, ctx->stream);
-    if (e == hipSuccess && a.n_blocks > 0) {
+    if (e == hipSuccess) e = hipMemsetAsync((uint8_t *)p + (size_t)sc.rows * (size_t)sc.width, 0, kPad, ctx->stream);
+    if (e == hipSuccess && a.n_blocks > 0 && sc.codec == IMM3_PFOR_INT) {
         LaunchTimer t(ctx, 5);
         const int64_t want = (a.n_blocks + kWavesPerBlock - 1) / kWavesPerBlock;
         launch_pfor_decode(a, (int)std::min<int64_t>(want, 2048), ctx->stream, t.start, t.stop);
+        e = hipGetLastError();
+    } else if (e == hipSuccess && a.n_blocks > 0) {
+        SnappyArgs sa;
+        std::memset(&sa, 0, sizeof(sa));
+        sa.data = sc.d_data;
+        sa.block_off = sc.d_block_off;
+        sa.row_base = sc.d_row_base;
+        sa.xpow8 = ctx->d_xpow8;
+        sa.n_blocks = a.n_blocks;
+        sa.width = sc.width;
+        sa.in_cap = sc.in_cap;
+        sa.out_cap = sc.out_cap;
+        sa.out = (uint8_t *)p;
+        sa.status = d_status;
+        LaunchTimer t(ctx, 5);
+        // one wave per work-group; LDS per group decides how many are resident: ask for up to 16 per CU
+        launch_snappy_decode(sa, (int)std::min<int64_t>(sa.n_blocks, 4096), ctx->stream, t.start, t.stop);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&status, d_status, sizeof(status), hipMemcpyDeviceToHost, ctx->stream);
@@ -557,7 +672,8 @@ static int ensure_dense(imm3_ctx *ctx, const imm3_segment *cseg, int32_t col) {
     if (e != hipSuccess || status) {
         (void)hipFree(p);
         HIPCHK(e);
-        return fail(IMM3_ERR_LAYOUT, "malformed PFOR_INT block (width above 32, data past the block end, or count mismatch)");
+        return fail(IMM3_ERR_LAYOUT, sc.codec == IMM3_PFOR_INT ? "malformed PFOR_INT block (width above 32, data past the block end, or count mismatch)"
+                                                              : "malformed snappy block (bad element, length mismatch or CRC-32C mismatch)");
     }
     sc.d_dense = (uint8_t *)p;
     seg->device_bytes += bytes;
@@ -579,6 +695,7 @@ static int segment_build(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, 
         if (c.n_offsets < 0 || (c.n_offsets > 0 && !c.block_offsets)) return fail(IMM3_ERR_ARG, "bad block offset table");
         if (c.dat_bytes > 0 && !c.dat) return fail(IMM3_ERR_ARG, "column data pointer is null");
         s.codec = c.codec;
+        s.vcodec = value_codec(c.codec);
         s.width = c.width;
         s.bytes = c.dat_bytes;
         s.offsets.assign(c.block_offsets, c.block_offsets + c.n_offsets);
@@ -598,8 +715,8 @@ static int segment_build(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, 
     }
     HIPCHK(hipStreamSynchronize(ctx->stream)); // host buffers may be unmapped after we return
     for (auto &sc : seg->cols) {
-        if (sc.codec != IMM3_PFOR_INT) continue;
-        const int rc = pfor_index(ctx, seg.get(), sc);
+        if (!is_compressed(sc.codec)) continue;
+        const int rc = sc.codec == IMM3_PFOR_INT ? pfor_index(ctx, seg.get(), sc) : snappy_index(ctx, seg.get(), sc);
         if (rc) return rc;
     }
     *out = seg.release();
@@ -690,7 +807,7 @@ struct SegLayout {
 
 // rows of block k of a column: DENSE_* = bytes / width; PFOR_INT = the count the block declares
 static inline int64_t block_rows_of(const SegCol &sc, int32_t k, int64_t len) {
-    return sc.codec == IMM3_PFOR_INT ? (int64_t)sc.block_rows[(size_t)k] : len / sc.width;
+    return is_compressed(sc.codec) ? (int64_t)sc.block_rows[(size_t)k] : len / sc.width;
 }
 
 static int segment_layout(const imm3_segment *seg, const std::vector<int32_t> &used, int32_t table_block_size, SegLayout &L) {
@@ -703,7 +820,7 @@ static int segment_layout(const imm3_segment *seg, const std::vector<int32_t> &u
     for (int32_t k = 0; k < nb; ++k) {
         const int64_t len = (int64_t)first.offsets[(size_t)k + 1] - (int64_t)first.offsets[(size_t)k];
         if (len < 0) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": negative length (NegativeArraySizeException in the reference)");
-        if (len % first.width) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": byte length is not a multiple of the value width (malformed segment)");
+        if (!is_compressed(first.codec) && len % first.width) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": byte length is not a multiple of the value width (malformed segment)");
         if (cursor + (uint64_t)len > first.bytes) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": bytes [" + std::to_string(cursor) + ", " + std::to_string(cursor + (uint64_t)len) + ") run past the segment data of " + std::to_string(first.bytes) + " bytes (BufferUnderflowException in the reference)");
         const int64_t n = block_rows_of(first, k, len);
         L.size[(size_t)k] = (int32_t)n;
@@ -722,7 +839,7 @@ static int segment_layout(const imm3_segment *seg, const std::vector<int32_t> &u
         uint64_t cur = 0;
         for (int32_t k = 0; k < nb; ++k) {
             const int64_t len = (int64_t)sc.offsets[(size_t)k + 1] - (int64_t)sc.offsets[(size_t)k];
-            if (len < 0 || len % sc.width || block_rows_of(sc, k, len) != L.size[(size_t)k])
+            if (len < 0 || (!is_compressed(sc.codec) && len % sc.width) || block_rows_of(sc, k, len) != L.size[(size_t)k])
                 return fail(IMM3_ERR_LAYOUT, "used column " + std::to_string(i) + " block " + std::to_string(k) + " does not hold the same rows as the first used column");
             if (cur + (uint64_t)len > sc.bytes) return fail(IMM3_ERR_LAYOUT, "used column " + std::to_string(i) + " block " + std::to_string(k) + " runs past the segment data");
             cur += (uint64_t)len;
@@ -813,15 +930,16 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
             const SegCol &sc = seg->cols[(size_t)q->used[(size_t)i]];
             // PFOR_INT: the reference dispatches it too (Scan.scala:37-39) but its decode throws on every block
             // (PFORCodec.scala:43-50); here the blocks its encoder writes are decoded (imm3_codec.hip).
-            if (sc.codec != IMM3_DENSE_INT && sc.codec != IMM3_DENSE_TINYINT && sc.codec != IMM3_DENSE_STRING && sc.codec != IMM3_PFOR_INT)
+            // Snappy-coded columns (IMM3_SNAPPY_*) are this library's extension: the reference only has the encoder.
+            if (sc.vcodec != IMM3_DENSE_INT && sc.vcodec != IMM3_DENSE_TINYINT && sc.vcodec != IMM3_DENSE_STRING)
                 return fail(IMM3_ERR_NO_CODEC, "No implementation for codec " + std::to_string(sc.codec));
-            if (((sc.codec == IMM3_DENSE_INT || sc.codec == IMM3_PFOR_INT) && sc.width != 4) || (sc.codec == IMM3_DENSE_TINYINT && sc.width != 1))
+            if ((sc.vcodec == IMM3_DENSE_INT && sc.width != 4) || (sc.vcodec == IMM3_DENSE_TINYINT && sc.width != 1))
                 return fail(IMM3_ERR_ARG, "width does not match codec");
         }
         // ... and each SelectIterator dispatches on the vector type (Select.scala:41,80,118,156).
         for (int32_t i = 0; i < n_sels; ++i) {
             const SegCol &sc = seg->cols[(size_t)q->used[(size_t)sels[i].column]];
-            const bool is_str = sc.codec == IMM3_DENSE_STRING;
+            const bool is_str = sc.vcodec == IMM3_DENSE_STRING;
             if ((sels[i].cond == IMM3_MATCH) != is_str) return fail(IMM3_ERR_UNSUPPORTED_VECTOR, "Unsupported column vector");
         }
     }
@@ -841,8 +959,8 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
                 fp = &q->preds.back();
                 fp->seg_col = sci;
                 fp->width = sc.width;
-                if (sc.codec == IMM3_DENSE_INT || sc.codec == IMM3_PFOR_INT) { fp->kind = KIND_I32; fp->lo = INT32_MIN; fp->hi = INT32_MAX; }
-                else if (sc.codec == IMM3_DENSE_TINYINT) { fp->kind = KIND_I8; fp->lo = -128; fp->hi = 127; }
+                if (sc.vcodec == IMM3_DENSE_INT) { fp->kind = KIND_I32; fp->lo = INT32_MIN; fp->hi = INT32_MAX; }
+                else if (sc.vcodec == IMM3_DENSE_TINYINT) { fp->kind = KIND_I8; fp->lo = -128; fp->hi = 127; }
                 else fp->kind = KIND_STR;
             }
             if (fp->kind == KIND_STR) {
@@ -877,13 +995,14 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
         for (int32_t i = 0; i < n_used; ++i) {
             const int32_t sci = q->used[(size_t)i];
             const SegCol &sc = seg->cols[(size_t)sci];
-            if (sc.codec != IMM3_PFOR_INT) continue;
+            if (!is_compressed(sc.codec)) continue;
             bool projected = false;
             for (int32_t pj : q->proj) projected |= (pj == i);
             FoldedPred *fp = nullptr;
             for (auto &p : q->preds)
                 if (p.seg_col == sci) fp = &p;
-            const bool fused = fp && !table && !q->ragged && sc.tile_aligned && !projected && ctx->filter_variant != 1 && ctx->filter_variant != 5;
+            const bool fused = sc.codec == IMM3_PFOR_INT && fp && !table && !q->ragged && sc.tile_aligned && !projected &&
+                               ctx->filter_variant != 1 && ctx->filter_variant != 5;
             if (fused) fp->pfor = true;
             else if (!table) { // a table decodes its PFOR_INT columns when it is created
                 const int drc = ensure_dense(ctx, seg, sci);
@@ -1575,7 +1694,7 @@ static int query_create_agg_impl(imm3_ctx *ctx, const imm3_segment *seg, const i
     for (int32_t j = 0; j < n_aggs; ++j) {
         if (aggs[j].column < 0 || aggs[j].column >= n_used) return fail(IMM3_ERR_ARG, "aggregate column is not among the used columns");
         const SegCol &sc = seg->cols[(size_t)q->used[(size_t)aggs[j].column]];
-        const bool is_str = sc.codec == IMM3_DENSE_STRING;
+        const bool is_str = sc.vcodec == IMM3_DENSE_STRING;
         if (aggs[j].kind != IMM3_AGG_COUNT && aggs[j].kind != IMM3_AGG_MIN && aggs[j].kind != IMM3_AGG_MAX) return fail(IMM3_ERR_ARG, "Unknown Aggregate type");
         // ProjectAggregate.scala:176-220: a String vector only takes CountAggr / MaxStringAggr
         if (has_batches && is_str && aggs[j].kind == IMM3_AGG_MIN) return fail(IMM3_ERR_UNSUPPORTED_VECTOR, "bad aggregator for this data type");
@@ -1585,7 +1704,7 @@ static int query_create_agg_impl(imm3_ctx *ctx, const imm3_segment *seg, const i
     if (!table) {
         auto need_dense = [&](int32_t used_idx) -> int {
             const int32_t sci = q->used[(size_t)used_idx];
-            if (seg->cols[(size_t)sci].codec != IMM3_PFOR_INT) return IMM3_OK;
+            if (!is_compressed(seg->cols[(size_t)sci].codec)) return IMM3_OK;
             for (auto &fp : q->preds)
                 if (fp.seg_col == sci) fp.pfor = false;
             return ensure_dense(ctx, seg, sci);
@@ -1657,7 +1776,7 @@ static void fill_agg_args(const imm3_query *q, AggArgs &a) {
         a.aggs[j].tile_ptrs = q->table ? (const void *const *)q->table->d_tile_ptrs[(size_t)q->used[(size_t)q->aggs[j].column]] : nullptr;
         a.aggs[j].width = sc.width;
         a.aggs[j].kind = q->aggs[j].kind;
-        a.aggs[j].is_str = sc.codec == IMM3_DENSE_STRING;
+        a.aggs[j].is_str = sc.vcodec == IMM3_DENSE_STRING;
     }
     a.n_agg = (int32_t)q->aggs.size();
     a.keys = q->d_akeys;
@@ -1785,5 +1904,19 @@ extern "C" int imm3_pfor_encode_column(const int32_t *values, uint64_t n_values,
         offsets_out[++k] = (int32_t)pos;
     }
     *bytes_out = pos;
+    return IMM3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// write side of the snappy block format (host only; host/codec.hpp)
+// ---------------------------------------------------------------------------------------------
+extern "C" uint64_t imm3_snappy_encode_bound(uint64_t n_bytes) { return (uint64_t)immutabledb::codec::snappyEncodeBound((size_t)n_bytes); }
+
+extern "C" int imm3_snappy_encode_block(const void *bytes, uint64_t n_bytes, void *out, uint64_t cap, uint64_t *bytes_out) {
+    if ((n_bytes > 0 && !bytes) || !out || !bytes_out) return fail(IMM3_ERR_ARG, "bad argument");
+    const std::vector<uint8_t> blk = immutabledb::codec::snappyEncodeBlock((const uint8_t *)bytes, (size_t)n_bytes);
+    if (blk.size() > cap) return fail(IMM3_ERR_ARG, "output buffer too small (see imm3_snappy_encode_bound)");
+    std::memcpy(out, blk.data(), blk.size());
+    *bytes_out = blk.size();
     return IMM3_OK;
 }

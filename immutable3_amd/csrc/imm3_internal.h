@@ -195,6 +195,22 @@ void launch_pfor_counts(const uint8_t *data, const uint32_t *block_off, int64_t 
 void launch_filter_pfor(const PforArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 void launch_pfor_decode(const PforArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 
+// ---- snappy-coded blocks (imm3_snappy.hip) ----
+struct SnappyArgs {
+    const uint8_t *data;          // the column's .dat bytes in HBM (blocks start on any byte)
+    const uint32_t *block_off;    // n_blocks + 1 byte offsets
+    const uint32_t *row_base;     // n_blocks + 1 first rows
+    const uint32_t *xpow8;        // 32769 entries: x^(8 n) mod the CRC-32C polynomial, reflected
+    int64_t n_blocks;
+    int32_t width;                // bytes per value of the decoded column
+    int32_t in_cap, out_cap;      // LDS bytes for the staged block / one chunk
+    int32_t pad;
+    uint8_t *out;                 // dense column
+    uint32_t *status;             // bit 0 set when a block is malformed or a checksum does not match
+};
+void launch_snappy_sizes(const uint8_t *data, const uint32_t *block_off, int64_t n_blocks, uint32_t *sizes, uint32_t *max_chunk, hipStream_t s);
+void launch_snappy_decode(const SnappyArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+
 bool launch_filter_tile(const TileArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 void launch_filter_generic(const FilterArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 void launch_total(const TotalArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);

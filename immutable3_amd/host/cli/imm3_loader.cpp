@@ -20,6 +20,9 @@ static Column parseCol(const std::string &arg) { // parseCol / parseColOptions, 
         }
     if (parts[1] == "DENSE_INT") return Column::make(parts[0], CodecType::DENSE_INT);
     if (parts[1] == "PFOR_INT") return Column::make(parts[0], CodecType::PFOR_INT); // not offered by LoaderCli.scala:118-122; SegmentWriter handles it
+    if (parts[1] == "SNAPPY_INT") return Column::make(parts[0], CodecType::SNAPPY_INT);             // extension codecs (schema.hpp)
+    if (parts[1] == "SNAPPY_TINYINT") return Column::make(parts[0], CodecType::SNAPPY_TINYINT);
+    if (parts[1] == "SNAPPY_STRING") return Column::make(parts[0], CodecType::SNAPPY_STRING, opts);
     if (parts[1] == "DENSE_TINYINT") return Column::make(parts[0], CodecType::DENSE_TINYINT);
     if (parts[1] == "DENSE_STRING") return Column::make(parts[0], CodecType::DENSE_STRING, opts);
     throw Exception("MatchError: " + parts[1]); // LoaderCli.scala:118-122 has no other case

@@ -1,4 +1,4 @@
-// codec.hpp -- write side of the PFOR_INT block codec: PFORCodecInt.encode (core/src/main/scala/immutabledb/codec/
+// codec.hpp -- write side of the compressed block codecs (PFOR_INT below, snappy further down).  PFOR_INT: PFORCodecInt.encode (core/src/main/scala/immutabledb/codec/
 // PFORCodec.scala:19-31), which SegmentWriter.flush applies to every block of a PFOR_INT column
 // (core/.../storage/Segment.scala:115-122).
 //
@@ -125,6 +125,121 @@ inline std::vector<uint8_t> pforEncodeBlock(const int32_t *v, int32_t n) {
         out[4 * i + 1] = (uint8_t)(w >> 16);
         out[4 * i + 2] = (uint8_t)(w >> 8);
         out[4 * i + 3] = (uint8_t)w;
+    }
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Snappy-coded blocks: SnappyCodec.encode (core/src/main/scala/immutabledb/codec/SnappyCodec.scala:15-27) writes the
+// block's raw value bytes through `new SnappyOutputStream(...)` of org.iq80.snappy 0.4:
+//     "snappy\0" | per chunk of <= 32768 input bytes: flag (1 compressed / 0 stored), payload length (2 bytes, big-
+//     endian), masked CRC-32C of the chunk's input bytes (4 bytes, big-endian), payload
+// with the chunk stored compressed only when compressed / input <= 7/8.  The payload is raw Snappy (varint length,
+// literal / copy elements).  Any valid Snappy stream is readable by any Snappy reader; the matcher below is a plain
+// greedy one (one candidate per 4-byte hash, offsets below 64 KiB), not a byte-for-byte clone of iq80's.
+// ---------------------------------------------------------------------------------------------------------------
+inline uint32_t crc32c(const uint8_t *p, size_t n) {
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            table[i] = c;
+        }
+        ready = true;
+    }
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 255u] ^ (c >> 8);
+    return ~c;
+}
+
+inline uint32_t maskedCrc32c(const uint8_t *p, size_t n) {
+    const uint32_t c = crc32c(p, n);
+    return ((c >> 15) | (c << 17)) + 0xa282ead8u;
+}
+
+class SnappyWriter { // raw Snappy elements appended to a byte vector
+  public:
+    explicit SnappyWriter(std::vector<uint8_t> &out) : out_(out) {}
+    void varint(uint32_t v) {
+        for (; v > 127; v >>= 7) out_.push_back((uint8_t)(v | 128));
+        out_.push_back((uint8_t)v);
+    }
+    void literal(const uint8_t *p, size_t len) {
+        if (!len) return;
+        const size_t n = len - 1;
+        if (n < 60) out_.push_back((uint8_t)(n << 2));
+        else {
+            const int bytes = n < 256 ? 1 : n < 65536 ? 2 : n < (1u << 24) ? 3 : 4;
+            out_.push_back((uint8_t)((59 + bytes) << 2));
+            for (int k = 0; k < bytes; ++k) out_.push_back((uint8_t)(n >> (8 * k)));
+        }
+        out_.insert(out_.end(), p, p + len);
+    }
+    void copy(size_t offset, size_t len) { // offset < 65536
+        while (len) {
+            size_t l = len < 64 ? len : 64;
+            if (len > 64 && len - 64 < 4) l = 60; // never leave a remainder shorter than a match
+            if (l >= 4 && l <= 11 && offset < 2048) {
+                out_.push_back((uint8_t)(1u | ((l - 4) << 2) | ((offset >> 8) << 5)));
+                out_.push_back((uint8_t)offset);
+            } else {
+                out_.push_back((uint8_t)(2u | ((l - 1) << 2)));
+                out_.push_back((uint8_t)offset);
+                out_.push_back((uint8_t)(offset >> 8));
+            }
+            len -= l;
+        }
+    }
+
+  private:
+    std::vector<uint8_t> &out_;
+};
+
+inline void snappyCompress(const uint8_t *in, size_t n, std::vector<uint8_t> &out) { // n <= 32768 here
+    SnappyWriter w(out);
+    w.varint((uint32_t)n);
+    std::vector<int32_t> last(1u << 13, -1); // most recent position of each 4-byte hash
+    size_t anchor = 0, i = 0;
+    while (i + 4 <= n) {
+        uint32_t four;
+        std::memcpy(&four, in + i, 4);
+        const uint32_t h = (four * 2654435761u) >> 19;
+        const int32_t c = last[h];
+        last[h] = (int32_t)i;
+        if (c >= 0 && i - (size_t)c <= 65535 && std::memcmp(in + c, in + i, 4) == 0) {
+            size_t len = 4;
+            while (i + len < n && in[(size_t)c + len] == in[i + len]) ++len;
+            w.literal(in + anchor, i - anchor);
+            w.copy(i - (size_t)c, len);
+            i += len;
+            anchor = i;
+        } else {
+            ++i;
+        }
+    }
+    w.literal(in + anchor, n - anchor);
+}
+
+inline size_t snappyEncodeBound(size_t n) { return 7 + (n / 32768 + 1) * 7 + n + n / 6 + 32; }
+
+// SnappyCodec.encode(bytes): one storage block's raw value bytes -> the bytes SegmentWriter appends to the .dat
+inline std::vector<uint8_t> snappyEncodeBlock(const uint8_t *in, size_t n) {
+    std::vector<uint8_t> out = {'s', 'n', 'a', 'p', 'p', 'y', 0};
+    std::vector<uint8_t> packed;
+    for (size_t s = 0; s < n; s += 32768) {
+        const size_t len = n - s < 32768 ? n - s : 32768;
+        packed.clear();
+        snappyCompress(in + s, len, packed);
+        const bool compressed = (double)packed.size() / (double)len <= 7.0 / 8.0;
+        const size_t plen = compressed ? packed.size() : len;
+        const uint32_t crc = maskedCrc32c(in + s, len);
+        const uint8_t hdr[7] = {(uint8_t)(compressed ? 1 : 0), (uint8_t)(plen >> 8), (uint8_t)plen,
+                                (uint8_t)(crc >> 24), (uint8_t)(crc >> 16), (uint8_t)(crc >> 8), (uint8_t)crc};
+        out.insert(out.end(), hdr, hdr + 7);
+        if (compressed) out.insert(out.end(), packed.begin(), packed.end());
+        else out.insert(out.end(), in + s, in + s + len);
     }
     return out;
 }

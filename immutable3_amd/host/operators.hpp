@@ -237,10 +237,10 @@ class ScanOp : public ColumnVectorOperator {
         std::vector<uint64_t> words((size_t)nwords);
         imm3Check(imm3_query_bitmap(h.q, words.data(), nwords));
         auto it = std::make_unique<VectorIterator<ColumnVectorBatch>>();
-        // PFOR_INT columns: the vectors of the batches are the GPU's decode of the segment (one projection, no predicate)
+        // PFOR_INT / snappy columns: the vectors of the batches are the GPU's decode of the segment (one projection, no predicate)
         std::vector<std::shared_ptr<std::vector<uint8_t>>> decoded(cols_.size());
         for (size_t ci = 0; ci < cols_.size(); ++ci) {
-            if (cols_[ci].codec != CodecType::PFOR_INT || nrows == 0) continue;
+            if ((cols_[ci].codec != CodecType::PFOR_INT && !isSnappy(cols_[ci].codec)) || nrows == 0) continue;
             QueryHandle d;
             const Table &t = table();
             const int32_t used = t.columnIndex(cols_[ci].name), proj = 0;
@@ -248,7 +248,7 @@ class ScanOp : public ColumnVectorOperator {
             imm3Check(imm3_query_run(d.q));
             uint64_t n = 0;
             imm3Check(imm3_query_row_count(d.q, &n));
-            decoded[ci] = std::make_shared<std::vector<uint8_t>>((size_t)n * 4);
+            decoded[ci] = std::make_shared<std::vector<uint8_t>>((size_t)n * (size_t)cols_[ci].width());
             void *outp = decoded[ci]->data();
             imm3Check(imm3_query_fetch_rows(d.q, nullptr, &outp, n));
         }
@@ -619,7 +619,7 @@ class Engine {
             if (ci < 0) throw Exception("NoSuchElementException: next on empty iterator");
             const Column &c = p.used[(size_t)ci];
             if (leaves[i].cond.kind == SelectCondition::Match &&
-                (c.codec != CodecType::DENSE_STRING || c.width() != 2 || leaves[i].cond.values.empty() || leaves[i].cond.values.size() > 8))
+                (c.columnType != ColumnType::STRING || c.width() != 2 || leaves[i].cond.values.empty() || leaves[i].cond.values.size() > 8))
                 return false; // the tile kernels take 2-byte strings with <= 8 IN-list values
             p.sels[i] = imm3_select{};
             p.sels[i].column = ci;

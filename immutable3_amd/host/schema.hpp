@@ -26,12 +26,16 @@ struct Exception : std::runtime_error {
 };
 
 // ---- CodecType (codec/Codec.scala:21-24) / ColumnType (Column.scala:13-16) ----
-enum class CodecType : int { PFOR_INT = 0, DENSE_INT = 1, DENSE_TINYINT = 2, DENSE_STRING = 3 };
+// SNAPPY_* are this library's extension (include/imm3.h): blocks as SnappyCodec.encode writes them
+// (codec/SnappyCodec.scala:15-43); the reference has no CodecType for them and cannot read them.
+enum class CodecType : int { PFOR_INT = 0, DENSE_INT = 1, DENSE_TINYINT = 2, DENSE_STRING = 3, SNAPPY_INT = 16, SNAPPY_TINYINT = 17, SNAPPY_STRING = 18 };
+inline bool isSnappy(CodecType c) { return (int)c >= 16; }
 enum class ColumnType : int { INT = 0, TINYINT = 1, STRING = 2 };
 
 inline const char *toString(CodecType c) {
     static const char *n[] = {"PFOR_INT", "DENSE_INT", "DENSE_TINYINT", "DENSE_STRING"};
-    return n[(int)c];
+    static const char *x[] = {"SNAPPY_INT", "SNAPPY_TINYINT", "SNAPPY_STRING"};
+    return isSnappy(c) ? x[(int)c - 16] : n[(int)c];
 }
 inline const char *toString(ColumnType c) {
     static const char *n[] = {"INT", "TINYINT", "STRING"};
@@ -39,6 +43,8 @@ inline const char *toString(ColumnType c) {
 }
 inline CodecType codecWithName(const std::string &s) {
     for (int i = 0; i < 4; ++i)
+        if (s == toString((CodecType)i)) return (CodecType)i;
+    for (int i = 16; i < 19; ++i)
         if (s == toString((CodecType)i)) return (CodecType)i;
     throw Exception("No value found for '" + s + "'"); // Enumeration.withName
 }
@@ -62,8 +68,11 @@ struct Column {
         c.dtypeAttrs = std::move(attrs);
         switch (codec) {
         case CodecType::DENSE_INT:
+        case CodecType::SNAPPY_INT:
         case CodecType::PFOR_INT: c.columnType = ColumnType::INT; break;
+        case CodecType::SNAPPY_TINYINT:
         case CodecType::DENSE_TINYINT: c.columnType = ColumnType::TINYINT; break;
+        case CodecType::SNAPPY_STRING:
         case CodecType::DENSE_STRING: c.columnType = ColumnType::STRING; break;
         }
         return c;
@@ -77,8 +86,11 @@ struct Column {
     int width() const {
         switch (codec) {
         case CodecType::DENSE_INT:
+        case CodecType::SNAPPY_INT:
         case CodecType::PFOR_INT: return 4;
+        case CodecType::SNAPPY_TINYINT:
         case CodecType::DENSE_TINYINT: return 1;
+        case CodecType::SNAPPY_STRING:
         case CodecType::DENSE_STRING: return std::stoi(attr("size"));
         }
         throw Exception("");

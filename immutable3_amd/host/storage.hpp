@@ -31,6 +31,7 @@ inline std::string stringToBytes(const Column &col, const std::string &s) {
     };
     switch (col.codec) {
     case CodecType::DENSE_INT:
+    case CodecType::SNAPPY_INT:
     case CodecType::PFOR_INT: { // s.toInt, IntType.valueToBytes :40-47 (little-endian)
         const int32_t v = (int32_t)parseInt(INT32_MIN, INT32_MAX);
         std::string b(4, '\0');
@@ -40,8 +41,10 @@ inline std::string stringToBytes(const Column &col, const std::string &s) {
         b[0] = (char)(v & 0xFF);
         return b;
     }
+    case CodecType::SNAPPY_TINYINT:
     case CodecType::DENSE_TINYINT: // s.toByte
         return std::string(1, (char)(int8_t)parseInt(-128, 127));
+    case CodecType::SNAPPY_STRING:
     case CodecType::DENSE_STRING: // value.getBytes(): NO padding / truncation to dtypeAttrs("size") (:69)
         return s;
     }
@@ -94,6 +97,9 @@ class SegmentWriter {
             std::vector<int32_t> vals(buf_.size() / 4);
             std::memcpy(vals.data(), buf_.data(), vals.size() * 4);
             const std::vector<uint8_t> enc = codec::pforEncodeBlock(vals.data(), (int32_t)vals.size());
+            buf_.assign((const char *)enc.data(), enc.size());
+        } else if (isSnappy(column_.codec)) { // SnappyCodec.encode (codec/SnappyCodec.scala:15-27)
+            const std::vector<uint8_t> enc = codec::snappyEncodeBlock((const uint8_t *)buf_.data(), buf_.size());
             buf_.assign((const char *)enc.data(), enc.size());
         }
         file_.write(buf_.data(), (std::streamsize)buf_.size());

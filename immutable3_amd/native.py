@@ -17,6 +17,8 @@ LIB_PATH = os.path.join(_PKG, "lib", "libimm3.so")
 
 # CodecType (core/src/main/scala/immutabledb/codec/Codec.scala:21-24)
 PFOR_INT, DENSE_INT, DENSE_TINYINT, DENSE_STRING = 0, 1, 2, 3
+SNAPPY_INT, SNAPPY_TINYINT, SNAPPY_STRING = 16, 17, 18   # extension: blocks as SnappyCodec.encode writes them
+INT_CODECS, TINYINT_CODECS = (DENSE_INT, PFOR_INT, SNAPPY_INT), (DENSE_TINYINT, SNAPPY_TINYINT)
 # SelectCondition (core/src/main/scala/immutabledb/Query.scala:3-9)
 MATCH, NOTMATCH, EQ, GT, LT, NOOP = 0, 1, 2, 3, 4, 5
 
@@ -37,6 +39,7 @@ EXPORTS = [
     "imm3_query_row_count", "imm3_query_fetch_rows", "imm3_query_device_ptr",
     "imm3_ctx_timing_enable", "imm3_ctx_timing_reset", "imm3_ctx_timing_mask", "imm3_ctx_timing_collect", "imm3_ctx_set_tuning", "imm3_ctx_measure_read_gbps", "imm3_ctx_devclock_enable", "imm3_ctx_devclock_collect",
     "imm3_pfor_encode_bound", "imm3_pfor_encode_block", "imm3_pfor_encode_column",
+    "imm3_snappy_encode_bound", "imm3_snappy_encode_block",
 ]
 
 
@@ -132,8 +135,11 @@ def load() -> C.CDLL:
     L.imm3_ctx_devclock_collect.argtypes = [vp, vp, i32, P(i32)]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name not in ("imm3_last_error", "imm3_pfor_encode_bound"):
+        if name not in ("imm3_last_error", "imm3_pfor_encode_bound", "imm3_snappy_encode_bound"):
             fn.restype = C.c_int
+    L.imm3_snappy_encode_bound.restype = C.c_uint64
+    L.imm3_snappy_encode_bound.argtypes = [C.c_uint64]
+    L.imm3_snappy_encode_block.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.imm3_pfor_encode_bound.restype = C.c_uint64
     L.imm3_pfor_encode_bound.argtypes = [C.c_int32]
     L.imm3_pfor_encode_block.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -168,6 +174,16 @@ def pfor_encode_column(values, block_rows: int):
     n = C.c_uint64(0)
     _check(load().imm3_pfor_encode_column(v.ctypes.data, v.size, block_rows, out.ctypes.data, cap, offs.ctypes.data, C.byref(n)))
     return out[:n.value].copy(), offs
+
+
+def snappy_encode_block(raw) -> bytes:
+    """SnappyCodec.encode (core/codec/SnappyCodec.scala:15-27) of one block's raw value bytes (host code)."""
+    a = np.frombuffer(bytes(raw), dtype=np.uint8) if not isinstance(raw, np.ndarray) else np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+    cap = load().imm3_snappy_encode_bound(a.size)
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_uint64(0)
+    _check(load().imm3_snappy_encode_block(a.ctypes.data, a.size, out.ctypes.data, cap, C.byref(n)))
+    return out[:n.value].tobytes()
 
 
 def device_count() -> int:

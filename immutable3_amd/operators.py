@@ -258,14 +258,22 @@ class ScanOp(ColumnVectorOperator):
             q.run()
             _, cols = q.fetch_rows()
             q.close()
-            cache[c.name] = cols[0].reshape(-1).view("<i4").copy()
+            raw = cols[0]
+            cache[c.name] = (raw.reshape(-1).view("<i4").copy() if c.codec in CodecType.INT_CODECS else
+                             raw.reshape(-1).view(np.int8).copy() if c.codec in CodecType.TINYINT_CODECS else raw.reshape(-1, c.width).copy())
         return cache[c.name]
 
     def _host_vectors(self, k: int, start_row: int, size: int) -> List[ColumnVector]:
         out = []
         for c in self.cols:
-            if c.codec == CodecType.PFOR_INT:
-                out.append(IntColumnVector(self._pfor_decoded(c)[start_row:start_row + size]))
+            if c.codec == CodecType.PFOR_INT or c.codec in CodecType.SNAPPY:   # compressed: the GPU's decode
+                dec = self._pfor_decoded(c)
+                if c.codec in CodecType.INT_CODECS:
+                    out.append(IntColumnVector(dec[start_row:start_row + size]))
+                elif c.codec in CodecType.TINYINT_CODECS:
+                    out.append(TinyIntColumnVector(dec[start_row:start_row + size]))
+                else:
+                    out.append(StringColumnVector(dec[start_row:start_row + size]))
                 continue
             dat = self.sm.sm.segments[f"{self.tableName}.{c.name}"][self.segIdx]
             out.append(_decode_view(c, np.asarray(dat[start_row * c.width: (start_row + size) * c.width])))
@@ -349,9 +357,9 @@ class ProjectOp(ProjectionOperator):
         idx, cols = q.fetch_rows()
         out = []
         for raw, codec in zip(cols, q.proj_codecs):
-            if codec in (native.DENSE_INT, native.PFOR_INT):
+            if codec in native.INT_CODECS:
                 out.append(raw.reshape(-1).view("<i4"))
-            elif codec == native.DENSE_TINYINT:
+            elif codec in native.TINYINT_CODECS:
                 out.append(raw.reshape(-1).view(np.int8))
             else:
                 out.append(raw)
@@ -574,9 +582,9 @@ class ProjectAggOp(Operator):
 
 
 def _key_part(col: Column, raw: bytes) -> str:
-    if col.codec in (CodecType.DENSE_INT, CodecType.PFOR_INT):
+    if col.codec in CodecType.INT_CODECS:
         return str(int.from_bytes(raw, "little", signed=True))
-    if col.codec == CodecType.DENSE_TINYINT:
+    if col.codec in CodecType.TINYINT_CODECS:
         return str(int.from_bytes(raw, "little", signed=True))
     return raw.decode("utf-8", errors="replace")
 
@@ -679,7 +687,7 @@ class Engine:
                 raise Exception(f"Unsupported condition: {op.cond}")
             code, operand = _cond_spec(op.cond)
             col = used[names.index(op.col)]
-            if code == native.MATCH and (col.codec != CodecType.DENSE_STRING or col.width != 2 or not (0 < len(operand) <= 8)):
+            if code == native.MATCH and (col.codec not in CodecType.STRING_CODECS or col.width != 2 or not (0 < len(operand) <= 8)):
                 return None                      # the tile kernels take 2-byte strings with <= 8 IN-list values
             sels.append((names.index(op.col), code, operand))
         tnames = [c.name for c in table.columns]
@@ -730,8 +738,8 @@ class Engine:
         seg, row = q.locate_rows(idx)
         out = []
         for raw, codec in zip(cols, q.proj_codecs):
-            out.append(raw.reshape(-1).view("<i4") if codec in (native.DENSE_INT, native.PFOR_INT) else
-                       raw.reshape(-1).view(np.int8) if codec == native.DENSE_TINYINT else raw)
+            out.append(raw.reshape(-1).view("<i4") if codec in native.INT_CODECS else
+                       raw.reshape(-1).view(np.int8) if codec in native.TINYINT_CODECS else raw)
         q.close()
         seg_ids = np.asarray(getattr(dt, "segment_ids", list(range(len(dt.segs)))), dtype=np.uint32)
         return seg_ids[seg] if seg.size else seg, row, out

@@ -15,10 +15,17 @@ class ColumnType:                  # Column.scala:13-16
 class CodecType:                   # codec/Codec.scala:21-24
     PFOR_INT, DENSE_INT, DENSE_TINYINT, DENSE_STRING = "PFOR_INT", "DENSE_INT", "DENSE_TINYINT", "DENSE_STRING"
     ORDER = ["PFOR_INT", "DENSE_INT", "DENSE_TINYINT", "DENSE_STRING"]
+    # EXTENSION, not in the reference's enumeration: blocks written by SnappyCodec.encode (codec/SnappyCodec.scala:15-43).
+    # The reference cannot name or read such a column (no CodecType, decode = ???); ids follow include/imm3.h.
+    SNAPPY_INT, SNAPPY_TINYINT, SNAPPY_STRING = "SNAPPY_INT", "SNAPPY_TINYINT", "SNAPPY_STRING"
+    SNAPPY = {"SNAPPY_INT": 16, "SNAPPY_TINYINT": 17, "SNAPPY_STRING": 18}
+    INT_CODECS = ("DENSE_INT", "PFOR_INT", "SNAPPY_INT")
+    TINYINT_CODECS = ("DENSE_TINYINT", "SNAPPY_TINYINT")
+    STRING_CODECS = ("DENSE_STRING", "SNAPPY_STRING")
 
     @staticmethod
     def id_of(name: str) -> int:
-        return CodecType.ORDER.index(name)
+        return CodecType.SNAPPY[name] if name in CodecType.SNAPPY else CodecType.ORDER.index(name)
 
 
 @dataclass(frozen=True)
@@ -35,6 +42,9 @@ class Column:                      # Column.scala:18
             CodecType.PFOR_INT: ColumnType.INT,
             CodecType.DENSE_TINYINT: ColumnType.TINYINT,
             CodecType.DENSE_STRING: ColumnType.STRING,
+            CodecType.SNAPPY_INT: ColumnType.INT,
+            CodecType.SNAPPY_TINYINT: ColumnType.TINYINT,
+            CodecType.SNAPPY_STRING: ColumnType.STRING,
         }.get(codec)
         if ctype is None:
             raise Exception("")
@@ -47,11 +57,11 @@ class Column:                      # Column.scala:18
     @property
     def width(self) -> int:
         """dtype.size of the column's codec (DataType.scala:34,54; Column.scala:60 for strings)."""
-        if self.codec in (CodecType.DENSE_INT, CodecType.PFOR_INT):
+        if self.codec in CodecType.INT_CODECS:
             return 4
-        if self.codec == CodecType.DENSE_TINYINT:
+        if self.codec in CodecType.TINYINT_CODECS:
             return 1
-        if self.codec == CodecType.DENSE_STRING:
+        if self.codec in CodecType.STRING_CODECS:
             return int(self.attrs["size"])
         raise Exception("")
 

@@ -27,15 +27,15 @@ _INT_RE = re.compile(r"^[+-]?\d+$")
 # DataType.stringToValue / valueToBytes (core/.../DataType.scala:31-71)
 # ------------------------------------------------------------------------------------------
 def string_to_bytes(col: Column, s: str) -> bytes:
-    if col.codec in (CodecType.DENSE_INT, CodecType.PFOR_INT):
+    if col.codec in CodecType.INT_CODECS:
         if not _INT_RE.match(s) or not (-(2 ** 31) <= int(s) <= 2 ** 31 - 1):
             raise ValueError(f'NumberFormatException: For input string: "{s}"')  # s.toInt
         return int(s).to_bytes(4, "little", signed=True)                          # IntType.valueToBytes :40-47
-    if col.codec == CodecType.DENSE_TINYINT:
+    if col.codec in CodecType.TINYINT_CODECS:
         if not _INT_RE.match(s) or not (-128 <= int(s) <= 127):
             raise ValueError(f'NumberFormatException: Value out of range. Value:"{s}" Radix:10')  # s.toByte
         return int(s).to_bytes(1, "little", signed=True)
-    if col.codec == CodecType.DENSE_STRING:
+    if col.codec in CodecType.STRING_CODECS:
         return s.encode("utf-8")   # value.getBytes(): NO padding / truncation to dtypeAttrs("size") (:69)
     raise Exception("")
 
@@ -95,6 +95,9 @@ class SegmentWriter:
         if self.column.codec == CodecType.PFOR_INT:              # PFORCodecInt.encode (PFORCodec.scala:19-31), host code of libimm3
             from . import native
             encoded = native.pfor_encode_block(np.frombuffer(bytes(self._buf), dtype="<i4"))
+        elif self.column.codec in CodecType.SNAPPY:              # SnappyCodec.encode (SnappyCodec.scala:15-27), host code of libimm3
+            from . import native
+            encoded = native.snappy_encode_block(bytes(self._buf))
         else:
             encoded = bytes(self._buf)                           # DenseCodec.encode(bytes) is the identity (DenseCodec.scala:18-22)
         self._file.write(encoded)
@@ -153,9 +156,9 @@ def write_segment_arrays(dataDir: str, table: Table, seg_id: int, arrays: Dict[s
     for c in table.columns:
         a = arrays[c.name]
         n = a.shape[0]
-        if c.codec in (CodecType.DENSE_INT, CodecType.PFOR_INT):
+        if c.codec in CodecType.INT_CODECS:
             raw = np.ascontiguousarray(a, dtype="<i4").view(np.uint8)
-        elif c.codec == CodecType.DENSE_TINYINT:
+        elif c.codec in CodecType.TINYINT_CODECS:
             raw = np.ascontiguousarray(a, dtype=np.int8).view(np.uint8)
         else:
             raw = np.ascontiguousarray(a, dtype=np.uint8).reshape(n, c.width).reshape(-1)
@@ -179,6 +182,16 @@ def write_segment_arrays(dataDir: str, table: Table, seg_id: int, arrays: Dict[s
                 raw, offs = np.frombuffer(b"".join(parts), dtype=np.uint8), np.array(offs, dtype=np.int32)
             raw.tofile(os.path.join(base, f"{c.name}_{seg_id}.dat"))
             SegmentMeta.store(os.path.join(base, f"{c.name}_{seg_id}.meta"), SegmentMeta(offs))
+            continue
+        if c.codec in CodecType.SNAPPY:     # each block through SnappyCodec.encode
+            from . import native
+            parts, offs, pos = [], [0], 0
+            for r in br:
+                parts.append(native.snappy_encode_block(raw[pos * c.width:(pos + r) * c.width]))
+                offs.append(offs[-1] + len(parts[-1]))
+                pos += r
+            np.frombuffer(b"".join(parts), dtype=np.uint8).tofile(os.path.join(base, f"{c.name}_{seg_id}.dat"))
+            SegmentMeta.store(os.path.join(base, f"{c.name}_{seg_id}.meta"), SegmentMeta(np.array(offs, dtype=np.int32)))
             continue
         offs = np.concatenate([[0], np.cumsum(np.array(br, dtype=np.int64) * c.width)]).astype(np.int32)
         raw.tofile(os.path.join(base, f"{c.name}_{seg_id}.dat"))

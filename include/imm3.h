@@ -39,6 +39,15 @@ extern "C" {
  * decodes the blocks on the GPU (csrc/imm3_codec.hip), a documented departure from the reference's failure. */
 enum { IMM3_PFOR_INT = 0, IMM3_DENSE_INT = 1, IMM3_DENSE_TINYINT = 2, IMM3_DENSE_STRING = 3 };
 
+/* EXTENSION (not CodecType values): columns whose blocks are what SnappyCodec.encode writes
+ * (core/codec/SnappyCodec.scala:15-43: iq80 snappy 0.4 SnappyOutputStream framing -- "snappy\0", then per <= 32768
+ * input bytes a flag, a 2-byte big-endian payload length, the masked CRC-32C of the input, and the stored or
+ * raw-Snappy payload).  The reference defines the encoder only: `decode = ???` (SnappyCodec.scala:45), no CodecType
+ * names the codec and nothing instantiates it, so a reference table cannot declare such a column; the ids sit outside
+ * the enumeration's range on purpose.  Values decode to int32 / int8 / fixed-width strings exactly as the DENSE_*
+ * codecs of the same type; blocks are decompressed on the GPU (csrc/imm3_snappy.hip), checksums verified. */
+enum { IMM3_SNAPPY_INT = 16, IMM3_SNAPPY_TINYINT = 17, IMM3_SNAPPY_STRING = 18 };
+
 /* SelectCondition (core/Query.scala:3-9) */
 enum { IMM3_MATCH = 0, IMM3_NOTMATCH = 1, IMM3_EQ = 2, IMM3_GT = 3, IMM3_LT = 4, IMM3_NOOP = 5 };
 
@@ -218,7 +227,7 @@ int imm3_query_device_ptr(imm3_query *q, int32_t which, void **ptr);
 /* ---- live kernel timing (HIP events on the context's stream) ----
  * When enabled, every kernel launch of this context is bracketed by an event pair.
  * kernel ids: 0 = scan+select, 1 = offsets scan, 2 = compact+gather, 3 = count reduce, 4 = group-by aggregation,
- *             5 = PFOR_INT column decode. */
+ *             5 = PFOR_INT / snappy column decode. */
 int imm3_ctx_timing_enable(imm3_ctx *ctx, int32_t max_records);
 int imm3_ctx_timing_reset(imm3_ctx *ctx);
 /* Only launches whose kernel id has its bit set in `kernel_mask` are bracketed (default: all). */
@@ -245,6 +254,10 @@ uint64_t imm3_pfor_encode_bound(int32_t n_values);
 int imm3_pfor_encode_block(const int32_t *values, int32_t n_values, void *out, uint64_t cap, uint64_t *bytes_out);
 int imm3_pfor_encode_column(const int32_t *values, uint64_t n_values, int32_t block_rows, void *out, uint64_t cap,
                             int32_t *offsets_out, uint64_t *bytes_out);
+
+/* Write side of the snappy block format (host code): SnappyCodec.encode of one storage block's raw value bytes. */
+uint64_t imm3_snappy_encode_bound(uint64_t n_bytes);
+int imm3_snappy_encode_block(const void *bytes, uint64_t n_bytes, void *out, uint64_t cap, uint64_t *bytes_out);
 
 /* Tuning knobs (0 = default): filter variant, grid size in workgroups.  For experiments/bench.
  * variant 1 = word-at-a-time kernel only, 2 = count reduce on the aux stream, 3 = no survivor staging,

@@ -124,6 +124,20 @@ int64_t imm3o_pfor_encode_block(const int32_t *vals, int32_t n, uint8_t *out, in
 int32_t imm3o_pfor_block_count(const uint8_t *blk, int64_t len);
 int32_t imm3o_pfor_decode_block(const uint8_t *blk, int64_t len, int32_t *out, int32_t cap);
 
+/* ---- snappy-coded blocks (imm3_oracle_snappy.c; core/codec/SnappyCodec.scala:14-43 + iq80 snappy 0.4) ----
+ * The block format is what SnappyCodec.encode writes (SnappyOutputStream framing around raw Snappy); the reference
+ * has no decoder (`???`) and no CodecType for it.  Raw-Snappy layer pinned against pyarrow's Google snappy. */
+uint32_t imm3o_crc32c(const uint8_t *p, int64_t n);
+uint32_t imm3o_crc32c_masked(const uint8_t *p, int64_t n);
+int64_t imm3o_snappy_raw_bound(int64_t n);
+int64_t imm3o_snappy_raw_encode(const uint8_t *in, int64_t n, uint8_t *out, int64_t cap);
+int64_t imm3o_snappy_raw_uncompressed_length(const uint8_t *in, int64_t n);
+int64_t imm3o_snappy_raw_decode(const uint8_t *in, int64_t n, uint8_t *out, int64_t cap);
+int64_t imm3o_snappy_block_bound(int64_t n);
+int64_t imm3o_snappy_block_encode(const uint8_t *in, int64_t n, uint8_t *out, int64_t cap);
+int64_t imm3o_snappy_block_length(const uint8_t *blk, int64_t n);
+int64_t imm3o_snappy_block_decode(const uint8_t *blk, int64_t n, uint8_t *out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

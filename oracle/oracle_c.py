@@ -55,7 +55,7 @@ class _CSelect(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the oracle with its own Makefile (gcc -O2).  Building the checker is not using it."""
-    srcs = [os.path.join(_HERE, f) for f in ("imm3_oracle.c", "imm3_oracle_pfor.c", "imm3_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("imm3_oracle.c", "imm3_oracle_pfor.c", "imm3_oracle_snappy.c", "imm3_oracle.h")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return _LIB_PATH
@@ -99,6 +99,18 @@ def lib():
         L.imm3o_pfor_block_count.argtypes = [C.c_void_p, C.c_int64]
         L.imm3o_pfor_decode_block.restype = C.c_int32
         L.imm3o_pfor_decode_block.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]
+        for name in ("imm3o_crc32c", "imm3o_crc32c_masked"):
+            getattr(L, name).restype = C.c_uint32
+            getattr(L, name).argtypes = [C.c_void_p, C.c_int64]
+        for name in ("imm3o_snappy_raw_bound", "imm3o_snappy_block_bound"):
+            getattr(L, name).restype = C.c_int64
+            getattr(L, name).argtypes = [C.c_int64]
+        for name in ("imm3o_snappy_raw_encode", "imm3o_snappy_raw_decode", "imm3o_snappy_block_encode", "imm3o_snappy_block_decode"):
+            getattr(L, name).restype = C.c_int64
+            getattr(L, name).argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        for name in ("imm3o_snappy_raw_uncompressed_length", "imm3o_snappy_block_length"):
+            getattr(L, name).restype = C.c_int64
+            getattr(L, name).argtypes = [C.c_void_p, C.c_int64]
         _lib = L
     return _lib
 
@@ -265,3 +277,52 @@ def pfor_decode_column(dat: np.ndarray, offs: np.ndarray) -> np.ndarray:
     d = np.ascontiguousarray(dat, dtype=np.uint8)
     out = [pfor_decode_block(d[int(offs[k]):int(offs[k + 1])].tobytes()) for k in range(len(offs) - 1)]
     return np.concatenate(out) if out else np.zeros(0, dtype=np.int32)
+
+
+# ---- snappy-coded blocks (imm3_oracle_snappy.c) ------------------------------------------------------------
+def _buf(b) -> np.ndarray:
+    return np.frombuffer(bytes(b), dtype=np.uint8) if not isinstance(b, np.ndarray) else np.ascontiguousarray(b, dtype=np.uint8)
+
+
+def crc32c(b) -> int:
+    a = _buf(b)
+    return int(lib().imm3o_crc32c(a.ctypes.data, a.size))
+
+
+def crc32c_masked(b) -> int:
+    a = _buf(b)
+    return int(lib().imm3o_crc32c_masked(a.ctypes.data, a.size))
+
+
+def _codec_call(fn, bound, b) -> bytes:
+    a = _buf(b)
+    out = np.zeros(max(int(bound), 1), dtype=np.uint8)
+    n = fn(a.ctypes.data, a.size, out.ctypes.data, out.size)
+    if n < 0:
+        raise OracleError(ERR_INDEX, "malformed snappy data")
+    return out[:n].tobytes()
+
+
+def snappy_raw_encode(b) -> bytes:
+    return _codec_call(lib().imm3o_snappy_raw_encode, lib().imm3o_snappy_raw_bound(len(_buf(b))), b)
+
+
+def snappy_raw_decode(b) -> bytes:
+    a = _buf(b)
+    n = lib().imm3o_snappy_raw_uncompressed_length(a.ctypes.data, a.size)
+    if n < 0:
+        raise OracleError(ERR_INDEX, "malformed snappy preamble")
+    return _codec_call(lib().imm3o_snappy_raw_decode, n, b)
+
+
+def snappy_block_encode(b) -> bytes:
+    """SnappyCodec.encode of one block's raw value bytes (SnappyCodec.scala:15-27): SnappyOutputStream framing."""
+    return _codec_call(lib().imm3o_snappy_block_encode, lib().imm3o_snappy_block_bound(len(_buf(b))), b)
+
+
+def snappy_block_decode(b) -> bytes:
+    a = _buf(b)
+    n = lib().imm3o_snappy_block_length(a.ctypes.data, a.size)
+    if n < 0:
+        raise OracleError(ERR_INDEX, "malformed snappy block")
+    return _codec_call(lib().imm3o_snappy_block_decode, n, b)

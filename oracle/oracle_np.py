@@ -406,3 +406,90 @@ def pfor_decode_block(blk: bytes) -> np.ndarray:
             init = (init + val) & 0xFFFFFFFF
             out[k] = init
     return out.view(np.int32)
+
+
+# ------------------------------------------------------------------------------------------
+# snappy-coded blocks -- second, independent restatement (table-driven CRC, slice-based decoder).  Format: what
+# SnappyCodec.encode writes (core/codec/SnappyCodec.scala:14-43) = iq80 snappy 0.4 SnappyOutputStream framing around
+# raw Snappy; see imm3_oracle_snappy.c for the statement of the format.  TEST INFRASTRUCTURE ONLY; parity unpinned.
+# ------------------------------------------------------------------------------------------
+_CRC32C_TABLE = None
+
+
+def _crc32c_table():
+    global _CRC32C_TABLE
+    if _CRC32C_TABLE is None:
+        t = []
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+            t.append(c)
+        _CRC32C_TABLE = t
+    return _CRC32C_TABLE
+
+
+def crc32c(data: bytes) -> int:
+    t = _crc32c_table()
+    c = 0xFFFFFFFF
+    for b in data:
+        c = t[(c ^ b) & 255] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def crc32c_masked(data: bytes) -> int:
+    c = crc32c(data)
+    return (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def snappy_raw_decode(data: bytes) -> bytes:
+    ip, want, shift = 0, 0, 0
+    while True:
+        b = data[ip]; ip += 1
+        want |= (b & 127) << shift
+        if not b & 128:
+            break
+        shift += 7
+    out = bytearray()
+    while ip < len(data):
+        tag = data[ip]; ip += 1
+        kind = tag & 3
+        if kind == 0:
+            ln = (tag >> 2) + 1
+            if ln > 60:
+                nb = ln - 60
+                ln = int.from_bytes(data[ip:ip + nb], "little") + 1
+                ip += nb
+            out += data[ip:ip + ln]
+            ip += ln
+            continue
+        if kind == 1:
+            ln, off = 4 + ((tag >> 2) & 7), ((tag >> 5) << 8) | data[ip]
+            ip += 1
+        elif kind == 2:
+            ln, off = 1 + (tag >> 2), int.from_bytes(data[ip:ip + 2], "little")
+            ip += 2
+        else:
+            ln, off = 1 + (tag >> 2), int.from_bytes(data[ip:ip + 4], "little")
+            ip += 4
+        assert 0 < off <= len(out)
+        start = len(out) - off
+        pattern = bytes(out[start:start + min(off, ln)])       # an overlapping copy repeats its first `off` bytes
+        out += (pattern * (ln // len(pattern) + 1))[:ln]
+    assert len(out) == want
+    return bytes(out)
+
+
+def snappy_block_decode(blk: bytes) -> bytes:
+    assert blk[:7] == b"snappy\x00"
+    ip, out = 7, bytearray()
+    while ip < len(blk):
+        flag, plen, crc = blk[ip], int.from_bytes(blk[ip + 1:ip + 3], "big"), int.from_bytes(blk[ip + 3:ip + 7], "big")
+        ip += 7
+        payload = blk[ip:ip + plen]
+        assert len(payload) == plen and flag in (0, 1)
+        chunk = snappy_raw_decode(payload) if flag else bytes(payload)
+        assert crc32c_masked(chunk) == crc
+        out += chunk
+        ip += plen
+    return bytes(out)

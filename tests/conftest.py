@@ -81,6 +81,50 @@ class PforColumn:
         return (self.codec, self.width, self.dat, self.dat.size, self.offsets)
 
 
+SNAPPY_INT, SNAPPY_TINYINT, SNAPPY_STRING = 16, 17, 18
+
+
+class SnappyColumn:
+    """A snappy-coded column: every block is what SnappyCodec.encode writes for its raw value bytes (oracle encoder, or
+    -- encoder="google" -- the stream framing built here around pyarrow's Google-snappy payload, chunked at 32768 input
+    bytes).  The oracle side sees the DENSE_* column with the same values in the same blocks."""
+
+    def __init__(self, dense_codec, width, values, block_rows, encoder="oracle"):
+        from oracle import oracle_c
+        self.codec = {DENSE_INT: SNAPPY_INT, DENSE_TINYINT: SNAPPY_TINYINT, DENSE_STRING: SNAPPY_STRING}[dense_codec]
+        self.width = width
+        self._dense = RawColumn(dense_codec, width, values, block_rows)
+        raw = self._dense.dat
+        parts, offs, pos = [], [0], 0
+        for n in block_rows:
+            chunk = raw[pos * width:(pos + n) * width].tobytes()
+            if encoder == "oracle":
+                blk = oracle_c.snappy_block_encode(chunk)
+            else:
+                import pyarrow as pa
+                codec = pa.Codec("snappy")
+                blk = b"snappy\x00"
+                for s in range(0, len(chunk), 32768):
+                    piece = chunk[s:s + 32768]
+                    payload = codec.compress(piece, asbytes=True)
+                    blk += bytes([1]) + len(payload).to_bytes(2, "big") + oracle_c.crc32c_masked(piece).to_bytes(4, "big") + payload
+            parts.append(blk)
+            offs.append(offs[-1] + len(blk))
+            pos += n
+        self.dat = np.frombuffer(b"".join(parts) or b"", dtype=np.uint8).copy()
+        self.offsets = np.array(offs, dtype=np.int32)
+        self.values = values
+
+    def ocol(self):
+        return self._dense.ocol()
+
+    def npcol(self):
+        return self._dense.npcol()
+
+    def native(self):
+        return (self.codec, self.width, self.dat, self.dat.size, self.offsets)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle_c

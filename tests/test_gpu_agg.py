@@ -46,14 +46,14 @@ def check(ctx, cols, used, sels, group, aggs, block_size=1024):
         for gi in group:
             c = ucols[gi]
             chunk = raw[off: off + c.width]
-            parts.append(chunk.decode() if c.codec == DENSE_STRING else str(int.from_bytes(chunk, "little", signed=True)))
+            parts.append(chunk.decode() if getattr(c, "_dense", c).codec == DENSE_STRING else str(int.from_bytes(chunk, "little", signed=True)))
             off += c.width
         st = []
         for j, (kind, ci) in enumerate(aggs):
             c = ucols[ci]
             if kind == "count":
                 st.append(int(counts[g]))
-            elif c.codec == DENSE_STRING:
+            elif getattr(c, "_dense", c).codec == DENSE_STRING:
                 st.append(int(vals[g, j]).to_bytes(8, "big", signed=True)[8 - c.width:].decode())
             else:
                 st.append(float(int(vals[g, j])))

@@ -134,3 +134,40 @@ def test_pfor_segment_writer_matches_oracle_encoder(tmp_path):
     offs = SegmentMeta.load(str(tmp_path / "a" / "pf" / "v_0.meta")).blockOffsets
     assert len(offs) == 4 and offs[-1] == len(want)
     assert open(tmp_path / "a" / "pf" / "v_0.meta").read() == open(tmp_path / "c" / "pf" / "v_0.meta").read()
+
+
+def test_snappy_writer_is_readable_by_the_oracle_and_google_snappy(tmp_path):
+    """The product's SnappyCodec.encode restatement (host/codec.hpp): its blocks decode with the oracle's reader, and the
+    raw payload of a compressed chunk decodes with pyarrow's Google snappy.  Writers (Python row-at-a-time, bulk, C++
+    loader) agree byte for byte."""
+    import subprocess
+    from oracle import oracle_c
+    from immutable3_amd.build import build_native
+    build_native()
+    rng = np.random.default_rng(4)
+    for raw in (b"", b"a", bytes(5000), rng.integers(0, 256, 5000, dtype=np.uint8).tobytes(), (np.arange(20000) // 9).astype("<i4").tobytes(),
+                b"CANYTX" * 7000):
+        blk = native.snappy_encode_block(raw)
+        assert blk[:7] == b"snappy\x00" and oracle_c.snappy_block_decode(blk) == raw
+        if raw and blk[7] == 1:
+            pa = pytest.importorskip("pyarrow")
+            plen = int.from_bytes(blk[8:10], "big")
+            first = raw[:32768]
+            assert pa.Codec("snappy").decompress(blk[14:14 + plen], decompressed_size=len(first), asbytes=True) == first
+    vals = [str((i * 37) % 1000 // 10) for i in range(300)]
+    t = Table("sn", [Column.make("v", CodecType.SNAPPY_INT), Column.make("s", CodecType.SNAPPY_STRING, {"size": "2"})], 128)
+    rows = [[v, synth.CODES7[i % 7]] for i, v in enumerate(vals)]
+    load_rows(str(tmp_path / "a"), t, rows, segmentSize=100)
+    write_segment_arrays(str(tmp_path / "b"), t, 0, {"v": np.array([int(v) for v in vals], dtype=np.int32),
+                                                     "s": np.array([list(synth.CODES7[i % 7].encode()) for i in range(300)], dtype=np.uint8)})
+    csv = tmp_path / "in.csv"
+    csv.write_text("v,s\n" + "\n".join(",".join(r) for r in rows) + "\n")
+    subprocess.check_call([os.path.join(ROOT, "immutable3_amd", "bin", "imm3_loader"), "-t", "sn", "-c", "v:SNAPPY_INT,s:SNAPPY_STRING:size=2",
+                           "-d", str(tmp_path / "c"), "-i", str(csv), "--block-size", "128", "--segment-size", "100"])
+    for f in ("v_0.dat", "v_0.meta", "s_0.dat", "s_0.meta"):
+        ref = open(tmp_path / "a" / "sn" / f, "rb").read()
+        assert ref == open(tmp_path / "b" / "sn" / f, "rb").read() == open(tmp_path / "c" / "sn" / f, "rb").read(), f
+    offs = SegmentMeta.load(str(tmp_path / "a" / "sn" / "v_0.meta")).blockOffsets
+    dat = open(tmp_path / "a" / "sn" / "v_0.dat", "rb").read()
+    got = b"".join(oracle_c.snappy_block_decode(dat[offs[k]:offs[k + 1]]) for k in range(len(offs) - 1))
+    assert np.frombuffer(got, dtype="<i4").tolist() == [int(v) for v in vals]
