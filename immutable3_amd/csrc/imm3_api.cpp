@@ -1068,7 +1068,7 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
         if (rc) return rc;
     }
     // Survivor staging (k_filter_tile / k_gather): an unlimited projection whose select chain is ONE tile-kernel pass
-    // stages the values of every SELECT-list column that is also an int32 / int8 predicate column.
+    // stages the values of every SELECT-list column that is also an int32 / int8 / 2-byte-string predicate column.
     if (n_proj > 0 && limit <= 0 && !q->ragged && !q->always_false && ctx->filter_variant != 1 && ctx->filter_variant != 3 &&
         !q->preds.empty() && q->preds.size() <= (size_t)kMaxTileCols) {
         int n_s2 = 0;
@@ -1081,8 +1081,8 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
         if (all_tile && n_s2 <= 1) {
             const int64_t n_full = table ? q->n_tiles : q->n_rows / kTileRows; // staging slots (table: one per virtual tile)
             for (auto &fp : q->preds) {
-                if (fp.kind == KIND_STR || n_full == 0) continue;
-                if (fp.kind == KIND_I8 && ctx->filter_variant == 4) continue; // experiment: stage int32 columns only
+                if (n_full == 0) continue; // (a string predicate here is a 2-byte one: all_tile)
+                if (fp.kind != KIND_I32 && ctx->filter_variant == 4) continue; // experiment: stage int32 columns only
                 bool projected = false;
                 for (int32_t pj : q->proj) projected |= (q->used[(size_t)pj] == fp.seg_col);
                 if (!projected) continue;

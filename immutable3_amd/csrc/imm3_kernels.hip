@@ -139,6 +139,7 @@ template <int KIND>
 struct StageBytes { static constexpr int value = 0; };
 template <> struct StageBytes<TK_I32> { static constexpr int value = kTileRows * 4; };
 template <> struct StageBytes<TK_I8> { static constexpr int value = kTileRows; };
+template <> struct StageBytes<TK_S2> { static constexpr int value = kTileRows * 2; };
 
 template <int KIND>
 __device__ __forceinline__ void stage_col(ColRegs<KIND> &, void *, int64_t, int, uint64_t, uint32_t, uint32_t, uint8_t *) {}
@@ -182,6 +183,30 @@ __device__ __forceinline__ void stage_col<TK_I8>(ColRegs<TK_I8> &c, void *stage,
     lds_wave_sync();
     uint32_t *out = (uint32_t *)((uint8_t *)stage + tile * kTileRows);
     const uint32_t ndw = (cnt + 3) >> 2; // whole dwords; the tile's staging slot is 1024 bytes, so over-copy is harmless
+    for (uint32_t i = lane; i < ndw; i += 64) out[i] = ((const uint32_t *)lds)[i];
+    lds_wave_sync();
+}
+
+template <>
+__device__ __forceinline__ void stage_col<TK_S2>(ColRegs<TK_S2> &c, void *stage, int64_t tile, int lane, uint64_t mine,
+                                                 uint32_t wprefix, uint32_t cnt, uint8_t *lds) {
+    if (!stage) return;
+    uint16_t *l16 = (uint16_t *)lds;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) { // load g, lane l holds rows 512g + 8l .. +7 = bits [8(l&7), +8) of word 8g + (l>>3)
+        const int wi = 8 * g + (lane >> 3), bo = 8 * (lane & 7);
+        const uint32_t wlo = lane_read((uint32_t)mine, wi), whi = lane_read((uint32_t)(mine >> 32), wi);
+        const uint64_t word = ((uint64_t)whi << 32) | wlo;
+        uint32_t pos = lane_read(wprefix, wi) + (uint32_t)__popcll(word & ((1ULL << bo) - 1ULL));
+        const uint64_t blo = ((uint64_t)(uint32_t)c.v[g][1] << 32) | (uint32_t)c.v[g][0], bhi = ((uint64_t)(uint32_t)c.v[g][3] << 32) | (uint32_t)c.v[g][2];
+        for (uint32_t b = (uint32_t)(word >> bo) & 0xFFu; b; b &= b - 1u) { // the lane's set bits only
+            const int k = __builtin_ctz(b);
+            l16[pos++] = (uint16_t)((k < 4 ? blo : bhi) >> (16 * (k & 3)));
+        }
+    }
+    lds_wave_sync();
+    uint32_t *out = (uint32_t *)((uint8_t *)stage + tile * (kTileRows * 2));
+    const uint32_t ndw = (cnt + 1) >> 1; // whole dwords; the tile's staging slot is 2048 bytes
     for (uint32_t i = lane; i < ndw; i += 64) out[i] = ((const uint32_t *)lds)[i];
     lds_wave_sync();
 }
@@ -549,6 +574,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_gather(const GatherArgs a) {
                 if (pc2.staged && staged_tile) { // survivors' values were compacted per tile by the filter kernel
                     const int64_t sidx = tile * kTileRows + (i - s_toff[r >> 10]);
                     if (pc2.width == 4) ((uint32_t *)pc2.dst)[out] = ((const uint32_t *)pc2.staged)[sidx];
+                    else if (pc2.width == 2) copy_elem<uint16_t>(pc2.staged, pc2.dst, sidx, out);
                     else copy_elem<uint8_t>(pc2.staged, pc2.dst, sidx, out);
                     continue;
                 }
