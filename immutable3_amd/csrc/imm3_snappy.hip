@@ -111,7 +111,20 @@ __global__ __launch_bounds__(64) void k_snappy_decode(const SnappyArgs a) {
         if (!bad) {
             const uint32_t *src = (const uint32_t *)(a.data + (o - skew));
             const uint32_t nd = (blen + skew + 3) >> 2;
-            for (uint32_t i = lane; i < nd; i += 64) ((uint32_t *)in)[i] = __builtin_nontemporal_load(src + i);
+            // eight loads in flight per lane: one load per trip would be one HBM round trip per 256 bytes of the block
+            for (uint32_t base = 0; base < nd; base += 512) {
+                uint32_t r[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t i = base + 64u * u + (uint32_t)lane;
+                    r[u] = __builtin_nontemporal_load(src + (i < nd ? i : nd - 1));
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t i = base + 64u * u + (uint32_t)lane;
+                    if (i < nd) ((uint32_t *)in)[i] = r[u];
+                }
+            }
         }
         lds_wave_sync();
         const uint8_t *ib = in + skew;
@@ -147,40 +160,56 @@ __global__ __launch_bounds__(64) void k_snappy_decode(const SnappyArgs a) {
                     if (!ok || pos > end || want > (uint32_t)a.out_cap) { bad = true; break; }
                 }
                 uint32_t op = 0;
+                // Elements are parsed 64 byte positions at a time: lane l decodes the tag that WOULD start at pos + l (kind,
+                // length, offset, header size) in vector code; the serial walk along the real element starts then costs two
+                // v_readlane and a handful of scalar instructions per element instead of a full scalar decode (the scalar unit
+                // is shared by the CU's four SIMDs and was the bottleneck: 150 scalar instructions per element).
                 while (pos < end) {
-                    const uint32_t eb = lane < 5 && pos + lane < end ? ib[pos + lane] : 0u; // tag + up to 4 following bytes
-                    const uint32_t tag = (uint32_t)__builtin_amdgcn_readlane((int)eb, 0);
-                    const uint32_t b1 = (uint32_t)__builtin_amdgcn_readlane((int)eb, 1), b2 = (uint32_t)__builtin_amdgcn_readlane((int)eb, 2);
-                    const uint32_t b3 = (uint32_t)__builtin_amdgcn_readlane((int)eb, 3), b4 = (uint32_t)__builtin_amdgcn_readlane((int)eb, 4);
+                    const uint32_t p = pos + (uint32_t)lane;
+                    const uint32_t tag = p < end ? ib[p] : 0u;
+                    const uint32_t c1 = p + 1 < end ? ib[p + 1] : 0u, c2 = p + 2 < end ? ib[p + 2] : 0u;
+                    const uint32_t c3 = p + 3 < end ? ib[p + 3] : 0u, c4 = p + 4 < end ? ib[p + 4] : 0u;
+                    const uint32_t le = c1 | (c2 << 8) | (c3 << 16) | (c4 << 24);
                     const uint32_t kind = tag & 3u;
-                    if (kind == 0) { // literal
-                        uint32_t len = (tag >> 2) + 1, hdr = 1;
-                        if (len > 60) {
-                            const uint32_t nb = len - 60;
-                            const uint32_t le = b1 | (b2 << 8) | (b3 << 16) | (b4 << 24);
-                            len = (nb == 4 ? le : (le & ((1u << (8 * nb)) - 1u))) + 1u;
-                            hdr = 1 + nb;
+                    uint32_t len = (tag >> 2) + 1u, off = 0u, hdr = 1u;
+                    if (kind == 0) {
+                        if (len > 60u) {
+                            const uint32_t nb = len - 60u;
+                            len = (nb == 4u ? le : (le & ((1u << (8u * nb)) - 1u))) + 1u;
+                            hdr = 1u + nb;
                         }
-                        if (pos + hdr + len > end || op + len > want || len == 0) { bad = true; break; }
-                        pos += hdr;
-                        for (uint32_t i = lane; i < len; i += 64) outb[op + i] = ib[pos + i];
-                        pos += len;
-                        op += len;
-                    } else {
-                        uint32_t len, off, hdr;
-                        if (kind == 1) { len = 4 + ((tag >> 2) & 7u); off = ((tag >> 5) << 8) | b1; hdr = 2; }
-                        else if (kind == 2) { len = 1 + (tag >> 2); off = b1 | (b2 << 8); hdr = 3; }
-                        else { len = 1 + (tag >> 2); off = b1 | (b2 << 8) | (b3 << 16) | (b4 << 24); hdr = 5; }
-                        if (pos + hdr > end || off == 0 || off > op || op + len > want) { bad = true; break; }
-                        pos += hdr;
-                        // len <= 64: one byte per lane; an overlapping copy (off < len) repeats its first `off` bytes
-                        if ((uint32_t)lane < len) {
-                            const uint32_t r = off >= len ? (uint32_t)lane : (uint32_t)lane % off;
-                            outb[op + lane] = outb[op - off + r];
+                    } else if (kind == 1) { len = 4u + ((tag >> 2) & 7u); off = ((tag >> 5) << 8) | c1; hdr = 2u; }
+                    else if (kind == 2) { off = le & 0xFFFFu; hdr = 3u; }
+                    else { off = le; hdr = 5u; }
+                    if (len > 0x00FFFFFFu) len = 0x00FFFFFFu; // cannot be valid (a chunk holds <= 32768 bytes): fails the bound checks
+                    const uint32_t packed = len | (hdr << 24) | (kind << 28);
+                    uint32_t s = 0;
+                    while (s < 64u && pos + s < end) {
+                        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)s);
+                        const uint32_t eoff = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)s);
+                        const uint32_t elen = pk & 0x00FFFFFFu, ehdr = (pk >> 24) & 15u, ekind = pk >> 28;
+                        const uint32_t src = pos + s + ehdr;
+                        if (ekind == 0) {
+                            if (src + elen > end || op + elen > want) { bad = true; break; }
+                            for (uint32_t i = lane; i < elen; i += 64) outb[op + i] = ib[src + i];
+                            s += ehdr + elen;
+                        } else {
+                            if (src > end || eoff == 0 || eoff > op || op + elen > want) { bad = true; break; }
+                            if ((uint32_t)lane < elen) { // elen <= 64: one byte per lane; an overlapping copy repeats its first eoff bytes
+                                uint32_t r = (uint32_t)lane;
+                                if (eoff < elen) { // lane mod eoff without an integer division (both < 64)
+                                    const uint32_t q = (uint32_t)((float)lane * __frcp_rn((float)eoff));
+                                    r = (uint32_t)lane - q * eoff;
+                                    r = (int32_t)r < 0 ? r + eoff : (r >= eoff ? r - eoff : r);
+                                }
+                                outb[op + lane] = outb[op - eoff + r];
+                            }
+                            s += ehdr;
                         }
-                        op += len;
+                        op += elen;
                     }
-                    lds_wave_sync(); // the next element may read these bytes
+                    if (bad) break;
+                    pos += s;
                 }
                 if (bad) break;
                 if (op != want) { bad = true; break; }
