@@ -1034,10 +1034,14 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
     q->d_chunk_sums = (uint32_t *)p;
     HIPCHK(pool_alloc(ctx, &p, kMaxFilterGrid * sizeof(uint32_t)));
     q->d_block_partials = (uint32_t *)p;
-    HIPCHK(pool_alloc(ctx, &p, 3 * sizeof(unsigned long long)));
+    HIPCHK(pool_alloc(ctx, &p, 5 * sizeof(unsigned long long))); // {total, n_emit, status, limit, tally} (block_partial_finish)
     q->d_total = (unsigned long long *)p;
     q->d_n_emit = q->d_total + 1;
-    HIPCHK(hipMemsetAsync(q->d_total, 0, 3 * sizeof(unsigned long long), ctx->stream));
+    {
+        const unsigned long long init[5] = {0, 0, 0, (unsigned long long)limit, 0};
+        HIPCHK(hipMemcpyAsync(q->d_total, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream)); // `init` is a stack array
+    }
     HIPCHK(hipMemsetAsync(q->d_bitmap, 0, words_alloc * sizeof(uint64_t), ctx->stream));
     if (q->ragged) {
         std::vector<uint32_t> base((size_t)q->n_tiles * kTileWords, 0u);
@@ -1299,6 +1303,7 @@ static int run_select(imm3_query *q, bool overlap_total) {
                      [](const FoldedPred *x, const FoldedPred *y) { return tile_kind(*x) < tile_kind(*y); });
     int pass = 0;
     int grid = 1;
+    bool count_done = false; // the filter kernel's last work-group has written total / n_emit
     q->stage_written = false;
     const bool single_tile_pass = generic_preds.empty() && pfor_preds.empty() && tile_preds.size() <= (size_t)kMaxTileCols;
     // tile passes (a query without predicates is one tile pass with zero columns)
@@ -1342,6 +1347,8 @@ static int run_select(imm3_query *q, bool overlap_total) {
         a.n_tiles = q->n_tiles;
         a.bitmap = q->d_bitmap;
         a.block_partials = q->d_block_partials;
+        // a select chain that is ONE tile pass also reduces its count: no k_total launch (tuning variant 7 keeps it)
+        if (single_tile_pass && !overlap_total && ctx->filter_variant != 7) { a.finish = q->d_total; count_done = true; }
         a.tile_rows = q->table ? q->table->d_tile_rows : nullptr; // table query: address the columns through the tile table
         bool any_i32 = false;
         for (int k = 0; k < kMaxTileCols; ++k) any_i32 |= (a.kinds[k] == TK_I32);
@@ -1410,7 +1417,7 @@ static int run_select(imm3_query *q, bool overlap_total) {
         gi += take;
         ++pass;
     }
-    {   // the last pass's per-workgroup partials -> selected-row count (+ rows ProjectOp will emit)
+    if (!count_done) { // the last pass's per-workgroup partials -> selected-row count (+ rows ProjectOp will emit)
         TotalArgs ta;
         std::memset(&ta, 0, sizeof(ta));
         ta.block_partials = q->d_block_partials;

@@ -305,7 +305,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
         }
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) lane_total += __shfl_xor(lane_total, d);
-        block_partial_store(a.block_partials, lane_total, lane, wave);
+        if (a.finish) block_partial_finish(a.finish, lane_total, lane, wave);
+        else block_partial_store(a.block_partials, lane_total, lane, wave);
         if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x + 1] = wall_clock64();
         return;
     } else {
@@ -343,7 +344,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
     }
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) lane_total += __shfl_xor(lane_total, d); // lanes 0..15 -> lane 0
-    block_partial_store(a.block_partials, lane_total, lane, wave);
+    if (a.finish) block_partial_finish(a.finish, lane_total, lane, wave); // the last pass also reduces the count
+    else block_partial_store(a.block_partials, lane_total, lane, wave);
     if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x + 1] = wall_clock64(); // after the barrier in the store above
     }
 }

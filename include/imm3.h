@@ -261,7 +261,8 @@ int imm3_snappy_encode_block(const void *bytes, uint64_t n_bytes, void *out, uin
 
 /* Tuning knobs (0 = default): filter variant, grid size in workgroups.  For experiments/bench.
  * variant 1 = word-at-a-time kernel only, 2 = count reduce on the aux stream, 3 = no survivor staging,
- * 4 = stage int32 columns only, 5 = PFOR_INT predicates read the decoded column instead of the compressed blocks. */
+ * 4 = stage int32 columns only, 5 = PFOR_INT predicates read the decoded column instead of the compressed blocks,
+ * 7 = reduce the count with a separate k_total launch instead of inside the filter kernel. */
 int imm3_ctx_set_tuning(imm3_ctx *ctx, int32_t filter_variant, int32_t grid_blocks);
 
 #ifdef __cplusplus
