@@ -128,7 +128,13 @@ def main():
         local_rank = 0
     backend = os.environ.get("IMM3_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # IMM3_BENCH_FORCE_DIST=1 (rehearsal): take the N > 1 code path -- RCCL init, per-step count all-reduce, barriers --
+    # even with one rank, so that path can be exercised on a 1-GPU box with the real backend.
+    use_dist = world > 1 or os.environ.get("IMM3_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
@@ -169,41 +175,55 @@ def main():
         assert words.tobytes() == np.packbits(keep, bitorder="little").tobytes(), "bitmap mismatch"
         del keep, words
 
-    counts = torch.zeros(args.steps + args.warmup, dtype=torch.int64, device="cuda")
-    views = [torch.as_tensor(_DevArray(q.device_ptr(1), 1), device="cuda") for q in queries]
-    works = []
+    # N > 1: "RCCL over xGMI only for the final selected-row-count reduction".  Every scan stores its count into a
+    # device-side log from the kernel that produces it (imm3_query_log_counts: no copy kernel, no host call per step);
+    # the K per-step counts are summed over the ranks by ONE all-reduce at the end of the timed region, inside it.
+    nq = len(queries)
+    per_query = (args.steps + nq - 1) // nq + 1
+    logs = [torch.zeros(per_query, dtype=torch.int64, device="cuda") for _ in queries]
+    counts = torch.zeros(args.steps, dtype=torch.int64, device="cuda")
+
+    def arm_logs():
+        for q, lg in zip(queries, logs):
+            lg.zero_()
+            torch.cuda.synchronize()
+            q.log_counts(lg.data_ptr() if use_dist else 0, per_query)
 
     def step(i: int):
-        q = queries[i % len(queries)]
-        q.run_select()                                   # fused ScanOp -> SelectOp(GT) -> SelectOp(LT) kernel
-        if world > 1:                                    # final selected-row-count reduction over RCCL / xGMI
-            q.join_count()                               # the count is reduced on the library's aux stream
-            counts[i:i + 1].copy_(views[i % len(queries)])
-            works.append(dist.all_reduce(counts[i:i + 1], op=dist.ReduceOp.SUM, async_op=True))
+        queries[i % nq].run_select()                     # fused ScanOp -> SelectOp(GT) -> SelectOp(LT) kernel (+ count)
+
+    def reduce_counts():
+        # step i of the timed region ran query i % nq as that query's (i // nq)-th logged run
+        for j in range(nq):
+            counts[j::nq] = logs[j][: len(range(j, args.steps, nq))]
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)    # final selected-row-count reduction over RCCL / xGMI
 
     for i in range(args.warmup):
         step(i)
-    for w in works:
-        w.wait()
-    works.clear()
-
+    torch.cuda.synchronize()
+    arm_logs()
+    # start the timed steps on query 0 again so that log slot k of query j is timed step j + k * nq
     # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides ----
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
-    for w in works:
-        w.wait()
+        step(i)
+    if use_dist:
+        reduce_counts()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    expected_counts = counts.clone() if use_dist else None
+    if use_dist and world == 1 and rank == 0:   # one rank: the reduced count of step 0 is segment 0's count (parity gate above)
+        assert int(expected_counts[0].item()) == cnt, (int(expected_counts[0].item()), cnt)
+    for q in queries:
+        q.log_counts(0, 0)
 
     # ---- the same K steps again with the scan+select kernel bracketed by HIP events on its stream.  Kept out
     # of the region above because the event packets themselves cost ~5 us per step; the work is identical. ----
-    works.clear()
     ctx.timing_enable(args.steps + 8)
     ctx.timing_mask(1 << 0)
     ctx.timing_reset()
@@ -211,16 +231,14 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
-    for w in works:
-        w.wait()
+        step(i)
     torch.cuda.synchronize()
     elapsed_events = time.perf_counter() - t1
     kernel_ms = ctx.timing_collect(0)
     devclock_ms = ctx.devclock_collect()
     ctx.timing_enable(0)
     ctx.devclock_enable(0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -261,7 +279,7 @@ def main():
                 "block_rows": 1024,
                 "segments_rotated_per_gpu": args.segments,
                 "selectivity": 0.5,
-                "parallelism": f"segment-sharded x{world}, count all-reduce over RCCL" if world > 1 else "1 GPU",
+                "parallelism": f"segment-sharded x{world}, one count all-reduce over RCCL per K steps" if world > 1 else "1 GPU",
             },
             "roofline": {
                 "bound": "hbm",
@@ -284,8 +302,10 @@ def main():
             },
             "staging": {"host_to_hbm_s_per_segment": stage_s / args.segments, "note": "PCIe staging incl. synthetic generation; never part of value"},
         }
-        if world > 1:
-            result["count_allreduce_last"] = int(counts[args.warmup + args.steps - 1].item())
+        if use_dist:
+            result["count_allreduce"] = {"collective": "one RCCL all_reduce(SUM) over the K per-step counts at the end of the timed region",
+                                         "last_step_global_count": int(expected_counts[-1].item()),
+                                         "sum_over_steps": int(expected_counts.sum().item())}
 
     if args.extra and rank == 0 and world == 1:
         result["extra"] = extra_workloads(ctx, native, synth, n)
@@ -300,7 +320,7 @@ def main():
     for s in segs:
         s.close()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

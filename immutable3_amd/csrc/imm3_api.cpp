@@ -1034,11 +1034,11 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
     q->d_chunk_sums = (uint32_t *)p;
     HIPCHK(pool_alloc(ctx, &p, kMaxFilterGrid * sizeof(uint32_t)));
     q->d_block_partials = (uint32_t *)p;
-    HIPCHK(pool_alloc(ctx, &p, 5 * sizeof(unsigned long long))); // {total, n_emit, status, limit, tally} (block_partial_finish)
+    HIPCHK(pool_alloc(ctx, &p, 8 * sizeof(unsigned long long))); // {total, n_emit, status, limit, tally, log, log index, log capacity}
     q->d_total = (unsigned long long *)p;
     q->d_n_emit = q->d_total + 1;
     {
-        const unsigned long long init[5] = {0, 0, 0, (unsigned long long)limit, 0};
+        const unsigned long long init[8] = {0, 0, 0, (unsigned long long)limit, 0, 0, 0, 0};
         HIPCHK(hipMemcpyAsync(q->d_total, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream)); // `init` is a stack array
     }
@@ -1283,7 +1283,7 @@ static int run_select(imm3_query *q, bool overlap_total) {
     }
     if (q->always_false || q->n_tiles == 0) {
         // an empty interval / empty IN-list clears every bit; nothing to read
-        HIPCHK(hipMemsetAsync(q->d_total, 0, 2 * sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync(q->d_total, 0, 2 * sizeof(unsigned long long), s)); // (an always-false query logs nothing)
         HIPCHK(hipMemsetAsync(q->d_bitmap, 0, (size_t)std::max<int64_t>(q->n_tiles * kTileWords, 1) * sizeof(uint64_t), s));
         q->ran_select = true;
         return IMM3_OK;
@@ -1582,6 +1582,15 @@ extern "C" int imm3_query_batches(const imm3_query *q, int32_t *batch_size, int3
     if (batch_size && nb) std::memcpy(batch_size, q->batch_size.data(), nb * sizeof(int32_t));
     if (batch_oid && nb) std::memcpy(batch_oid, q->batch_oid.data(), nb * sizeof(int32_t));
     if (batch_word_off && nb) std::memcpy(batch_word_off, q->batch_word_off.data(), nb * sizeof(int64_t));
+    return IMM3_OK;
+}
+
+extern "C" int imm3_query_log_counts(imm3_query *q, uint64_t *device_log, uint64_t capacity) {
+    if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    HIPCHK(hipSetDevice(q->ctx->device));
+    const unsigned long long v[3] = {(unsigned long long)(uintptr_t)device_log, 0ULL, device_log ? (unsigned long long)capacity : 0ULL};
+    HIPCHK(hipMemcpyAsync(q->d_total + 5, v, sizeof(v), hipMemcpyHostToDevice, q->ctx->stream));
+    HIPCHK(hipStreamSynchronize(q->ctx->stream)); // `v` is a stack array; also orders the switch after earlier runs
     return IMM3_OK;
 }
 

@@ -56,8 +56,18 @@ __device__ __forceinline__ void block_partial_store(uint32_t *block_partials, ui
     }
 }
 
+// imm3_query_log_counts: finish[5] = device log (0 = off), finish[6] = next index, finish[7] = capacity.  Called by the
+// one thread that produces the count of a run.
+__device__ __forceinline__ void count_log_append(unsigned long long *finish, unsigned long long total) {
+    unsigned long long *log = (unsigned long long *)finish[5];
+    if (!log) return;
+    const unsigned long long idx = finish[6];
+    if (idx < finish[7]) log[idx] = total;
+    finish[6] = idx + 1;
+}
+
 // Same, and the count is reduced in the kernel instead of a k_total launch of its own (~4 us of kernel plus a
-// dependent-launch gap per scan).  `finish` = {total, n_emit, status, limit, tally}: every work-group adds
+// dependent-launch gap per scan).  `finish` = {total, n_emit, status, limit, tally, log, log index, log capacity}: every work-group adds
 // (its survivors | 1 << 40) to the 64-bit tally with ONE relaxed device-scope atomic -- arrivals in the high bits, the
 // running count in the low 40 -- so the group that sees grid - 1 earlier arrivals holds the complete total: no partials
 // to re-read, no ordering between two atomics, and no release/acquire fence (a device-scope fence writes back and
@@ -77,6 +87,7 @@ __device__ __forceinline__ void block_partial_finish(unsigned long long *finish,
             const long long limit = (long long)finish[3];
             finish[0] = total;
             finish[1] = (limit > 0 && total > (unsigned long long)limit) ? (unsigned long long)limit : total;
+            count_log_append(finish, total);
             __hip_atomic_store(finish + 4, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
         }
     }

@@ -59,7 +59,7 @@ struct TileArgs {
     int64_t n_rows, n_words, n_tiles;
     uint64_t *bitmap;
     uint32_t *block_partials;
-    unsigned long long *finish;     // {total, n_emit, status, limit, tally}: the count is reduced in the kernel (block_partial_finish); null = k_total does
+    unsigned long long *finish;     // {total, n_emit, status, limit, tally, log, log index, log capacity}: the count is reduced in the kernel (block_partial_finish); null = k_total does
     void *stage[kMaxTileCols];      // per column: dense per-tile staging of the survivors' values, or null
     unsigned long long *stamps;     // diagnostics only: per work-group {start, end} of the 100 MHz device clock, or null
     // table queries (imm3_table): the tile table replaces cols[k].data / n_rows.  Tile t holds tile_rows[t] valid rows

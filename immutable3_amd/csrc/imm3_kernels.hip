@@ -442,6 +442,7 @@ __global__ __launch_bounds__(64) void k_total(const TotalArgs a) {
     if (lane == 0) {
         *a.total = v;
         *a.n_emit = (a.limit > 0 && v > (unsigned long long)a.limit) ? (unsigned long long)a.limit : v;
+        count_log_append(a.total, v); // a.total is the head of the query's {total, n_emit, status, limit, tally, log ...} block
     }
 }
 

@@ -34,7 +34,7 @@ EXPORTS = [
     "imm3_query_segment_starts", "imm3_query_locate_rows",
     "imm3_query_create", "imm3_query_create_agg", "imm3_query_group_count", "imm3_query_fetch_groups",
     "imm3_query_destroy", "imm3_query_reserve_rows",
-    "imm3_query_run", "imm3_query_run_select", "imm3_query_sync", "imm3_query_join_count",
+    "imm3_query_run", "imm3_query_run_select", "imm3_query_sync", "imm3_query_join_count", "imm3_query_log_counts",
     "imm3_query_layout", "imm3_query_batches", "imm3_query_count", "imm3_query_bitmap",
     "imm3_query_row_count", "imm3_query_fetch_rows", "imm3_query_device_ptr",
     "imm3_ctx_timing_enable", "imm3_ctx_timing_reset", "imm3_ctx_timing_mask", "imm3_ctx_timing_collect", "imm3_ctx_set_tuning", "imm3_ctx_measure_read_gbps", "imm3_ctx_devclock_enable", "imm3_ctx_devclock_collect",
@@ -118,6 +118,7 @@ def load() -> C.CDLL:
     L.imm3_query_run_select.argtypes = [vp]
     L.imm3_query_sync.argtypes = [vp]
     L.imm3_query_join_count.argtypes = [vp]
+    L.imm3_query_log_counts.argtypes = [vp, vp, C.c_uint64]
     L.imm3_query_layout.argtypes = [vp, P(i32), P(i64), P(i64)]
     L.imm3_query_batches.argtypes = [vp, vp, vp, vp]
     L.imm3_query_count.argtypes = [vp, P(u64)]
@@ -434,6 +435,10 @@ class DeviceQuery:
 
     def join_count(self):
         _check(load().imm3_query_join_count(self._h))
+
+    def log_counts(self, device_ptr: int, capacity: int):
+        """Every later run stores its selected-row count at device_ptr[k] (uint64, k = runs since this call)."""
+        _check(load().imm3_query_log_counts(self._h, C.c_void_p(device_ptr), C.c_uint64(capacity)))
 
     def count(self) -> int:
         n = C.c_uint64(0)

@@ -205,6 +205,12 @@ int imm3_query_sync(imm3_query *q);
  * the context's main stream calls this first: it makes the main stream wait (stream-side, no host block). */
 int imm3_query_join_count(imm3_query *q);
 
+/* Device-side log of the selected-row count of every later run of this query: run k (counted from this call) stores its
+ * count at device_log[k] while k < capacity, from the kernel that produces the count -- no copy kernel, no host call
+ * per run.  For consumers that reduce many runs' counts in one collective (bench.py's count all-reduce over RCCL).
+ * device_log = NULL switches the log off. */
+int imm3_query_log_counts(imm3_query *q, uint64_t *device_log, uint64_t capacity);
+
 /* ---- results ---- */
 /* Batches as ScanOp yields them (FilledColumnVectorBatch, core/DataVector.scala:24-31): */
 int imm3_query_layout(const imm3_query *q, int32_t *n_batches, int64_t *total_words, int64_t *n_rows);

@@ -42,3 +42,37 @@ def test_bench_cpu_baseline_object():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "rows/s"
+
+
+def test_count_log_and_rccl_path_with_one_rank():
+    """imm3_query_log_counts: every run's count lands in the device log without a host call; bench.py's N > 1 path (RCCL
+    init, logged counts, one all-reduce) exercised with a single rank."""
+    import numpy as np
+    import torch
+    from immutable3_amd import native, synth
+    ctx = native.Context(0, torch.cuda.current_stream().cuda_stream)
+    n = 300_000
+    v = synth.uniform_int30(7, n)
+    seg = native.DeviceSegment(ctx, [(native.DENSE_INT, 4, v.view(np.uint8), n * 4, synth.block_offsets(n, 4))])
+    q1 = native.DeviceQuery(ctx, seg, [0], [(0, native.GT, float(2 ** 28))])                               # single tile pass: count in the kernel
+    q2 = native.DeviceQuery(ctx, seg, [0], [(0, native.GT, float(2 ** 28)), (0, native.LT, float(2 ** 29))], [0], 0)  # with projection
+    for q, want in ((q1, int((v > 2 ** 28).sum())), (q2, int(((v > 2 ** 28) & (v < 2 ** 29)).sum()))):
+        log = torch.zeros(6, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        q.log_counts(log.data_ptr(), 4)
+        for _ in range(5):
+            q.run_select()
+        torch.cuda.synchronize()
+        assert log.tolist() == [want] * 4 + [0, 0]          # capacity 4: the fifth run is not logged
+        q.log_counts(0, 0)
+        q.run_select()
+        assert q.count() == want
+        q.close()
+    seg.close()
+    ctx.close()
+    env = dict(os.environ, IMM3_BENCH_FORCE_DIST="1", MASTER_PORT="29577")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "2000000", "--steps", "10", "--warmup", "3", "--segments", "3",
+                        "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["count_allreduce"]["sum_over_steps"] > 0
