@@ -354,14 +354,17 @@ def extra_workloads(ctx, native, synth, n, steps: int = 30):
         for _ in range(3):
             q.run()
         torch.cuda.synchronize()
-        ctx.timing_enable(4 * steps + 8)
-        ctx.timing_mask(0xFFFFFFFF)
-        ctx.timing_reset()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(steps):                       # wall time without instrumentation ...
             q.run()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        ctx.timing_enable(4 * steps + 8)             # ... kernel durations from a second, event-bracketed pass
+        ctx.timing_mask(0xFFFFFFFF)
+        ctx.timing_reset()
+        for _ in range(steps):
+            q.run()
+        torch.cuda.synchronize()
         k = [ctx.timing_collect(i) for i in range(3)]
         ctx.timing_enable(0)
         sel = cnt / n
