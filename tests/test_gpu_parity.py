@@ -258,3 +258,14 @@ def test_staged_projection_selectivities(ctx, oracle, lo, hi):
     check(ctx, oracle, cols, [1, 0, 2], [(0, GT, lo), (0, LT, hi), (1, GT, lo), (1, LT, hi)], proj=[1, 0, 2, 1])
     check(ctx, oracle, cols, [0], [(0, GT, lo), (0, LT, hi)], proj=[0])
     check(ctx, oracle, cols, [1], [(0, GT, lo), (0, LT, hi)], proj=[0])
+
+
+# ---- dense survivor lists: more survivors per 16-tile span than one LDS list batch holds (4096) ------------------
+@pytest.mark.parametrize("keep", [1.0, 0.6, 0.26, 0.24])
+def test_projection_at_high_selectivity(ctx, oracle, keep):
+    rng = np.random.default_rng(int(keep * 100))
+    n = 16384 * 3 + 5000
+    cols = make_cols(rng, n, blocks_of(n, 1024), small_ids=True)           # ids uniform in [-50, 50)
+    t = -50 + 100 * (1 - keep)
+    check(ctx, oracle, cols, [0, 1, 2], [(0, GT, float(t) - 0.5)], proj=[2, 0, 1])
+    check(ctx, oracle, cols, [0], [(0, GT, float(t) - 0.5)], proj=[0], limit=9000)
