@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
 from immutable3_amd import native, synth
 n = 100_000_000
 ctx = native.Context(0)
