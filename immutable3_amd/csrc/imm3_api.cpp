@@ -1347,8 +1347,6 @@ static int run_select(imm3_query *q, bool overlap_total) {
         a.n_tiles = q->n_tiles;
         a.bitmap = q->d_bitmap;
         a.block_partials = q->d_block_partials;
-        // a select chain that is ONE tile pass also reduces its count: no k_total launch (tuning variant 7 keeps it)
-        if (single_tile_pass && !overlap_total && ctx->filter_variant != 7) { a.finish = q->d_total; count_done = true; }
         a.tile_rows = q->table ? q->table->d_tile_rows : nullptr; // table query: address the columns through the tile table
         bool any_i32 = false;
         for (int k = 0; k < kMaxTileCols; ++k) any_i32 |= (a.kinds[k] == TK_I32);
@@ -1357,6 +1355,13 @@ static int run_select(imm3_query *q, bool overlap_total) {
         // staging adds ~2x the VALU work per tile: 8 work-groups per CU overlap it with the loads (measured on C3:
         // filter+stage 135 us at 512 WGs, 102 us at 2048; whole query 198 us unstaged -> 169 us)
         if (q->stage_written && ctx->grid_blocks <= 0) grid = filter_grid(q->n_tiles, true, false, 0);
+        // A select chain that is ONE tile pass also reduces its count in the kernel (one relaxed atomic per work-group): no
+        // k_total launch.  Only at <= 512 work-groups: same-address atomics serialise at ~12 ns each, and 1536-2048 of them
+        // at the tail of a short kernel cost more than the launch they save (int8: 32 vs 25 + 4 us).  Variant 7 = never.
+        if (single_tile_pass && !overlap_total && ctx->filter_variant != 7 && (grid <= 512 || ctx->filter_variant == 11)) {
+            a.finish = q->d_total;
+            count_done = true;
+        }
         if (a.stamps) { ctx->stamp_grids.push_back(grid); ++ctx->stamp_used; }
         LaunchTimer t(ctx, 0);
         if (!launch_filter_tile(a, grid, s, t.start, t.stop)) return fail(IMM3_ERR_ARG, "internal: no tile kernel for this column combination");

@@ -30,13 +30,15 @@ cases = {
     "I32+I32+I8": ([0, 1, 2], [(0, GT, 1e6), (1, LT, 3 * 2.0 ** 28), (2, GT, 18.0)], 9),
     "none": ([0], [], 0),
 }
+import os
+VARIANT = int(os.environ.get("IMM3_VARIANT", "0"))
 grids = [int(g) for g in sys.argv[1:]] or [0]
 print(f"{'kinds':12s} {'grid':>6s} {'us':>8s} {'GB/s (cols + bitmap)':>22s} {'% of 8 TB/s':>12s}")
 for name, (used, sels, bpr) in [(k, v) for k, v in cases.items() for _ in grids]:
     pass
 for name, (used, sels, bpr) in cases.items():
   for grid in grids:
-    ctx.set_tuning(0, grid)
+    ctx.set_tuning(VARIANT, grid)
     q = native.DeviceQuery(ctx, seg, used, sels)
     for _ in range(3):
         q.run_select()
