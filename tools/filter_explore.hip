@@ -133,6 +133,41 @@ __global__ __launch_bounds__(256) void k_v0m(Args a) {
     if (lane == 0) a.total[1 + blockIdx.x * 4 + wave] = wave_total;
 }
 
+// ---- W waves per work-group (nt loads + nt stores): waves per CU between the 8 and 16 a 256-thread block allows
+template <int W>
+__global__ __launch_bounds__(W * 64) void k_fw(Args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long wave_total = 0;
+    for (int64_t tile = (int64_t)blockIdx.x * W + wave; tile < a.n_tiles; tile += (int64_t)gridDim.x * W) {
+        const int64_t row0 = tile * 1024;
+        if (row0 + 1024 > a.n_rows) continue;
+        const int32_t *p = a.data + row0 + lane;
+        int32_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(p + 64 * j);
+        int lo = 0, hi = 0;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint64_t m = __ballot(in_closed(v[j], a.lo, a.hi));
+            lo = wl_i32((int)(uint32_t)m, j, lo);
+            hi = wl_i32((int)(uint32_t)(m >> 32), j, hi);
+            cnt += __popcll(m);
+        }
+        const uint64_t mine = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+        if (lane < 16) __builtin_nontemporal_store(mine, a.bitmap + tile * 16 + lane);
+        wave_total += cnt;
+    }
+    if (lane == 0 && blockIdx.x * W + wave < 4 * 2048) a.total[1 + blockIdx.x * W + wave] = wave_total;
+}
+#define LAUNCHER_W(fn, W) static void fn(const Args &a, int grid, hipStream_t s) { hipLaunchKernelGGL((k_fw<W>), dim3(grid), dim3(W * 64), 0, s, a); }
+LAUNCHER_W(l_fw2, 2)
+LAUNCHER_W(l_fw3, 3)
+LAUNCHER_W(l_fw4, 4)
+LAUNCHER_W(l_fw5, 5)
+LAUNCHER_W(l_fw6, 6)
+LAUNCHER_W(l_fw8, 8)
+
 // ---- V3: nt loads + nt stores, T tiles (T x 16 dword loads) in flight per wave
 template <int T>
 __global__ __launch_bounds__(256) void k_v3(Args a) {
@@ -387,7 +422,8 @@ int main(int argc, char **argv) {
         if (host[(size_t)i] >= lo && host[(size_t)i] <= hi) ref[(size_t)(i >> 6)] |= 1ULL << (i & 63);
 
     std::vector<Variant> vars = {
-        {"read_x1_nt", l_rx1nt}, {"f_x1_nt", l_v0_ntls}, {"v4_nt_contiguous", l_v4},
+        {"read_x1_nt", l_rx1nt}, {"f_x1_nt", l_v0_ntls}, {"fw2 (128 thr)", l_fw2}, {"fw3 (192 thr)", l_fw3}, {"fw4 (256 thr)", l_fw4},
+        {"fw5 (320 thr)", l_fw5}, {"fw6 (384 thr)", l_fw6}, {"fw8 (512 thr)", l_fw8},
     };
     std::vector<int> grids = {256, 512, 768, 1024, 2048};
     hipEvent_t e0, e1;
