@@ -42,6 +42,7 @@ struct ColPred {
 // ---- tile kernel (compile-time column kinds) ----
 enum TileKind : int32_t { TK_I32 = 0, TK_I8 = 1, TK_S2 = 2, TK_NONE = 3 };
 constexpr int kMaxTileCols = 3;
+constexpr int kDeferLines = 64;     // bitmap lines a wave parks in LDS between store bursts (32 KiB per work-group)
 constexpr int kMaxTileMatch = 8;
 
 struct TileCol {
@@ -56,6 +57,8 @@ struct TileArgs {
     TileCol cols[kMaxTileCols];
     int32_t kinds[kMaxTileCols];    // sorted ascending, TK_NONE last (selects the template instance)
     int32_t and_existing;
+    int32_t defer_lines;            // > 0: park the bitmap lines in (dynamic) LDS and store them in bursts (single segment only)
+    int32_t pad0;
     int64_t n_rows, n_words, n_tiles;
     uint64_t *bitmap;
     uint32_t *block_partials;

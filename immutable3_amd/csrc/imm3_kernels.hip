@@ -215,7 +215,7 @@ __device__ __forceinline__ void stage_col<TK_S2>(ColRegs<TK_S2> &c, void *stage,
 // values where asked, return in lanes 0..15 the popcount of the words they own.
 template <int K0, int K1, int K2>
 __device__ __forceinline__ uint32_t finish_full_tile(const TileArgs &a, int64_t tile, int lane, ColRegs<K0> &c0,
-                                                     ColRegs<K1> &c1, ColRegs<K2> &c2, uint8_t *lds) {
+                                                     ColRegs<K1> &c1, ColRegs<K2> &c2, uint8_t *lds, uint64_t *park = nullptr) {
     constexpr bool any_i32 = (K0 == TK_I32) || (K1 == TK_I32) || (K2 == TK_I32);
     const int64_t w = tile * kTileWords + lane; // lane j < 16 owns bitmap word j of the tile
     uint64_t mine = ~0ULL;
@@ -228,7 +228,10 @@ __device__ __forceinline__ uint32_t finish_full_tile(const TileArgs &a, int64_t 
     c2.eval(a.cols[2], acc, mine, lane);
     if (any_i32) mine &= words_to_lanes(acc);
     if (lane >= kTileWords) mine = 0;
-    if (lane < kTileWords) __builtin_nontemporal_store(mine, a.bitmap + w); // 16 lanes x 8 B = one 128-B line
+    if (lane < kTileWords) { // 16 lanes x 8 B = one 128-B line
+        if (park) park[lane] = mine; // deferred: the line waits in LDS for the wave's next store burst
+        else __builtin_nontemporal_store(mine, a.bitmap + w);
+    }
     const uint32_t pc = (uint32_t)__popcll(mine);
     if (a.stage[0] || a.stage[1] || a.stage[2]) { // wave-uniform
         uint32_t incl = pc; // exclusive prefix of the word popcounts over lanes 0..15
@@ -280,6 +283,12 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint8_t *lds = s_stage[wave];
+    // Deferred bitmap (a.defer_lines > 0; dynamic LDS): the 128-byte bitmap lines of a wave's tiles are parked in LDS and
+    // written in bursts of a.defer_lines lines (one burst at the end for 100 M rows) instead of one line per tile in between
+    // the streaming loads -- HBM read/write turnarounds cost more than the 3 % of bytes the bitmap is (tools/filter_explore:
+    // 67.3 -> 62.2 us).
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_park[]; // [kWavesPerBlock][a.defer_lines][16] when deferring
+    uint64_t *park = a.defer_lines ? s_park + (size_t)wave * a.defer_lines * kTileWords : nullptr;
     if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x] = wall_clock64(); // instrumented pass of bench.py only
     uint32_t lane_total = 0; // lanes 0..15: survivors in the words they stored
     const int64_t wave_id = (int64_t)blockIdx.x * kWavesPerBlock + wave;
@@ -313,6 +322,17 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
     const int64_t n_full = a.n_rows / kTileRows;
     const int64_t n_groups = n_full / T;
 
+    int parked = 0;           // lines waiting in LDS
+    int64_t first_grp = wave_id; // group of the first parked line
+    auto flush = [&]() {      // 4 lines (4 x 16 lanes) per store instruction
+        lds_wave_sync();
+        for (int q = lane >> 4; q < parked; q += 4) {
+            const int64_t tile = (first_grp + (int64_t)(q / T) * n_waves) * T + (q % T);
+            __builtin_nontemporal_store(park[q * kTileWords + (lane & 15)], a.bitmap + tile * kTileWords + (lane & 15));
+        }
+        lds_wave_sync();
+        parked = 0;
+    };
     for (int64_t grp = wave_id; grp < n_groups; grp += n_waves) {
         ColRegs<K0> c0[T];
         ColRegs<K1> c1[T];
@@ -324,9 +344,16 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
             c1[t].load(a.cols[1].data, row0, lane);
             c2[t].load(a.cols[2].data, row0, lane);
         }
+        if (park && parked == 0) first_grp = grp;
 #pragma unroll
-        for (int t = 0; t < T; ++t) lane_total += finish_full_tile<K0, K1, K2>(a, grp * T + t, lane, c0[t], c1[t], c2[t], lds);
+        for (int t = 0; t < T; ++t)
+            lane_total += finish_full_tile<K0, K1, K2>(a, grp * T + t, lane, c0[t], c1[t], c2[t], lds, park ? park + (parked + t) * kTileWords : nullptr);
+        if (park) {
+            parked += T;
+            if (parked + T > a.defer_lines) flush(); // wave-uniform
+        }
     }
+    if (park && parked) flush();
     // leftovers: fewer than T full tiles, then the one partial tile at the end of the segment
     for (int64_t tile = n_groups * T + wave_id; tile < a.n_tiles; tile += n_waves) {
         const int64_t row0 = tile * kTileRows;
@@ -642,11 +669,14 @@ int filter_grid(int64_t units, bool generic, bool any_i32, int grid_blocks) {
 // time is the kernel's duration (what rocprofv3 reports), not launch-to-launch.
 #define IMM3_LAUNCH(kern, grid, block, s, ev0, ev1, args) \
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, s, ev0, ev1, 0, args)
+#define IMM3_LAUNCH_LDS(kern, grid, block, lds, s, ev0, ev1, args) \
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, ev0, ev1, 0, args)
 
 #define IMM3_TILE_CASE(k0, k1, k2, T)                                                           \
     if (a.kinds[0] == k0 && a.kinds[1] == k1 && a.kinds[2] == k2) {                             \
         if (a.tile_rows) IMM3_LAUNCH((k_filter_tile<k0, k1, k2, 1, true>), grid, kBlockThreads, s, ev0, ev1, a); \
-        else IMM3_LAUNCH((k_filter_tile<k0, k1, k2, T, false>), grid, kBlockThreads, s, ev0, ev1, a);             \
+        else IMM3_LAUNCH_LDS((k_filter_tile<k0, k1, k2, T, false>), grid, kBlockThreads,                          \
+                             (size_t)kWavesPerBlock * (size_t)a.defer_lines * kTileWords * sizeof(uint64_t), s, ev0, ev1, a); \
         return true;                                                                            \
     }
 

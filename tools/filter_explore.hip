@@ -160,6 +160,42 @@ __global__ __launch_bounds__(W * 64) void k_fw(Args a) {
     }
     if (lane == 0 && blockIdx.x * W + wave < 4 * 2048) a.total[1 + blockIdx.x * W + wave] = wave_total;
 }
+// ---- deferred bitmap: the tile lines are parked in LDS and written in one burst after the wave's last load (needs
+// n_tiles / (grid * 4) <= 64), to keep HBM read/write turnarounds out of the streaming phase
+__global__ __launch_bounds__(256) void k_fdef(Args a) {
+    __shared__ uint64_t s_bm[4][64][16]; // 32 KiB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long wave_total = 0;
+    int k = 0;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < a.n_tiles; tile += (int64_t)gridDim.x * 4, ++k) {
+        const int64_t row0 = tile * 1024;
+        if (row0 + 1024 > a.n_rows) { if (lane < 16) s_bm[wave][k & 63][lane] = 0; continue; }
+        const int32_t *p = a.data + row0 + lane;
+        int32_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(p + 64 * j);
+        int lo = 0, hi = 0;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint64_t m = __ballot(in_closed(v[j], a.lo, a.hi));
+            lo = wl_i32((int)(uint32_t)m, j, lo);
+            hi = wl_i32((int)(uint32_t)(m >> 32), j, hi);
+            cnt += __popcll(m);
+        }
+        if (lane < 16) s_bm[wave][k & 63][lane] = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+        wave_total += cnt;
+    }
+    // burst: 4 tiles (4 x 16 lanes) per store instruction
+    const int n_mine = k;
+    for (int q = lane >> 4; q < n_mine; q += 4) {
+        const int64_t tile = (int64_t)blockIdx.x * 4 + wave + (int64_t)q * gridDim.x * 4;
+        if ((tile + 1) * 1024 <= a.n_rows) __builtin_nontemporal_store(s_bm[wave][q & 63][lane & 15], a.bitmap + tile * 16 + (lane & 15));
+    }
+    if (lane == 0 && blockIdx.x * 4 + wave < 4 * 2048) a.total[1 + blockIdx.x * 4 + wave] = wave_total;
+}
+static void l_fdef(const Args &a, int grid, hipStream_t s) { hipLaunchKernelGGL(k_fdef, dim3(grid < 384 ? 384 : grid), dim3(256), 0, s, a); }
+
 #define LAUNCHER_W(fn, W) static void fn(const Args &a, int grid, hipStream_t s) { hipLaunchKernelGGL((k_fw<W>), dim3(grid), dim3(W * 64), 0, s, a); }
 LAUNCHER_W(l_fw2, 2)
 LAUNCHER_W(l_fw3, 3)
@@ -423,7 +459,7 @@ int main(int argc, char **argv) {
 
     std::vector<Variant> vars = {
         {"read_x1_nt", l_rx1nt}, {"f_x1_nt", l_v0_ntls}, {"fw2 (128 thr)", l_fw2}, {"fw3 (192 thr)", l_fw3}, {"fw4 (256 thr)", l_fw4},
-        {"fw5 (320 thr)", l_fw5}, {"fw6 (384 thr)", l_fw6}, {"fw8 (512 thr)", l_fw8},
+        {"fw5 (320 thr)", l_fw5}, {"fw6 (384 thr)", l_fw6}, {"fw8 (512 thr)", l_fw8}, {"v_deferred_bitmap", l_fdef},
     };
     std::vector<int> grids = {256, 512, 768, 1024, 2048};
     hipEvent_t e0, e1;
