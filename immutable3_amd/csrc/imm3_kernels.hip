@@ -276,7 +276,9 @@ __device__ __forceinline__ uint32_t partial_tile(const TileArgs &a, int64_t tile
 // T = tiles per wave iteration: narrow columns take several tiles at once so that every wave keeps >= 4 KiB of
 // loads in flight (8 waves/CU x 4 KiB is what saturates HBM, see the header comment).
 // TABLE selects the tile-table walk (table queries) at compile time, so the single-segment kernel carries none of it.
-template <int K0, int K1, int K2, int T, bool TABLE>
+// DEFER (compile time, like TABLE): the deferred-bitmap path costs ~12 VGPRs; the staging launches, which run without it,
+// are one wave per SIMD short of their occupancy with them (C3 filter 104 -> 115 us), so they use the DEFER = false instance.
+template <int K0, int K1, int K2, int T, bool TABLE, bool DEFER>
 __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a) {
     constexpr int kStage = StageBytes<K0>::value + StageBytes<K1>::value + StageBytes<K2>::value;
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerBlock][kStage > 0 ? kStage : 16];
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
     // the streaming loads -- HBM read/write turnarounds cost more than the 3 % of bytes the bitmap is (tools/filter_explore:
     // 67.3 -> 62.2 us).
     extern __shared__ __attribute__((aligned(16))) uint64_t s_park[]; // [kWavesPerBlock][a.defer_lines][16] when deferring
-    uint64_t *park = a.defer_lines ? s_park + (size_t)wave * a.defer_lines * kTileWords : nullptr;
+    uint64_t *park = DEFER ? s_park + (size_t)wave * a.defer_lines * kTileWords : nullptr;
     if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x] = wall_clock64(); // instrumented pass of bench.py only
     uint32_t lane_total = 0; // lanes 0..15: survivors in the words they stored
     const int64_t wave_id = (int64_t)blockIdx.x * kWavesPerBlock + wave;
@@ -344,16 +346,16 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
             c1[t].load(a.cols[1].data, row0, lane);
             c2[t].load(a.cols[2].data, row0, lane);
         }
-        if (park && parked == 0) first_grp = grp;
+        if (DEFER && parked == 0) first_grp = grp;
 #pragma unroll
         for (int t = 0; t < T; ++t)
-            lane_total += finish_full_tile<K0, K1, K2>(a, grp * T + t, lane, c0[t], c1[t], c2[t], lds, park ? park + (parked + t) * kTileWords : nullptr);
-        if (park) {
+            lane_total += finish_full_tile<K0, K1, K2>(a, grp * T + t, lane, c0[t], c1[t], c2[t], lds, DEFER ? park + (parked + t) * kTileWords : nullptr);
+        if (DEFER) {
             parked += T;
             if (parked + T > a.defer_lines) flush(); // wave-uniform
         }
     }
-    if (park && parked) flush();
+    if (DEFER && parked) flush();
     // leftovers: fewer than T full tiles, then the one partial tile at the end of the segment
     for (int64_t tile = n_groups * T + wave_id; tile < a.n_tiles; tile += n_waves) {
         const int64_t row0 = tile * kTileRows;
@@ -674,9 +676,10 @@ int filter_grid(int64_t units, bool generic, bool any_i32, int grid_blocks) {
 
 #define IMM3_TILE_CASE(k0, k1, k2, T)                                                           \
     if (a.kinds[0] == k0 && a.kinds[1] == k1 && a.kinds[2] == k2) {                             \
-        if (a.tile_rows) IMM3_LAUNCH((k_filter_tile<k0, k1, k2, 1, true>), grid, kBlockThreads, s, ev0, ev1, a); \
-        else IMM3_LAUNCH_LDS((k_filter_tile<k0, k1, k2, T, false>), grid, kBlockThreads,                          \
+        if (a.tile_rows) IMM3_LAUNCH((k_filter_tile<k0, k1, k2, 1, true, false>), grid, kBlockThreads, s, ev0, ev1, a); \
+        else if (a.defer_lines) IMM3_LAUNCH_LDS((k_filter_tile<k0, k1, k2, T, false, true>), grid, kBlockThreads,       \
                              (size_t)kWavesPerBlock * (size_t)a.defer_lines * kTileWords * sizeof(uint64_t), s, ev0, ev1, a); \
+        else IMM3_LAUNCH((k_filter_tile<k0, k1, k2, T, false, false>), grid, kBlockThreads, s, ev0, ev1, a);        \
         return true;                                                                            \
     }
 
