@@ -1362,10 +1362,10 @@ static int run_select(imm3_query *q, bool overlap_total) {
             a.finish = q->d_total;
             count_done = true;
         }
-        // bitmap lines parked in LDS and stored in bursts: single segment, no staging (whose LDS and 2048 work-groups
+        // bitmap lines parked in LDS and stored in bursts: no staging (whose LDS and 2048 work-groups
         // leave no room for 32 KiB more per group); tuning variant 12 switches it off
         // (64 lines = 32 KiB per work-group at <= 4 groups per CU; 16 lines = 8 KiB for the 1536-group narrow-column kernels)
-        a.defer_lines = (!q->table && !q->stage_written && ctx->filter_variant != 12) ? (grid <= 1024 ? kDeferLines : 16) : 0;
+        a.defer_lines = (!q->stage_written && ctx->filter_variant != 12) ? (grid <= 1024 ? kDeferLines : 16) : 0;
         if (a.stamps) { ctx->stamp_grids.push_back(grid); ++ctx->stamp_used; }
         LaunchTimer t(ctx, 0);
         if (!launch_filter_tile(a, grid, s, t.start, t.stop)) return fail(IMM3_ERR_ARG, "internal: no tile kernel for this column combination");

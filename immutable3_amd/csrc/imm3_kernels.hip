@@ -297,6 +297,16 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
     const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
 
     if constexpr (TABLE) { // table query: tiles come from the tile table (one partial tile per segment), one tile per step
+        // deferred bitmap: the parked lines' tile numbers are kept next to them (partial tiles are stored directly)
+        uint64_t *pidx = DEFER ? s_park + (size_t)kWavesPerBlock * a.defer_lines * kTileWords + (size_t)wave * a.defer_lines : nullptr;
+        int parked = 0;
+        auto flush = [&]() {
+            lds_wave_sync();
+            for (int q = lane >> 4; q < parked; q += 4)
+                __builtin_nontemporal_store(park[q * kTileWords + (lane & 15)], a.bitmap + (int64_t)pidx[q] * kTileWords + (lane & 15));
+            lds_wave_sync();
+            parked = 0;
+        };
         for (int64_t tile = wave_id; tile < a.n_tiles; tile += n_waves) {
             const uint32_t rows_here = a.tile_rows[tile];
             const void *d0 = K0 != TK_NONE ? a.tile_ptrs[0][tile] : nullptr;
@@ -309,11 +319,16 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
                 c0.load(d0, 0, lane);
                 c1.load(d1, 0, lane);
                 c2.load(d2, 0, lane);
-                lane_total += finish_full_tile<K0, K1, K2>(a, tile, lane, c0, c1, c2, lds);
+                lane_total += finish_full_tile<K0, K1, K2>(a, tile, lane, c0, c1, c2, lds, DEFER ? park + parked * kTileWords : nullptr);
+                if (DEFER) {
+                    if (lane == 0) pidx[parked] = (uint64_t)tile;
+                    if (++parked == a.defer_lines) flush(); // wave-uniform
+                }
             } else {
                 lane_total += partial_tile<K0, K1, K2>(a, tile, lane, d0, d1, d2, 0, rows_here, c0, c1, c2);
             }
         }
+        if (DEFER && parked) flush();
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) lane_total += __shfl_xor(lane_total, d);
         if (a.finish) block_partial_finish(a.finish, lane_total, lane, wave);
@@ -676,7 +691,9 @@ int filter_grid(int64_t units, bool generic, bool any_i32, int grid_blocks) {
 
 #define IMM3_TILE_CASE(k0, k1, k2, T)                                                           \
     if (a.kinds[0] == k0 && a.kinds[1] == k1 && a.kinds[2] == k2) {                             \
-        if (a.tile_rows) IMM3_LAUNCH((k_filter_tile<k0, k1, k2, 1, true, false>), grid, kBlockThreads, s, ev0, ev1, a); \
+        if (a.tile_rows && a.defer_lines) IMM3_LAUNCH_LDS((k_filter_tile<k0, k1, k2, 1, true, true>), grid, kBlockThreads, \
+                             (size_t)kWavesPerBlock * (size_t)a.defer_lines * (kTileWords + 1) * sizeof(uint64_t), s, ev0, ev1, a); \
+        else if (a.tile_rows) IMM3_LAUNCH((k_filter_tile<k0, k1, k2, 1, true, false>), grid, kBlockThreads, s, ev0, ev1, a); \
         else if (a.defer_lines) IMM3_LAUNCH_LDS((k_filter_tile<k0, k1, k2, T, false, true>), grid, kBlockThreads,       \
                              (size_t)kWavesPerBlock * (size_t)a.defer_lines * kTileWords * sizeof(uint64_t), s, ev0, ev1, a); \
         else IMM3_LAUNCH((k_filter_tile<k0, k1, k2, T, false, false>), grid, kBlockThreads, s, ev0, ev1, a);        \
