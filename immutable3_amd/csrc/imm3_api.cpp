@@ -114,6 +114,12 @@ struct imm3_table { // all segments of one table as one scan unit: the tile tabl
     int64_t n_tiles = 0, n_rows = 0;
     uint32_t *d_tile_rows = nullptr;   // valid rows per tile
     std::vector<void **> d_tile_ptrs;  // per column: device array of per-tile pointers
+    // batches of all segments (every column shares one block layout: checked at creation), built once: a query over 98
+    // README-style segments otherwise spends ~0.4 ms of host time re-deriving them
+    std::vector<int32_t> batch_size, batch_k; // rows; index of the batch within its segment (oid = k * table.blockSize)
+    std::vector<int64_t> batch_word_off;
+    std::vector<int32_t> seg_first_batch;     // n_segs + 1
+    std::vector<int64_t> seg_first_word;      // n_segs + 1
 };
 
 struct FoldedPred { // all SelectOp leaves on one segment column, folded
@@ -130,8 +136,7 @@ struct imm3_query {
     imm3_ctx *ctx = nullptr;
     const imm3_segment *seg = nullptr;   // the segment (table queries: the first one, for the schema)
     const imm3_table *table = nullptr;   // table query: columns are addressed through the tile table
-    std::vector<int32_t> seg_first_batch; // table query: n_segs + 1
-    std::vector<int64_t> seg_first_word;  // table query: n_segs + 1
+    int32_t table_block_size = 0;   // table.blockSize as given at creation (oid of a batch = index in its segment * blockSize)
     std::vector<int32_t> used;     // segment column index of each used column
     std::vector<int32_t> proj;     // index into `used`
     int64_t limit = 0;
@@ -147,6 +152,7 @@ struct imm3_query {
     uint32_t *d_tile_offsets = nullptr, *d_chunk_sums = nullptr, *d_block_partials = nullptr;
     unsigned long long *d_total = nullptr, *d_n_emit = nullptr; // adjacent: d_n_emit = d_total + 1; d_total + 2 = status word
     bool has_pfor_pass = false;   // a k_filter_pfor pass may flag malformed blocks in the status word
+    unsigned long long h_init[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // host image of the block above at creation
     uint32_t *d_word_row_base = nullptr;
     uint8_t *d_word_nvalid = nullptr;
     uint32_t *d_row_index = nullptr;
@@ -882,6 +888,7 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
     q->ctx = ctx;
     q->seg = seg;
     q->table = table;
+    q->table_block_size = table_block_size;
     q->used.assign(used_cols, used_cols + n_used);
     q->proj.assign(proj, proj + n_proj);
     q->limit = limit;
@@ -902,22 +909,9 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
         q->ragged = L.ragged;
         q->n_tiles = (q->n_words + kTileWords - 1) / kTileWords;
     } else {
-        for (size_t si = 0; si < table->segs.size(); ++si) {
-            SegLayout L;
-            const int lrc = segment_layout(table->segs[si], q->used, table_block_size, L);
-            if (lrc) return lrc;
-            if (L.ragged || L.rows != table->seg_rows[si]) return fail(IMM3_ERR_LAYOUT, "segment " + std::to_string(si) + " does not have the uniform layout a table query needs");
-            q->seg_first_batch.push_back((int32_t)q->batch_size.size());
-            q->seg_first_word.push_back(table->tile_start[si] * kTileWords);
-            for (size_t k = 0; k < L.size.size(); ++k) {
-                q->batch_size.push_back(L.size[k]);
-                q->batch_oid.push_back(L.oid[k]);
-                q->batch_word_off.push_back(table->tile_start[si] * kTileWords + L.word_off[k]);
-            }
-        }
-        q->seg_first_batch.push_back((int32_t)q->batch_size.size());
-        q->seg_first_word.push_back(table->n_tiles * kTileWords);
-        nb = (int32_t)q->batch_size.size();
+        // every column of a table shares one block layout (imm3_table_create), so the batches do not depend on which
+        // columns are used: they live in the table
+        nb = (int32_t)table->batch_size.size();
         q->n_rows = table->n_rows;
         q->n_tiles = table->n_tiles;
         q->n_words = table->n_tiles * kTileWords; // virtual: every segment padded to whole tiles
@@ -1037,11 +1031,9 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
     HIPCHK(pool_alloc(ctx, &p, 8 * sizeof(unsigned long long))); // {total, n_emit, status, limit, tally, log, log index, log capacity}
     q->d_total = (unsigned long long *)p;
     q->d_n_emit = q->d_total + 1;
-    {
-        const unsigned long long init[8] = {0, 0, 0, (unsigned long long)limit, 0, 0, 0, 0};
-        HIPCHK(hipMemcpyAsync(q->d_total, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream)); // `init` is a stack array
-    }
+    std::memset(q->h_init, 0, sizeof(q->h_init)); // lives as long as the query; creation ends with a stream sync anyway
+    q->h_init[3] = (unsigned long long)limit;
+    HIPCHK(hipMemcpyAsync(q->d_total, q->h_init, sizeof(q->h_init), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(q->d_bitmap, 0, words_alloc * sizeof(uint64_t), ctx->stream));
     if (q->ragged) {
         std::vector<uint32_t> base((size_t)q->n_tiles * kTileWords, 0u);
@@ -1149,10 +1141,19 @@ extern "C" int imm3_table_create(imm3_ctx *ctx, const imm3_segment *const *segs,
         }
         t->segs.push_back(sg);
         t->seg_rows.push_back(L.rows);
+        t->seg_first_batch.push_back((int32_t)t->batch_size.size());
+        t->seg_first_word.push_back(t->tile_start.back() * kTileWords);
+        for (size_t k = 0; k < L.size.size(); ++k) {
+            t->batch_size.push_back(L.size[k]);
+            t->batch_k.push_back((int32_t)k);
+            t->batch_word_off.push_back(t->tile_start.back() * kTileWords + L.word_off[k]);
+        }
         t->tile_start.push_back(t->tile_start.back() + (L.rows + kTileRows - 1) / kTileRows);
         t->n_rows += L.rows;
     }
     t->n_tiles = t->tile_start.back();
+    t->seg_first_batch.push_back((int32_t)t->batch_size.size());
+    t->seg_first_word.push_back(t->n_tiles * kTileWords);
     if (t->n_tiles * (int64_t)kTileRows > 0xFFFFFFFFLL) return fail(IMM3_ERR_LAYOUT, "table too large for 32-bit virtual row ids on one device");
     std::vector<uint32_t> rows((size_t)std::max<int64_t>(t->n_tiles, 1), 0);
     std::vector<std::vector<const void *>> ptrs(ncols, std::vector<const void *>((size_t)std::max<int64_t>(t->n_tiles, 1), nullptr));
@@ -1199,8 +1200,8 @@ extern "C" int imm3_query_segment_starts(const imm3_query *q, int32_t *n_segment
     }
     const size_t n = q->table->segs.size();
     if (n_segments) *n_segments = (int32_t)n;
-    if (first_batch) std::memcpy(first_batch, q->seg_first_batch.data(), (n + 1) * sizeof(int32_t));
-    if (first_word) std::memcpy(first_word, q->seg_first_word.data(), (n + 1) * sizeof(int64_t));
+    if (first_batch) std::memcpy(first_batch, q->table->seg_first_batch.data(), (n + 1) * sizeof(int32_t));
+    if (first_word) std::memcpy(first_word, q->table->seg_first_word.data(), (n + 1) * sizeof(int64_t));
     return IMM3_OK;
 }
 
@@ -1579,7 +1580,7 @@ extern "C" int imm3_query_sync(imm3_query *q) {
 // ---------------------------------------------------------------------------------------------
 extern "C" int imm3_query_layout(const imm3_query *q, int32_t *n_batches, int64_t *total_words, int64_t *n_rows) {
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
-    if (n_batches) *n_batches = (int32_t)q->batch_size.size();
+    if (n_batches) *n_batches = (int32_t)(q->table ? q->table->batch_size.size() : q->batch_size.size());
     if (total_words) *total_words = q->n_words;
     if (n_rows) *n_rows = q->n_rows;
     return IMM3_OK;
@@ -1587,6 +1588,15 @@ extern "C" int imm3_query_layout(const imm3_query *q, int32_t *n_batches, int64_
 
 extern "C" int imm3_query_batches(const imm3_query *q, int32_t *batch_size, int32_t *batch_oid, int64_t *batch_word_off) {
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    if (q->table) {
+        const imm3_table *t = q->table;
+        const size_t nb = t->batch_size.size();
+        if (batch_size && nb) std::memcpy(batch_size, t->batch_size.data(), nb * sizeof(int32_t));
+        if (batch_oid)
+            for (size_t k = 0; k < nb; ++k) batch_oid[k] = (int32_t)((uint32_t)t->batch_k[k] * (uint32_t)q->table_block_size); // vecCounter * table.blockSize
+        if (batch_word_off && nb) std::memcpy(batch_word_off, t->batch_word_off.data(), nb * sizeof(int64_t));
+        return IMM3_OK;
+    }
     const size_t nb = q->batch_size.size();
     if (batch_size && nb) std::memcpy(batch_size, q->batch_size.data(), nb * sizeof(int32_t));
     if (batch_oid && nb) std::memcpy(batch_oid, q->batch_oid.data(), nb * sizeof(int32_t));
@@ -1715,7 +1725,7 @@ static int query_create_agg_impl(imm3_ctx *ctx, const imm3_segment *seg, const i
         key_bytes += seg->cols[(size_t)q->used[(size_t)group_cols[g]]].width;
     }
     if (key_bytes > 8) return fail(IMM3_ERR_ARG, "group key wider than 8 bytes is not supported on the GPU path");
-    const bool has_batches = !q->batch_size.empty();
+    const bool has_batches = table ? !table->batch_size.empty() : !q->batch_size.empty();
     for (int32_t j = 0; j < n_aggs; ++j) {
         if (aggs[j].column < 0 || aggs[j].column >= n_used) return fail(IMM3_ERR_ARG, "aggregate column is not among the used columns");
         const SegCol &sc = seg->cols[(size_t)q->used[(size_t)aggs[j].column]];
