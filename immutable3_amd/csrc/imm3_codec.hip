@@ -211,6 +211,12 @@ __global__ void k_pfor_counts(const uint8_t *data, const uint32_t *block_off, in
 __global__ __launch_bounds__(kBlockThreads) void k_filter_pfor(const PforArgs a) {
     __shared__ uint32_t s_win[kWavesPerBlock][kPforLds];
     __shared__ uint32_t s_vb[kWavesPerBlock][32];
+    // bitmap lines are parked in LDS and stored in bursts of kPark tiles, as in k_filter_tile (stores in between streaming
+    // loads cost HBM read/write turnarounds)
+    constexpr int kPark = 16;
+    __shared__ uint64_t s_park[kWavesPerBlock][kPark][kTileWords]; // 8 KiB
+    __shared__ long long s_ptile[kWavesPerBlock][kPark];
+    int parked = 0;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform by construction: tile indices stay in SGPRs
     uint32_t *win = s_win[wave];
@@ -256,9 +262,16 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_pfor(const PforArgs a)
         mine &= low_mask(expect - 64 * (int64_t)lane);
         if (lane >= kTileWords) mine = 0;
         if (a.and_existing && lane < kTileWords) mine &= a.bitmap[w];
-        if (lane < kTileWords) __builtin_nontemporal_store(mine, a.bitmap + w); // the bitmap is allocated in whole tiles
+        if (lane < kTileWords) s_park[wave][parked][lane] = mine; // the bitmap is allocated in whole tiles
+        if (lane == 0) s_ptile[wave][parked] = tile;
         lane_total += (uint32_t)__popcll(mine);
         lds_wave_sync(); // the window is reused by the next tile
+        if (++parked == kPark || tile + n_waves >= a.n_tiles) { // wave-uniform: burst
+            for (int q = lane >> 4; q < parked; q += 4)
+                __builtin_nontemporal_store(s_park[wave][q][lane & 15], a.bitmap + s_ptile[wave][q] * kTileWords + (lane & 15));
+            lds_wave_sync();
+            parked = 0;
+        }
     }
 #pragma unroll
     for (int dd = 8; dd >= 1; dd >>= 1) lane_total += __shfl_xor(lane_total, dd);
