@@ -69,6 +69,20 @@ def test_count_log_and_rccl_path_with_one_rank():
         assert q.count() == want
         q.close()
     seg.close()
+    # a multi-pass chain (four predicate columns -> two tile passes) reduces its count in k_total: logged there
+    cols = [synth.uniform_int30(20 + c, n) for c in range(4)]
+    seg = native.DeviceSegment(ctx, [(native.DENSE_INT, 4, c.view(np.uint8), n * 4, synth.block_offsets(n, 4)) for c in cols])
+    q = native.DeviceQuery(ctx, seg, [0, 1, 2, 3], [(c, native.GT, float(2 ** 27)) for c in range(4)])
+    want = int(np.logical_and.reduce([c > 2 ** 27 for c in cols]).sum())
+    log = torch.zeros(3, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    q.log_counts(log.data_ptr(), 3)
+    for _ in range(2):
+        q.run_select()
+    torch.cuda.synchronize()
+    assert log.tolist() == [want, want, 0] and q.count() == want
+    q.close()
+    seg.close()
     ctx.close()
     env = dict(os.environ, IMM3_BENCH_FORCE_DIST="1", MASTER_PORT="29577")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "2000000", "--steps", "10", "--warmup", "3", "--segments", "3",
