@@ -5,8 +5,9 @@ Workload at every N (weak scaling): each rank owns 100 M-row DENSE_INT segments 
 (BASELINE.json: "100M-row RangeFilter"; SURVEY 8d config C2 at 100 M rows: int32 uniform in [0, 2^30) from
 splitmix64, predicate GT(2^28) AND LT(3*2^28), ~50 % selectivity).  One STEP = one pass of the hot path
 ScanOp -> SelectOp(GT) -> SelectOp(LT) over one segment: the fused scan+select kernel producing the
-selection bitmap (12.5 MB) and the selected-row count, followed -- when N > 1 -- by the RCCL all-reduce of
-that 8-byte count (the only collective on the path; asynchronous, overlapped with the next step).
+selection bitmap (12.5 MB) and the selected-row count (reduced inside the same kernel).  When N > 1 every step's
+count is logged on the device by that kernel (imm3_query_log_counts) and the K counts are summed over the ranks by
+ONE RCCL all-reduce at the end of the timed region, inside it -- the only collective on the path.
 Three distinct segments per rank are rotated so the 256 MiB Infinity Cache cannot serve the reads.
 
     python bench.py --gpus N --steps K --warmup W
