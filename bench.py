@@ -1,30 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py -- scanned rows/s + fraction of the HBM roofline of the RangeFilter hot path.
+"""bench.py -- scanned rows/s + fraction of the HBM roofline of the scan / filter / project hot path.
 
-Workload at every N (weak scaling): each rank owns 100 M-row DENSE_INT segments resident in ITS GPU's HBM
-(BASELINE.json: "100M-row RangeFilter"; SURVEY 8d config C2 at 100 M rows: int32 uniform in [0, 2^30) from
-splitmix64, predicate GT(2^28) AND LT(3*2^28), ~50 % selectivity).  One STEP = one pass of the hot path
-ScanOp -> SelectOp(GT) -> SelectOp(LT) over one segment: the fused scan+select kernel producing the
-selection bitmap (12.5 MB) and the selected-row count (reduced inside the same kernel).  When N > 1 every step's
-count is logged on the device by that kernel (imm3_query_log_counts) and the K counts are summed over the ranks by
-ONE RCCL all-reduce at the end of the timed region, inside it -- the only collective on the path.
-Three distinct segments per rank are rotated so the 256 MiB Infinity Cache cannot serve the reads.
+    python bench.py --gpus N --steps K --warmup W          # N > 1: starts its own N ranks (one process per GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # or is started as a rank
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+N = 1 (headline; BASELINE.json "100M-row RangeFilter", SURVEY 8d config C2 at 100 M rows): three 100 M-row DENSE_INT
+segments resident in HBM (int32 uniform in [0, 2^30) from splitmix64, rotated so the 256 MiB Infinity Cache cannot
+serve the reads), predicate GT(2^28) AND LT(3*2^28), ~50 % selectivity.  One STEP = one pass of ScanOp -> SelectOp(GT)
+-> SelectOp(LT) over one segment: the fused scan+select kernel producing the selection bitmap (12.5 MB) and the
+selected-row count (reduced inside the same kernel).  The line also carries an `extra` block, measured in the same
+run: C3 (range on age and id + Project), C4 (Match(state) + Project), group-by aggregation, and C5 at G = 1.
 
-Prints ONE JSON line on rank 0.  value = rows scanned by all ranks / max-over-ranks wall time, inputs
-already resident in HBM.  roofline.achieved = algorithmic bytes per launch (4.125 B/row: 4 B column read +
-1/8 B bitmap write) / mean duration of the scan+select kernel measured live with HIP events on the
-launching stream.  cpu_baseline = the oracle's faithful C restatement of the reference CPU operators
-(kind "port": the Scala/JVM reference cannot run here), one thread -- the reference runs one thread per
-segment (Engine.scala:176-180) -- timed on rank 0 at N = 1 only.
+N > 1 (BASELINE config C5, strong scaling): 8 segments x 100 M rows (segment s: age from splitmix64 seed 100+s,
+id = s*10^8 + i), segment s on rank s mod N (Engine.scala:176-180 fans out one pipeline per segment), query
+RangeFilter(age) AND RangeFilter(id) + Project(id, age).  One STEP = one pass over all 8 segments (each rank runs its
+own) followed by ONE count all-reduce: ncclAllReduce(sum, uint64, 1) over RCCL / xGMI, issued by libimm3
+(imm3_comm_allreduce_count) on the communicator's stream behind the scans that produce the counts.  value = 8e8 rows x K /
+max-over-ranks wall time.  The same line carries `c2_weak`: the N = 1 headline workload run by every rank (weak scaling).
+
+Prints ONE JSON line on rank 0.  Inputs are resident in HBM before any timed region.  roofline.achieved = algorithmic
+bytes per launch / mean kernel duration measured live with HIP events on the launching stream.  cpu_baseline = the
+oracle's faithful C restatement of the reference CPU operators (kind "port": the Scala/JVM reference cannot run
+here), one thread -- the reference runs one thread per segment -- timed on rank 0 at N = 1 only.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,18 +39,73 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s)
 ROWS_PER_SEGMENT = 100_000_000
-ALGO_BYTES_PER_ROW = 4.125     # SURVEY 8d: 4 B int32 read + 1/8 B bitmap write
+ALGO_BYTES_PER_ROW = 4.125     # SURVEY 8d C2: 4 B int32 read + 1/8 B bitmap write
+C5_SEGMENTS = 8
+METRIC = "scanned rows/sec + %HBM-roofline, 100M-row RangeFilter, 1/2/4/8 MI355X"
 
 
-class _DevArray:
-    """Zero-copy view of library-owned device memory for torch (cuda array interface)."""
-
-    def __init__(self, ptr: int, n: int, typestr: str = "<i8"):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 3}
+def c3_bytes_per_row(sel: float) -> float:
+    """(4+1) predicate columns + 1/8 bitmap + sigma x [4 B index + (4+1) gathered + (4+1) written]."""
+    return 5 + 0.125 + sel * (4 + 5 + 5)
 
 
+def c4_bytes_per_row(sel: float) -> float:
+    """2 (state) + 1/8 + sigma x [4 + 7 + 7]."""
+    return 2 + 0.125 + sel * (4 + 7 + 7)
+
+
+# =====================================================================================================================
+# launcher: `python bench.py --gpus N` with N > 1 and no rank environment starts the N ranks itself
+# =====================================================================================================================
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n: int) -> int:
+    """One child process per GPU, started BEFORE this process touches the GPU (it never does: no torch import, no HIP
+    call).  Rank 0's stdout (the JSON line) is relayed; any rank failing fails the run and ends the others."""
+    import tempfile
+    port = _free_port()
+    procs = []
+    with tempfile.TemporaryFile(mode="w+") as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                          stdout=out0 if r == 0 else sys.stderr, stderr=sys.stderr))
+        failed = None
+        while failed is None and any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            for r, p in enumerate(procs):
+                if p.poll() not in (None, 0):
+                    failed = (r, p.returncode)
+        if failed is not None:                          # a dead rank leaves the others waiting in a barrier: end exactly the children we started
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            for p in procs:
+                p.wait()
+            print(f"bench.py: rank {failed[0]} exited with code {failed[1]}; run aborted", file=sys.stderr)
+            return 1
+        out0.seek(0)
+        text = out0.read()
+    sys.stdout.write(text)
+    sys.stdout.flush()
+    if not any(l.startswith("{") for l in text.splitlines()):
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    return 0
+
+
+# =====================================================================================================================
+# CPU baseline (oracle; rank 0, N = 1 only)
+# =====================================================================================================================
 def cpu_baseline(values: np.ndarray, offsets: np.ndarray, sels, budget_s: float = 10.0):
     """The oracle (kind 'port': the Scala/JVM reference cannot run here), on the same 100 M-row segment.
     Primary figure: faithful flavour (the reference's per-block copy / per-element decode / per-row BitSet cost
@@ -98,67 +158,149 @@ def cpu_baseline(values: np.ndarray, offsets: np.ndarray, sels, budget_s: float 
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--rows", type=int, default=ROWS_PER_SEGMENT, help="rows per segment (default 100M)")
-    ap.add_argument("--segments", type=int, default=3, help="distinct resident segments rotated per rank")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extra", action="store_true", help="also time C3 (range+project) and C4 (match+project)")
-    ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--grid", type=int, default=0)
-    args = ap.parse_args()
+# =====================================================================================================================
+# per-rank environment
+# =====================================================================================================================
+class Env:
+    """What every measurement needs: the rank's context (on a torch stream, so the library's work and torch's sit on ONE
+    stream), host-side control collectives (gloo: barrier, max, object exchange -- never on the data path), and the
+    library's RCCL communicator for the count reduce."""
 
-    import torch
-    import torch.distributed as dist
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.args = torch, dist, args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the immutable3 hot path has no CPU fallback")
+        # Rehearsal knob (not used by the driver): IMM3_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 so the N > 1 code
+        # path can be exercised on a 1-GPU box.  RCCL refuses two ranks on one device, so the count all-reduce then goes
+        # over gloo (labelled in the line).
+        self.one_device = os.environ.get("IMM3_BENCH_ONE_DEVICE") == "1"
+        if self.one_device:
+            self.local_rank = 0
+        elif self.world > torch.cuda.device_count():
+            raise SystemExit(f"bench.py: {self.world} ranks but {torch.cuda.device_count()} GPUs "
+                             "(IMM3_BENCH_ONE_DEVICE=1 rehearses the N > 1 path on one GPU)")
+        torch.cuda.set_device(self.local_rank)
+        self.use_dist = self.world > 1
+        if self.use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="gloo")     # host-side control plane only
+        from immutable3_amd import native, synth
+        self.native, self.synth = native, synth
+        self.stream = torch.cuda.Stream()               # a REAL stream: 0 (torch's default) would make the library create its own
+        self.ctx = native.Context(self.local_rank, self.stream.cuda_stream)
+        self.ctx.set_tuning(args.variant, args.grid)
+        self.comm = None
+        self.count_reduce = "none (1 GPU)"
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        args.gpus = world
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the immutable3 hot path has no CPU fallback")
-    # Rehearsal knobs (not used by the driver): IMM3_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
-    # IMM3_BENCH_BACKEND=gloo swaps RCCL for gloo, so the N > 1 code path can be exercised on a 1-GPU box.
-    if os.environ.get("IMM3_BENCH_ONE_DEVICE") == "1":
-        local_rank = 0
-    backend = os.environ.get("IMM3_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
-    # IMM3_BENCH_FORCE_DIST=1 (rehearsal): take the N > 1 code path -- RCCL init, per-step count all-reduce, barriers --
-    # even with one rank, so that path can be exercised on a 1-GPU box with the real backend.
-    use_dist = world > 1 or os.environ.get("IMM3_BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # "nccl" IS RCCL on ROCm
-        else:
-            dist.init_process_group(backend=backend)
+    def make_comm(self):
+        """The library's RCCL communicator (also with one rank: the G = 1 point of the C5 curve runs the same code)."""
+        if self.comm is not None or (self.use_dist and self.one_device):
+            if self.use_dist and self.one_device:
+                self.count_reduce = "REHEARSAL: torch.distributed gloo all_reduce of host counts (ranks share one GPU; RCCL refuses that)"
+            return
+        native = self.native
+        # RCCL prints a version banner on stdout when it initialises; stdout carries the ONE JSON line, so the banner goes to stderr
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            uid = [native.comm_unique_id() if self.rank == 0 else None]
+            if self.use_dist:
+                self.dist.broadcast_object_list(uid, src=0)
+            self.comm = native.Comm(self.ctx, self.world, self.rank, uid[0])
+            self.sync()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        self.count_reduce = ("ncclAllReduce(sum, ncclUint64, 1) per pass, issued by libimm3 (imm3_comm_allreduce_count) on the "
+                             "communicator's stream behind the scans; RCCL over xGMI")
 
-    from immutable3_amd import native, synth
+    def sync(self):
+        self.torch.cuda.synchronize()                   # device-wide: the context's stream and the communicator's
 
+    def barrier(self):
+        if self.use_dist:
+            self.dist.barrier()
+
+    def max_over_ranks(self, x: float) -> float:
+        if not self.use_dist:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, x: int) -> int:
+        if not self.use_dist:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.int64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return int(t.item())
+
+    def gather_objects(self, obj):
+        if not self.use_dist:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def timed_steps(self, step, steps: int, warmup: int) -> float:
+        """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+        for i in range(warmup):
+            step(i)
+        self.sync()
+        self.barrier()
+        self.sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        self.sync()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def kernel_times(self, run, reps: int, ids=(0, 1, 2, 3), launches_per_run: int = 8):
+        """Duration (ms) per kernel id and run, averaged over `reps` more runs, each launch bracketed by HIP events on the
+        context's stream (kept out of the wall-clock regions: the event packets cost ~5 us per launch)."""
+        ctx = self.ctx
+        ctx.timing_enable(launches_per_run * reps + 16)
+        ctx.timing_mask(0xFFFFFFFF)
+        ctx.timing_reset()
+        for _ in range(reps):
+            run()
+        self.sync()
+        ks = {i: ctx.timing_collect(i) for i in ids}
+        ctx.timing_enable(0)
+        return {i: (float(np.mean(k)) * (k.size / reps) if k.size else None) for i, k in ks.items()}   # ms per run (sums multi-launch ids)
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+        self.ctx.close()
+        if self.use_dist:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+KERNEL_NAMES = {0: "scan_select", 1: "offsets_scan", 2: "compact_gather", 3: "count_reduce", 4: "group_agg"}
+
+
+# =====================================================================================================================
+# C2: the N = 1 headline (and the weak-scaling leg at N > 1)
+# =====================================================================================================================
+def measure_c2(env: Env, steps: int, warmup: int, with_cpu_baseline: bool):
+    torch, native, synth, ctx, args = env.torch, env.native, env.synth, env.ctx, env.args
     n = args.rows
     sels = [(0, native.GT, float(2 ** 28)), (0, native.LT, float(3 * 2 ** 28))]
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = native.Context(local_rank, stream)   # launch on torch's current stream: its synchronize() covers us
-    ctx.set_tuning(args.variant, args.grid)
     offsets = synth.block_offsets(n, 4)
-
-    # ---- stage: segments resident in HBM before any timed region (PCIe staging is not part of `value`) ----
     segs, queries, host0 = [], [], None
     t_stage = time.perf_counter()
     for s in range(args.segments):
-        seed = 1 + s + 1000 * rank          # rank r, slot s: its own splitmix64 stream
-        v = synth.uniform_int30(seed, n)
-        if s == 0 and rank == 0:
+        v = synth.uniform_int30(1 + s + 1000 * env.rank, n)          # rank r, slot s: its own splitmix64 stream
+        if s == 0:
             host0 = v
         seg = native.DeviceSegment(ctx, [(native.DENSE_INT, 4, v.view(np.uint8), n * 4, offsets)])
         segs.append(seg)
@@ -166,172 +308,197 @@ def main():
         del v
     stage_s = time.perf_counter() - t_stage
 
-    # parity gate for the reported number: popcount(bitmap) == count == numpy evaluation of segment 0
-    if rank == 0:
-        queries[0].run_select()
-        words = queries[0].bitmap()
-        cnt = queries[0].count()
-        keep = (host0 > 2 ** 28) & (host0 < 3 * 2 ** 28)
-        assert cnt == int(keep.sum()), (cnt, int(keep.sum()))
-        assert words.tobytes() == np.packbits(keep, bitorder="little").tobytes(), "bitmap mismatch"
-        del keep, words
-
-    # N > 1: "RCCL over xGMI only for the final selected-row-count reduction".  Every scan stores its count into a
-    # device-side log from the kernel that produces it (imm3_query_log_counts: no copy kernel, no host call per step);
-    # the K per-step counts are summed over the ranks by ONE all-reduce at the end of the timed region, inside it.
+    # parity gate for the reported number: popcount(bitmap) == count == numpy evaluation of this rank's segment 0
+    queries[0].run_select()
+    words, cnt = queries[0].bitmap(), queries[0].count()
+    keep = (host0 > 2 ** 28) & (host0 < 3 * 2 ** 28)
+    assert cnt == int(keep.sum()), (cnt, int(keep.sum()))
+    assert words.tobytes() == np.packbits(keep, bitorder="little").tobytes(), "bitmap mismatch"
+    del keep, words
     nq = len(queries)
-    per_query = (args.steps + nq - 1) // nq + 1
-    logs = [torch.zeros(per_query, dtype=torch.int64, device="cuda") for _ in queries]
-    counts = torch.zeros(args.steps, dtype=torch.int64, device="cuda")
-
-    def arm_logs():
-        for q, lg in zip(queries, logs):
-            lg.zero_()
-            torch.cuda.synchronize()
-            q.log_counts(lg.data_ptr() if use_dist else 0, per_query)
 
     def step(i: int):
-        queries[i % nq].run_select()                     # fused ScanOp -> SelectOp(GT) -> SelectOp(LT) kernel (+ count)
+        queries[i % nq].run_select()                    # fused ScanOp -> SelectOp(GT) -> SelectOp(LT) kernel (+ count)
 
-    def reduce_counts():
-        # step i of the timed region ran query i % nq as that query's (i // nq)-th logged run
-        for j in range(nq):
-            counts[j::nq] = logs[j][: len(range(j, args.steps, nq))]
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)    # final selected-row-count reduction over RCCL / xGMI
+    elapsed = env.timed_steps(step, steps, warmup)
 
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    arm_logs()
-    # start the timed steps on query 0 again so that log slot k of query j is timed step j + k * nq
-    # ---- timed region: EXACTLY K steps, barrier + synchronize on both sides ----
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    if use_dist:
-        reduce_counts()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    expected_counts = counts.clone() if use_dist else None
-    if use_dist and world == 1 and rank == 0:   # one rank: the reduced count of step 0 is segment 0's count (parity gate above)
-        assert int(expected_counts[0].item()) == cnt, (int(expected_counts[0].item()), cnt)
-    for q in queries:
-        q.log_counts(0, 0)
-
-    # ---- the same K steps again with the scan+select kernel bracketed by HIP events on its stream.  Kept out
-    # of the region above because the event packets themselves cost ~5 us per step; the work is identical. ----
-    ctx.timing_enable(args.steps + 8)
+    # the same K steps again with the scan+select kernel bracketed by HIP events on its stream (and device-clock stamps)
+    ctx.timing_enable(steps + 8)
     ctx.timing_mask(1 << 0)
     ctx.timing_reset()
-    ctx.devclock_enable(args.steps + 8)
-    torch.cuda.synchronize()
+    ctx.devclock_enable(steps + 8)
+    env.sync()
     t1 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(i)
-    torch.cuda.synchronize()
+    env.sync()
     elapsed_events = time.perf_counter() - t1
     kernel_ms = ctx.timing_collect(0)
     devclock_ms = ctx.devclock_collect()
     ctx.timing_enable(0)
     ctx.devclock_enable(0)
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    read_ceiling = ctx.measure_read_gbps(4 * n, 30) if env.rank == 0 else None   # read-only streaming kernel on this box
+    mean_ms = float(np.mean(kernel_ms)) if kernel_ms.size else float("nan")
+    per_rank = env.gather_objects({"rank": env.rank, "kernel_ms_mean": mean_ms, "selected_rows_segment0": int(cnt)})
 
-    result = None
-    read_ceiling = ctx.measure_read_gbps(4 * n, 30) if rank == 0 else None   # read-only streaming kernel on this box
-    if rank == 0:
-        total_rows = float(n) * args.steps * world
-        mean_ms = float(np.mean(kernel_ms)) if kernel_ms.size else float("nan")
+    out = None
+    if env.rank == 0:
         achieved = ALGO_BYTES_PER_ROW * n / (mean_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, tsrc = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("workload") == "range_filter_i32" and tj.get("rows") == n:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    tsrc = ("from profiles/traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes of this "
+                            "command, committed; NOT re-measured in this run")
             except Exception:
                 traffic = None
-        result = {
-            "metric": "scanned rows/sec + %HBM-roofline, 100M-row RangeFilter, 1/2/4/8 MI355X",
-            "value": total_rows / elapsed,
-            "unit": "rows/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "ms_per_step_with_kernel_events": elapsed_events / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "i32",
-            "data": "synthetic",
+        out = {
+            "value": float(n) * steps * env.world / elapsed,
+            "ms_per_step": elapsed / steps * 1e3,
+            "ms_per_step_with_kernel_events": elapsed_events / steps * 1e3,
             "config": {
                 "workload": "C2@100M: RangeFilter GT(2^28) AND LT(3*2^28) over one 100M-row DENSE_INT segment "
                             "-> selection bitmap + selected-row count",
-                "rows_per_step_per_gpu": n,
-                "block_rows": 1024,
-                "segments_rotated_per_gpu": args.segments,
-                "selectivity": 0.5,
-                "parallelism": f"segment-sharded x{world}, one count all-reduce over RCCL per K steps" if world > 1 else "1 GPU",
+                "rows_per_step_per_gpu": n, "block_rows": 1024, "segments_rotated_per_gpu": args.segments, "selectivity": 0.5,
+                "parallelism": "1 GPU" if env.world == 1 else f"every rank scans its own segments (weak scaling) x{env.world}",
             },
             "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": tsrc,
                 "kernel": "imm3::k_filter_tile<TK_I32>",
                 "kernel_ms_mean": mean_ms,
                 "kernel_ms_min": float(np.min(kernel_ms)) if kernel_ms.size else None,
                 "kernel_launches_timed": int(kernel_ms.size),
                 "kernel_ms_mean_device_clock": float(np.mean(devclock_ms)) if devclock_ms.size else None,
                 "timing": "HIP events stamped by hipExtLaunchKernelGGL on the launching stream, second pass of the same K steps; "
-                          "reads ~4 us above rocprofv3's kernel-only duration (start stamp precedes dispatch), see DESIGN.md section 6; "
+                          "reads ~4 us above rocprofv3's kernel-only duration under the profiler (start stamp precedes dispatch), see DESIGN.md section 6; "
                           "kernel_ms_mean_device_clock = first work-group entry to last work-group exit on the 100 MHz device clock, same launches",
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ROW * n,
                 "empirical_read_ceiling_GBps": read_ceiling,
                 "frac_of_empirical_read_ceiling": (achieved / read_ceiling) if read_ceiling else None,
             },
             "staging": {"host_to_hbm_s_per_segment": stage_s / args.segments, "note": "PCIe staging incl. synthetic generation; never part of value"},
+            "per_rank": per_rank,
         }
-        if use_dist:
-            result["count_allreduce"] = {"collective": "one RCCL all_reduce(SUM) over the K per-step counts at the end of the timed region",
-                                         "last_step_global_count": int(expected_counts[-1].item()),
-                                         "sum_over_steps": int(expected_counts.sum().item())}
-
-    if args.extra and rank == 0 and world == 1:
-        result["extra"] = extra_workloads(ctx, native, synth, n)
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(host0, offsets, [(0, 3, float(2 ** 28)), (0, 4, float(3 * 2 ** 28))])
-    elif rank == 0:
-        result["cpu_baseline"] = None
-
+        if with_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(host0, offsets, [(0, 3, float(2 ** 28)), (0, 4, float(3 * 2 ** 28))])
     for q in queries:
         q.close()
     for s in segs:
         s.close()
-    ctx.close()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(result))
+    return out
 
 
-def extra_workloads(ctx, native, synth, n, steps: int = 30):
+# =====================================================================================================================
+# C5: 8 segments x 100 M rows sharded s mod G, RangeFilter(age) AND RangeFilter(id) + Project(id, age), count all-reduce
+# =====================================================================================================================
+C5_ID_LO, C5_ID_HI = 1.0e6, 7.9e8        # the C3 id range stretched over the 8-segment id space [0, 8e8)
+
+
+def measure_c5(env: Env, steps: int, warmup: int):
+    torch, native, synth, ctx, args = env.torch, env.native, env.synth, env.ctx, env.args
+    from immutable3_amd.distributed import owned_segments
+    n = args.rows
+    env.make_comm()
+    mine = owned_segments(C5_SEGMENTS, env.rank, env.world)
+    sels = [(0, native.GT, 18.0), (0, native.LT, 30.0), (1, native.GT, C5_ID_LO), (1, native.LT, C5_ID_HI)]
+    segs, queries, expect = [], [], []
+    t_stage = time.perf_counter()
+    for s in mine:
+        c = synth.c3_segment(n, seed=100 + s, id_base=s * n)
+        seg = native.DeviceSegment(ctx, [(native.DENSE_INT, 4, c["id"].view(np.uint8), n * 4, synth.block_offsets(n, 4)),
+                                         (native.DENSE_TINYINT, 1, c["age"].view(np.uint8), n, synth.block_offsets(n, 1))])
+        q = native.DeviceQuery(ctx, seg, [1, 0], sels, [1, 0], 0, 1024)     # used columns [age, id] (Engine.getColumns), SELECT id, age
+        keep = (c["age"] > 18) & (c["age"] < 30) & (c["id"] > C5_ID_LO) & (c["id"] < C5_ID_HI)
+        want = int(keep.sum())
+        # parity gate: count, ordered rows and values of every owned segment against numpy
+        q.run()
+        assert q.count() == want, (s, q.count(), want)
+        q.reserve_rows(want + 1024)
+        q.run()
+        idx, vals = q.fetch_rows()
+        rows = np.flatnonzero(keep)
+        assert idx.size == want and (idx == rows).all(), f"segment {s}: row order"
+        assert (vals[0].view("<i4").reshape(-1) == c["id"][rows]).all() and (vals[1].view(np.int8).reshape(-1) == c["age"][rows]).all(), f"segment {s}: values"
+        expect.append(want)
+        segs.append(seg)
+        queries.append(q)
+        del c, keep, rows, idx, vals
+    stage_s = time.perf_counter() - t_stage
+    expect_total = env.sum_over_ranks(sum(expect))     # over gloo: independent of the collective under test
+
+    log = torch.zeros(max(steps, warmup, 1), dtype=torch.int64, device="cuda")
+    env.sync()
+    host_counts = []
+
+    def step(i: int):
+        for q in queries:
+            q.run()                                     # scan+select(+stage) -> offsets scan -> compact+gather, per owned segment
+        if env.comm is not None:
+            env.comm.allreduce_count(queries, device_out=log.data_ptr() + 8 * i, wait=False)
+        else:                                           # rehearsal on one device: host counts over gloo
+            host_counts.append(env.sum_over_ranks(sum(q.count() for q in queries)))
+
+    elapsed = env.timed_steps(step, steps, warmup)
+    got = log[:steps].tolist() if env.comm is not None else host_counts[-steps:]
+    assert all(g == expect_total for g in got), (got[:4], expect_total)
+
+    # per-kernel durations of one pass over this rank's segments (second, event-bracketed pass)
+    def one_pass():
+        for q in queries:
+            q.run()
+    k = env.kernel_times(one_pass, max(3, min(steps, 20)), launches_per_run=8 * len(queries))
+    per_query = {KERNEL_NAMES[i]: (v / len(queries) if v is not None else None) for i, v in k.items()}
+    sel = sum(expect) / (n * len(mine))
+    kernel_ms_per_query = sum(v for v in per_query.values() if v)
+    per_rank = env.gather_objects({"rank": env.rank, "segments": mine, "selected_rows": sum(expect), "kernel_ms_per_query": per_query})
+
+    out = None
+    if env.rank == 0:
+        algo = c3_bytes_per_row(sel) * n
+        achieved = algo / (kernel_ms_per_query * 1e-3) / 1e9
+        out = {
+            "value": float(n) * C5_SEGMENTS * steps / elapsed,
+            "ms_per_step": elapsed / steps * 1e3,
+            "global_selected_rows_per_pass": int(expect_total),
+            "count_allreduce": {"collective": env.count_reduce, "checked": f"all {steps} per-pass global counts == {expect_total} (numpy, summed over ranks via gloo)"},
+            "config": {
+                "workload": "C5: 8 x 100M-row segments (age seed 100+s, id = s*1e8 + i), segment s -> rank s mod G, "
+                            "RangeFilter(age > 18 AND age < 30) AND RangeFilter(id > 1e6 AND id < 7.9e8) + Project(id, age), "
+                            "one count all-reduce per pass",
+                "rows_per_step": n * C5_SEGMENTS, "segments": C5_SEGMENTS, "segments_per_gpu": len(mine), "block_rows": 1024,
+                "selectivity": sel, "parallelism": f"segment-sharded x{env.world} (s mod G), no data-path collective but the count",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "per-segment query: scan+select(+stage) -> offsets scan -> compact+gather (rank 0)",
+                "kernel_ms_per_query": per_query, "kernel_ms_sum_per_query": kernel_ms_per_query,
+                "algorithmic_bytes_per_query": algo,
+                "algorithmic_bytes_per_row": c3_bytes_per_row(sel),
+                "timing": "HIP events on the launching stream, second pass; frac = SURVEY 8d C3 bytes/row x rows / sum of kernel durations",
+            },
+            "staging": {"host_to_hbm_s_per_segment": stage_s / max(len(mine), 1), "note": "incl. synthetic generation and the parity gate; never part of value"},
+            "per_rank": per_rank,
+        }
+    for q in queries:
+        q.close()
+    for s in segs:
+        s.close()
+    return out
+
+
+# =====================================================================================================================
+# extra block of the N = 1 line: C3, C4, aggregation (the other BASELINE configs at full size), staging
+# =====================================================================================================================
+def extra_workloads(env: Env, steps: int = 20):
     """C3 (conjunctive RangeFilter on age and id + Project(id, age)) and C4 (MatchFilter(state)=='CA' +
-    Project(id, state, age)) over one 100 M-row segment: not bench lines, reported for the record."""
-    import torch
+    Project(id, state, age)) over one 100 M-row segment, group-by aggregation, PFOR_INT: per config the algorithmic
+    bytes, every kernel's mean duration (HIP events) and the fraction of the 8 TB/s peak."""
+    torch, native, synth, ctx = env.torch, env.native, env.synth, env.ctx
+    n = env.args.rows
     out = {}
     ids = np.arange(n, dtype=np.int32)
     age = synth.uniform_below(2, n, 100, np.int8)
@@ -341,99 +508,131 @@ def extra_workloads(ctx, native, synth, n, steps: int = 30):
         (native.DENSE_STRING, 2, st.reshape(-1), n * 2, synth.block_offsets(n, 2)),
         (native.DENSE_TINYINT, 1, age.view(np.uint8), n, synth.block_offsets(n, 1)),
     ])
+    lo, hi = 1e6 * n / 1e8, 9e7 * n / 1e8
+    keep3 = (age > 18) & (age < 30) & (ids > lo) & (ids < hi)
+    keep4 = (st[:, 0] == ord("C")) & (st[:, 1] == ord("A"))
     cases = {
-        "c3_range_age_id_project": ([2, 0], [(0, native.GT, 18.0), (0, native.LT, 30.0), (1, native.GT, 1e6), (1, native.LT, 9e7)], [1, 0],
-                                    lambda sel: 5 + 0.125 + sel * (4 + 5 + 5)),
-        "c4_match_state_project": ([1, 0, 2], [(0, native.MATCH, [b"CA"])], [1, 0, 2],
-                                   lambda sel: 2 + 0.125 + sel * (4 + 7 + 7)),
+        "c3_range_age_id_project": ([2, 0], [(0, native.GT, 18.0), (0, native.LT, 30.0), (1, native.GT, lo), (1, native.LT, hi)], [1, 0],
+                                    c3_bytes_per_row, keep3),
+        "c4_match_state_project": ([1, 0, 2], [(0, native.MATCH, [b"CA"])], [1, 0, 2], c4_bytes_per_row, keep4),
     }
-    for name, (used, sels, proj, bytes_per_row) in cases.items():
+    for name, (used, sels, proj, bytes_per_row, keep) in cases.items():
         q = native.DeviceQuery(ctx, seg, used, sels, proj, 0, 1024)
         q.run()
         cnt = q.count()
+        assert cnt == int(keep.sum()), (name, cnt, int(keep.sum()))
         q.reserve_rows(cnt + 1024)
-        for _ in range(3):
-            q.run()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):                       # wall time without instrumentation ...
-            q.run()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        ctx.timing_enable(4 * steps + 8)             # ... kernel durations from a second, event-bracketed pass
-        ctx.timing_mask(0xFFFFFFFF)
-        ctx.timing_reset()
-        for _ in range(steps):
-            q.run()
-        torch.cuda.synchronize()
-        k = [ctx.timing_collect(i) for i in range(3)]
-        ctx.timing_enable(0)
+        q.run()
+        idx, _ = q.fetch_rows()
+        assert (idx == np.flatnonzero(keep)).all(), name           # ordered rows (values are covered by tests/test_gpu_large.py)
+        del idx
+        dt = env.timed_steps(lambda i: q.run(), steps, 3) / steps
+        k = env.kernel_times(q.run, steps)
+        kms = {KERNEL_NAMES[i]: v for i, v in k.items()}
+        ksum = sum(v for v in kms.values() if v)
         sel = cnt / n
+        algo = bytes_per_row(sel) * n
         out[name] = {
             "rows_per_s": n / dt, "ms_per_query": dt * 1e3, "selected_rows": int(cnt), "selectivity": sel,
-            "algorithmic_bytes_per_row": bytes_per_row(sel),
-            "algorithmic_GBps": bytes_per_row(sel) * n / dt / 1e9,
-            "kernel_ms": {"scan_select": float(np.mean(k[0])) if k[0].size else None,
-                          "offsets_scan": float(np.mean(k[1])) if k[1].size else None,
-                          "compact_gather": float(np.mean(k[2])) if k[2].size else None},
+            "algorithmic_bytes_per_row": bytes_per_row(sel), "algorithmic_bytes": algo,
+            "kernel_ms": kms, "kernel_ms_sum": ksum,
+            "achieved_GBps": algo / (ksum * 1e-3) / 1e9,
+            "frac": algo / (ksum * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "frac_wall": algo / dt / 1e9 / HBM_PEAK_GBS,
         }
         q.close()
+    del keep3, keep4
     # group-by aggregation: select count(id), max(age) from t [where age > 18 and age < 30] group by state
     for name, sels in (("agg_group_by_state_all_rows", []),
                        ("agg_group_by_state_range_age", [(1, native.GT, 18.0), (1, native.LT, 30.0)])):
         q = native.DeviceQuery(ctx, seg, [1, 2, 0], sels, (), 0, 1024, group_cols=[0], aggs=[(native.AGG_COUNT, 2), (native.AGG_MAX, 1)])
-        for _ in range(2):
-            q.run()
-        torch.cuda.synchronize()
-        ctx.timing_enable(8 * 10 + 8)
-        ctx.timing_mask(0xFFFFFFFF)
-        ctx.timing_reset()
-        t0 = time.perf_counter()
-        for _ in range(10):
-            q.run()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 10
-        k0, k4 = ctx.timing_collect(0), ctx.timing_collect(4)
-        ctx.timing_enable(0)
+        dt = env.timed_steps(lambda i: q.run(), 10, 2) / 10
+        k = env.kernel_times(q.run, 10, ids=(0, 3, 4))
         keys, first, counts, vals = q.fetch_groups()
+        sel = float(counts.sum()) / n
+        algo = ((1 if sels else 0) + 0.125 + sel * (2 + 1)) * n   # predicate column (age) + bitmap + sigma x (group key state + aggregated age)
         out[name] = {"rows_per_s": n / dt, "ms_per_query": dt * 1e3, "groups": int(keys.shape[0]), "selected_rows": int(counts.sum()),
-                     "kernel_ms": {"scan_select": float(np.mean(k0)) if k0.size else None, "group_agg": float(np.mean(k4)) if k4.size else None}}
+                     "kernel_ms": {KERNEL_NAMES[i]: v for i, v in k.items()}, "algorithmic_bytes": algo,
+                     "frac": algo / (sum(v for v in k.values() if v) * 1e-3) / 1e9 / HBM_PEAK_GBS}
         q.close()
     seg.close()
-    # host -> HBM staging of one 400 MB column from pageable memory (the step before the path)
+    # host -> HBM staging of one 400 MB column (the step before the path)
     t0 = time.perf_counter()
     s2 = native.DeviceSegment(ctx, [(native.DENSE_INT, 4, ids.view(np.uint8), n * 4, synth.block_offsets(n, 4))])
     dt = time.perf_counter() - t0
-    out["staging_400MB_pageable"] = {"seconds": dt, "GBps": n * 4 / dt / 1e9}
+    out["staging_400MB"] = {"seconds": dt, "GBps": n * 4 / dt / 1e9, "note": "imm3_segment_create from pageable host memory"}
     s2.close()
     # PFOR_INT: the id column as PFORCodecInt.encode writes it; the range predicate is evaluated on the
     # compressed blocks (k_filter_pfor), HBM traffic = compressed bytes.  VALU-bound, not HBM-bound.
     dat, offs = native.pfor_encode_column(ids, 1024)
-    t0 = time.perf_counter()
     sp = native.DeviceSegment(ctx, [(native.PFOR_INT, 4, dat, dat.size, offs)])
-    stage_s = time.perf_counter() - t0
-    q = native.DeviceQuery(ctx, sp, [0], [(0, native.GT, 1e6), (0, native.LT, 9e7)])
-    for _ in range(3):
-        q.run_select()
+    q = native.DeviceQuery(ctx, sp, [0], [(0, native.GT, lo), (0, native.LT, hi)])
+    q.run_select()
     cnt = q.count()
-    torch.cuda.synchronize()
-    ctx.timing_enable(steps + 8)
-    ctx.timing_mask(1)
-    ctx.timing_reset()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        q.run_select()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    k0 = ctx.timing_collect(0)
-    ctx.timing_enable(0)
+    dt = env.timed_steps(lambda i: q.run_select(), steps, 3) / steps
+    k = env.kernel_times(q.run_select, steps, ids=(0, 3))
     out["pfor_range_id"] = {"rows_per_s": n / dt, "ms_per_query": dt * 1e3, "selected_rows": int(cnt), "compressed_bytes": int(dat.size),
-                            "compression_ratio": n * 4 / dat.size, "kernel_ms": {"scan_select": float(np.mean(k0)) if k0.size else None},
-                            "hbm_GBps": (dat.size + n / 8) / (float(np.mean(k0)) * 1e-3) / 1e9 if k0.size else None,
-                            "staging_seconds": stage_s, "bound": "valu"}
+                            "compression_ratio": n * 4 / dat.size, "kernel_ms": {KERNEL_NAMES[i]: v for i, v in k.items()},
+                            "hbm_GBps": (dat.size + n / 8) / (k[0] * 1e-3) / 1e9 if k[0] else None, "bound": "valu"}
     q.close()
     sp.close()
     return out
+
+
+# =====================================================================================================================
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=ROWS_PER_SEGMENT, help="rows per segment (default 100M)")
+    ap.add_argument("--segments", type=int, default=3, help="distinct resident C2 segments rotated per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the extra block (C3, C4, aggregation, C5 at G = 1)")
+    ap.add_argument("--no-c2-weak", action="store_true", help="N > 1: skip the weak-scaling C2 leg")
+    ap.add_argument("--extra", action="store_true", help="(kept for compatibility: the extra block is on by default)")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--grid", type=int, default=0)
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(spawn_ranks(args.gpus))            # before anything touches the GPU; the parent only relays rank 0's line
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: refusing to report a line for a different GPU count")
+
+    env = Env(args)
+    base = {"metric": METRIC, "unit": "rows/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": True, "vs_baseline": None, "data": "synthetic"}
+    result = None
+    if env.world == 1:
+        c2 = measure_c2(env, args.steps, args.warmup, with_cpu_baseline=not args.no_cpu_baseline)
+        result = dict(base, scaling="weak", dtype="i32", **{k: c2[k] for k in ("value", "ms_per_step", "ms_per_step_with_kernel_events", "config", "roofline", "staging")})
+        result["cpu_baseline"] = c2.get("cpu_baseline")
+        if not args.no_extra:
+            extra = extra_workloads(env)
+            c5 = measure_c5(env, max(3, min(args.steps, 10)), 2)
+            extra["c5_g1"] = {k: c5[k] for k in ("value", "ms_per_step", "global_selected_rows_per_pass", "count_allreduce", "config", "roofline")}
+            extra["c5_g1"]["note"] = "the G = 1 point of the C5 strong-scaling curve whose G > 1 points are the `value` of the --gpus N lines"
+            result["extra"] = extra
+        result["scaling_note"] = ("N = 1: value = C2 (headline).  N > 1: value = C5 aggregate (strong scaling, 8e8 rows per pass); its G = 1 point is "
+                                  "extra.c5_g1.value; the like-for-like weak-scaling curve of the headline workload is c2_weak.value at N > 1")
+    else:
+        c5 = measure_c5(env, args.steps, args.warmup)
+        c2 = None if args.no_c2_weak else measure_c2(env, max(10, min(args.steps, 50)), 5, with_cpu_baseline=False)
+        if env.rank == 0:
+            result = dict(base, scaling="strong", dtype="i32/i8", **c5)
+            result["cpu_baseline"] = None               # timed at N = 1 only (contract)
+            if c2 is not None:
+                result["c2_weak"] = {k: c2[k] for k in ("value", "ms_per_step", "config", "roofline", "per_rank")}
+                result["c2_weak"]["scaling"] = "weak"
+            result["scaling_note"] = ("value = C5 aggregate rows/s (strong scaling: 8 segments fixed, sharded s mod G); G = 1 point: extra.c5_g1.value of the "
+                                      "--gpus 1 line.  c2_weak.value = the N = 1 headline workload run by every rank (weak scaling)")
+    env.close()
+    if env.rank == 0:
+        print(json.dumps(result))
 
 
 if __name__ == "__main__":

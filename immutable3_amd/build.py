@@ -11,8 +11,10 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 def build_native(force: bool = False) -> str:
     csrc = os.path.join(_PKG, "csrc")
     out = os.path.join(_PKG, "lib", "libimm3.so")
-    srcs = [os.path.join(csrc, f) for f in ("imm3_kernels.hip", "imm3_agg.hip", "imm3_api.cpp", "imm3_internal.h")]
-    srcs.append(os.path.join(_PKG, "..", "include", "imm3.h"))
+    # every file the Makefile's rules depend on: an edit to any of them rebuilds under force=False
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".h")) or f == "Makefile"]
+    inc = os.path.join(_PKG, "..", "include")
+    srcs += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
     host = os.path.join(_PKG, "host")
     srcs += [os.path.join(host, f) for f in os.listdir(host) if f.endswith(".hpp")]
     srcs += [os.path.join(host, "cli", f) for f in os.listdir(os.path.join(host, "cli"))]

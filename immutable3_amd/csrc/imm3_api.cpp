@@ -3,6 +3,7 @@
 // Compiled with hipcc for gfx950.  There is NO CPU fallback: without a HIP device every entry point that
 // touches data fails with IMM3_ERR_DEVICE.
 #include "../../include/imm3.h"
+#include "../../include/imm3_diag.h"
 #include "imm3_internal.h"
 #include "../host/codec.hpp"
 
@@ -17,6 +18,8 @@
 #include <string>
 #include <vector>
 
+#include "imm3_handles.h"
+
 using namespace imm3;
 
 // ---------------------------------------------------------------------------------------------
@@ -24,157 +27,16 @@ using namespace imm3;
 // ---------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 
-static int fail(int code, const std::string &msg) {
+int imm3::fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
 }
 
-#define HIPCHK(expr)                                                                              \
-    do {                                                                                          \
-        hipError_t _e = (expr);                                                                   \
-        if (_e != hipSuccess)                                                                     \
-            return fail(IMM3_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+#define CTX_LIVE(c)                                                                                   \
+    do {                                                                                              \
+        if (!(c)) return fail(IMM3_ERR_ARG, "ctx is null");                                           \
+        if ((c)->closed) return fail(IMM3_ERR_STATE, "the context of this handle has been destroyed"); \
     } while (0)
-
-// ---------------------------------------------------------------------------------------------
-// handles
-// ---------------------------------------------------------------------------------------------
-struct TimingRecord {
-    int32_t kernel_id;
-    hipEvent_t start, stop;
-};
-
-struct imm3_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    hipStream_t aux = nullptr;      // count reduce of select-only runs: overlaps the next scan on `stream`
-    int filter_variant = 0;
-    int grid_blocks = 0;
-    bool timing = false;
-    uint32_t timing_mask = 0xFFFFFFFFu;
-    std::vector<TimingRecord> pool; // pre-created event pairs
-    size_t used = 0;
-    // Caching allocator for per-query buffers.  Every user of such a buffer runs on `stream`, so a block freed by one
-    // query and handed to the next is reused in stream order: no synchronisation, no hipMalloc/hipFree (each ~50-100 us)
-    // on the query path once the pool is warm.
-    std::mutex pool_mu;
-    std::multimap<size_t, void *> pool_free;
-    std::unordered_map<void *, size_t> pool_size;
-    size_t pool_cached = 0;
-    // device-clock stamps (diagnostics): slot i = kMaxFilterGrid {start, end} pairs for the i-th tile launch
-    unsigned long long *d_stamps = nullptr;
-    int32_t stamp_slots = 0, stamp_used = 0;
-    std::vector<int32_t> stamp_grids;
-    uint32_t *d_xpow8 = nullptr;    // snappy CRC-32C check: x^(8 n) mod P for n = 0 .. 32768
-};
-
-static inline bool is_snappy(int32_t c) { return c == IMM3_SNAPPY_INT || c == IMM3_SNAPPY_TINYINT || c == IMM3_SNAPPY_STRING; }
-static inline bool is_compressed(int32_t c) { return c == IMM3_PFOR_INT || is_snappy(c); }
-// the DENSE_* codec whose decoded vectors a column's values are (type dispatch of ScanOp / SelectOp / ProjectAggOp)
-static inline int32_t value_codec(int32_t c) {
-    if (c == IMM3_PFOR_INT || c == IMM3_SNAPPY_INT) return IMM3_DENSE_INT;
-    if (c == IMM3_SNAPPY_TINYINT) return IMM3_DENSE_TINYINT;
-    if (c == IMM3_SNAPPY_STRING) return IMM3_DENSE_STRING;
-    return c;
-}
-
-struct SegCol {
-    int32_t codec = 0, width = 0;
-    int32_t vcodec = 0;                // value_codec(codec)
-    uint8_t *d_data = nullptr;
-    bool owned = false;
-    uint64_t bytes = 0;
-    std::vector<int32_t> offsets;
-    // PFOR_INT (imm3_codec.hip) / snappy (imm3_snappy.hip): the blocks stay compressed in d_data
-    std::vector<int32_t> block_rows;   // the rows each block declares (PFOR: its count word; snappy: uncompressed bytes / width)
-    int32_t in_cap = 0, out_cap = 0;   // snappy: LDS bytes k_snappy_decode needs for the largest block / chunk
-    int64_t rows = 0;
-    bool tile_aligned = false;         // every block but the last holds exactly 1024 rows: block k == bitmap tile k
-    uint32_t *d_block_off = nullptr;   // n_blocks + 1 byte offsets
-    uint32_t *d_row_base = nullptr;    // n_blocks + 1 first rows
-    uint8_t *d_dense = nullptr;        // decoded int32 column, made on first need (Project, aggregation, ragged, table)
-};
-
-struct imm3_segment {
-    imm3_ctx *ctx = nullptr;
-    std::vector<SegCol> cols;
-    uint64_t device_bytes = 0;
-    std::mutex decode_mu;              // guards the lazy d_dense of PFOR_INT columns
-};
-
-// the flat, fixed-width form of a column (what every kernel but k_filter_pfor reads)
-static inline const uint8_t *col_flat(const SegCol &sc) { return is_compressed(sc.codec) ? sc.d_dense : sc.d_data; }
-
-struct imm3_table { // all segments of one table as one scan unit: the tile table
-    imm3_ctx *ctx = nullptr;
-    std::vector<const imm3_segment *> segs;
-    std::vector<int64_t> seg_rows;     // rows per segment
-    std::vector<int64_t> tile_start;   // n_segs + 1: first (virtual) tile of each segment
-    int64_t n_tiles = 0, n_rows = 0;
-    uint32_t *d_tile_rows = nullptr;   // valid rows per tile
-    std::vector<void **> d_tile_ptrs;  // per column: device array of per-tile pointers
-    // batches of all segments (every column shares one block layout: checked at creation), built once: a query over 98
-    // README-style segments otherwise spends ~0.4 ms of host time re-deriving them
-    std::vector<int32_t> batch_size, batch_k; // rows; index of the batch within its segment (oid = k * table.blockSize)
-    std::vector<int64_t> batch_word_off;
-    std::vector<int32_t> seg_first_batch;     // n_segs + 1
-    std::vector<int64_t> seg_first_word;      // n_segs + 1
-};
-
-struct FoldedPred { // all SelectOp leaves on one segment column, folded
-    int32_t seg_col = 0;
-    int32_t kind = 0, width = 0;
-    int64_t lo = 0, hi = 0;                // numeric closed interval
-    std::vector<std::string> match;        // string: surviving IN-list values (each exactly width bytes)
-    uint8_t *d_blob = nullptr;             // device copy when it does not fit the kernel arguments
-    uint8_t *d_stage = nullptr;            // survivors' values staged per tile (column is also projected)
-    bool pfor = false;                     // PFOR_INT column evaluated on its compressed blocks (k_filter_pfor)
-};
-
-struct imm3_query {
-    imm3_ctx *ctx = nullptr;
-    const imm3_segment *seg = nullptr;   // the segment (table queries: the first one, for the schema)
-    const imm3_table *table = nullptr;   // table query: columns are addressed through the tile table
-    int32_t table_block_size = 0;   // table.blockSize as given at creation (oid of a batch = index in its segment * blockSize)
-    std::vector<int32_t> used;     // segment column index of each used column
-    std::vector<int32_t> proj;     // index into `used`
-    int64_t limit = 0;
-    // layout (Scan.scala:55-60)
-    std::vector<int32_t> batch_size, batch_oid;
-    std::vector<int64_t> batch_word_off;
-    int64_t n_rows = 0, n_words = 0, n_tiles = 0, n_chunks = 0;
-    bool ragged = false;
-    bool always_false = false;
-    std::vector<FoldedPred> preds;
-    // device buffers
-    uint64_t *d_bitmap = nullptr;
-    uint32_t *d_tile_offsets = nullptr, *d_chunk_sums = nullptr, *d_block_partials = nullptr;
-    unsigned long long *d_total = nullptr, *d_n_emit = nullptr; // adjacent: d_n_emit = d_total + 1; d_total + 2 = status word
-    bool has_pfor_pass = false;   // a k_filter_pfor pass may flag malformed blocks in the status word
-    unsigned long long h_init[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // host image of the block above at creation
-    uint32_t *d_word_row_base = nullptr;
-    uint8_t *d_word_nvalid = nullptr;
-    uint32_t *d_row_index = nullptr;
-    std::vector<uint8_t *> d_proj;
-    uint64_t cap_rows = 0;
-    bool reserved = false;
-    bool ran_select = false, ran_project = false;
-    // group-by aggregation
-    bool is_agg = false;
-    std::vector<int32_t> group_cols;           // index into `used`
-    std::vector<imm3_aggregate> aggs;
-    uint32_t agg_mask = 0;
-    unsigned long long *d_akeys = nullptr, *d_acounts = nullptr, *d_okeys = nullptr, *d_ocounts = nullptr;
-    uint32_t *d_afirst = nullptr, *d_ofirst = nullptr, *d_ameta = nullptr; // d_ameta: {n_groups, overflow}
-    long long *d_avals = nullptr, *d_ovals = nullptr;
-    uint32_t out_cap = 0;
-    bool ran_agg = false;
-    // select-only runs: the count reduce goes to ctx->aux, fenced by these events
-    hipEvent_t ev_filter_done = nullptr, ev_total_done = nullptr;
-    bool total_on_aux = false;
-    bool stage_written = false;   // the last select run filled the staging buffers (single tile pass)
-};
 
 // ---------------------------------------------------------------------------------------------
 // context-level caching allocator (see imm3_ctx::pool_*)
@@ -299,25 +161,41 @@ extern "C" int imm3_ctx_create(int device, void *stream, imm3_ctx **out) {
     return IMM3_OK;
 }
 
+void imm3::ctx_retain(imm3_ctx *c) { c->refs.fetch_add(1, std::memory_order_relaxed); }
+void imm3::ctx_release(imm3_ctx *c) {
+    if (c->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete c;
+}
+
+// Destroying a context with live segments / tables / queries is allowed (see imm3_handles.h, "Lifetimes"): everything the
+// context owns on the device goes now, the struct itself when the last dependant is destroyed.
 extern "C" int imm3_ctx_destroy(imm3_ctx *ctx) {
     if (!ctx) return IMM3_OK;
+    if (ctx->closed) return fail(IMM3_ERR_STATE, "context destroyed twice");
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto &r : ctx->pool) {
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);
     }
-    if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+    ctx->pool.clear();
+    ctx->used = 0;
+    ctx->timing = false;
+    if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); ctx->aux = nullptr; }
     (void)hipFree(ctx->d_stamps);
+    ctx->d_stamps = nullptr;
+    ctx->stamp_slots = 0;
     (void)hipFree(ctx->d_xpow8);
+    ctx->d_xpow8 = nullptr;
     pool_drain(ctx);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
-    delete ctx;
+    ctx->stream = nullptr;
+    ctx->closed = true;
+    ctx_release(ctx);
     return IMM3_OK;
 }
 
 extern "C" int imm3_ctx_sync(imm3_ctx *ctx) {
-    if (!ctx) return fail(IMM3_ERR_ARG, "ctx is null");
+    CTX_LIVE(ctx);
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->aux) HIPCHK(hipStreamSynchronize(ctx->aux));
@@ -325,25 +203,24 @@ extern "C" int imm3_ctx_sync(imm3_ctx *ctx) {
 }
 
 extern "C" int imm3_ctx_stream(imm3_ctx *ctx, void **stream_out) {
-    if (!ctx || !stream_out) return fail(IMM3_ERR_ARG, "null argument");
+    if (!stream_out) return fail(IMM3_ERR_ARG, "null argument");
+    CTX_LIVE(ctx);
     *stream_out = (void *)ctx->stream;
     return IMM3_OK;
 }
 
 extern "C" int imm3_ctx_set_tuning(imm3_ctx *ctx, int32_t filter_variant, int32_t grid_blocks) {
-    if (!ctx) return fail(IMM3_ERR_ARG, "ctx is null");
+    CTX_LIVE(ctx);
     ctx->filter_variant = filter_variant;
     ctx->grid_blocks = grid_blocks;
     return IMM3_OK;
 }
 
 extern "C" int imm3_ctx_devclock_enable(imm3_ctx *ctx, int32_t max_launches) {
-    if (!ctx) return fail(IMM3_ERR_ARG, "ctx is null");
+    CTX_LIVE(ctx);
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    (void)hipFree(ctx->d_stamps);
-    (void)hipFree(ctx->d_xpow8);
-    pool_drain(ctx);
+    (void)hipFree(ctx->d_stamps); // the stamp buffer only: the snappy CRC table and the buffer pool are not this call's to free
     ctx->d_stamps = nullptr;
     ctx->stamp_slots = 0;
     ctx->stamp_used = 0;
@@ -358,7 +235,8 @@ extern "C" int imm3_ctx_devclock_enable(imm3_ctx *ctx, int32_t max_launches) {
 }
 
 extern "C" int imm3_ctx_devclock_collect(imm3_ctx *ctx, float *ms_out, int32_t cap, int32_t *n_out) {
-    if (!ctx || !n_out) return fail(IMM3_ERR_ARG, "null argument");
+    if (!n_out) return fail(IMM3_ERR_ARG, "null argument");
+    CTX_LIVE(ctx);
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const int32_t n = ctx->stamp_used;
@@ -375,7 +253,8 @@ extern "C" int imm3_ctx_devclock_collect(imm3_ctx *ctx, float *ms_out, int32_t c
 }
 
 extern "C" int imm3_ctx_measure_read_gbps(imm3_ctx *ctx, uint64_t bytes, int32_t iters, double *gbps) {
-    if (!ctx || !gbps) return fail(IMM3_ERR_ARG, "null argument");
+    if (!gbps) return fail(IMM3_ERR_ARG, "null argument");
+    CTX_LIVE(ctx);
     if (iters < 1) iters = 1;
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t n_tiles = (int64_t)(bytes / (kTileRows * 4));
@@ -410,7 +289,7 @@ extern "C" int imm3_ctx_measure_read_gbps(imm3_ctx *ctx, uint64_t bytes, int32_t
 }
 
 extern "C" int imm3_ctx_timing_enable(imm3_ctx *ctx, int32_t max_records) {
-    if (!ctx) return fail(IMM3_ERR_ARG, "ctx is null");
+    CTX_LIVE(ctx);
     HIPCHK(hipSetDevice(ctx->device));
     while ((int32_t)ctx->pool.size() < max_records) {
         TimingRecord r{};
@@ -424,19 +303,20 @@ extern "C" int imm3_ctx_timing_enable(imm3_ctx *ctx, int32_t max_records) {
 }
 
 extern "C" int imm3_ctx_timing_mask(imm3_ctx *ctx, uint32_t kernel_mask) {
-    if (!ctx) return fail(IMM3_ERR_ARG, "ctx is null");
+    CTX_LIVE(ctx);
     ctx->timing_mask = kernel_mask;
     return IMM3_OK;
 }
 
 extern "C" int imm3_ctx_timing_reset(imm3_ctx *ctx) {
-    if (!ctx) return fail(IMM3_ERR_ARG, "ctx is null");
+    CTX_LIVE(ctx);
     ctx->used = 0;
     return IMM3_OK;
 }
 
 extern "C" int imm3_ctx_timing_collect(imm3_ctx *ctx, int32_t kernel_id, float *ms_out, int32_t cap, int32_t *n_out) {
-    if (!ctx || !n_out) return fail(IMM3_ERR_ARG, "null argument");
+    if (!n_out) return fail(IMM3_ERR_ARG, "null argument");
+    CTX_LIVE(ctx);
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->aux) HIPCHK(hipStreamSynchronize(ctx->aux));
@@ -475,15 +355,23 @@ struct LaunchTimer {
 // ---------------------------------------------------------------------------------------------
 static constexpr uint64_t kPad = 16384; // readable slack past every column: a partial last tile is read as a whole (1024 rows x <= 16 B)
 
+// last reference gone: free the columns (hipFree waits for the device by itself) and let go of the context
 static void segment_free(imm3_segment *seg) {
     if (!seg) return;
+    if (seg->ctx) (void)hipSetDevice(seg->ctx->device);
     for (auto &c : seg->cols) {
         if (c.owned && c.d_data) (void)hipFree(c.d_data);
         if (c.d_block_off) (void)hipFree(c.d_block_off);
         if (c.d_row_base) (void)hipFree(c.d_row_base);
         if (c.d_dense) (void)hipFree(c.d_dense);
     }
+    if (seg->ctx) ctx_release(seg->ctx);
     delete seg;
+}
+static void segment_retain(const imm3_segment *seg) { const_cast<imm3_segment *>(seg)->refs.fetch_add(1, std::memory_order_relaxed); }
+static void segment_release(const imm3_segment *cseg) {
+    imm3_segment *seg = const_cast<imm3_segment *>(cseg);
+    if (seg->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) segment_free(seg);
 }
 
 // PFOR_INT column: the rows of a block are not implied by its byte length; read the count word of every block
@@ -687,12 +575,14 @@ static int ensure_dense(imm3_ctx *ctx, const imm3_segment *cseg, int32_t col) {
 }
 
 static int segment_build(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, bool wrap, imm3_segment **out) {
-    if (!ctx || !out) return fail(IMM3_ERR_ARG, "null argument");
+    if (!out) return fail(IMM3_ERR_ARG, "null argument");
     *out = nullptr;
+    CTX_LIVE(ctx);
     if (ncols <= 0 || !cols) return fail(IMM3_ERR_ARG, "a segment needs at least one column");
     HIPCHK(hipSetDevice(ctx->device));
     std::unique_ptr<imm3_segment, void (*)(imm3_segment *)> seg(new imm3_segment(), segment_free);
     seg->ctx = ctx;
+    ctx_retain(ctx);
     seg->cols.resize((size_t)ncols);
     for (int32_t i = 0; i < ncols; ++i) {
         const imm3_column &c = cols[i];
@@ -738,9 +628,13 @@ extern "C" int imm3_segment_wrap_device(imm3_ctx *ctx, const imm3_column *cols, 
 
 extern "C" int imm3_segment_destroy(imm3_segment *seg) {
     if (!seg) return IMM3_OK;
-    (void)hipSetDevice(seg->ctx->device);
-    (void)hipStreamSynchronize(seg->ctx->stream);
-    segment_free(seg);
+    if (seg->closed) return fail(IMM3_ERR_STATE, "segment destroyed twice");
+    seg->closed = true;
+    if (!seg->ctx->closed) { // (a destroyed context has already drained its streams)
+        (void)hipSetDevice(seg->ctx->device);
+        (void)hipStreamSynchronize(seg->ctx->stream);
+    }
+    segment_release(seg); // tables / queries built on it keep the columns alive until they are destroyed
     return IMM3_OK;
 }
 
@@ -753,9 +647,12 @@ extern "C" int imm3_segment_bytes(const imm3_segment *seg, uint64_t *device_byte
 // ---------------------------------------------------------------------------------------------
 // query planning
 // ---------------------------------------------------------------------------------------------
+static void table_release(const imm3_table *t);
+
 static void query_free(imm3_query *q) {
     if (!q) return;
     imm3_ctx *ctx = q->ctx;
+    if (!ctx) { delete q; return; }
     (void)hipSetDevice(ctx->device);
     // no synchronisation: every buffer goes back to the context's pool and is only ever reused in stream order
     if (ctx->aux && q->total_on_aux) (void)hipStreamSynchronize(ctx->aux);
@@ -774,6 +671,10 @@ static void query_free(imm3_query *q) {
     pool_release(ctx, q->d_avals); pool_release(ctx, q->d_ovals);
     if (q->ev_filter_done) (void)hipEventDestroy(q->ev_filter_done);
     if (q->ev_total_done) (void)hipEventDestroy(q->ev_total_done);
+    // the query kept its inputs alive (imm3_handles.h, "Lifetimes")
+    if (q->table) table_release(q->table);
+    else if (q->seg) segment_release(q->seg);
+    ctx_release(ctx);
     delete q;
 }
 
@@ -859,8 +760,10 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
                                  const imm3_select *sels, int32_t n_sels,
                                  const int32_t *proj, int32_t n_proj, int64_t limit,
                                  int32_t table_block_size, imm3_query **out) {
-    if (!ctx || !seg || !out) return fail(IMM3_ERR_ARG, "null argument");
+    if (!seg || !out) return fail(IMM3_ERR_ARG, "null argument");
     *out = nullptr;
+    CTX_LIVE(ctx);
+    if (seg->closed || (table && table->closed)) return fail(IMM3_ERR_STATE, "the segment / table has been destroyed");
     if (seg->ctx->device != ctx->device) return fail(IMM3_ERR_ARG, "segment lives on another device");
     if (n_used <= 0 || !used_cols) return fail(IMM3_ERR_ARG, "a scan needs at least one used column");
     if (n_sels < 0 || (n_sels > 0 && !sels)) return fail(IMM3_ERR_ARG, "bad select list");
@@ -886,8 +789,11 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
 
     std::unique_ptr<imm3_query, void (*)(imm3_query *)> q(new imm3_query(), query_free);
     q->ctx = ctx;
+    ctx_retain(ctx);
     q->seg = seg;
     q->table = table;
+    if (table) const_cast<imm3_table *>(table)->refs.fetch_add(1, std::memory_order_relaxed); // (the table holds its segments)
+    else segment_retain(seg);
     q->table_block_size = table_block_size;
     q->used.assign(used_cols, used_cols + n_used);
     q->proj.assign(proj, proj + n_proj);
@@ -1113,13 +1019,29 @@ extern "C" int imm3_query_create_table(imm3_ctx *ctx, const imm3_table *table,
 // ---------------------------------------------------------------------------------------------
 // table: the tile table over all segments
 // ---------------------------------------------------------------------------------------------
+static void table_free(imm3_table *t) {
+    if (!t) return;
+    if (t->ctx) (void)hipSetDevice(t->ctx->device);
+    (void)hipFree(t->d_tile_rows);
+    for (auto p : t->d_tile_ptrs) (void)hipFree(p);
+    for (auto sg : t->segs) segment_release(sg);
+    if (t->ctx) ctx_release(t->ctx);
+    delete t;
+}
+static void table_release(const imm3_table *ct) {
+    imm3_table *t = const_cast<imm3_table *>(ct);
+    if (t->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) table_free(t);
+}
+
 extern "C" int imm3_table_create(imm3_ctx *ctx, const imm3_segment *const *segs, int32_t n_segs, imm3_table **out) {
-    if (!ctx || !out) return fail(IMM3_ERR_ARG, "null argument");
+    if (!out) return fail(IMM3_ERR_ARG, "null argument");
     *out = nullptr;
+    CTX_LIVE(ctx);
     if (n_segs <= 0 || !segs) return fail(IMM3_ERR_ARG, "a table needs at least one segment");
     HIPCHK(hipSetDevice(ctx->device));
-    std::unique_ptr<imm3_table> t(new imm3_table());
+    std::unique_ptr<imm3_table, void (*)(imm3_table *)> t(new imm3_table(), table_free);
     t->ctx = ctx;
+    ctx_retain(ctx);
     const size_t ncols = segs[0]->cols.size();
     std::vector<int32_t> all_cols(ncols);
     for (size_t c = 0; c < ncols; ++c) all_cols[c] = (int32_t)c;
@@ -1127,6 +1049,7 @@ extern "C" int imm3_table_create(imm3_ctx *ctx, const imm3_segment *const *segs,
     for (int32_t si = 0; si < n_segs; ++si) {
         const imm3_segment *sg = segs[si];
         if (!sg || sg->ctx->device != ctx->device) return fail(IMM3_ERR_ARG, "segment is null or lives on another device");
+        if (sg->closed) return fail(IMM3_ERR_STATE, "segment " + std::to_string(si) + " has been destroyed");
         if (sg->cols.size() != ncols) return fail(IMM3_ERR_ARG, "segments of one table must have the same columns");
         for (size_t c = 0; c < ncols; ++c)
             if (sg->cols[c].codec != segs[0]->cols[c].codec || sg->cols[c].width != segs[0]->cols[c].width)
@@ -1140,6 +1063,7 @@ extern "C" int imm3_table_create(imm3_ctx *ctx, const imm3_segment *const *segs,
             if (drc) return drc;
         }
         t->segs.push_back(sg);
+        segment_retain(sg); // the tile table points into the segment's columns
         t->seg_rows.push_back(L.rows);
         t->seg_first_batch.push_back((int32_t)t->batch_size.size());
         t->seg_first_word.push_back(t->tile_start.back() * kTileWords);
@@ -1182,11 +1106,13 @@ extern "C" int imm3_table_create(imm3_ctx *ctx, const imm3_segment *const *segs,
 
 extern "C" int imm3_table_destroy(imm3_table *t) {
     if (!t) return IMM3_OK;
-    (void)hipSetDevice(t->ctx->device);
-    (void)hipStreamSynchronize(t->ctx->stream);
-    (void)hipFree(t->d_tile_rows);
-    for (auto p : t->d_tile_ptrs) (void)hipFree(p);
-    delete t;
+    if (t->closed) return fail(IMM3_ERR_STATE, "table destroyed twice");
+    t->closed = true;
+    if (!t->ctx->closed) {
+        (void)hipSetDevice(t->ctx->device);
+        (void)hipStreamSynchronize(t->ctx->stream);
+    }
+    table_release(t); // queries built on it keep the tile table (and its segments) alive until they are destroyed
     return IMM3_OK;
 }
 
@@ -1229,6 +1155,7 @@ extern "C" int imm3_query_destroy(imm3_query *q) {
 
 extern "C" int imm3_query_reserve_rows(imm3_query *q, uint64_t rows) {
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    CTX_LIVE(q->ctx);
     HIPCHK(hipSetDevice(q->ctx->device));
     const int rc = ensure_row_capacity(q, rows);
     if (rc) return rc;
@@ -1272,6 +1199,7 @@ static int join_total(imm3_query *q, hipStream_t s) {
     if (q->total_on_aux) HIPCHK(hipStreamWaitEvent(s, q->ev_total_done, 0));
     return IMM3_OK;
 }
+int imm3::join_query_count(imm3_query *q, hipStream_t s) { return join_total(q, s); }
 
 static int run_select(imm3_query *q, bool overlap_total) {
     imm3_ctx *ctx = q->ctx;
@@ -1302,30 +1230,35 @@ static int run_select(imm3_query *q, bool overlap_total) {
     if (q->table && !generic_preds.empty()) return fail(IMM3_ERR_ARG, "table queries support int32 / int8 / 2-byte string predicates (<= 8 IN-list values); use per-segment queries");
     std::stable_sort(tile_preds.begin(), tile_preds.end(),
                      [](const FoldedPred *x, const FoldedPred *y) { return tile_kind(*x) < tile_kind(*y); });
-    int pass = 0;
-    int grid = 1;
-    bool count_done = false; // the filter kernel's last work-group has written total / n_emit
-    q->stage_written = false;
-    const bool single_tile_pass = generic_preds.empty() && pfor_preds.empty() && tile_preds.size() <= (size_t)kMaxTileCols;
-    // tile passes (a query without predicates is one tile pass with zero columns)
-    size_t ti = 0;
-    const bool need_empty_pass = q->preds.empty() && !q->ragged && ctx->filter_variant != 1;
-    while (ti < tile_preds.size() || (need_empty_pass && pass == 0)) {
-        TileArgs a;
-        std::memset(&a, 0, sizeof(a));
-        int n = 0, n_s2 = 0;
-        for (int k = 0; k < kMaxTileCols; ++k) a.kinds[k] = TK_NONE;
+    // Plan the tile passes first: up to 3 columns per launch, numeric kinds first (sorted), at most one 2-byte string
+    // column per launch -- so two string predicates are two passes even when only two columns are filtered.  A query
+    // without predicates is one tile pass with zero columns.
+    std::vector<std::vector<const FoldedPred *>> tile_passes;
+    while (!tile_preds.empty()) {
         std::vector<const FoldedPred *> take;
-        // numeric first (sorted), then at most one S2: scan the remaining list in order
-        for (size_t i = ti; i < tile_preds.size() && n < kMaxTileCols; ++i) {
+        int n_s2 = 0;
+        for (size_t i = 0; i < tile_preds.size() && take.size() < (size_t)kMaxTileCols; ++i) {
             const int tk = tile_kind(*tile_preds[i]);
             if (tk == TK_S2 && n_s2 == 1) continue;
             take.push_back(tile_preds[i]);
             n_s2 += tk == TK_S2;
-            ++n;
         }
-        // remove the taken ones (they are a prefix unless a second S2 was skipped)
         for (const FoldedPred *fp : take) tile_preds.erase(std::find(tile_preds.begin(), tile_preds.end(), fp));
+        tile_passes.push_back(take);
+    }
+    if (q->preds.empty() && !q->ragged && ctx->filter_variant != 1) tile_passes.emplace_back();
+    int pass = 0;
+    int grid = 1;
+    bool count_done = false; // the filter kernel's last work-group has written total / n_emit
+    q->stage_written = false;
+    // exactly ONE launch in the whole select chain: only then may that launch publish the count (and append to the count
+    // log) itself, and only then are the survivors' values staged
+    const bool single_tile_pass = generic_preds.empty() && pfor_preds.empty() && tile_passes.size() == 1;
+    for (const auto &take : tile_passes) {
+        TileArgs a;
+        std::memset(&a, 0, sizeof(a));
+        const int n = (int)take.size();
+        for (int k = 0; k < kMaxTileCols; ++k) a.kinds[k] = TK_NONE;
         for (int k = 0; k < n; ++k) {
             const FoldedPred &fp = *take[(size_t)k];
             TileCol &c = a.cols[k];
@@ -1543,18 +1476,21 @@ static int run_agg(imm3_query *q);
 
 extern "C" int imm3_query_run_select(imm3_query *q) {
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    CTX_LIVE(q->ctx);
     q->ran_project = false;
     return run_select(q, q->ctx->filter_variant == 2);
 }
 
 extern "C" int imm3_query_join_count(imm3_query *q) {
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    CTX_LIVE(q->ctx);
     HIPCHK(hipSetDevice(q->ctx->device));
     return join_total(q, q->ctx->stream);
 }
 
 extern "C" int imm3_query_run(imm3_query *q) {
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    CTX_LIVE(q->ctx);
     q->ran_project = false;
     // Reducing the count on the aux stream (tuning variant 2) measured SLOWER on MI355X / ROCm 7.2 (75.6 vs 67.1 us
     // per step: the cross-queue event packets cost more than the two same-queue launch gaps they remove), so the
@@ -1569,6 +1505,7 @@ extern "C" int imm3_query_run(imm3_query *q) {
 
 extern "C" int imm3_query_sync(imm3_query *q) {
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    CTX_LIVE(q->ctx);
     HIPCHK(hipSetDevice(q->ctx->device));
     HIPCHK(hipStreamSynchronize(q->ctx->stream));
     if (q->ctx->aux) HIPCHK(hipStreamSynchronize(q->ctx->aux));
@@ -1606,6 +1543,7 @@ extern "C" int imm3_query_batches(const imm3_query *q, int32_t *batch_size, int3
 
 extern "C" int imm3_query_log_counts(imm3_query *q, uint64_t *device_log, uint64_t capacity) {
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    CTX_LIVE(q->ctx);
     HIPCHK(hipSetDevice(q->ctx->device));
     const unsigned long long v[3] = {(unsigned long long)(uintptr_t)device_log, 0ULL, device_log ? (unsigned long long)capacity : 0ULL};
     HIPCHK(hipMemcpyAsync(q->d_total + 5, v, sizeof(v), hipMemcpyHostToDevice, q->ctx->stream));
@@ -1615,6 +1553,7 @@ extern "C" int imm3_query_log_counts(imm3_query *q, uint64_t *device_log, uint64
 
 extern "C" int imm3_query_count(imm3_query *q, uint64_t *selected_rows) {
     if (!q || !selected_rows) return fail(IMM3_ERR_ARG, "null argument");
+    CTX_LIVE(q->ctx);
     if (!q->ran_select) return fail(IMM3_ERR_STATE, "imm3_query_run has not been called");
     HIPCHK(hipSetDevice(q->ctx->device));
     unsigned long long total = 0;
@@ -1633,6 +1572,7 @@ extern "C" int imm3_query_count(imm3_query *q, uint64_t *selected_rows) {
 
 extern "C" int imm3_query_bitmap(imm3_query *q, uint64_t *words_out, int64_t n_words) {
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    CTX_LIVE(q->ctx);
     if (!q->ran_select) return fail(IMM3_ERR_STATE, "imm3_query_run has not been called");
     if (n_words < 0 || n_words > q->n_words) return fail(IMM3_ERR_ARG, "n_words exceeds the bitmap");
     if (n_words && !words_out) return fail(IMM3_ERR_ARG, "words_out is null");
@@ -1643,6 +1583,7 @@ extern "C" int imm3_query_bitmap(imm3_query *q, uint64_t *words_out, int64_t n_w
 }
 
 static int settle_rows(imm3_query *q, uint64_t *rows) {
+    CTX_LIVE(q->ctx);
     if (!q->ran_project) return fail(IMM3_ERR_STATE, "no projection has been run (n_proj == 0 or imm3_query_run not called)");
     HIPCHK(hipSetDevice(q->ctx->device));
     unsigned long long emit = 0;
@@ -1842,6 +1783,7 @@ static int run_agg(imm3_query *q) {
 
 // collect the occupied slots; grows the dense output and collects again if it was too small
 static int settle_groups(imm3_query *q, uint32_t *n_groups) {
+    CTX_LIVE(q->ctx);
     if (!q->is_agg || !q->ran_agg) return fail(IMM3_ERR_STATE, "no aggregation has been run");
     imm3_ctx *ctx = q->ctx;
     HIPCHK(hipSetDevice(ctx->device));

@@ -1,0 +1,328 @@
+// imm3_comm.cpp -- the one collective of the path, behind the C ABI: the selected-row counts of the per-segment
+// pipelines (one PipelineThread per segment, engine/src/main/scala/immutabledb/engine/Engine.scala:176-180, whose
+// results meet on the consumer thread, :190-196) summed over the GPUs with ONE 8-byte ncclAllReduce(sum, ncclUint64)
+// over RCCL / xGMI.  Nothing else is exchanged: segments are sharded s mod G and bitmaps, row
+// lists and oids stay on the GPU that produced them.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1): a host that never creates a communicator -- one GPU -- does not
+// need the library, and a host that already carries it (PyTorch-ROCm ships its own copy under the same soname) gets
+// that copy instead of a second one.
+#include "imm3_handles.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types and enums only; every call goes through the table below
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <mutex>
+
+using namespace imm3;
+
+namespace {
+
+struct Rccl {
+    void *so = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error; // why the library could not be bound
+};
+
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+void rccl_bind() {
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        g_rccl.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (g_rccl.so) break;
+    }
+    if (!g_rccl.so) {
+        const char *e = dlerror();
+        g_rccl.error = std::string("cannot load librccl.so.1: ") + (e ? e : "?");
+        return;
+    }
+    auto sym = [&](const char *name) -> void * {
+        void *p = dlsym(g_rccl.so, name);
+        if (!p && g_rccl.error.empty()) g_rccl.error = std::string("librccl has no symbol ") + name;
+        return p;
+    };
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+    g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+}
+
+int rccl_ready() {
+    std::call_once(g_rccl_once, rccl_bind);
+    if (!g_rccl.error.empty()) return fail(IMM3_ERR_DEVICE, g_rccl.error);
+    return IMM3_OK;
+}
+
+#define NCCLCHK(expr)                                                                                              \
+    do {                                                                                                           \
+        ncclResult_t _r = (expr);                                                                                  \
+        if (_r != ncclSuccess) return fail(IMM3_ERR_DEVICE, std::string(#expr) + ": " + g_rccl.GetErrorString(_r)); \
+    } while (0)
+
+} // namespace
+
+// Streams.  The collective runs on the communicator's OWN stream, fenced by events: it starts after everything already
+// enqueued on the context's stream (the scans that produce the counts, the kernel that sums them) and the context's
+// stream never waits for it -- the next pass's scans start right behind the sum while the 8 bytes cross xGMI (a
+// latency-bound message: tens of microseconds that would otherwise sit between two 60-200 us scans).  imm3_comm_sync
+// (host) / imm3_comm_join (stream side) are the ways back.
+struct imm3_comm {
+    imm3_ctx *ctx = nullptr;      // the GPU this rank drives
+    ncclComm_t nccl = nullptr;
+    int32_t world = 1, rank = 0;
+    hipStream_t stream = nullptr; // where the collectives run
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    bool in_flight = false;       // a collective has been enqueued since the last join / sync
+    unsigned long long *d_slot = nullptr; // send/receive word of imm3_comm_allreduce_count when the caller passes no buffer
+};
+
+// the collective on `buf` may start once the context's stream has reached this point
+static int fence_in(imm3_comm *c) {
+    HIPCHK(hipEventRecord(c->ev_ready, c->ctx->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_ready, 0));
+    return IMM3_OK;
+}
+static int fence_out(imm3_comm *c) {
+    HIPCHK(hipEventRecord(c->ev_done, c->stream));
+    c->in_flight = true;
+    return IMM3_OK;
+}
+
+static int comm_finish(imm3_ctx *ctx, ncclComm_t nc, int32_t world, int32_t rank, imm3_comm **out) {
+    std::unique_ptr<imm3_comm> c(new imm3_comm());
+    c->nccl = nc;
+    c->world = world;
+    c->rank = rank;
+    void *p = nullptr;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipMalloc(&p, 64);
+    if (e == hipSuccess) e = hipMemset(p, 0, 64);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        (void)g_rccl.CommDestroy(nc);
+        (void)hipFree(p);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+        if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+        return fail(IMM3_ERR_DEVICE, std::string("communicator scratch: ") + hipGetErrorString(e));
+    }
+    c->d_slot = (unsigned long long *)p;
+    c->ctx = ctx;
+    ctx_retain(ctx);
+    *out = c.release();
+    return IMM3_OK;
+}
+
+extern "C" int imm3_comm_unique_id(uint8_t *id_out) {
+    if (!id_out) return fail(IMM3_ERR_ARG, "id_out is null");
+    const int rc = rccl_ready();
+    if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == IMM3_COMM_ID_BYTES, "IMM3_COMM_ID_BYTES must be RCCL's unique-id size");
+    ncclUniqueId id;
+    NCCLCHK(g_rccl.GetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof(id));
+    return IMM3_OK;
+}
+
+extern "C" int imm3_comm_create(imm3_ctx *ctx, int32_t world, int32_t rank, const uint8_t *id, imm3_comm **out) {
+    if (!out) return fail(IMM3_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (!ctx) return fail(IMM3_ERR_ARG, "ctx is null");
+    if (ctx->closed) return fail(IMM3_ERR_STATE, "the context has been destroyed");
+    if (world < 1 || rank < 0 || rank >= world || !id) return fail(IMM3_ERR_ARG, "bad world / rank / id");
+    const int rc = rccl_ready();
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof(uid));
+    ncclComm_t nc = nullptr;
+    NCCLCHK(g_rccl.CommInitRank(&nc, world, uid, rank));
+    return comm_finish(ctx, nc, world, rank, out);
+}
+
+extern "C" int imm3_comm_create_all(imm3_ctx *const *ctxs, int32_t n, imm3_comm **out) {
+    if (!out) return fail(IMM3_ERR_ARG, "out is null");
+    for (int32_t i = 0; i < n; ++i) out[i] = nullptr;
+    if (n < 1 || !ctxs) return fail(IMM3_ERR_ARG, "a communicator needs at least one context");
+    std::vector<int> devs((size_t)n);
+    for (int32_t i = 0; i < n; ++i) {
+        if (!ctxs[i]) return fail(IMM3_ERR_ARG, "ctx is null");
+        if (ctxs[i]->closed) return fail(IMM3_ERR_STATE, "a context has been destroyed");
+        devs[(size_t)i] = ctxs[i]->device;
+        for (int32_t j = 0; j < i; ++j)
+            if (devs[(size_t)j] == devs[(size_t)i]) return fail(IMM3_ERR_ARG, "one context per device: two contexts share device " + std::to_string(devs[(size_t)i]));
+    }
+    const int rc = rccl_ready();
+    if (rc) return rc;
+    std::vector<ncclComm_t> ncs((size_t)n, nullptr);
+    NCCLCHK(g_rccl.CommInitAll(ncs.data(), n, devs.data()));
+    for (int32_t i = 0; i < n; ++i) {
+        const int frc = comm_finish(ctxs[i], ncs[(size_t)i], n, i, &out[i]);
+        if (frc) {
+            for (int32_t j = i + 1; j < n; ++j) (void)g_rccl.CommDestroy(ncs[(size_t)j]);
+            return frc;
+        }
+    }
+    return IMM3_OK;
+}
+
+extern "C" int imm3_comm_destroy(imm3_comm *c) {
+    if (!c) return IMM3_OK;
+    (void)hipSetDevice(c->ctx->device);
+    if (!c->ctx->closed) (void)hipStreamSynchronize(c->ctx->stream);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
+    (void)hipStreamDestroy(c->stream);
+    (void)hipEventDestroy(c->ev_ready);
+    (void)hipEventDestroy(c->ev_done);
+    (void)hipFree(c->d_slot);
+    ctx_release(c->ctx);
+    delete c;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_comm_info(const imm3_comm *c, int32_t *world, int32_t *rank) {
+    if (!c) return fail(IMM3_ERR_ARG, "comm is null");
+    if (world) *world = c->world;
+    if (rank) *rank = c->rank;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_comm_allreduce_u64(imm3_comm *c, uint64_t *device_buf, uint64_t n) {
+    if (!c || !device_buf || n == 0) return fail(IMM3_ERR_ARG, "bad argument");
+    if (c->ctx->closed) return fail(IMM3_ERR_STATE, "the context of this communicator has been destroyed");
+    HIPCHK(hipSetDevice(c->ctx->device));
+    int rc = fence_in(c);
+    if (rc) return rc;
+    NCCLCHK(g_rccl.AllReduce(device_buf, device_buf, (size_t)n, ncclUint64, ncclSum, c->nccl, c->stream));
+    return fence_out(c);
+}
+
+extern "C" int imm3_comm_sync(imm3_comm *c) {
+    if (!c) return fail(IMM3_ERR_ARG, "comm is null");
+    HIPCHK(hipSetDevice(c->ctx->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->in_flight = false;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_comm_join(imm3_comm *c) {
+    if (!c) return fail(IMM3_ERR_ARG, "comm is null");
+    if (c->ctx->closed) return fail(IMM3_ERR_STATE, "the context of this communicator has been destroyed");
+    HIPCHK(hipSetDevice(c->ctx->device));
+    if (c->in_flight) HIPCHK(hipStreamWaitEvent(c->ctx->stream, c->ev_done, 0));
+    return IMM3_OK;
+}
+
+// this rank's part: the counts of its queries summed into `dst` on the context's stream, behind the scans that
+// produce them (same stream; a count reduced on the aux stream is joined first)
+static int local_sum(imm3_comm *c, imm3_query *const *queries, int32_t n_queries, unsigned long long *dst) {
+    imm3_ctx *ctx = c->ctx;
+    hipStream_t s = ctx->stream;
+    // the communicator's own word may still be travelling from the previous call: wait for that collective (stream side)
+    if (dst == c->d_slot && c->in_flight) HIPCHK(hipStreamWaitEvent(s, c->ev_done, 0));
+    if (n_queries == 0) {
+        HIPCHK(hipMemsetAsync(dst, 0, sizeof(unsigned long long), s));
+        return IMM3_OK;
+    }
+    for (int32_t base = 0; base < n_queries; base += kMaxSumCounts) {
+        SumCountsArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.n = std::min<int32_t>(kMaxSumCounts, n_queries - base);
+        for (int32_t i = 0; i < a.n; ++i) {
+            imm3_query *q = queries[base + i];
+            if (!q) return fail(IMM3_ERR_ARG, "query is null");
+            if (q->ctx != ctx) return fail(IMM3_ERR_ARG, "the query runs on another context than the communicator");
+            if (!q->ran_select) return fail(IMM3_ERR_STATE, "imm3_query_run has not been called");
+            const int jrc = join_query_count(q, s);
+            if (jrc) return jrc;
+            a.src[i] = q->d_total;
+        }
+        a.accumulate = base > 0;
+        a.dst = dst;
+        launch_sum_counts(a, s);
+        HIPCHK(hipGetLastError());
+    }
+    return IMM3_OK;
+}
+
+extern "C" int imm3_comm_allreduce_count(imm3_comm *c, imm3_query *const *queries, int32_t n_queries, uint64_t *device_out,
+                                         uint64_t *host_out) {
+    if (!c || n_queries < 0 || (n_queries > 0 && !queries)) return fail(IMM3_ERR_ARG, "bad argument");
+    if (c->ctx->closed) return fail(IMM3_ERR_STATE, "the context of this communicator has been destroyed");
+    HIPCHK(hipSetDevice(c->ctx->device));
+    unsigned long long *dst = device_out ? (unsigned long long *)device_out : c->d_slot;
+    int rc = local_sum(c, queries, n_queries, dst);
+    if (rc) return rc;
+    rc = fence_in(c);
+    if (rc) return rc;
+    NCCLCHK(g_rccl.AllReduce(dst, dst, 1, ncclUint64, ncclSum, c->nccl, c->stream));
+    rc = fence_out(c);
+    if (rc) return rc;
+    if (host_out) {
+        unsigned long long v = 0;
+        HIPCHK(hipMemcpyAsync(&v, dst, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->in_flight = false;
+        *host_out = v;
+    }
+    return IMM3_OK;
+}
+
+// Single-process shape (one JVM, every GPU): the per-device collectives are issued by ONE thread, so they go into a
+// ncclGroupStart / ncclGroupEnd section (RCCL would otherwise wait in the first call for the ranks behind it).
+extern "C" int imm3_comm_allreduce_count_all(imm3_comm *const *comms, int32_t n_comms, imm3_query *const *const *queries,
+                                             const int32_t *n_queries, uint64_t *host_out) {
+    if (!comms || n_comms < 1 || !n_queries || !queries) return fail(IMM3_ERR_ARG, "bad argument");
+    for (int32_t i = 0; i < n_comms; ++i) {
+        if (!comms[i] || n_queries[i] < 0 || (n_queries[i] > 0 && !queries[i])) return fail(IMM3_ERR_ARG, "bad argument");
+        if (comms[i]->ctx->closed) return fail(IMM3_ERR_STATE, "the context of a communicator has been destroyed");
+        HIPCHK(hipSetDevice(comms[i]->ctx->device));
+        int rc = local_sum(comms[i], queries[i], n_queries[i], comms[i]->d_slot);
+        if (!rc) rc = fence_in(comms[i]);
+        if (rc) return rc;
+    }
+    NCCLCHK(g_rccl.GroupStart());
+    for (int32_t i = 0; i < n_comms; ++i) {
+        imm3_comm *c = comms[i];
+        const ncclResult_t r = g_rccl.AllReduce(c->d_slot, c->d_slot, 1, ncclUint64, ncclSum, c->nccl, c->stream);
+        if (r != ncclSuccess) {
+            (void)g_rccl.GroupEnd();
+            return fail(IMM3_ERR_DEVICE, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+        }
+    }
+    NCCLCHK(g_rccl.GroupEnd());
+    for (int32_t i = 0; i < n_comms; ++i) {
+        HIPCHK(hipSetDevice(comms[i]->ctx->device));
+        const int rc = fence_out(comms[i]);
+        if (rc) return rc;
+    }
+    if (host_out) {
+        imm3_comm *c = comms[0];
+        unsigned long long v = 0;
+        HIPCHK(hipSetDevice(c->ctx->device));
+        HIPCHK(hipMemcpyAsync(&v, c->d_slot, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->in_flight = false;
+        *host_out = v;
+    }
+    return IMM3_OK;
+}

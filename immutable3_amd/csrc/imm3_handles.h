@@ -1,0 +1,188 @@
+// imm3_handles.h -- the handle structs behind include/imm3.h, shared by the translation units of the C ABI
+// (imm3_api.cpp: planning + launches; imm3_comm.cpp: the RCCL count reduce).  Private to csrc/.
+#pragma once
+
+#include "../../include/imm3.h"
+#include "imm3_internal.h"
+
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+namespace imm3 {
+int fail(int code, const std::string &msg); // sets the calling thread's imm3_last_error() text (imm3_api.cpp)
+}
+using imm3::fail;
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail(IMM3_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------------------------
+struct TimingRecord {
+    int32_t kernel_id;
+    hipEvent_t start, stop;
+};
+
+// Lifetimes.  Every handle is reference counted: the caller's handle holds one reference, and every handle created
+// FROM it holds another (segment / table / query / comm -> context; table -> its segments; query -> its segment or
+// table).  imm3_*_destroy marks the handle closed and drops the caller's reference; the memory behind it goes when
+// the last dependant is destroyed, so handles may be destroyed in ANY order (a JVM finalizer or a Python __del__ run
+// by the garbage collector gives no order).  Work submitted through a handle whose context has been destroyed fails
+// with IMM3_ERR_STATE; destroying the same handle twice while dependants keep it alive does too.
+struct imm3_ctx {
+    std::atomic<int> refs{1};
+    bool closed = false;            // imm3_ctx_destroy has run: streams, events and the buffer pool are gone
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipStream_t aux = nullptr;      // count reduce of select-only runs: overlaps the next scan on `stream`
+    int filter_variant = 0;
+    int grid_blocks = 0;
+    bool timing = false;
+    uint32_t timing_mask = 0xFFFFFFFFu;
+    std::vector<TimingRecord> pool; // pre-created event pairs
+    size_t used = 0;
+    // Caching allocator for per-query buffers.  Every user of such a buffer runs on `stream`, so a block freed by one
+    // query and handed to the next is reused in stream order: no synchronisation, no hipMalloc/hipFree (each ~50-100 us)
+    // on the query path once the pool is warm.
+    std::mutex pool_mu;
+    std::multimap<size_t, void *> pool_free;
+    std::unordered_map<void *, size_t> pool_size;
+    size_t pool_cached = 0;
+    // device-clock stamps (diagnostics): slot i = kMaxFilterGrid {start, end} pairs for the i-th tile launch
+    unsigned long long *d_stamps = nullptr;
+    int32_t stamp_slots = 0, stamp_used = 0;
+    std::vector<int32_t> stamp_grids;
+    uint32_t *d_xpow8 = nullptr;    // snappy CRC-32C check: x^(8 n) mod P for n = 0 .. 32768
+};
+
+static inline bool is_snappy(int32_t c) { return c == IMM3_SNAPPY_INT || c == IMM3_SNAPPY_TINYINT || c == IMM3_SNAPPY_STRING; }
+static inline bool is_compressed(int32_t c) { return c == IMM3_PFOR_INT || is_snappy(c); }
+// the DENSE_* codec whose decoded vectors a column's values are (type dispatch of ScanOp / SelectOp / ProjectAggOp)
+static inline int32_t value_codec(int32_t c) {
+    if (c == IMM3_PFOR_INT || c == IMM3_SNAPPY_INT) return IMM3_DENSE_INT;
+    if (c == IMM3_SNAPPY_TINYINT) return IMM3_DENSE_TINYINT;
+    if (c == IMM3_SNAPPY_STRING) return IMM3_DENSE_STRING;
+    return c;
+}
+
+struct SegCol {
+    int32_t codec = 0, width = 0;
+    int32_t vcodec = 0;                // value_codec(codec)
+    uint8_t *d_data = nullptr;
+    bool owned = false;
+    uint64_t bytes = 0;
+    std::vector<int32_t> offsets;
+    // PFOR_INT (imm3_codec.hip) / snappy (imm3_snappy.hip): the blocks stay compressed in d_data
+    std::vector<int32_t> block_rows;   // the rows each block declares (PFOR: its count word; snappy: uncompressed bytes / width)
+    int32_t in_cap = 0, out_cap = 0;   // snappy: LDS bytes k_snappy_decode needs for the largest block / chunk
+    int64_t rows = 0;
+    bool tile_aligned = false;         // every block but the last holds exactly 1024 rows: block k == bitmap tile k
+    uint32_t *d_block_off = nullptr;   // n_blocks + 1 byte offsets
+    uint32_t *d_row_base = nullptr;    // n_blocks + 1 first rows
+    uint8_t *d_dense = nullptr;        // decoded int32 column, made on first need (Project, aggregation, ragged, table)
+};
+
+struct imm3_segment {
+    std::atomic<int> refs{1};
+    bool closed = false;
+    imm3_ctx *ctx = nullptr;
+    std::vector<SegCol> cols;
+    uint64_t device_bytes = 0;
+    std::mutex decode_mu;              // guards the lazy d_dense of PFOR_INT columns
+};
+
+// the flat, fixed-width form of a column (what every kernel but k_filter_pfor reads)
+static inline const uint8_t *col_flat(const SegCol &sc) { return is_compressed(sc.codec) ? sc.d_dense : sc.d_data; }
+
+struct imm3_table { // all segments of one table as one scan unit: the tile table
+    std::atomic<int> refs{1};
+    bool closed = false;
+    imm3_ctx *ctx = nullptr;
+    std::vector<const imm3_segment *> segs;
+    std::vector<int64_t> seg_rows;     // rows per segment
+    std::vector<int64_t> tile_start;   // n_segs + 1: first (virtual) tile of each segment
+    int64_t n_tiles = 0, n_rows = 0;
+    uint32_t *d_tile_rows = nullptr;   // valid rows per tile
+    std::vector<void **> d_tile_ptrs;  // per column: device array of per-tile pointers
+    // batches of all segments (every column shares one block layout: checked at creation), built once: a query over 98
+    // README-style segments otherwise spends ~0.4 ms of host time re-deriving them
+    std::vector<int32_t> batch_size, batch_k; // rows; index of the batch within its segment (oid = k * table.blockSize)
+    std::vector<int64_t> batch_word_off;
+    std::vector<int32_t> seg_first_batch;     // n_segs + 1
+    std::vector<int64_t> seg_first_word;      // n_segs + 1
+};
+
+struct FoldedPred { // all SelectOp leaves on one segment column, folded
+    int32_t seg_col = 0;
+    int32_t kind = 0, width = 0;
+    int64_t lo = 0, hi = 0;                // numeric closed interval
+    std::vector<std::string> match;        // string: surviving IN-list values (each exactly width bytes)
+    uint8_t *d_blob = nullptr;             // device copy when it does not fit the kernel arguments
+    uint8_t *d_stage = nullptr;            // survivors' values staged per tile (column is also projected)
+    bool pfor = false;                     // PFOR_INT column evaluated on its compressed blocks (k_filter_pfor)
+};
+
+struct imm3_query {
+    imm3_ctx *ctx = nullptr;
+    const imm3_segment *seg = nullptr;   // the segment (table queries: the first one, for the schema)
+    const imm3_table *table = nullptr;   // table query: columns are addressed through the tile table
+    int32_t table_block_size = 0;   // table.blockSize as given at creation (oid of a batch = index in its segment * blockSize)
+    std::vector<int32_t> used;     // segment column index of each used column
+    std::vector<int32_t> proj;     // index into `used`
+    int64_t limit = 0;
+    // layout (Scan.scala:55-60)
+    std::vector<int32_t> batch_size, batch_oid;
+    std::vector<int64_t> batch_word_off;
+    int64_t n_rows = 0, n_words = 0, n_tiles = 0, n_chunks = 0;
+    bool ragged = false;
+    bool always_false = false;
+    std::vector<FoldedPred> preds;
+    // device buffers
+    uint64_t *d_bitmap = nullptr;
+    uint32_t *d_tile_offsets = nullptr, *d_chunk_sums = nullptr, *d_block_partials = nullptr;
+    unsigned long long *d_total = nullptr, *d_n_emit = nullptr; // adjacent: d_n_emit = d_total + 1; d_total + 2 = status word
+    bool has_pfor_pass = false;   // a k_filter_pfor pass may flag malformed blocks in the status word
+    unsigned long long h_init[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // host image of the block above at creation
+    uint32_t *d_word_row_base = nullptr;
+    uint8_t *d_word_nvalid = nullptr;
+    uint32_t *d_row_index = nullptr;
+    std::vector<uint8_t *> d_proj;
+    uint64_t cap_rows = 0;
+    bool reserved = false;
+    bool ran_select = false, ran_project = false;
+    // group-by aggregation
+    bool is_agg = false;
+    std::vector<int32_t> group_cols;           // index into `used`
+    std::vector<imm3_aggregate> aggs;
+    uint32_t agg_mask = 0;
+    unsigned long long *d_akeys = nullptr, *d_acounts = nullptr, *d_okeys = nullptr, *d_ocounts = nullptr;
+    uint32_t *d_afirst = nullptr, *d_ofirst = nullptr, *d_ameta = nullptr; // d_ameta: {n_groups, overflow}
+    long long *d_avals = nullptr, *d_ovals = nullptr;
+    uint32_t out_cap = 0;
+    bool ran_agg = false;
+    // select-only runs: the count reduce goes to ctx->aux, fenced by these events
+    hipEvent_t ev_filter_done = nullptr, ev_total_done = nullptr;
+    bool total_on_aux = false;
+    bool stage_written = false;   // the last select run filled the staging buffers (single tile pass)
+};
+
+
+// reference counting (imm3_api.cpp)
+namespace imm3 {
+void ctx_retain(imm3_ctx *c);
+void ctx_release(imm3_ctx *c);
+int join_query_count(imm3_query *q, hipStream_t s); // make `s` wait for the query's count if it was reduced on the aux stream
+}

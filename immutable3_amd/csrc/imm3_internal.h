@@ -215,6 +215,17 @@ struct SnappyArgs {
 void launch_snappy_sizes(const uint8_t *data, const uint32_t *block_off, int64_t n_blocks, uint32_t *sizes, uint32_t *max_chunk, hipStream_t s);
 void launch_snappy_decode(const SnappyArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 
+// k_sum_counts: the selected-row counts of up to kMaxSumCounts queries (device words) -> one device word; the send buffer
+// of the RCCL count all-reduce (imm3_comm.cpp)
+constexpr int kMaxSumCounts = 32;
+struct SumCountsArgs {
+    const unsigned long long *src[kMaxSumCounts];
+    int32_t n;
+    int32_t accumulate;          // 1: add to *dst instead of overwriting it (more than kMaxSumCounts queries)
+    unsigned long long *dst;
+};
+void launch_sum_counts(const SumCountsArgs &a, hipStream_t s);
+
 bool launch_filter_tile(const TileArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 void launch_filter_generic(const FilterArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 void launch_total(const TotalArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);

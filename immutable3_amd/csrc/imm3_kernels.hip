@@ -491,6 +491,20 @@ __global__ __launch_bounds__(64) void k_total(const TotalArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_sum_counts: one wave adds the counts of the queries a rank ran in this pass (lane i reads query i's count word)
+// into the word the RCCL all-reduce sends (Engine.scala:176-196: the per-segment pipelines' results meet in one place).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_sum_counts(const SumCountsArgs a) {
+    const int lane = threadIdx.x;
+    unsigned long long v = lane < a.n ? *a.src[lane] : 0ULL;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if (lane == 0) *a.dst = (a.accumulate ? *a.dst : 0ULL) + v;
+}
+
+void launch_sum_counts(const SumCountsArgs &a, hipStream_t s) { hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(64), 0, s, a); }
+
+// ---------------------------------------------------------------------------------------------
 // k_scan: per-tile survivor counts straight from the bitmap (thread t popcounts the 16 words = one 128-B line
 // of tile t), exclusive prefix within chunks of 1024 tiles, per-chunk sums.  Reading the 12.5 MB bitmap here
 // is cheaper than making the hot filter kernel store a 4-byte count per tile.

@@ -37,10 +37,17 @@ EXPORTS = [
     "imm3_query_run", "imm3_query_run_select", "imm3_query_sync", "imm3_query_join_count", "imm3_query_log_counts",
     "imm3_query_layout", "imm3_query_batches", "imm3_query_count", "imm3_query_bitmap",
     "imm3_query_row_count", "imm3_query_fetch_rows", "imm3_query_device_ptr",
-    "imm3_ctx_timing_enable", "imm3_ctx_timing_reset", "imm3_ctx_timing_mask", "imm3_ctx_timing_collect", "imm3_ctx_set_tuning", "imm3_ctx_measure_read_gbps", "imm3_ctx_devclock_enable", "imm3_ctx_devclock_collect",
+    "imm3_comm_unique_id", "imm3_comm_create", "imm3_comm_create_all", "imm3_comm_destroy", "imm3_comm_info",
+    "imm3_comm_sync", "imm3_comm_join", "imm3_comm_allreduce_u64", "imm3_comm_allreduce_count", "imm3_comm_allreduce_count_all",
     "imm3_pfor_encode_bound", "imm3_pfor_encode_block", "imm3_pfor_encode_column",
     "imm3_snappy_encode_bound", "imm3_snappy_encode_block",
 ]
+# include/imm3_diag.h: measurement / tuning hooks, not part of the drop-in boundary
+DIAG_EXPORTS = [
+    "imm3_ctx_timing_enable", "imm3_ctx_timing_reset", "imm3_ctx_timing_mask", "imm3_ctx_timing_collect", "imm3_ctx_set_tuning",
+    "imm3_ctx_measure_read_gbps", "imm3_ctx_devclock_enable", "imm3_ctx_devclock_collect",
+]
+COMM_ID_BYTES = 128
 
 
 class Imm3Error(Exception):
@@ -134,7 +141,17 @@ def load() -> C.CDLL:
     L.imm3_ctx_measure_read_gbps.argtypes = [vp, u64, i32, P(C.c_double)]
     L.imm3_ctx_devclock_enable.argtypes = [vp, i32]
     L.imm3_ctx_devclock_collect.argtypes = [vp, vp, i32, P(i32)]
-    for name in EXPORTS:
+    L.imm3_comm_unique_id.argtypes = [vp]
+    L.imm3_comm_create.argtypes = [vp, i32, i32, vp, P(vp)]
+    L.imm3_comm_create_all.argtypes = [P(vp), i32, P(vp)]
+    L.imm3_comm_destroy.argtypes = [vp]
+    L.imm3_comm_info.argtypes = [vp, P(i32), P(i32)]
+    L.imm3_comm_sync.argtypes = [vp]
+    L.imm3_comm_join.argtypes = [vp]
+    L.imm3_comm_allreduce_u64.argtypes = [vp, vp, u64]
+    L.imm3_comm_allreduce_count.argtypes = [vp, P(vp), i32, vp, P(u64)]
+    L.imm3_comm_allreduce_count_all.argtypes = [P(vp), i32, P(P(vp)), P(i32), P(u64)]
+    for name in EXPORTS + DIAG_EXPORTS:
         fn = getattr(L, name)
         if name not in ("imm3_last_error", "imm3_pfor_encode_bound", "imm3_snappy_encode_bound"):
             fn.restype = C.c_int
@@ -199,8 +216,14 @@ class Context:
     """imm3_ctx: device id + HIP stream."""
 
     def __init__(self, device: int = 0, stream: Optional[int] = None):
+        """stream: a hipStream_t as an int (e.g. torch.cuda.Stream().cuda_stream), or None to let the library create its
+        own non-blocking stream.  0 -- what torch reports for its default stream -- cannot be named through the C ABI
+        (NULL means "create one"), and silently getting a private stream is how work ends up unordered: refuse it."""
+        if stream is not None and int(stream) == 0:
+            raise ValueError("stream 0 is HIP's legacy default stream and cannot be passed to imm3_ctx_create; pass None "
+                             "(library-owned stream) or a real stream such as torch.cuda.Stream().cuda_stream")
         self._h = C.c_void_p()
-        _check(load().imm3_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        _check(load().imm3_ctx_create(device, C.c_void_p(int(stream)) if stream is not None else None, C.byref(self._h)))
         self.device = device
         # handles created on this context; closed before the context itself (they hold raw pointers into it)
         self._children = weakref.WeakSet()
@@ -251,8 +274,10 @@ class Context:
 
     def close(self):
         if self._h:
+            # The C ABI allows any destruction order (handles are reference counted); closing dependants first simply
+            # returns their device memory now instead of when the garbage collector gets to them.
             kids = list(self._children)
-            for kind in (DeviceQuery, DeviceTable, DeviceSegment):   # queries -> tables -> segments
+            for kind in (Comm, DeviceQuery, DeviceTable, DeviceSegment):   # comms, queries -> tables -> segments
                 for k in kids:
                     if isinstance(k, kind):
                         k.close()
@@ -486,6 +511,80 @@ class DeviceQuery:
     def close(self):
         if self._h:
             load().imm3_query_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_unique_id() -> bytes:
+    """imm3_comm_unique_id: rank 0 makes it, the host hands it to every rank (any channel)."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(load().imm3_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """imm3_comm: this rank's end of the RCCL communicator; the one collective of the path is the count all-reduce."""
+
+    def __init__(self, ctx: Context, world: int, rank: int, unique_id: bytes):
+        assert len(unique_id) == COMM_ID_BYTES
+        self.ctx, self.world, self.rank = ctx, world, rank
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(load().imm3_comm_create(ctx._h, world, rank, buf, C.byref(self._h)))
+        ctx._adopt(self)
+
+    @classmethod
+    def create_all(cls, ctxs: Sequence[Context]) -> List["Comm"]:
+        """Single-process flavour (ncclCommInitAll): one context per device, one Comm per context."""
+        n = len(ctxs)
+        harr = (C.c_void_p * n)(*[c._h for c in ctxs])
+        out = (C.c_void_p * n)()
+        _check(load().imm3_comm_create_all(harr, n, out))
+        comms = []
+        for i, c in enumerate(ctxs):
+            o = cls.__new__(cls)
+            o.ctx, o.world, o.rank, o._h = c, n, i, C.c_void_p(out[i])
+            c._adopt(o)
+            comms.append(o)
+        return comms
+
+    def sync(self):
+        _check(load().imm3_comm_sync(self._h))
+
+    def join(self):
+        """The context's stream waits (stream side) for the last collective."""
+        _check(load().imm3_comm_join(self._h))
+
+    def allreduce_u64(self, device_ptr: int, n: int):
+        _check(load().imm3_comm_allreduce_u64(self._h, C.c_void_p(device_ptr), n))
+
+    def allreduce_count(self, queries: Sequence["DeviceQuery"], device_out: int = 0, wait: bool = True) -> Optional[int]:
+        """Sum of the queries' selected-row counts over all ranks.  wait=False only enqueues (device_out receives it)."""
+        qs = (C.c_void_p * max(1, len(queries)))(*[q._h for q in queries])
+        host = C.c_uint64(0)
+        _check(load().imm3_comm_allreduce_count(self._h, qs, len(queries), C.c_void_p(device_out) if device_out else None,
+                                                C.byref(host) if wait else None))
+        return host.value if wait else None
+
+    @staticmethod
+    def allreduce_count_all(comms: Sequence["Comm"], queries_per_comm: Sequence[Sequence["DeviceQuery"]]) -> int:
+        n = len(comms)
+        carr = (C.c_void_p * n)(*[c._h for c in comms])
+        qarrs = [(C.c_void_p * max(1, len(qs)))(*[q._h for q in qs]) for qs in queries_per_comm]
+        qq = (C.POINTER(C.c_void_p) * n)(*[C.cast(a, C.POINTER(C.c_void_p)) for a in qarrs])
+        nq = (C.c_int32 * n)(*[len(qs) for qs in queries_per_comm])
+        host = C.c_uint64(0)
+        _check(load().imm3_comm_allreduce_count_all(carr, n, qq, nq, C.byref(host)))
+        return host.value
+
+    def close(self):
+        if self._h:
+            load().imm3_comm_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

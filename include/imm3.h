@@ -60,7 +60,7 @@ enum {
     IMM3_ERR_LAYOUT = 4,                /* block tables the reference would fault on / mis-join      */
     IMM3_ERR_ARG = 5,                   /* bad handle / index / null pointer                         */
     IMM3_ERR_DEVICE = 6,                /* HIP runtime error (message carries hipGetErrorString)     */
-    IMM3_ERR_STATE = 7                  /* result requested before imm3_query_run()                  */
+    IMM3_ERR_STATE = 7                  /* result requested before imm3_query_run(); destroyed context */
 };
 
 typedef struct imm3_ctx imm3_ctx;         /* device + stream + scratch                                   */
@@ -100,7 +100,12 @@ const char *imm3_last_error(void); /* thread-local; valid until the next failing
 int imm3_device_count(int *count);
 
 /* ---- context: device id + stream ---- */
-/* stream: a hipStream_t to launch on (e.g. the caller's current stream), or NULL to create one. */
+/* stream: a hipStream_t to launch on, or NULL to create one (non-blocking).  NULL is also what HIP calls the legacy
+ * default stream, so that stream cannot be named here: a caller that wants its own work ordered with the library's
+ * passes a real stream (and enqueues on it), or synchronises through imm3_ctx_sync / imm3_query_sync.
+ * Handles may be destroyed in any order: a context outlives, internally, the segments / tables / queries / comms made
+ * from it, a segment the tables and queries that read it.  Calls through a handle whose context was destroyed fail
+ * with IMM3_ERR_STATE. */
 int imm3_ctx_create(int device, void *stream, imm3_ctx **out);
 int imm3_ctx_destroy(imm3_ctx *ctx);
 int imm3_ctx_sync(imm3_ctx *ctx);
@@ -111,8 +116,9 @@ int imm3_ctx_stream(imm3_ctx *ctx, void **stream_out);
  * process lifetime, SegmentManager.scala:22,81-87).  The library owns the device copy; the host
  * buffers may be unmapped after the call returns. ---- */
 int imm3_segment_create(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, imm3_segment **out);
-/* same, but `dat` fields are DEVICE pointers that stay owned by the caller (no copy; they must be
- * readable for 4 KiB past dat_bytes, or padded; see DESIGN.md "data layout"). */
+/* same, but `dat` fields are DEVICE pointers that stay owned by the caller (no copy).  Each must be 16-byte aligned and
+ * readable for 16 KiB past dat_bytes: the partial last tile of a column is read as a whole tile (1024 rows x width),
+ * and the aggregation / gather kernels fetch the aligned dword around a narrow value. */
 int imm3_segment_wrap_device(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, imm3_segment **out);
 int imm3_segment_destroy(imm3_segment *seg);
 int imm3_segment_bytes(const imm3_segment *seg, uint64_t *device_bytes);
@@ -230,26 +236,38 @@ int imm3_query_fetch_rows(imm3_query *q, uint32_t *row_index_out, void *const *c
  *        3 = emitted row count (one uint64), 16+j = projected column j */
 int imm3_query_device_ptr(imm3_query *q, int32_t which, void **ptr);
 
-/* ---- live kernel timing (HIP events on the context's stream) ----
- * When enabled, every kernel launch of this context is bracketed by an event pair.
- * kernel ids: 0 = scan+select, 1 = offsets scan, 2 = compact+gather, 3 = count reduce, 4 = group-by aggregation,
- *             5 = PFOR_INT / snappy column decode. */
-int imm3_ctx_timing_enable(imm3_ctx *ctx, int32_t max_records);
-int imm3_ctx_timing_reset(imm3_ctx *ctx);
-/* Only launches whose kernel id has its bit set in `kernel_mask` are bracketed (default: all). */
-int imm3_ctx_timing_mask(imm3_ctx *ctx, uint32_t kernel_mask);
-/* Synchronises, then writes up to cap durations (ms) of launches of `kernel_id`, oldest first. */
-int imm3_ctx_timing_collect(imm3_ctx *ctx, int32_t kernel_id, float *ms_out, int32_t cap, int32_t *n_out);
-
-/* Cross-check of the event timing: when enabled, every tile-kernel launch also records, per work-group, the 100 MHz
- * device clock at entry and exit; collect() returns per launch (last work-group's exit - first work-group's entry) in
- * ms, oldest first.  Diagnostics only (bench.py's instrumented pass); costs two stores per work-group. */
-int imm3_ctx_devclock_enable(imm3_ctx *ctx, int32_t max_launches);
-int imm3_ctx_devclock_collect(imm3_ctx *ctx, float *ms_out, int32_t cap, int32_t *n_out);
-
-/* Empirical read-only streaming ceiling of this GPU: times a kernel that only reads `bytes` (non-temporal dword loads,
- * same tiling and grid as the scan+select kernel, three rotated buffers) and returns the median GB/s over `iters`. */
-int imm3_ctx_measure_read_gbps(imm3_ctx *ctx, uint64_t bytes, int32_t iters, double *gbps);
+/* ---- multi-GPU: the count reduce.  Segments shard one per GPU -- segment s belongs to GPU s mod G -- and
+ * every GPU runs its own PipelineThreads (Engine.scala:176-180); bitmaps, row lists and oids stay where they were
+ * produced.  The ONE exchange is the selected-row count, summed over the GPUs with one 8-byte
+ * ncclAllReduce(sum, ncclUint64) over RCCL / xGMI, ordered behind the scans that produce the counts.
+ * RCCL is bound at run time (librccl.so.1); a single-GPU host never needs it.
+ *   one process per GPU : rank 0 calls imm3_comm_unique_id, the host hands the 128 bytes to every rank (any channel:
+ *                         a file, a socket, a key-value store), every rank calls imm3_comm_create
+ *   one process, G GPUs : imm3_comm_create_all over one context per device (the JVM host's shape: one Engine, one
+ *                         GpuSegmentManager per device); collectives through imm3_comm_allreduce_count_all ---- */
+#define IMM3_COMM_ID_BYTES 128
+typedef struct imm3_comm imm3_comm;
+int imm3_comm_unique_id(uint8_t *id_out /* IMM3_COMM_ID_BYTES */);
+int imm3_comm_create(imm3_ctx *ctx, int32_t world, int32_t rank, const uint8_t *id, imm3_comm **out);
+int imm3_comm_create_all(imm3_ctx *const *ctxs, int32_t n, imm3_comm **out /* n handles */);
+int imm3_comm_destroy(imm3_comm *c);
+int imm3_comm_info(const imm3_comm *c, int32_t *world, int32_t *rank);
+/* Streams: a collective runs on the communicator's OWN stream.  It starts after everything enqueued so far on the
+ * context's stream, and the context's stream does not wait for it: the next pass's scans overlap the message.
+ * imm3_comm_sync blocks the host until the communicator's stream is idle; imm3_comm_join makes the context's stream
+ * wait for the last collective (stream side, no host block) -- for a device consumer of the reduced words. */
+int imm3_comm_sync(imm3_comm *c);
+int imm3_comm_join(imm3_comm *c);
+/* In-place sum of n device words over the ranks (asynchronous). */
+int imm3_comm_allreduce_u64(imm3_comm *c, uint64_t *device_buf, uint64_t n);
+/* The selected-row counts of this rank's queries (each already run on the communicator's context) are summed on the
+ * device, then all-reduced over the ranks.  device_out: where the global count lands (a device word; NULL = a word the
+ * communicator owns); host_out: if not NULL the call waits and also returns the value to the host. */
+int imm3_comm_allreduce_count(imm3_comm *c, imm3_query *const *queries, int32_t n_queries, uint64_t *device_out, uint64_t *host_out);
+/* Single-process flavour: comms[i] drives device i with its queries[i][0 .. n_queries[i]); one thread issues all G
+ * collectives inside a group.  host_out (may be NULL) receives the global count. */
+int imm3_comm_allreduce_count_all(imm3_comm *const *comms, int32_t n_comms, imm3_query *const *const *queries,
+                                  const int32_t *n_queries, uint64_t *host_out);
 
 /* ---- write side of the PFOR_INT codec (host code, no device involved) ----
  * PFORCodecInt.encode (core/codec/PFORCodec.scala:19-31), which SegmentWriter.flush applies to each block of a PFOR_INT
@@ -264,12 +282,6 @@ int imm3_pfor_encode_column(const int32_t *values, uint64_t n_values, int32_t bl
 /* Write side of the snappy block format (host code): SnappyCodec.encode of one storage block's raw value bytes. */
 uint64_t imm3_snappy_encode_bound(uint64_t n_bytes);
 int imm3_snappy_encode_block(const void *bytes, uint64_t n_bytes, void *out, uint64_t cap, uint64_t *bytes_out);
-
-/* Tuning knobs (0 = default): filter variant, grid size in workgroups.  For experiments/bench.
- * variant 1 = word-at-a-time kernel only, 2 = count reduce on the aux stream, 3 = no survivor staging,
- * 4 = stage int32 columns only, 5 = PFOR_INT predicates read the decoded column instead of the compressed blocks,
- * 7 = reduce the count with a separate k_total launch instead of inside the filter kernel. */
-int imm3_ctx_set_tuning(imm3_ctx *ctx, int32_t filter_variant, int32_t grid_blocks);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,46 @@
+/*
+ * imm3_diag.h -- measurement and tuning hooks of libimm3.so.  NOT part of the drop-in boundary (include/imm3.h): nothing
+ * a GpuScanOp / GpuSelectOp / GpuProjectOp binds lives here.  bench.py, tools/ and the roofline tests use them to time
+ * kernels with HIP events, to cross-check that timing against the device clock, to measure the GPU's read-only
+ * streaming ceiling, and to A/B kernel variants.
+ */
+#ifndef IMM3_DIAG_H
+#define IMM3_DIAG_H
+
+#include "imm3.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- live kernel timing (HIP events on the context's stream) ----
+ * When enabled, every kernel launch of this context is bracketed by an event pair.
+ * kernel ids: 0 = scan+select, 1 = offsets scan, 2 = compact+gather, 3 = count reduce, 4 = group-by aggregation,
+ *             5 = PFOR_INT / snappy column decode. */
+int imm3_ctx_timing_enable(imm3_ctx *ctx, int32_t max_records);
+int imm3_ctx_timing_reset(imm3_ctx *ctx);
+/* Only launches whose kernel id has its bit set in `kernel_mask` are bracketed (default: all). */
+int imm3_ctx_timing_mask(imm3_ctx *ctx, uint32_t kernel_mask);
+/* Synchronises, then writes up to cap durations (ms) of launches of `kernel_id`, oldest first. */
+int imm3_ctx_timing_collect(imm3_ctx *ctx, int32_t kernel_id, float *ms_out, int32_t cap, int32_t *n_out);
+
+/* Cross-check of the event timing: when enabled, every tile-kernel launch also records, per work-group, the 100 MHz
+ * device clock at entry and exit; collect() returns per launch (last work-group's exit - first work-group's entry) in
+ * ms, oldest first.  Diagnostics only (bench.py's instrumented pass); costs two stores per work-group. */
+int imm3_ctx_devclock_enable(imm3_ctx *ctx, int32_t max_launches);
+int imm3_ctx_devclock_collect(imm3_ctx *ctx, float *ms_out, int32_t cap, int32_t *n_out);
+
+/* Empirical read-only streaming ceiling of this GPU: times a kernel that only reads `bytes` (non-temporal dword loads,
+ * same tiling and grid as the scan+select kernel, three rotated buffers) and returns the median GB/s over `iters`. */
+int imm3_ctx_measure_read_gbps(imm3_ctx *ctx, uint64_t bytes, int32_t iters, double *gbps);
+
+/* Tuning knobs (0 = default): filter variant, grid size in workgroups.  For experiments/bench.
+ * variant 1 = word-at-a-time kernel only, 2 = count reduce on the aux stream, 3 = no survivor staging,
+ * 4 = stage int32 columns only, 5 = PFOR_INT predicates read the decoded column instead of the compressed blocks,
+ * 7 = reduce the count with a separate k_total launch instead of inside the filter kernel. */
+int imm3_ctx_set_tuning(imm3_ctx *ctx, int32_t filter_variant, int32_t grid_blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMM3_DIAG_H */

@@ -125,3 +125,39 @@ def test_world2_sharded_aggregate():
         per_seg.append(oracle_np.project_agg(cols, [1], AGGS, masks))
     expect = oracle_np.combine_agg(per_seg, AGGS)
     assert out[0] == out[1] == [(k, v) for k, v in expect.items()]
+
+
+def _c5_worker(rank, world, port, out):
+    """BASELINE config C5's partition: 8 segments, segment s on rank s mod G, one count all-reduce."""
+    import torch.distributed as dist
+    from immutable3_amd.distributed import ShardedCount, owned_segments
+    from oracle import oracle_c
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def local_count(seg):
+        v = _segment(seg, 3000)
+        col = RawColumn(DENSE_INT, 4, v, blocks_of(v.size, 1024))
+        return oracle_c.scan_select([col.ocol()], SELS, 1024)[1]
+
+    local, total = ShardedCount(8, rank, world, local_count).run()
+    out[rank] = (local, total, owned_segments(8, rank, world))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_c5_partition_8_segments_over_g_ranks(world):
+    out = mp.Manager().dict()
+    mp.spawn(_c5_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    each = []
+    for seg in range(8):
+        v = _segment(seg, 3000)
+        each.append(int(((v > 2 ** 28) & (v < 3 * 2 ** 28)).sum()))
+    owned = [out[r][2] for r in range(world)]
+    assert sorted(s for o in owned for s in o) == list(range(8))               # every segment exactly once
+    assert all(o == [s for s in range(8) if s % world == r] for r, o in enumerate(owned))
+    assert all(len(o) == 8 // world for o in owned)                             # balanced for G in {1, 2, 4, 8}
+    for r in range(world):
+        assert out[r][0] == sum(each[s] for s in owned[r]) and out[r][1] == sum(each)

@@ -20,7 +20,7 @@ def run_bench(*flags):
 
 
 def test_bench_line_has_the_contract_fields():
-    d = run_bench("--rows", "2000000", "--steps", "10", "--warmup", "3", "--segments", "2", "--no-cpu-baseline")
+    d = run_bench("--rows", "2000000", "--steps", "10", "--warmup", "3", "--segments", "2", "--no-cpu-baseline", "--no-extra")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -36,21 +36,58 @@ def test_bench_line_has_the_contract_fields():
     assert d["cpu_baseline"] is None   # --no-cpu-baseline
 
 
-def test_bench_cpu_baseline_object():
+def test_bench_cpu_baseline_and_extra_block():
+    """Default line: cpu_baseline plus the extra block -- C3, C4 (algorithmic bytes, per-kernel ms, frac), aggregation and
+    the G = 1 point of the C5 curve (real one-rank RCCL count all-reduce inside libimm3)."""
     d = run_bench("--rows", "1000000", "--steps", "5", "--warmup", "2", "--segments", "2")
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "rows/s"
+    x = d["extra"]
+    for name in ("c3_range_age_id_project", "c4_match_state_project"):
+        e = x[name]
+        for k in ("algorithmic_bytes", "kernel_ms", "frac", "selected_rows", "ms_per_query"):
+            assert k in e, (name, k)
+        assert e["kernel_ms"]["scan_select"] > 0 and e["kernel_ms"]["compact_gather"] > 0 and 0 < e["frac"] < 1.2
+    assert x["agg_group_by_state_all_rows"]["groups"] == 51
+    c5 = x["c5_g1"]
+    assert c5["config"]["segments"] == 8 and c5["value"] > 0 and "ncclAllReduce" in c5["count_allreduce"]["collective"]
 
 
-def test_count_log_and_rccl_path_with_one_rank():
-    """imm3_query_log_counts: every run's count lands in the device log without a host call; bench.py's N > 1 path (RCCL
-    init, logged counts, one all-reduce) exercised with a single rank."""
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no rank environment starts two ranks itself and prints an n_gpus = 2 line for the C5
+    shape.  One-device rehearsal: both ranks share cuda:0, so the count all-reduce goes over gloo (RCCL refuses that)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["IMM3_BENCH_ONE_DEVICE"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "1000000", "--steps", "4", "--warmup", "1",
+                        "--segments", "2"], capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 4 and d["cpu_baseline"] is None
+    assert d["config"]["segments"] == 8 and d["config"]["segments_per_gpu"] == 4 and d["config"]["workload"].startswith("C5")
+    assert abs(d["value"] - 8 * 1000000 * 4 / (d["ms_per_step"] * 1e-3 * 4)) / d["value"] < 1e-6
+    assert [r["segments"] for r in d["per_rank"]] == [[0, 2, 4, 6], [1, 3, 5, 7]]
+    assert d["global_selected_rows_per_pass"] == sum(r["selected_rows"] for r in d["per_rank"])
+    assert d["c2_weak"]["per_rank"][1]["rank"] == 1 and d["c2_weak"]["value"] > 0
+    # a rank count that contradicts the environment is refused, not silently reported as another N
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "100000"], capture_output=True, text=True, cwd=ROOT, timeout=300, env=env2)
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
+
+
+def test_count_log():
+    """imm3_query_log_counts: every run's count lands in the device log without a host call."""
     import numpy as np
     import torch
     from immutable3_amd import native, synth
-    ctx = native.Context(0, torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(ValueError):
+        native.Context(0, torch.cuda.current_stream().cuda_stream)     # 0 = torch's default stream: refused loudly
+    ts = torch.cuda.Stream()
+    ctx = native.Context(0, ts.cuda_stream)                            # the library's work rides a torch stream
+    assert ctx.stream == ts.cuda_stream
     n = 300_000
     v = synth.uniform_int30(7, n)
     seg = native.DeviceSegment(ctx, [(native.DENSE_INT, 4, v.view(np.uint8), n * 4, synth.block_offsets(n, 4))])
@@ -62,7 +99,7 @@ def test_count_log_and_rccl_path_with_one_rank():
         q.log_counts(log.data_ptr(), 4)
         for _ in range(5):
             q.run_select()
-        torch.cuda.synchronize()
+        ts.synchronize()                                    # torch's handle on the same stream covers the library's launches
         assert log.tolist() == [want] * 4 + [0, 0]          # capacity 4: the fifth run is not logged
         q.log_counts(0, 0)
         q.run_select()
@@ -79,14 +116,8 @@ def test_count_log_and_rccl_path_with_one_rank():
     q.log_counts(log.data_ptr(), 3)
     for _ in range(2):
         q.run_select()
-    torch.cuda.synchronize()
+    ts.synchronize()
     assert log.tolist() == [want, want, 0] and q.count() == want
     q.close()
     seg.close()
     ctx.close()
-    env = dict(os.environ, IMM3_BENCH_FORCE_DIST="1", MASTER_PORT="29577")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "2000000", "--steps", "10", "--warmup", "3", "--segments", "3",
-                        "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, timeout=600, env=env)
-    assert p.returncode == 0, p.stderr[-2000:]
-    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
-    assert d["n_gpus"] == 1 and d["count_allreduce"]["sum_over_steps"] > 0

@@ -1,0 +1,201 @@
+"""GPU suite: handle lifetimes and the RCCL count reduce, through the raw C ABI (ctypes, not the Python wrapper's
+ordered close) -- what a JNI host whose finalizers run in any order does.
+
+Root cause on record (round 1, gpurun_out/table.log): a DeviceSegment's imm3_segment_destroy ran from __del__ during
+garbage collection AFTER its context had been destroyed and dereferenced the freed imm3_ctx.  The C ABI now reference
+counts its handles (csrc/imm3_handles.h, "Lifetimes"), so every destruction order is safe."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import DENSE_INT, GT, LT, RawColumn, SnappyColumn, blocks_of
+from immutable3_amd import native, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _raw_segment(L, ctx_h, v):
+    col = RawColumn(DENSE_INT, 4, v, blocks_of(v.size, 1024))
+    arr, keep = native._ccolumns([col.native()])
+    h = C.c_void_p()
+    assert L.imm3_segment_create(ctx_h, arr, 1, C.byref(h)) == 0, L.imm3_last_error()
+    return h
+
+
+def _raw_query(L, ctx_h, seg_h, table=False):
+    used = np.array([0], np.int32)
+    cs = (native.CSelect * 2)()
+    cs[0].column, cs[0].cond, cs[0].value = 0, GT, float(2 ** 28)
+    cs[1].column, cs[1].cond, cs[1].value = 0, LT, float(3 * 2 ** 28)
+    proj = np.array([0], np.int32)
+    h = C.c_void_p()
+    fn = L.imm3_query_create_table if table else L.imm3_query_create
+    assert fn(ctx_h, seg_h, used.ctypes.data, 1, cs, 2, proj.ctypes.data, 1, 0, 1024, C.byref(h)) == 0, L.imm3_last_error()
+    return h
+
+
+def test_context_destroyed_before_its_segment_table_and_query():
+    L = native.load()
+    v = synth.uniform_int30(5, 50_000)
+    want = int(((v > 2 ** 28) & (v < 3 * 2 ** 28)).sum())
+    ctx = C.c_void_p()
+    assert L.imm3_ctx_create(0, None, C.byref(ctx)) == 0
+    seg = _raw_segment(L, ctx, v)
+    segs = (C.c_void_p * 1)(seg)
+    tab = C.c_void_p()
+    assert L.imm3_table_create(ctx, segs, 1, C.byref(tab)) == 0
+    q = _raw_query(L, ctx, seg)
+    qt = _raw_query(L, ctx, tab, table=True)
+    n = C.c_uint64(0)
+    for h in (q, qt):
+        assert L.imm3_query_run(h) == 0
+        assert L.imm3_query_count(h, C.byref(n)) == 0 and n.value == want
+    # the context goes FIRST, then the children in the worst order: segment, table, queries
+    assert L.imm3_ctx_destroy(ctx) == 0
+    assert L.imm3_query_run(q) == native.ERR_STATE and b"destroyed" in L.imm3_last_error()
+    assert L.imm3_query_count(qt, C.byref(n)) == native.ERR_STATE
+    assert L.imm3_segment_create(ctx, (native.CColumn * 1)(), 1, C.byref(C.c_void_p())) == native.ERR_STATE
+    assert L.imm3_segment_destroy(seg) == 0
+    assert L.imm3_segment_destroy(seg) == native.ERR_STATE      # still referenced by the table and the query: refused, not a double free
+    assert L.imm3_table_destroy(tab) == 0
+    assert L.imm3_query_destroy(q) == 0
+    assert L.imm3_query_destroy(qt) == 0                         # the last reference: segment, table and context memory go here
+
+
+def test_segment_destroyed_before_the_query_that_reads_it():
+    L = native.load()
+    v = synth.uniform_int30(6, 200_000)
+    keep = np.flatnonzero((v > 2 ** 28) & (v < 3 * 2 ** 28))
+    ctx = C.c_void_p()
+    assert L.imm3_ctx_create(0, None, C.byref(ctx)) == 0
+    seg = _raw_segment(L, ctx, v)
+    q = _raw_query(L, ctx, seg)
+    assert L.imm3_segment_destroy(seg) == 0                      # the query keeps the columns alive
+    assert L.imm3_query_create(ctx, seg, np.array([0], np.int32).ctypes.data, 1, None, 0, None, 0, 0, 1024, C.byref(C.c_void_p())) == native.ERR_STATE
+    assert L.imm3_query_run(q) == 0
+    rows = C.c_uint64(0)
+    assert L.imm3_query_row_count(q, C.byref(rows)) == 0 and rows.value == keep.size
+    idx = np.zeros(keep.size, np.uint32)
+    vals = np.zeros(keep.size, np.int32)
+    ptrs = (C.c_void_p * 1)(vals.ctypes.data)
+    assert L.imm3_query_fetch_rows(q, idx.ctypes.data, ptrs, keep.size) == 0
+    assert (idx == keep).all() and (vals == v[keep]).all()
+    assert L.imm3_query_destroy(q) == 0
+    assert L.imm3_ctx_destroy(ctx) == 0
+
+
+def test_python_wrappers_collected_in_any_order():
+    import gc
+    ctx = native.Context(0)
+    v = synth.uniform_int30(8, 30_000)
+    seg = native.DeviceSegment(ctx, [RawColumn(DENSE_INT, 4, v, blocks_of(v.size, 1024)).native()])
+    q = native.DeviceQuery(ctx, seg, [0], [(0, GT, float(2 ** 28))])
+    q.run_select()
+    want = int((v > 2 ** 28).sum())
+    assert q.count() == want
+    # drop the context first WITHOUT the wrapper's ordered close: raw destroy, then let the GC take the rest
+    native.load().imm3_ctx_destroy(ctx._h)
+    ctx._h = C.c_void_p()
+    del ctx
+    gc.collect()
+    with pytest.raises(native.Imm3Error) as e:
+        q.run_select()
+    assert e.value.code == native.ERR_STATE
+    del seg
+    gc.collect()
+    del q
+    gc.collect()
+
+
+def test_devclock_enable_leaves_the_snappy_tables_and_the_pool_alone():
+    """imm3_ctx_devclock_enable used to free the CRC table (without nulling it) and drain the buffer pool."""
+    ctx = native.Context(0)
+    n = 20_000
+    v = np.sort(synth.uniform_int30(9, n))
+    br = blocks_of(n, 1024)
+    want = int(((v > 2 ** 28) & (v < 3 * 2 ** 28)).sum())
+    sels = [(0, GT, float(2 ** 28)), (0, LT, float(3 * 2 ** 28))]
+
+    def decode_once():
+        seg = native.DeviceSegment(ctx, [SnappyColumn(DENSE_INT, 4, v, br).native()])
+        q = native.DeviceQuery(ctx, seg, [0], sels)
+        q.run_select()
+        assert q.count() == want
+        q.close()
+        seg.close()
+
+    decode_once()                 # builds the CRC-32C power table on the context
+    ctx.devclock_enable(4)
+    decode_once()                 # ... which must still be there
+    ctx.devclock_enable(0)
+    decode_once()
+    ctx.close()
+
+
+def test_two_string_predicates_log_one_count_per_run():
+    """Two 2-byte string predicate columns are two tile passes: the count (and its log entry) comes from k_total, once."""
+    import torch
+    ctx = native.Context(0)
+    n = 100_000
+    a = synth.state_codes(11, n)
+    b = synth.state_codes(12, n)
+    br = blocks_of(n, 1024)
+    seg = native.DeviceSegment(ctx, [RawColumn(3, 2, a, br).native(), RawColumn(3, 2, b, br).native()])
+    q = native.DeviceQuery(ctx, seg, [0, 1], [(0, native.MATCH, [b"CA", b"NY"]), (1, native.MATCH, [b"TX"])])
+    want = int((((a[:, 0] == ord("C")) & (a[:, 1] == ord("A"))) | ((a[:, 0] == ord("N")) & (a[:, 1] == ord("Y")))).__and__(
+        (b[:, 0] == ord("T")) & (b[:, 1] == ord("X"))).sum())
+    log = torch.zeros(4, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    q.log_counts(log.data_ptr(), 4)
+    for _ in range(3):
+        q.run_select()
+    ctx.sync()
+    assert log.tolist() == [want, want, want, 0] and q.count() == want
+    q.close()
+    seg.close()
+    ctx.close()
+
+
+def test_rccl_count_reduce_one_rank_both_flavours():
+    """The count all-reduce behind the C ABI with a single rank: unique-id flavour (one process per GPU) and
+    ncclCommInitAll flavour (one process, every GPU), real RCCL."""
+    import torch
+    ctx = native.Context(0)
+    segs, queries, want = [], [], 0
+    for s in range(3):
+        v = synth.uniform_int30(40 + s, 60_000 + 1000 * s)
+        seg = native.DeviceSegment(ctx, [RawColumn(DENSE_INT, 4, v, blocks_of(v.size, 1024)).native()])
+        q = native.DeviceQuery(ctx, seg, [0], [(0, GT, float(2 ** 28)), (0, LT, float(3 * 2 ** 28))], [0], 0)
+        q.run()
+        want += int(((v > 2 ** 28) & (v < 3 * 2 ** 28)).sum())
+        segs.append(seg)
+        queries.append(q)
+    comm = native.Comm(ctx, 1, 0, native.comm_unique_id())
+    assert comm.allreduce_count(queries) == want
+    out = torch.zeros(2, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    for q in queries:
+        q.run()
+    comm.allreduce_count(queries, device_out=out.data_ptr() + 8, wait=False)   # asynchronous, into a caller's device word
+    comm.sync()
+    assert out.tolist() == [0, want]
+    buf = torch.tensor([3, 4, 5], dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    comm.allreduce_u64(buf.data_ptr(), 3)
+    comm.join()                     # stream side: the context's stream now sits behind the collective
+    ctx.sync()
+    assert buf.tolist() == [3, 4, 5]
+    for _ in range(3):              # back-to-back calls on the communicator's own word (each waits for the one before)
+        comm.allreduce_count(queries, wait=False)
+    assert comm.allreduce_count(queries) == want
+    assert comm.allreduce_count([]) == 0
+    comm.close()
+    (c0,) = native.Comm.create_all([ctx])
+    assert native.Comm.allreduce_count_all([c0], [queries]) == want
+    c0.close()
+    for q in queries:
+        q.close()
+    for s in segs:
+        s.close()
+    ctx.close()
