@@ -546,80 +546,102 @@ __global__ __launch_bounds__(kChunkTiles) void k_scan(const ScanArgs a) {
 //   C  the list is walked densely: thread i handles survivor i, so row-index / value stores are contiguous
 //      and the column gathers are ascending.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ void copy_elem(const void *src, void *dst, int64_t row, uint64_t out) {
-    ((T *)dst)[out] = ((const T *)src)[row];
-}
-// 1- and 2-byte values are fetched as the aligned dword that contains them: sub-dword global loads are several
+// 1-, 2- and 4-byte values are fetched as the aligned dword that contains them: sub-dword global loads are several
 // times slower per instruction on this chip (see imm3_agg.hip), and neighbouring survivors share the dword anyway.
-template <>
-__device__ __forceinline__ void copy_elem<uint8_t>(const void *src, void *dst, int64_t row, uint64_t out) {
-    const uint32_t v = ((const uint32_t *)src)[row >> 2];
-    ((uint8_t *)dst)[out] = (uint8_t)(v >> (8 * (row & 3)));
+// The store truncates.
+template <int W>
+__device__ __forceinline__ uint32_t load_value(const void *src, int64_t idx) {
+    if constexpr (W == 4) return ((const uint32_t *)src)[idx];
+    else if constexpr (W == 2) return ((const uint32_t *)src)[idx >> 1] >> (16 * ((uint32_t)idx & 1u));
+    else return ((const uint32_t *)src)[idx >> 2] >> (8 * ((uint32_t)idx & 3u));
 }
-template <>
-__device__ __forceinline__ void copy_elem<uint16_t>(const void *src, void *dst, int64_t row, uint64_t out) {
-    const uint32_t v = ((const uint32_t *)src)[row >> 1];
-    ((uint16_t *)dst)[out] = (uint16_t)(v >> (16 * (row & 1)));
+template <int W>
+__device__ __forceinline__ void store_value(void *dst, uint64_t out, uint32_t v) {
+    if constexpr (W == 4) ((uint32_t *)dst)[out] = v;
+    else if constexpr (W == 2) ((uint16_t *)dst)[out] = (uint16_t)v;
+    else ((uint8_t *)dst)[out] = (uint8_t)v;
+}
+__device__ __forceinline__ uint32_t load_value_rt(const void *src, int width, int64_t idx) {
+    return width == 4 ? load_value<4>(src, idx) : (width == 2 ? load_value<2>(src, idx) : load_value<1>(src, idx));
+}
+__device__ __forceinline__ void store_value_rt(void *dst, int width, uint64_t out, uint32_t v) {
+    if (width == 4) store_value<4>(dst, out, v);
+    else if (width == 2) store_value<2>(dst, out, v);
+    else store_value<1>(dst, out, v);
 }
 
-__global__ __launch_bounds__(kBlockThreads) void k_gather(const GatherArgs a) {
-    __shared__ uint16_t s_list[kSpanWords * 64]; // 32 KiB
-    __shared__ uint32_t s_wave[kWavesPerBlock];
-    __shared__ uint32_t s_toff[kSpanTiles];       // survivors of the span before each of its tiles
-    __shared__ unsigned long long s_base;
+// phases A and B of the gather: the span's 256 bitmap words -> survivor count, the span's first output slot, and the
+// ascending list of in-span positions in LDS.  Returns the number of rows this span emits (limit / capacity clamped).
+struct SpanScratch {
+    uint16_t list[kSpanWords * 64]; // 32 KiB
+    uint32_t wave[kWavesPerBlock];
+    uint32_t toff[kSpanTiles];      // survivors of the span before each of its tiles
+    unsigned long long base;
+};
+
+__device__ __forceinline__ uint32_t span_expand(const GatherArgs &a, int64_t span, SpanScratch &S, unsigned long long &base_out) {
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = t >> 6;
-    const int64_t n_spans = (a.n_tiles + kSpanTiles - 1) / kSpanTiles;
+    const int64_t tile0 = span * kSpanTiles;
+    const int64_t w = span * kSpanWords + t;
+    uint64_t word = w < a.n_words ? a.bitmap[w] : 0ULL;
+    const uint32_t pc = (uint32_t)__popcll(word);
+    uint32_t incl = pc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) S.wave[wave] = incl;
+    if (wave == 0) { // offset of the span's first survivor among the segment's survivors
+        const int64_t chunk = tile0 / kChunkTiles;
+        unsigned long long part = 0;
+        for (int64_t i = lane; i < chunk; i += 64) part += a.chunk_sums[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+        if (lane == 0) S.base = part + a.tile_offsets[tile0];
+        if (lane < kSpanTiles) S.toff[lane] = tile0 + lane < a.n_tiles ? a.tile_offsets[tile0 + lane] - a.tile_offsets[tile0] : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    uint32_t off = incl - pc;
+    uint32_t total = 0;
+#pragma unroll
+    for (int i = 0; i < kWavesPerBlock; ++i) {
+        if (i < wave) off += S.wave[i];
+        total += S.wave[i];
+    }
+    const unsigned long long base = S.base;
+    uint32_t n_out = total;
+    if (a.limit > 0) {
+        if (base >= (unsigned long long)a.limit) n_out = 0;
+        else if (base + total > (unsigned long long)a.limit) n_out = (uint32_t)((unsigned long long)a.limit - base);
+    }
+    if (base + n_out > a.cap_rows) n_out = base >= a.cap_rows ? 0u : (uint32_t)(a.cap_rows - base);
+    if (n_out) { // block-uniform
+        while (word) {
+            const int b = __builtin_ctzll(word);
+            S.list[off++] = (uint16_t)(t * 64 + b);
+            word &= word - 1;
+        }
+    }
+    __syncthreads();
+    base_out = base;
+    return n_out;
+}
 
+// Phase C, general form: any layout (ragged, table), any width, any number of columns; one column at a time.
+__global__ __launch_bounds__(kBlockThreads) void k_gather(const GatherArgs a) {
+    __shared__ SpanScratch S;
+    const int t = threadIdx.x;
+    const int64_t n_spans = (a.n_tiles + kSpanTiles - 1) / kSpanTiles;
     for (int64_t span = blockIdx.x; span < n_spans; span += gridDim.x) { // block-uniform trip count
         const int64_t tile0 = span * kSpanTiles;
-        const int64_t w = span * kSpanWords + t;
-        uint64_t word = w < a.n_words ? a.bitmap[w] : 0ULL;
-        const uint32_t pc = (uint32_t)__popcll(word);
-        uint32_t incl = pc;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d);
-            if (lane >= d) incl += up;
-        }
-        if (lane == 63) s_wave[wave] = incl;
-        if (wave == 0) { // offset of the span's first survivor among the segment's survivors
-            const int64_t chunk = tile0 / kChunkTiles;
-            unsigned long long part = 0;
-            for (int64_t i = lane; i < chunk; i += 64) part += a.chunk_sums[i];
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
-            if (lane == 0) s_base = part + a.tile_offsets[tile0];
-            if (lane < kSpanTiles) s_toff[lane] = tile0 + lane < a.n_tiles ? a.tile_offsets[tile0 + lane] - a.tile_offsets[tile0] : 0xFFFFFFFFu;
-        }
-        __syncthreads();
-        uint32_t off = incl - pc;
-        uint32_t total = 0;
-#pragma unroll
-        for (int i = 0; i < kWavesPerBlock; ++i) {
-            if (i < wave) off += s_wave[i];
-            total += s_wave[i];
-        }
-        const unsigned long long base = s_base;
-        uint32_t n_out = total;
-        if (a.limit > 0) {
-            if (base >= (unsigned long long)a.limit) n_out = 0;
-            else if (base + total > (unsigned long long)a.limit) n_out = (uint32_t)((unsigned long long)a.limit - base);
-        }
-        if (n_out) { // block-uniform
-            while (word) {
-                const int b = __builtin_ctzll(word);
-                s_list[off++] = (uint16_t)(t * 64 + b);
-                word &= word - 1;
-            }
-        }
-        __syncthreads();
+        unsigned long long base;
+        const uint32_t n_out = span_expand(a, span, S, base);
         for (uint32_t i = t; i < n_out; i += kBlockThreads) {
-            const uint32_t r = s_list[i];
+            const uint32_t r = S.list[i];
             const unsigned long long out = base + i;
-            if (out >= a.cap_rows) continue;
             int64_t row = a.word_row_base
                               ? (int64_t)a.word_row_base[span * kSpanWords + (r >> 6)] + (r & 63)
                               : span * (int64_t)(kSpanWords * 64) + r;
@@ -633,26 +655,81 @@ __global__ __launch_bounds__(kBlockThreads) void k_gather(const GatherArgs a) {
                     row = r & (kTileRows - 1);
                 }
                 if (pc2.staged && staged_tile) { // survivors' values were compacted per tile by the filter kernel
-                    const int64_t sidx = tile * kTileRows + (i - s_toff[r >> 10]);
-                    if (pc2.width == 4) ((uint32_t *)pc2.dst)[out] = ((const uint32_t *)pc2.staged)[sidx];
-                    else if (pc2.width == 2) copy_elem<uint16_t>(pc2.staged, pc2.dst, sidx, out);
-                    else copy_elem<uint8_t>(pc2.staged, pc2.dst, sidx, out);
+                    const int64_t sidx = tile * kTileRows + (i - S.toff[r >> 10]);
+                    store_value_rt(pc2.dst, pc2.width, out, load_value_rt(pc2.staged, pc2.width, sidx));
                     continue;
                 }
-                switch (pc2.width) {
-                case 4: copy_elem<uint32_t>(pc2.src, pc2.dst, row, out); break;
-                case 1: copy_elem<uint8_t>(pc2.src, pc2.dst, row, out); break;
-                case 2: copy_elem<uint16_t>(pc2.src, pc2.dst, row, out); break;
-                case 8: copy_elem<uint64_t>(pc2.src, pc2.dst, row, out); break;
-                default: {
-                    const uint8_t *s = (const uint8_t *)pc2.src + row * (int64_t)pc2.width;
+                if (pc2.width == 1 || pc2.width == 2 || pc2.width == 4) {
+                    store_value_rt(pc2.dst, pc2.width, out, load_value_rt(pc2.src, pc2.width, row));
+                } else if (pc2.width == 8) {
+                    ((uint64_t *)pc2.dst)[out] = ((const uint64_t *)pc2.src)[row];
+                } else {
+                    const uint8_t *sp = (const uint8_t *)pc2.src + row * (int64_t)pc2.width;
                     uint8_t *d = (uint8_t *)pc2.dst + out * (uint64_t)pc2.width;
-                    for (int b = 0; b < pc2.width; ++b) d[b] = s[b];
-                }
+                    for (int b = 0; b < pc2.width; ++b) d[b] = sp[b];
                 }
             }
         }
-        __syncthreads(); // s_list / s_wave / s_base are reused by the next span
+        __syncthreads(); // the scratch is reused by the next span
+    }
+}
+
+// Phase C, the fast form: one uniform segment (no ragged map, no tile table), N4 + N2 + N1 <= 4 projected columns of 4, 2
+// and 1 bytes (the launcher sorts them in that order; widths are compile time, so the walk has no branches).  Every
+// thread takes kGatherUnroll survivors per step and issues EVERY load of the step -- all columns, all survivors --
+// before the first store.  The general form's load -> wait -> store per column cost one full memory round trip per
+// column and step, which is what that kernel's time was (C4, 3 columns: 72 us = 4.8 rounds of work-groups x 2 steps x
+// 3 round trips): it was latency-serialised, not bandwidth- or instruction-bound.
+constexpr int kGatherUnroll = 2;
+
+template <int N4, int N2, int N1>
+__global__ __launch_bounds__(kBlockThreads) void k_gather_plain(const GatherArgs a) {
+    constexpr int NP = N4 + N2 + N1;
+    __shared__ SpanScratch S;
+    const int t = threadIdx.x;
+    const int64_t n_spans = (a.n_tiles + kSpanTiles - 1) / kSpanTiles;
+    for (int64_t span = blockIdx.x; span < n_spans; span += gridDim.x) { // block-uniform trip count
+        const int64_t tile0 = span * kSpanTiles;
+        unsigned long long base;
+        const uint32_t n_out = span_expand(a, span, S, base);
+        for (uint32_t i0 = t; i0 < n_out; i0 += kGatherUnroll * kBlockThreads) {
+            uint32_t val[kGatherUnroll][NP > 0 ? NP : 1];
+            uint32_t rowv[kGatherUnroll];
+#pragma unroll
+            for (int u = 0; u < kGatherUnroll; ++u) { // all loads of the step (out-of-range survivors re-read survivor i0: no branch) ...
+                const uint32_t i = i0 + u * kBlockThreads < n_out ? i0 + u * kBlockThreads : i0;
+                const uint32_t r = S.list[i];
+                const int64_t row = span * (int64_t)(kSpanWords * 64) + r;
+                rowv[u] = (uint32_t)row;
+                const int64_t tile = tile0 + (r >> 10);
+                const bool staged_tile = tile < a.n_staged_tiles;
+                const int64_t sidx = tile * kTileRows + (i - S.toff[r >> 10]);
+#pragma unroll
+                for (int pj = 0; pj < NP; ++pj) {
+                    const bool st = a.proj[pj].staged != nullptr && staged_tile; // compacted per tile by the filter kernel
+                    const void *src = st ? a.proj[pj].staged : a.proj[pj].src;
+                    const int64_t idx = st ? sidx : row;
+                    if (pj < N4) val[u][pj] = load_value<4>(src, idx);
+                    else if (pj < N4 + N2) val[u][pj] = load_value<2>(src, idx);
+                    else val[u][pj] = load_value<1>(src, idx);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kGatherUnroll; ++u) { // ... before its first store
+                const uint32_t i = i0 + u * kBlockThreads;
+                if (i < n_out) {
+                    const unsigned long long out = base + i;
+                    if (a.row_index) a.row_index[out] = rowv[u];
+#pragma unroll
+                    for (int pj = 0; pj < NP; ++pj) {
+                        if (pj < N4) store_value<4>(a.proj[pj].dst, out, val[u][pj]);
+                        else if (pj < N4 + N2) store_value<2>(a.proj[pj].dst, out, val[u][pj]);
+                        else store_value<1>(a.proj[pj].dst, out, val[u][pj]);
+                    }
+                }
+            }
+        }
+        __syncthreads(); // the scratch is reused by the next span
     }
 }
 
@@ -749,10 +826,39 @@ void launch_scan(const ScanArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev
     IMM3_LAUNCH(k_scan, grid < 1 ? 1 : grid, kChunkTiles, s, ev0, ev1, a);
 }
 
+#define IMM3_GATHER_CASE(n4, n2, n1)                                                             \
+    if (c4 == n4 && c2 == n2 && c1 == n1) {                                                      \
+        IMM3_LAUNCH((k_gather_plain<n4, n2, n1>), grid, kBlockThreads, s, ev0, ev1, g);          \
+        return;                                                                                  \
+    }
+
 void launch_gather(const GatherArgs &a, int grid_blocks, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     const int cap = grid_blocks > 0 ? grid_blocks : 1024; // 4 x 32 KiB LDS lists per CU
     const int64_t n_spans = (a.n_tiles + kSpanTiles - 1) / kSpanTiles;
     const int grid = clamp_grid(n_spans, cap);
+    // the fast form: one uniform segment, <= 4 columns of 4 / 2 / 1 bytes, sorted by width (the order of the gathers is free)
+    bool plain = !a.word_row_base && !a.tile_rows && a.n_proj >= 1 && a.n_proj <= 4;
+    int c4 = 0, c2 = 0, c1 = 0;
+    for (int j = 0; j < a.n_proj; ++j) {
+        plain = plain && !a.proj[j].tile_ptrs && (a.proj[j].width == 1 || a.proj[j].width == 2 || a.proj[j].width == 4);
+        c4 += a.proj[j].width == 4;
+        c2 += a.proj[j].width == 2;
+        c1 += a.proj[j].width == 1;
+    }
+    if (plain) {
+        GatherArgs g = a;
+        int k = 0;
+        for (int wdt : {4, 2, 1})
+            for (int j = 0; j < a.n_proj; ++j)
+                if (a.proj[j].width == wdt) g.proj[k++] = a.proj[j];
+        IMM3_GATHER_CASE(1, 0, 0) IMM3_GATHER_CASE(0, 1, 0) IMM3_GATHER_CASE(0, 0, 1)
+        IMM3_GATHER_CASE(2, 0, 0) IMM3_GATHER_CASE(1, 1, 0) IMM3_GATHER_CASE(1, 0, 1) IMM3_GATHER_CASE(0, 2, 0) IMM3_GATHER_CASE(0, 1, 1) IMM3_GATHER_CASE(0, 0, 2)
+        IMM3_GATHER_CASE(3, 0, 0) IMM3_GATHER_CASE(2, 1, 0) IMM3_GATHER_CASE(2, 0, 1) IMM3_GATHER_CASE(1, 2, 0) IMM3_GATHER_CASE(1, 1, 1) IMM3_GATHER_CASE(1, 0, 2)
+        IMM3_GATHER_CASE(0, 3, 0) IMM3_GATHER_CASE(0, 2, 1) IMM3_GATHER_CASE(0, 1, 2) IMM3_GATHER_CASE(0, 0, 3)
+        IMM3_GATHER_CASE(4, 0, 0) IMM3_GATHER_CASE(3, 1, 0) IMM3_GATHER_CASE(3, 0, 1) IMM3_GATHER_CASE(2, 2, 0) IMM3_GATHER_CASE(2, 1, 1) IMM3_GATHER_CASE(2, 0, 2)
+        IMM3_GATHER_CASE(1, 3, 0) IMM3_GATHER_CASE(1, 2, 1) IMM3_GATHER_CASE(1, 1, 2) IMM3_GATHER_CASE(1, 0, 3)
+        IMM3_GATHER_CASE(0, 4, 0) IMM3_GATHER_CASE(0, 3, 1) IMM3_GATHER_CASE(0, 2, 2) IMM3_GATHER_CASE(0, 1, 3) IMM3_GATHER_CASE(0, 0, 4)
+    }
     IMM3_LAUNCH(k_gather, grid, kBlockThreads, s, ev0, ev1, a);
 }
 
