@@ -665,7 +665,8 @@ static void query_free(imm3_query *q) {
     pool_release(ctx, q->d_word_nvalid);
     pool_release(ctx, q->d_row_index);
     for (auto p : q->d_proj) pool_release(ctx, p);
-    for (auto &p : q->preds) { pool_release(ctx, p.d_blob); pool_release(ctx, p.d_stage); }
+    for (auto &p : q->preds) pool_release(ctx, p.d_blob);
+    pool_release(ctx, q->d_stage_rec);
     pool_release(ctx, q->d_akeys); pool_release(ctx, q->d_acounts); pool_release(ctx, q->d_okeys); pool_release(ctx, q->d_ocounts);
     pool_release(ctx, q->d_afirst); pool_release(ctx, q->d_ofirst); pool_release(ctx, q->d_ameta);
     pool_release(ctx, q->d_avals); pool_release(ctx, q->d_ovals);
@@ -753,6 +754,14 @@ static int segment_layout(const imm3_segment *seg, const std::vector<int32_t> &u
         }
     }
     return IMM3_OK;
+}
+
+// Can this folded predicate go through the tile kernel?
+static int tile_kind(const FoldedPred &fp) {
+    if (fp.kind == KIND_I32) return TK_I32;
+    if (fp.kind == KIND_I8) return TK_I8;
+    if (fp.kind == KIND_STR && fp.width == 2 && !fp.match.empty() && fp.match.size() <= (size_t)kMaxTileMatch) return TK_S2;
+    return TK_NONE;
 }
 
 static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_table *table,
@@ -969,29 +978,41 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
         const int rc = ensure_row_capacity(q.get(), (uint64_t)std::min<int64_t>(limit, std::max<int64_t>(q->n_rows, 1)));
         if (rc) return rc;
     }
-    // Survivor staging (k_filter_tile / k_gather): an unlimited projection whose select chain is ONE tile-kernel pass
-    // stages the values of every SELECT-list column that is also an int32 / int8 / 2-byte-string predicate column.
-    if (n_proj > 0 && limit <= 0 && !q->ragged && !q->always_false && ctx->filter_variant != 1 && ctx->filter_variant != 3 &&
-        !q->preds.empty() && q->preds.size() <= (size_t)kMaxTileCols) {
+    // Survivor records (k_filter_tile STAGE -> k_emit): an unlimited projection over one uniform segment whose select chain
+    // is ONE tile launch (<= 3 predicate columns of int32 / int8 / 2-byte string, at most one string; none is also fine:
+    // the record is then the position alone) and whose SELECT list is 1-, 2- and 4-byte columns, at most kMaxEmitGather of
+    // them not predicate columns.
+    if (n_proj > 0 && limit <= 0 && !table && !q->ragged && !q->always_false && nb >= 1 && q->n_rows > 0 && ctx->filter_variant != 1 &&
+        ctx->filter_variant != 3 && q->preds.size() <= (size_t)kMaxTileCols && n_proj <= kMaxProj) {
+        std::vector<const FoldedPred *> order;
         int n_s2 = 0;
-        bool all_tile = true;
+        bool ok = true;
         for (const auto &fp : q->preds) {
-            const bool s2 = fp.kind == KIND_STR && fp.width == 2 && !fp.match.empty() && fp.match.size() <= (size_t)kMaxTileMatch;
-            if ((fp.kind == KIND_STR && !s2) || fp.pfor) all_tile = false;
-            n_s2 += s2;
+            const int tk = fp.pfor ? (int)TK_NONE : tile_kind(fp);
+            if (tk == TK_NONE) ok = false;
+            n_s2 += tk == TK_S2;
+            order.push_back(&fp);
         }
-        if (all_tile && n_s2 <= 1) {
-            const int64_t n_full = table ? q->n_tiles : q->n_rows / kTileRows; // staging slots (table: one per virtual tile)
-            for (auto &fp : q->preds) {
-                if (n_full == 0) continue; // (a string predicate here is a 2-byte one: all_tile)
-                if (fp.kind != KIND_I32 && ctx->filter_variant == 4) continue; // experiment: stage int32 columns only
-                bool projected = false;
-                for (int32_t pj : q->proj) projected |= (q->used[(size_t)pj] == fp.seg_col);
-                if (!projected) continue;
-                void *d = nullptr;
-                HIPCHK(pool_alloc(ctx, &d, (size_t)n_full * kTileRows * (size_t)fp.width + 256));
-                fp.d_stage = (uint8_t *)d;
+        ok = ok && n_s2 <= 1;
+        std::stable_sort(order.begin(), order.end(), [](const FoldedPred *x, const FoldedPred *y) { return tile_kind(*x) < tile_kind(*y); });
+        int n_gather = 0;
+        for (int32_t pj : q->proj) {
+            const int32_t sci = q->used[(size_t)pj];
+            const int32_t w = seg->cols[(size_t)sci].width;
+            if (w != 1 && w != 2 && w != 4) ok = false;
+            bool is_pred = false;
+            for (const FoldedPred *fp : order) is_pred |= fp->seg_col == sci;
+            n_gather += !is_pred;
+        }
+        if (ok && n_gather <= kMaxEmitGather) {
+            for (size_t k = 0; k < order.size(); ++k) {
+                q->stage_kinds[k] = tile_kind(*order[k]);
+                q->stage_seg_col[k] = order[k]->seg_col;
             }
+            const int R = rec_layout(q->stage_kinds, -1).dwords;
+            void *d = nullptr;
+            HIPCHK(pool_alloc(ctx, &d, (size_t)q->n_tiles * kTileRows * 4 * (size_t)R + 256));
+            q->d_stage_rec = (uint8_t *)d;
         }
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1166,6 +1187,8 @@ extern "C" int imm3_query_reserve_rows(imm3_query *q, uint64_t rows) {
 // ---------------------------------------------------------------------------------------------
 // execution
 // ---------------------------------------------------------------------------------------------
+static int clamp_grid_api(int64_t want, int cap);
+
 static void fill_colpred(const imm3_query *q, const FoldedPred &fp, ColPred &cp) {
     std::memset(&cp, 0, sizeof(cp));
     const SegCol &sc = q->seg->cols[(size_t)fp.seg_col];
@@ -1184,14 +1207,6 @@ static void fill_colpred(const imm3_query *q, const FoldedPred &fp, ColPred &cp)
             cp.match[m] = v;
         }
     }
-}
-
-// Can this folded predicate go through the tile kernel?
-static int tile_kind(const FoldedPred &fp) {
-    if (fp.kind == KIND_I32) return TK_I32;
-    if (fp.kind == KIND_I8) return TK_I8;
-    if (fp.kind == KIND_STR && fp.width == 2 && !fp.match.empty() && fp.match.size() <= (size_t)kMaxTileMatch) return TK_S2;
-    return TK_NONE;
 }
 
 // join: make `s` wait for this query's count reduce on the aux stream (no-op when it ran on the main stream)
@@ -1267,14 +1282,20 @@ static int run_select(imm3_query *q, bool overlap_total) {
             c.lo = (int32_t)fp.lo;
             c.hi = (int32_t)fp.hi;
             a.kinds[k] = tile_kind(fp);
-            a.stage[k] = single_tile_pass ? fp.d_stage : nullptr;
-            if (a.stage[k]) q->stage_written = true;
             if (a.kinds[k] == TK_S2) {
                 c.n_match = (int32_t)fp.match.size();
                 for (size_t m = 0; m < fp.match.size(); ++m)
                     c.match[m] = (uint32_t)(uint8_t)fp.match[m][0] | ((uint32_t)(uint8_t)fp.match[m][1] << 8);
             }
         }
+        if (single_tile_pass && q->d_stage_rec) { // the columns are in the order the records were laid out for (same sort)
+            bool same = true;
+            for (int k = 0; k < kMaxTileCols; ++k) same = same && a.kinds[k] == q->stage_kinds[k] && (k >= n || take[(size_t)k]->seg_col == q->stage_seg_col[k]);
+            if (!same) return fail(IMM3_ERR_ARG, "internal: staged record layout does not match the tile launch");
+            a.stage_rec = q->d_stage_rec;
+            q->stage_written = true;
+        }
+        a.debug = (ctx->filter_variant == 20 || ctx->filter_variant == 21) ? ctx->filter_variant : 0;
         a.and_existing = pass > 0;
         a.n_rows = q->n_rows;
         a.n_words = q->n_words;
@@ -1286,9 +1307,13 @@ static int run_select(imm3_query *q, bool overlap_total) {
         for (int k = 0; k < kMaxTileCols; ++k) any_i32 |= (a.kinds[k] == TK_I32);
         if (ctx->d_stamps && ctx->stamp_used < ctx->stamp_slots) a.stamps = ctx->d_stamps + (size_t)ctx->stamp_used * kMaxFilterGrid * 2;
         grid = filter_grid(q->n_tiles, false, any_i32 || n == 0, ctx->grid_blocks);
-        // staging adds ~2x the VALU work per tile: 8 work-groups per CU overlap it with the loads (measured on C3:
-        // filter+stage 135 us at 512 WGs, 102 us at 2048; whole query 198 us unstaged -> 169 us)
-        if (q->stage_written && ctx->grid_blocks <= 0) grid = filter_grid(q->n_tiles, true, false, 0);
+        // a staging launch keeps a quarter tile of records per wave in LDS (1 KiB x R) next to the transpose buffers: as many
+        // work-groups per CU as that leaves room for, up to 8
+        if (q->stage_written && ctx->grid_blocks <= 0) {
+            const int R = rec_layout(q->stage_kinds, -1).dwords;
+            const int per_cu = std::min(8, (160 * 1024) / (kWavesPerBlock * (256 * 4 * R + 2048) + 512)); // 256 records per staging round
+            grid = clamp_grid_api((q->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, 256 * per_cu);
+        }
         // A select chain that is ONE tile pass also reduces its count in the kernel (one relaxed atomic per work-group): no
         // k_total launch.  Only at <= 512 work-groups: same-address atomics serialise at ~12 ns each, and 1536-2048 of them
         // at the tail of a short kernel cost more than the launch they save (int8: 32 vs 25 + 4 us).  Variant 7 = never.
@@ -1395,9 +1420,52 @@ static int run_select(imm3_query *q, bool overlap_total) {
     return IMM3_OK;
 }
 
+static int clamp_grid_api(int64_t want, int cap) { return (int)std::max<int64_t>(1, std::min<int64_t>(want, cap)); }
+
+// ProjectOp from the survivor records the select launch staged
+static int launch_emit_records(imm3_query *q) {
+    imm3_ctx *ctx = q->ctx;
+    EmitArgs e;
+    std::memset(&e, 0, sizeof(e));
+    e.stage = q->d_stage_rec;
+    e.tile_offsets = q->d_tile_offsets;
+    e.chunk_sums = q->d_chunk_sums;
+    e.n_tiles = q->n_tiles;
+    e.cap_rows = q->cap_rows;
+    e.row_index = q->d_row_index;
+    e.R = rec_layout(q->stage_kinds, -1).dwords;
+    std::vector<EmitCol> gathered, staged;
+    for (size_t j = 0; j < q->proj.size(); ++j) {
+        const int32_t sci = q->used[(size_t)q->proj[j]];
+        const SegCol &sc = q->seg->cols[(size_t)sci];
+        EmitCol c;
+        std::memset(&c, 0, sizeof(c));
+        c.dst = q->d_proj[j];
+        c.width = sc.width;
+        c.rec_dword = -1;
+        for (int k = 0; k < kMaxTileCols; ++k)
+            if (q->stage_seg_col[k] == sci) {
+                const RecField f = rec_layout(q->stage_kinds, k);
+                c.rec_dword = f.dword;
+                c.rec_shift = f.shift;
+            }
+        if (c.rec_dword < 0) { c.src = col_flat(sc); gathered.push_back(c); }
+        else staged.push_back(c);
+    }
+    int n = 0;
+    for (const auto &c : gathered) e.cols[n++] = c;
+    for (const auto &c : staged) e.cols[n++] = c;
+    e.n_cols = n;
+    LaunchTimer t(ctx, 2);
+    launch_emit(e, (int)gathered.size(), 0, ctx->stream, t.start, t.stop);
+    HIPCHK(hipGetLastError());
+    return IMM3_OK;
+}
+
 static int launch_project(imm3_query *q) {
     imm3_ctx *ctx = q->ctx;
     hipStream_t s = ctx->stream;
+    if (q->stage_written) return launch_emit_records(q);
     GatherArgs g;
     std::memset(&g, 0, sizeof(g));
     g.bitmap = q->d_bitmap;
@@ -1407,7 +1475,7 @@ static int launch_project(imm3_query *q) {
     g.n_words = q->n_words;
     g.limit = q->limit;
     g.cap_rows = q->cap_rows;
-    g.n_staged_tiles = q->n_rows / kTileRows;
+    g.n_staged_tiles = 0;
     g.word_row_base = q->d_word_row_base;
     g.tile_rows = q->table ? q->table->d_tile_rows : nullptr;
     // more SELECT-list columns than one launch carries: gather in groups (row indices written by the first)
@@ -1424,8 +1492,6 @@ static int launch_project(imm3_query *q) {
             g.proj[j].dst = q->d_proj[done + j];
             g.proj[j].width = sc.width;
             g.proj[j].staged = nullptr;
-            for (const auto &fp : q->preds)
-                if (q->stage_written && fp.d_stage && fp.seg_col == q->used[(size_t)q->proj[done + j]]) g.proj[j].staged = fp.d_stage;
         }
         {
             LaunchTimer t(ctx, 2);

@@ -131,7 +131,6 @@ struct FoldedPred { // all SelectOp leaves on one segment column, folded
     int64_t lo = 0, hi = 0;                // numeric closed interval
     std::vector<std::string> match;        // string: surviving IN-list values (each exactly width bytes)
     uint8_t *d_blob = nullptr;             // device copy when it does not fit the kernel arguments
-    uint8_t *d_stage = nullptr;            // survivors' values staged per tile (column is also projected)
     bool pfor = false;                     // PFOR_INT column evaluated on its compressed blocks (k_filter_pfor)
 };
 
@@ -176,7 +175,12 @@ struct imm3_query {
     // select-only runs: the count reduce goes to ctx->aux, fenced by these events
     hipEvent_t ev_filter_done = nullptr, ev_total_done = nullptr;
     bool total_on_aux = false;
-    bool stage_written = false;   // the last select run filled the staging buffers (single tile pass)
+    // survivor records (k_filter_tile STAGE instances -> k_emit): an unlimited projection over one uniform segment whose
+    // select chain is ONE tile launch
+    uint8_t *d_stage_rec = nullptr;
+    int32_t stage_kinds[imm3::kMaxTileCols] = {imm3::TK_NONE, imm3::TK_NONE, imm3::TK_NONE}; // of the staged launch, in its column order
+    int32_t stage_seg_col[imm3::kMaxTileCols] = {-1, -1, -1};                                 // segment column of each
+    bool stage_written = false;   // the last select run filled the records
 };
 
 

@@ -58,18 +58,80 @@ struct TileArgs {
     int32_t kinds[kMaxTileCols];    // sorted ascending, TK_NONE last (selects the template instance)
     int32_t and_existing;
     int32_t defer_lines;            // > 0: park the bitmap lines in (dynamic) LDS and store them in bursts (single segment only)
-    int32_t pad0;
+    int32_t debug;                  // ablation switch for experiments (0 in production)
     int64_t n_rows, n_words, n_tiles;
     uint64_t *bitmap;
     uint32_t *block_partials;
     unsigned long long *finish;     // {total, n_emit, status, limit, tally, log, log index, log capacity}: the count is reduced in the kernel (block_partial_finish); null = k_total does
-    void *stage[kMaxTileCols];      // per column: dense per-tile staging of the survivors' values, or null
+    void *stage_rec;                // survivor records, 1024 slots of rec_layout(kinds).dwords dwords per tile, or null
     unsigned long long *stamps;     // diagnostics only: per work-group {start, end} of the 100 MHz device clock, or null
     // table queries (imm3_table): the tile table replaces cols[k].data / n_rows.  Tile t holds tile_rows[t] valid rows
     // (1024 except the last tile of each segment) starting at tile_ptrs[k][t] in column k.  Null for one segment.
     const uint32_t *tile_rows;
     const void *const *tile_ptrs[kMaxTileCols];
 };
+
+// Survivor record (k_filter_tile's STAGE instances -> k_emit): dword 0 carries the row's position in its tile in bits 0-9;
+// the narrow predicate columns (int8: 8 bits, 2-byte string: 16 bits) are packed behind it from bit 16, a field that
+// does not fit starting the next dword at bit 0; every int32 predicate column takes a dword of its own after those.
+// 1, 2 or 4 dwords per record (3 is padded to 4: 16-byte LDS and global accesses).
+struct RecField {
+    int dword, shift, bits; // where column `col` sits
+    int dwords;             // record size
+};
+constexpr RecField rec_layout(const int (&kinds)[kMaxTileCols], int col) {
+    RecField f{0, 0, 0, 0};
+    int d = 0, b = 16;
+    for (int i = 0; i < kMaxTileCols; ++i) {
+        const int w = kinds[i] == TK_I8 ? 8 : (kinds[i] == TK_S2 ? 16 : 0);
+        if (!w) continue;
+        if (b + w > 32) {
+            ++d;
+            b = 0;
+        }
+        if (i == col) {
+            f.dword = d;
+            f.shift = b;
+            f.bits = w;
+        }
+        b += w;
+    }
+    int n = d + 1;
+    for (int i = 0; i < kMaxTileCols; ++i) {
+        if (kinds[i] != TK_I32) continue;
+        if (i == col) {
+            f.dword = n;
+            f.shift = 0;
+            f.bits = 32;
+        }
+        ++n;
+    }
+    f.dwords = n == 3 ? 4 : n;
+    return f;
+}
+
+// k_emit: ProjectOp from the staged records
+constexpr int kEmitTiles = 64;      // tiles per emit work-group (kChunkTiles % kEmitTiles == 0)
+constexpr int kMaxEmitGather = 4;   // SELECT-list columns that are not predicate columns: gathered at the record's position
+struct EmitCol {
+    void *dst;                      // packed output, width bytes per emitted row
+    const void *src;                // gathered column (flat), or null when the value comes out of the record
+    int32_t width;                  // 1, 2 or 4
+    int32_t rec_dword, rec_shift;   // staged column: where it sits in the record
+    int32_t pad;
+};
+struct EmitArgs {
+    const void *stage;              // records, 1024 slots of R dwords per tile
+    const uint32_t *tile_offsets;
+    const uint32_t *chunk_sums;
+    int64_t n_tiles;
+    uint64_t cap_rows;
+    uint32_t *row_index;
+    EmitCol cols[kMaxProj];         // gathered columns first
+    int32_t n_cols;
+    int32_t R;
+};
+void launch_emit(const EmitArgs &a, int n_gather, int grid_blocks, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 
 struct FilterArgs {
     ColPred cols[kMaxPredCols];

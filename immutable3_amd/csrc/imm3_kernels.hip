@@ -29,23 +29,36 @@ namespace imm3 {
 // grid-stride; column kinds are compile-time so the descriptors live in SGPRs and ALL loads of a tile
 // (every column) are issued before the first compare.
 //
-//   TK_I32  DENSE_INT      16 row-strided dword loads (lane l reads row 64j + l): the v_cmp result of load j
-//                          IS bitmap word j -- no cross-lane transpose.
-//   TK_I8   DENSE_TINYINT  one 16-byte load per lane (rows 16l .. 16l+15) -> 16 predicate bits per lane;
-//                          lane j < 16 collects word j from lanes 4j .. 4j+3 (ds_bpermute).
-//   TK_S2   DENSE_STRING(2) two 16-byte loads per lane (rows 512g + 8l .. +7) -> 8 bits per lane per load;
-//                          quads are OR-combined with DPP, lane j collects word j with ds_bpermute.
+// Every kind ends up ROW-STRIDED -- lane l holds row 64j + l of the tile in register j -- so that the v_cmp result
+// of register j IS bitmap word j (a wave-uniform SGPR pair): no per-lane bit assembly, no cross-lane gather of bits,
+// conjunction = s_and_b64, popcount = s_bcnt1, and the survivors' ranks come from v_mbcnt on that word.
+//
+//   TK_I32  DENSE_INT       16 row-strided dword loads (lane l reads row 64j + l) put it there directly.
+//   TK_I8   DENSE_TINYINT   one 16-byte load per lane (rows 16l .. 16l+15: narrow values stream best as 16-byte loads),
+//   TK_S2   DENSE_STRING(2) two of them; the tile is then TRANSPOSED THROUGH LDS: ds_write_b128 of the registers as
+//                           loaded (the tile's bytes in row order), 16 ds_read_i8 / ds_read_u16 at row 64j + lane.
+//                           17-18 LDS instructions per tile instead of ~100 vector instructions of byte extraction,
+//                           bit insertion and ds_bpermute: these kernels were VALU-bound (int8: 61 % of HBM peak).
 //
 // Measured on MI355X (tools/filter_explore.hip, 100 M int32 rows, 61 interleaved rounds): the column is
 // read once, so loads are non-temporal (65 us vs 74 us with the default cache policy; read-only ceiling
 // with nt loads 59 us); dword and dwordx4 loads stream at the same rate; the best grid is 512 workgroups
 // = 2 per CU = 8 waves/CU (more waves add DRAM page conflicts, fewer starve the memory pipeline).
 // ---------------------------------------------------------------------------------------------
+constexpr int kXposeBytes = 2048; // per wave: one tile of the widest transposed kind (2-byte strings)
+constexpr int kStageRecs = 256;   // survivor records a wave's LDS staging buffer holds
+
+// LDS hand-off between the lanes of ONE wave needs no wait at all: a wave's LDS instructions execute in order, so a
+// ds_read issued after a ds_write sees it.  Only the compiler must not reorder them.
+__device__ __forceinline__ void lds_wave_order() { asm volatile("" ::: "memory"); }
+
 template <int KIND>
 struct ColRegs { // TK_NONE: no column
     __device__ __forceinline__ void load(const void *, int64_t, int) {}
-    __device__ __forceinline__ void eval(const TileCol &, uint64_t (&)[kTileWords], uint64_t &, int) {}
+    __device__ __forceinline__ void eval(const TileCol &, uint64_t (&)[kTileWords], int, uint8_t *) {}
     __device__ __forceinline__ bool row(const void *, const TileCol &, int64_t) { return true; }
+    __device__ __forceinline__ uint32_t value(int) const { return 0u; }
+    __device__ __forceinline__ uint32_t rowval(const void *, int64_t) const { return 0u; }
 };
 
 template <>
@@ -56,207 +69,182 @@ struct ColRegs<TK_I32> {
 #pragma unroll
         for (int j = 0; j < kTileWords; ++j) v[j] = __builtin_nontemporal_load(p + 64 * j);
     }
-    __device__ __forceinline__ void eval(const TileCol &c, uint64_t (&acc)[kTileWords], uint64_t &, int) {
+    __device__ __forceinline__ void eval(const TileCol &c, uint64_t (&acc)[kTileWords], int, uint8_t *) {
 #pragma unroll
         for (int j = 0; j < kTileWords; ++j) acc[j] &= ballot64(in_closed(v[j], c.lo, c.hi));
     }
     __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return in_closed(((const int32_t *)data)[r], c.lo, c.hi); }
+    __device__ __forceinline__ uint32_t value(int j) const { return (uint32_t)v[j]; }
+    __device__ __forceinline__ uint32_t rowval(const void *data, int64_t r) const { return ((const uint32_t *)data)[r]; }
 };
 
 template <>
 struct ColRegs<TK_I8> {
-    v4i v;
+    v4i raw;
+    int32_t v[kTileWords]; // after eval(): row 64j + lane, sign-extended
     __device__ __forceinline__ void load(const void *data, int64_t row0, int lane) {
-        v = __builtin_nontemporal_load((const v4i *)((const int8_t *)data + row0) + lane);
+        raw = __builtin_nontemporal_load((const v4i *)((const int8_t *)data + row0) + lane);
     }
-    __device__ __forceinline__ void eval(const TileCol &c, uint64_t (&)[kTileWords], uint64_t &mine, int lane) {
-        uint32_t bits = 0;
+    __device__ __forceinline__ void eval(const TileCol &c, uint64_t (&acc)[kTileWords], int lane, uint8_t *xp) {
+        *(v4i *)(xp + 16 * lane) = raw; // the tile's 1024 bytes in row order
+        lds_wave_order();
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int32_t x = (int32_t)(int8_t)((uint32_t)v[k >> 2] >> (8 * (k & 3)));
-            bits |= in_closed(x, c.lo, c.hi) ? (1u << k) : 0u;
-        }
-        const int src = (lane & 15) << 2; // word j <- lanes 4j .. 4j+3, 16 bits each
-        const uint32_t lo = lane_read(bits, src) | (lane_read(bits, src + 1) << 16);
-        const uint32_t hi = lane_read(bits, src + 2) | (lane_read(bits, src + 3) << 16);
-        mine &= ((uint64_t)hi << 32) | lo;
+        for (int j = 0; j < kTileWords; ++j) v[j] = (int32_t)((const int8_t *)xp)[64 * j + lane];
+        lds_wave_order();
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) acc[j] &= ballot64(in_closed(v[j], c.lo, c.hi));
     }
     __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return in_closed((int32_t)((const int8_t *)data)[r], c.lo, c.hi); }
+    __device__ __forceinline__ uint32_t value(int j) const { return (uint32_t)v[j] & 0xFFu; }
+    __device__ __forceinline__ uint32_t rowval(const void *data, int64_t r) const { return ((const uint8_t *)data)[r]; }
 };
 
 template <>
 struct ColRegs<TK_S2> {
-    v4i v[2];
+    v4i raw[2];
+    uint32_t v[kTileWords]; // after eval(): the two bytes of row 64j + lane, little-endian
     __device__ __forceinline__ void load(const void *data, int64_t row0, int lane) {
         const v4i *p = (const v4i *)((const uint16_t *)data + row0) + lane;
-        v[0] = __builtin_nontemporal_load(p);
-        v[1] = __builtin_nontemporal_load(p + 64);
+        raw[0] = __builtin_nontemporal_load(p);
+        raw[1] = __builtin_nontemporal_load(p + 64);
     }
     __device__ __forceinline__ bool hit(const TileCol &c, uint32_t x) {
         bool f = false;
         for (int m = 0; m < c.n_match; ++m) f |= (x == c.match[m]);
         return f;
     }
-    __device__ __forceinline__ void eval(const TileCol &c, uint64_t (&)[kTileWords], uint64_t &mine, int lane) {
-        // IN-list outermost (usually one value): the value pair sits in one SGPR, each dword of the load holds
-        // two rows; x ^ mm has a zero half exactly where a row matches.
-        uint32_t bits[2] = {0u, 0u};
-        for (int m = 0; m < c.n_match; ++m) {
-            const uint32_t mm = c.match[m] | (c.match[m] << 16);
+    __device__ __forceinline__ void eval(const TileCol &c, uint64_t (&acc)[kTileWords], int lane, uint8_t *xp) {
+        *(v4i *)(xp + 16 * lane) = raw[0]; // the tile's 2048 bytes in row order
+        *(v4i *)(xp + 1024 + 16 * lane) = raw[1];
+        lds_wave_order();
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+        for (int j = 0; j < kTileWords; ++j) v[j] = ((const uint16_t *)xp)[64 * j + lane];
+        lds_wave_order();
+        if (c.n_match == 1) { // SelectIteratorMatch with the one-value list the SQL front end produces (SQLParser.scala:80-84)
+            const uint32_t m0 = c.match[0];
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const uint32_t t = (uint32_t)v[g][d] ^ mm;
-                    bits[g] |= ((t & 0xFFFFu) == 0u ? (1u << (2 * d)) : 0u) | ((t >> 16) == 0u ? (2u << (2 * d)) : 0u);
+            for (int j = 0; j < kTileWords; ++j) acc[j] &= ballot64(v[j] == m0);
+        } else { // IN-list outermost (the value sits in one SGPR), eight words at a time: 16 more SGPR pairs would spill
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                uint64_t h[kTileWords / 2];
+#pragma unroll
+                for (int j = 0; j < kTileWords / 2; ++j) h[j] = 0ULL;
+                for (int m = 0; m < c.n_match; ++m) {
+                    const uint32_t mm = c.match[m];
+#pragma unroll
+                    for (int j = 0; j < kTileWords / 2; ++j) h[j] |= ballot64(v[half * (kTileWords / 2) + j] == mm);
                 }
+#pragma unroll
+                for (int j = 0; j < kTileWords / 2; ++j) acc[half * (kTileWords / 2) + j] &= h[j];
             }
         }
-        uint32_t q[2];
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            uint32_t y = bits[g] << (8 * (lane & 3)); // OR over the quad -> 32 bitmap bits in every lane of the quad
-            y |= (uint32_t)__builtin_amdgcn_mov_dpp((int)y, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
-            y |= (uint32_t)__builtin_amdgcn_mov_dpp((int)y, 0x4E, 0xF, 0xF, true); // quad_perm [2,3,0,1]
-            q[g] = y;
-        }
-        // word j = load (j >> 3), lanes 8(j&7) .. 8(j&7)+7 = two quads
-        const int src = (lane & 7) << 3;
-        const uint32_t lo0 = lane_read(q[0], src), hi0 = lane_read(q[0], src + 4);
-        const uint32_t lo1 = lane_read(q[1], src), hi1 = lane_read(q[1], src + 4);
-        const bool second = (lane & 8) != 0;
-        mine &= ((uint64_t)(second ? hi1 : hi0) << 32) | (second ? lo1 : lo0);
     }
     __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return hit(c, ((const uint16_t *)data)[r]); }
+    __device__ __forceinline__ uint32_t value(int j) const { return v[j]; }
+    __device__ __forceinline__ uint32_t rowval(const void *data, int64_t r) const { return ((const uint16_t *)data)[r]; }
 };
 
-// ---- survivor staging -------------------------------------------------------------------------------------
-// When a SELECT-list column is also a predicate column its values are already in registers here.  Instead of
-// letting k_gather re-read the whole column (at 10 % selectivity nearly every 64-byte sector is touched again),
-// the survivors' values of the tile are compacted -- rank = number of set bits below the row -- through a small
-// per-wave LDS buffer and stored DENSELY at stage[tile * 1024 + rank].  k_gather then copies from there.
-template <int KIND>
-struct StageBytes { static constexpr int value = 0; };
-template <> struct StageBytes<TK_I32> { static constexpr int value = kTileRows * 4; };
-template <> struct StageBytes<TK_I8> { static constexpr int value = kTileRows; };
-template <> struct StageBytes<TK_S2> { static constexpr int value = kTileRows * 2; };
+// ---- survivor records ---------------------------------------------------------------------------------------
+// A projecting query whose select chain is ONE tile launch compacts, per tile, one RECORD per survivor -- its position
+// in the tile and the value of every predicate column, all of which are in registers here -- through a per-wave LDS
+// buffer and stores the tile's records DENSELY at stage[(tile * 1024 + rank) * R] (rank = set bits below the row:
+// s_bcnt1 of the earlier words + v_mbcnt on the row's own word).  k_emit then produces ProjectOp's rows from the
+// records alone: no second look at the bitmap, and no second read of a predicate column (at 10 % selectivity a gather
+// would touch nearly every 64-byte sector of the column again).  Layout: rec_layout() in imm3_internal.h.
+template <int R> struct RecVec;
+template <> struct RecVec<1> { typedef uint32_t type; };
+template <> struct RecVec<2> { typedef uint2 type; };
+template <> struct RecVec<4> { typedef uint4 type; };
 
-template <int KIND>
-__device__ __forceinline__ void stage_col(ColRegs<KIND> &, void *, int64_t, int, uint64_t, uint32_t, uint32_t, uint8_t *) {}
-
-template <>
-__device__ __forceinline__ void stage_col<TK_I32>(ColRegs<TK_I32> &c, void *stage, int64_t tile, int lane, uint64_t mine,
-                                                  uint32_t wprefix, uint32_t cnt, uint8_t *lds) {
-    if (!stage) return; // wave-uniform
-    uint32_t *l = (uint32_t *)lds;
-#pragma unroll
-    for (int j = 0; j < kTileWords; ++j) { // lane l holds row 64j + l of the tile
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, j);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), j);
-        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)wprefix, j);
-        const uint64_t m = ((uint64_t)hi << 32) | lo;
-        if ((m >> lane) & 1ULL) l[base + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u))] = (uint32_t)c.v[j];
-    }
-    lds_wave_sync();
-    uint32_t *out = (uint32_t *)stage + tile * kTileRows;
-    for (uint32_t i = lane; i < cnt; i += 64) out[i] = l[i];
-    lds_wave_sync();
-}
-
-template <>
-__device__ __forceinline__ void stage_col<TK_I8>(ColRegs<TK_I8> &c, void *stage, int64_t tile, int lane, uint64_t mine,
-                                                 uint32_t wprefix, uint32_t cnt, uint8_t *lds) {
-    if (!stage) return;
-    // lane l holds rows 16l .. 16l+15 = bits [16(l&3), +16) of word l>>2
-    const int wi = lane >> 2, bo = 16 * (lane & 3);
-    const uint32_t wlo = lane_read((uint32_t)mine, wi), whi = lane_read((uint32_t)(mine >> 32), wi);
-    const uint64_t word = ((uint64_t)whi << 32) | wlo;
-    const uint32_t base = lane_read(wprefix, wi) + (uint32_t)__popcll(word & ((1ULL << bo) - 1ULL));
-    const uint32_t bits = (uint32_t)(word >> bo) & 0xFFFFu;
-    // walk the lane's set bits only (popcount iterations instead of 16 predicated steps)
-    const uint64_t blo = ((uint64_t)(uint32_t)c.v[1] << 32) | (uint32_t)c.v[0], bhi = ((uint64_t)(uint32_t)c.v[3] << 32) | (uint32_t)c.v[2];
-    uint32_t pos = base;
-    for (uint32_t b = bits; b; b &= b - 1u) {
-        const int k = __builtin_ctz(b);
-        lds[pos++] = (uint8_t)((k < 8 ? blo : bhi) >> (8 * (k & 7)));
-    }
-    lds_wave_sync();
-    uint32_t *out = (uint32_t *)((uint8_t *)stage + tile * kTileRows);
-    const uint32_t ndw = (cnt + 3) >> 2; // whole dwords; the tile's staging slot is 1024 bytes, so over-copy is harmless
-    for (uint32_t i = lane; i < ndw; i += 64) out[i] = ((const uint32_t *)lds)[i];
-    lds_wave_sync();
-}
-
-template <>
-__device__ __forceinline__ void stage_col<TK_S2>(ColRegs<TK_S2> &c, void *stage, int64_t tile, int lane, uint64_t mine,
-                                                 uint32_t wprefix, uint32_t cnt, uint8_t *lds) {
-    if (!stage) return;
-    uint16_t *l16 = (uint16_t *)lds;
-#pragma unroll
-    for (int g = 0; g < 2; ++g) { // load g, lane l holds rows 512g + 8l .. +7 = bits [8(l&7), +8) of word 8g + (l>>3)
-        const int wi = 8 * g + (lane >> 3), bo = 8 * (lane & 7);
-        const uint32_t wlo = lane_read((uint32_t)mine, wi), whi = lane_read((uint32_t)(mine >> 32), wi);
-        const uint64_t word = ((uint64_t)whi << 32) | wlo;
-        uint32_t pos = lane_read(wprefix, wi) + (uint32_t)__popcll(word & ((1ULL << bo) - 1ULL));
-        const uint64_t blo = ((uint64_t)(uint32_t)c.v[g][1] << 32) | (uint32_t)c.v[g][0], bhi = ((uint64_t)(uint32_t)c.v[g][3] << 32) | (uint32_t)c.v[g][2];
-        for (uint32_t b = (uint32_t)(word >> bo) & 0xFFu; b; b &= b - 1u) { // the lane's set bits only
-            const int k = __builtin_ctz(b);
-            l16[pos++] = (uint16_t)((k < 4 ? blo : bhi) >> (16 * (k & 3)));
-        }
-    }
-    lds_wave_sync();
-    uint32_t *out = (uint32_t *)((uint8_t *)stage + tile * (kTileRows * 2));
-    const uint32_t ndw = (cnt + 1) >> 1; // whole dwords; the tile's staging slot is 2048 bytes
-    for (uint32_t i = lane; i < ndw; i += 64) out[i] = ((const uint32_t *)lds)[i];
-    lds_wave_sync();
-}
-
-// AND the per-kind results of one FULL tile (registers already loaded), store its bitmap line, stage survivors'
-// values where asked, return in lanes 0..15 the popcount of the words they own.
 template <int K0, int K1, int K2>
+struct Rec {
+    static constexpr int kinds[3] = {K0, K1, K2};
+    static constexpr int R = rec_layout(kinds, -1).dwords;
+    typedef typename RecVec<R>::type vec;
+    template <int K>
+    static __device__ __forceinline__ void put(uint32_t (&rec)[4], uint32_t value) {
+        constexpr RecField f = rec_layout(kinds, K);
+        if (kinds[K] == TK_NONE) return;
+        rec[f.dword] |= value << f.shift;
+    }
+    static __device__ __forceinline__ vec pack(const uint32_t (&rec)[4]) {
+        if constexpr (R == 1) return rec[0];
+        else if constexpr (R == 2) return make_uint2(rec[0], rec[1]);
+        else return make_uint4(rec[0], rec[1], rec[2], rec[3]);
+    }
+};
+
+template <int K0, int K1, int K2>
+__device__ __forceinline__ void stage_full_tile(const TileArgs &a, int64_t tile, int lane, const ColRegs<K0> &c0, const ColRegs<K1> &c1,
+                                                const ColRegs<K2> &c2, const uint64_t (&acc)[kTileWords], uint8_t *lds) {
+    typedef Rec<K0, K1, K2> L;
+    typedef typename L::vec vec;
+    vec *l = (vec *)lds;
+    vec *out = (vec *)a.stage_rec + tile * kTileRows;
+    // The wave's LDS buffer holds kStageRecs records: it is flushed to the tile's slots whenever the next word's survivors
+    // might not fit -- once per tile at <= 25 % selectivity, more often above -- so the LDS a wave needs stays small and 8
+    // work-groups fit a CU.
+    uint32_t base = 0; // wave-uniform: records in the buffer
+    auto flush = [&]() {
+        lds_wave_order();
+        if (a.debug != 20) // (ablation: records compacted in LDS but not stored)
+            for (uint32_t i = lane; i < base; i += 64) out[i] = l[i];
+        lds_wave_order();
+        out += base;
+        base = 0;
+    };
+#pragma unroll
+    for (int j = 0; j < kTileWords; ++j) {
+        const uint64_t m = acc[j];
+        const uint32_t pc = (uint32_t)__popcll(m);
+        if (base + pc > (uint32_t)kStageRecs) flush(); // wave-uniform
+        uint32_t rec[4] = {(uint32_t)(64 * j) | (uint32_t)lane, 0u, 0u, 0u};
+        L::template put<0>(rec, c0.value(j));
+        L::template put<1>(rec, c1.value(j));
+        L::template put<2>(rec, c2.value(j));
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
+        if (__builtin_amdgcn_inverse_ballot_w64(m)) l[rank] = L::pack(rec); // exec = the word itself
+        base += pc;
+    }
+    if (base) flush();
+}
+
+// AND the per-kind results of one FULL tile (registers already loaded), store / park its bitmap line, stage its
+// survivors' records where asked, return in lanes 0..15 the popcount of the words they own.
+template <int K0, int K1, int K2, bool STAGE>
 __device__ __forceinline__ uint32_t finish_full_tile(const TileArgs &a, int64_t tile, int lane, ColRegs<K0> &c0,
-                                                     ColRegs<K1> &c1, ColRegs<K2> &c2, uint8_t *lds, uint64_t *park = nullptr) {
-    constexpr bool any_i32 = (K0 == TK_I32) || (K1 == TK_I32) || (K2 == TK_I32);
+                                                     ColRegs<K1> &c1, ColRegs<K2> &c2, uint8_t *xp, uint8_t *lds, uint64_t *park = nullptr) {
     const int64_t w = tile * kTileWords + lane; // lane j < 16 owns bitmap word j of the tile
     uint64_t mine = ~0ULL;
     if (a.and_existing) mine = lane < kTileWords ? a.bitmap[w] : 0ULL;
-    uint64_t acc[kTileWords]; // wave-uniform words (SGPR pairs), fed by the TK_I32 columns
+    uint64_t acc[kTileWords]; // wave-uniform words (SGPR pairs)
 #pragma unroll
     for (int j = 0; j < kTileWords; ++j) acc[j] = ~0ULL;
-    c0.eval(a.cols[0], acc, mine, lane);
-    c1.eval(a.cols[1], acc, mine, lane);
-    c2.eval(a.cols[2], acc, mine, lane);
-    if (any_i32) mine &= words_to_lanes(acc);
+    c0.eval(a.cols[0], acc, lane, xp);
+    c1.eval(a.cols[1], acc, lane, xp);
+    c2.eval(a.cols[2], acc, lane, xp);
+    mine &= words_to_lanes(acc);
     if (lane >= kTileWords) mine = 0;
     if (lane < kTileWords) { // 16 lanes x 8 B = one 128-B line
         if (park) park[lane] = mine; // deferred: the line waits in LDS for the wave's next store burst
         else __builtin_nontemporal_store(mine, a.bitmap + w);
     }
-    const uint32_t pc = (uint32_t)__popcll(mine);
-    if (a.stage[0] || a.stage[1] || a.stage[2]) { // wave-uniform
-        uint32_t incl = pc; // exclusive prefix of the word popcounts over lanes 0..15
-#pragma unroll
-        for (int d = 1; d < kTileWords; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d);
-            if (lane >= d) incl += up;
-        }
-        const uint32_t wprefix = incl - pc;
-        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)incl, kTileWords - 1);
-        stage_col<K0>(c0, a.stage[0], tile, lane, mine, wprefix, cnt, lds);
-        stage_col<K1>(c1, a.stage[1], tile, lane, mine, wprefix, cnt, lds + StageBytes<K0>::value);
-        stage_col<K2>(c2, a.stage[2], tile, lane, mine, wprefix, cnt, lds + StageBytes<K0>::value + StageBytes<K1>::value);
-    }
-    return pc;
+    if constexpr (STAGE)
+        if (a.debug != 21) stage_full_tile<K0, K1, K2>(a, tile, lane, c0, c1, c2, acc, lds); // (a staging launch never ANDs into an existing bitmap; 21: ablation)
+    return (uint32_t)__popcll(mine);
 }
 
 // A tile with fewer than 1024 valid rows (the end of a segment): rolled, bounds-checked, row-at-a-time.
 // `valid_rows` rows starting at element `row0` of each column pointer.
-template <int K0, int K1, int K2>
+template <int K0, int K1, int K2, bool STAGE>
 __device__ __forceinline__ uint32_t partial_tile(const TileArgs &a, int64_t tile, int lane, const void *d0, const void *d1, const void *d2,
                                                  int64_t row0, int64_t valid_rows, ColRegs<K0> &c0, ColRegs<K1> &c1, ColRegs<K2> &c2) {
+    typedef Rec<K0, K1, K2> L;
     const int64_t w = tile * kTileWords + lane;
     uint64_t mine = ~0ULL;
     if (a.and_existing) mine = (lane < kTileWords && w < a.n_words) ? a.bitmap[w] : 0ULL;
+    uint32_t base = 0;
 #pragma unroll 1
     for (int j = 0; j < kTileWords; ++j) {
         const int64_t i = 64 * j + lane;
@@ -266,6 +254,15 @@ __device__ __forceinline__ uint32_t partial_tile(const TileArgs &a, int64_t tile
         if (valid) keep = c0.row(d0, a.cols[0], r) && c1.row(d1, a.cols[1], r) && c2.row(d2, a.cols[2], r);
         const uint64_t m = ballot64(keep);
         if (lane == j) mine &= m;
+        if constexpr (STAGE) { // one tile per segment: its records go straight to memory
+            uint32_t rec[4] = {(uint32_t)i, 0u, 0u, 0u};
+            L::template put<0>(rec, c0.rowval(d0, r));
+            L::template put<1>(rec, c1.rowval(d1, r));
+            L::template put<2>(rec, c2.rowval(d2, r));
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
+            if (keep) ((typename L::vec *)a.stage_rec + tile * kTileRows)[rank] = L::pack(rec);
+            base += (uint32_t)__popcll(m);
+        }
     }
     mine &= low_mask(valid_rows - 64 * (int64_t)lane); // rows past the end are not rows
     if (lane >= kTileWords) mine = 0;
@@ -276,15 +273,21 @@ __device__ __forceinline__ uint32_t partial_tile(const TileArgs &a, int64_t tile
 // T = tiles per wave iteration: narrow columns take several tiles at once so that every wave keeps >= 4 KiB of
 // loads in flight (8 waves/CU x 4 KiB is what saturates HBM, see the header comment).
 // TABLE selects the tile-table walk (table queries) at compile time, so the single-segment kernel carries none of it.
-// DEFER (compile time, like TABLE): the deferred-bitmap path costs ~12 VGPRs; the staging launches, which run without it,
-// are one wave per SIMD short of their occupancy with them (C3 filter 104 -> 115 us), so they use the DEFER = false instance.
-template <int K0, int K1, int K2, int T, bool TABLE, bool DEFER>
+// DEFER (compile time, like TABLE): the bitmap lines of a wave's tiles are parked in LDS and written in bursts.
+// STAGE: the survivors' records are compacted and stored per tile (projecting queries; never with DEFER).
+template <int K0, int K1, int K2, int T, bool TABLE, bool DEFER, bool STAGE>
 __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a) {
-    constexpr int kStage = StageBytes<K0>::value + StageBytes<K1>::value + StageBytes<K2>::value;
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerBlock][kStage > 0 ? kStage : 16];
+    constexpr bool kXpose = K0 == TK_I8 || K0 == TK_S2 || K1 == TK_I8 || K1 == TK_S2 || K2 == TK_I8 || K2 == TK_S2;
+    constexpr int kStage = STAGE ? kStageRecs * 4 * Rec<K0, K1, K2>::R : 16;
+    // narrow-only kernels spend longer on a tile (LDS transpose) than its loads take to issue: the next group's loads go
+    // out BEFORE the current group is evaluated.  (With an int32 column the same pipeline measured slower: DESIGN.md finding 8.)
+    constexpr bool kPipe = STAGE || (kXpose && K0 != TK_I32 && K1 != TK_I32 && K2 != TK_I32);
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerBlock][kStage];
+    __shared__ __attribute__((aligned(16))) uint8_t s_xpose[kWavesPerBlock][kXpose ? kXposeBytes : 16];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint8_t *lds = s_stage[wave];
+    uint8_t *xp = s_xpose[wave];
     // Deferred bitmap (a.defer_lines > 0; dynamic LDS): the 128-byte bitmap lines of a wave's tiles are parked in LDS and
     // written in bursts of a.defer_lines lines (one burst at the end for 100 M rows) instead of one line per tile in between
     // the streaming loads -- HBM read/write turnarounds cost more than the 3 % of bytes the bitmap is (tools/filter_explore:
@@ -319,13 +322,13 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
                 c0.load(d0, 0, lane);
                 c1.load(d1, 0, lane);
                 c2.load(d2, 0, lane);
-                lane_total += finish_full_tile<K0, K1, K2>(a, tile, lane, c0, c1, c2, lds, DEFER ? park + parked * kTileWords : nullptr);
+                lane_total += finish_full_tile<K0, K1, K2, STAGE>(a, tile, lane, c0, c1, c2, xp, lds, DEFER ? park + parked * kTileWords : nullptr);
                 if (DEFER) {
                     if (lane == 0) pidx[parked] = (uint64_t)tile;
                     if (++parked == a.defer_lines) flush(); // wave-uniform
                 }
             } else {
-                lane_total += partial_tile<K0, K1, K2>(a, tile, lane, d0, d1, d2, 0, rows_here, c0, c1, c2);
+                lane_total += partial_tile<K0, K1, K2, STAGE>(a, tile, lane, d0, d1, d2, 0, rows_here, c0, c1, c2);
             }
         }
         if (DEFER && parked) flush();
@@ -350,21 +353,38 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
         lds_wave_sync();
         parked = 0;
     };
+    ColRegs<K0> n0[T]; // kPipe: the group after the current one, already loading
+    ColRegs<K1> n1[T];
+    ColRegs<K2> n2[T];
+    auto load_group = [&](ColRegs<K0> (&r0)[T], ColRegs<K1> (&r1)[T], ColRegs<K2> (&r2)[T], int64_t grp) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int64_t row0 = (grp * T + t) * kTileRows;
+            r0[t].load(a.cols[0].data, row0, lane);
+            r1[t].load(a.cols[1].data, row0, lane);
+            r2[t].load(a.cols[2].data, row0, lane);
+        }
+    };
+    if (kPipe && wave_id < n_groups) load_group(n0, n1, n2, wave_id);
     for (int64_t grp = wave_id; grp < n_groups; grp += n_waves) {
         ColRegs<K0> c0[T];
         ColRegs<K1> c1[T];
         ColRegs<K2> c2[T];
+        if constexpr (kPipe) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int64_t row0 = (grp * T + t) * kTileRows;
-            c0[t].load(a.cols[0].data, row0, lane);
-            c1[t].load(a.cols[1].data, row0, lane);
-            c2[t].load(a.cols[2].data, row0, lane);
+            for (int t = 0; t < T; ++t) {
+                c0[t] = n0[t];
+                c1[t] = n1[t];
+                c2[t] = n2[t];
+            }
+            if (grp + n_waves < n_groups) load_group(n0, n1, n2, grp + n_waves); // wave-uniform
+        } else {
+            load_group(c0, c1, c2, grp);
         }
         if (DEFER && parked == 0) first_grp = grp;
 #pragma unroll
         for (int t = 0; t < T; ++t)
-            lane_total += finish_full_tile<K0, K1, K2>(a, grp * T + t, lane, c0[t], c1[t], c2[t], lds, DEFER ? park + (parked + t) * kTileWords : nullptr);
+            lane_total += finish_full_tile<K0, K1, K2, STAGE>(a, grp * T + t, lane, c0[t], c1[t], c2[t], xp, lds, DEFER ? park + (parked + t) * kTileWords : nullptr);
         if (DEFER) {
             parked += T;
             if (parked + T > a.defer_lines) flush(); // wave-uniform
@@ -381,9 +401,9 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
             c0.load(a.cols[0].data, row0, lane);
             c1.load(a.cols[1].data, row0, lane);
             c2.load(a.cols[2].data, row0, lane);
-            lane_total += finish_full_tile<K0, K1, K2>(a, tile, lane, c0, c1, c2, lds);
+            lane_total += finish_full_tile<K0, K1, K2, STAGE>(a, tile, lane, c0, c1, c2, xp, lds);
         } else { // rolled, bounds-checked
-            lane_total += partial_tile<K0, K1, K2>(a, tile, lane, a.cols[0].data, a.cols[1].data, a.cols[2].data, row0, a.n_rows - row0, c0, c1, c2);
+            lane_total += partial_tile<K0, K1, K2, STAGE>(a, tile, lane, a.cols[0].data, a.cols[1].data, a.cols[2].data, row0, a.n_rows - row0, c0, c1, c2);
         }
     }
 #pragma unroll
@@ -734,6 +754,94 @@ __global__ __launch_bounds__(kBlockThreads) void k_gather_plain(const GatherArgs
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_emit: ProjectOp over the survivor records the filter kernel staged (one uniform segment, unlimited projection).
+// One work-group per group of kEmitTiles tiles; the group's tile offsets sit in LDS and every THREAD owns one output
+// row: it finds the row's tile by binary search in LDS (6 steps), loads the row's record, takes the staged columns
+// out of it, gathers the others at the record's position -- all NG gathers of all kEmitUnroll rows in flight
+// together -- and stores.  No bitmap expansion, no per-tile lane waste (a tile has ~20 survivors at 2 % selectivity,
+// ~100 at 10 %), every thread independent of every other.
+// ---------------------------------------------------------------------------------------------
+constexpr int kEmitUnroll = 2;
+
+template <int R, int NG>
+__global__ __launch_bounds__(kBlockThreads) void k_emit(const EmitArgs a) {
+    typedef typename RecVec<R>::type vec;
+    __shared__ uint32_t s_off[kEmitTiles + 1];
+    __shared__ unsigned long long s_base;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int64_t n_groups = (a.n_tiles + kEmitTiles - 1) / kEmitTiles;
+    for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) { // block-uniform trip count
+        const int64_t tile0 = g * kEmitTiles;
+        const int64_t chunk = tile0 / kChunkTiles; // kChunkTiles % kEmitTiles == 0: a group never straddles chunks
+        if (t <= kEmitTiles) {
+            const int64_t tile = tile0 + t;
+            s_off[t] = (tile < a.n_tiles && tile / kChunkTiles == chunk) ? a.tile_offsets[tile] : a.chunk_sums[chunk];
+        } else if (t >= 128 && t < 192) { // one wave: survivors of the chunks before this one
+            unsigned long long part = 0;
+            for (int64_t i = lane; i < chunk; i += 64) part += a.chunk_sums[i];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+            if (lane == 0) s_base = part;
+        }
+        __syncthreads();
+        const uint32_t o0 = s_off[0];
+        const unsigned long long base = s_base + o0;
+        uint32_t n_here = s_off[kEmitTiles] - o0;
+        if (base + n_here > a.cap_rows) n_here = base >= a.cap_rows ? 0u : (uint32_t)(a.cap_rows - base); // block-uniform
+        for (uint32_t k0 = t; k0 < n_here; k0 += kEmitUnroll * kBlockThreads) {
+            vec rec[kEmitUnroll];
+            uint32_t rowv[kEmitUnroll];
+            uint32_t gv[kEmitUnroll][NG > 0 ? NG : 1];
+#pragma unroll
+            for (int u = 0; u < kEmitUnroll; ++u) { // the records of the step (an out-of-range row re-reads row k0: no branch)
+                const uint32_t k = k0 + u * kBlockThreads < n_here ? k0 + u * kBlockThreads : k0;
+                int lo = 0;
+#pragma unroll
+                for (int step = kEmitTiles / 2; step >= 1; step >>= 1)
+                    if (s_off[lo + step] - o0 <= k) lo += step; // the LAST tile whose first survivor is <= k: the one that holds row k
+                const int64_t tile = tile0 + lo;
+                const uint32_t j = k - (s_off[lo] - o0);
+                rec[u] = ((const vec *)a.stage)[tile * kTileRows + j];
+                rowv[u] = (uint32_t)tile; // (position added once the record is here)
+            }
+#pragma unroll
+            for (int u = 0; u < kEmitUnroll; ++u) { // every gather of the step before the first store
+                uint32_t r0;
+                if constexpr (R == 1) r0 = rec[u];
+                else r0 = rec[u].x;
+                rowv[u] = rowv[u] * (uint32_t)kTileRows + (r0 & (uint32_t)(kTileRows - 1));
+#pragma unroll
+                for (int c = 0; c < NG; ++c) { // the launcher puts the gathered columns first
+                    const int64_t byte = (int64_t)rowv[u] * a.cols[c].width;
+                    gv[u][c] = ((const uint32_t *)a.cols[c].src)[byte >> 2] >> (8 * ((uint32_t)byte & 3u));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kEmitUnroll; ++u) {
+                const uint32_t k = k0 + u * kBlockThreads;
+                if (k < n_here) {
+                    const unsigned long long out = base + k;
+                    if (a.row_index) a.row_index[out] = rowv[u];
+#pragma unroll
+                    for (int c = 0; c < NG; ++c) store_value_rt(a.cols[c].dst, a.cols[c].width, out, gv[u][c]);
+                    uint32_t rw[4];
+                    if constexpr (R == 1) { rw[0] = rec[u]; rw[1] = rw[2] = rw[3] = 0u; }
+                    else if constexpr (R == 2) { rw[0] = rec[u].x; rw[1] = rec[u].y; rw[2] = rw[3] = 0u; }
+                    else { rw[0] = rec[u].x; rw[1] = rec[u].y; rw[2] = rec[u].z; rw[3] = rec[u].w; }
+                    for (int c = NG; c < a.n_cols; ++c) { // staged columns: already in the record
+                        const int d = a.cols[c].rec_dword;
+                        const uint32_t word = d == 0 ? rw[0] : (d == 1 ? rw[1] : (d == 2 ? rw[2] : rw[3]));
+                        store_value_rt(a.cols[c].dst, a.cols[c].width, out, word >> a.cols[c].rec_shift);
+                    }
+                }
+            }
+        }
+        __syncthreads(); // s_off / s_base are reused by the next group
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_read_stream: read-only ceiling probe (same tiling, loads and grid as k_filter_tile<I32>, no compares, no stores)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlockThreads) void k_read_stream(const int32_t *data, int64_t n_tiles, int32_t *sink) {
@@ -782,12 +890,14 @@ int filter_grid(int64_t units, bool generic, bool any_i32, int grid_blocks) {
 
 #define IMM3_TILE_CASE(k0, k1, k2, T)                                                           \
     if (a.kinds[0] == k0 && a.kinds[1] == k1 && a.kinds[2] == k2) {                             \
-        if (a.tile_rows && a.defer_lines) IMM3_LAUNCH_LDS((k_filter_tile<k0, k1, k2, 1, true, true>), grid, kBlockThreads, \
+        if (a.stage_rec && a.tile_rows) IMM3_LAUNCH((k_filter_tile<k0, k1, k2, 1, true, false, true>), grid, kBlockThreads, s, ev0, ev1, a); \
+        else if (a.stage_rec) IMM3_LAUNCH((k_filter_tile<k0, k1, k2, T, false, false, true>), grid, kBlockThreads, s, ev0, ev1, a); \
+        else if (a.tile_rows && a.defer_lines) IMM3_LAUNCH_LDS((k_filter_tile<k0, k1, k2, 1, true, true, false>), grid, kBlockThreads, \
                              (size_t)kWavesPerBlock * (size_t)a.defer_lines * (kTileWords + 1) * sizeof(uint64_t), s, ev0, ev1, a); \
-        else if (a.tile_rows) IMM3_LAUNCH((k_filter_tile<k0, k1, k2, 1, true, false>), grid, kBlockThreads, s, ev0, ev1, a); \
-        else if (a.defer_lines) IMM3_LAUNCH_LDS((k_filter_tile<k0, k1, k2, T, false, true>), grid, kBlockThreads,       \
+        else if (a.tile_rows) IMM3_LAUNCH((k_filter_tile<k0, k1, k2, 1, true, false, false>), grid, kBlockThreads, s, ev0, ev1, a); \
+        else if (a.defer_lines) IMM3_LAUNCH_LDS((k_filter_tile<k0, k1, k2, T, false, true, false>), grid, kBlockThreads,       \
                              (size_t)kWavesPerBlock * (size_t)a.defer_lines * kTileWords * sizeof(uint64_t), s, ev0, ev1, a); \
-        else IMM3_LAUNCH((k_filter_tile<k0, k1, k2, T, false, false>), grid, kBlockThreads, s, ev0, ev1, a);        \
+        else IMM3_LAUNCH((k_filter_tile<k0, k1, k2, T, false, false, false>), grid, kBlockThreads, s, ev0, ev1, a); \
         return true;                                                                            \
     }
 
@@ -860,6 +970,26 @@ void launch_gather(const GatherArgs &a, int grid_blocks, hipStream_t s, hipEvent
         IMM3_GATHER_CASE(0, 4, 0) IMM3_GATHER_CASE(0, 3, 1) IMM3_GATHER_CASE(0, 2, 2) IMM3_GATHER_CASE(0, 1, 3) IMM3_GATHER_CASE(0, 0, 4)
     }
     IMM3_LAUNCH(k_gather, grid, kBlockThreads, s, ev0, ev1, a);
+}
+
+template <int R>
+static void launch_emit_r(const EmitArgs &a, int n_gather, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    switch (n_gather) {
+    case 0: IMM3_LAUNCH((k_emit<R, 0>), grid, kBlockThreads, s, ev0, ev1, a); break;
+    case 1: IMM3_LAUNCH((k_emit<R, 1>), grid, kBlockThreads, s, ev0, ev1, a); break;
+    case 2: IMM3_LAUNCH((k_emit<R, 2>), grid, kBlockThreads, s, ev0, ev1, a); break;
+    case 3: IMM3_LAUNCH((k_emit<R, 3>), grid, kBlockThreads, s, ev0, ev1, a); break;
+    default: IMM3_LAUNCH((k_emit<R, 4>), grid, kBlockThreads, s, ev0, ev1, a); break;
+    }
+}
+
+// cols[0 .. n_gather) are gathered (rec_dword < 0), the rest come out of the record; n_gather <= kMaxEmitGather
+void launch_emit(const EmitArgs &a, int n_gather, int grid_blocks, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    const int64_t n_groups = (a.n_tiles + kEmitTiles - 1) / kEmitTiles;
+    const int grid = clamp_grid(n_groups, grid_blocks > 0 ? grid_blocks : 2048);
+    if (a.R == 1) launch_emit_r<1>(a, n_gather, grid, s, ev0, ev1);
+    else if (a.R == 2) launch_emit_r<2>(a, n_gather, grid, s, ev0, ev1);
+    else launch_emit_r<4>(a, n_gather, grid, s, ev0, ev1);
 }
 
 } // namespace imm3

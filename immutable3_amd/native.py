@@ -89,13 +89,27 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("IMM3_LIB_PATH", LIB_PATH)   # development only: A/B an older build of the SAME library on one box
+    if not os.path.exists(path):
         raise ImportError(
             f"{LIB_PATH} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C immutable3_amd/csrc). "
             "The immutable3 GPU path has no CPU fallback."
         )
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
+    if path != LIB_PATH:   # an older build lacks the newer entry points: bind what is there
+        class _Tolerant:
+            def __init__(self, lib):
+                object.__setattr__(self, "_lib", lib)
+
+            def __getattr__(self, name):
+                try:
+                    return getattr(object.__getattribute__(self, "_lib"), name)
+                except AttributeError:
+                    class _Missing:
+                        argtypes = restype = None
+                    return _Missing()
+        L = _Tolerant(L)
     vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
     P = C.POINTER
     L.imm3_abi_version.restype = C.c_int

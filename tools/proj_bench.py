@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Development tool: C3 / C4 per-kernel times (HIP events) for a list of filter grids.  usage: proj_bench.py [grid ...]"""
+import sys
+import numpy as np
+sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
+from immutable3_amd import native, synth
+
+n = 100_000_000
+ctx = native.Context(0)
+ids = np.arange(n, dtype=np.int32)
+age = synth.uniform_below(2, n, 100, np.int8)
+st = synth.state_codes(3, n)
+seg = native.DeviceSegment(ctx, [
+    (native.DENSE_INT, 4, ids.view(np.uint8), n * 4, synth.block_offsets(n, 4)),
+    (native.DENSE_STRING, 2, st.reshape(-1), n * 2, synth.block_offsets(n, 2)),
+    (native.DENSE_TINYINT, 1, age.view(np.uint8), n, synth.block_offsets(n, 1))])
+cases = {
+    "C3": ([2, 0], [(0, native.GT, 18.0), (0, native.LT, 30.0), (1, native.GT, 1e6), (1, native.LT, 9e7)], [1, 0]),
+    "C4": ([1, 0, 2], [(0, native.MATCH, [b"CA"])], [1, 0, 2]),
+    "age->id": ([2, 0], [(0, native.GT, 18.0), (0, native.LT, 30.0)], [1]),          # projected column is NOT a predicate column
+    "id50%": ([0], [(0, native.GT, 5e7)], [0]),                                       # sigma = 0.5
+}
+names = {0: "filter", 1: "scan", 2: "project", 3: "count"}
+import os
+VARIANTS = [int(v) for v in os.environ.get("IMM3_VARIANTS", "0").split(",")]
+grids = [int(g) for g in sys.argv[1:]] or [0]
+for name, (used, sels, proj) in cases.items():
+  for variant in VARIANTS:
+    for grid in grids:
+        ctx.set_tuning(variant, grid)
+        q = native.DeviceQuery(ctx, seg, used, sels, proj, 0, 1024)
+        q.run()
+        cnt = q.count()
+        q.reserve_rows(cnt + 1024)
+        for _ in range(3):
+            q.run()
+        ctx.sync()
+        ctx.timing_enable(256); ctx.timing_mask(0xFFFFFFFF); ctx.timing_reset()
+        for _ in range(20):
+            q.run()
+        ctx.sync()
+        ks = {i: ctx.timing_collect(i) for i in range(4)}
+        ctx.timing_enable(0)
+        tot = sum(float(np.median(k)) for k in ks.values() if k.size)
+        print(f"{name:8s} v{variant:<3d} grid {grid:5d} sel {cnt / n:.4f}  " + "  ".join(f"{names[i]} {float(np.median(k)) * 1e3:6.1f}" for i, k in ks.items() if k.size) + f"  sum {tot * 1e3:6.1f} us")
+        q.close()
