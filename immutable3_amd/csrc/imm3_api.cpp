@@ -1216,7 +1216,8 @@ static int join_total(imm3_query *q, hipStream_t s) {
 }
 int imm3::join_query_count(imm3_query *q, hipStream_t s) { return join_total(q, s); }
 
-static int run_select(imm3_query *q, bool overlap_total) {
+// count_in_scan: a projection follows on the same stream; its offsets scan publishes the count (no k_total launch)
+static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = false) {
     imm3_ctx *ctx = q->ctx;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -1307,11 +1308,11 @@ static int run_select(imm3_query *q, bool overlap_total) {
         for (int k = 0; k < kMaxTileCols; ++k) any_i32 |= (a.kinds[k] == TK_I32);
         if (ctx->d_stamps && ctx->stamp_used < ctx->stamp_slots) a.stamps = ctx->d_stamps + (size_t)ctx->stamp_used * kMaxFilterGrid * 2;
         grid = filter_grid(q->n_tiles, false, any_i32 || n == 0, ctx->grid_blocks);
-        // a staging launch keeps a quarter tile of records per wave in LDS (1 KiB x R) next to the transpose buffers: as many
+        // a staging launch keeps one tile of records per wave in LDS (4 KiB x R) next to the transpose buffers: as many
         // work-groups per CU as that leaves room for, up to 8
         if (q->stage_written && ctx->grid_blocks <= 0) {
             const int R = rec_layout(q->stage_kinds, -1).dwords;
-            const int per_cu = std::min(8, (160 * 1024) / (kWavesPerBlock * (256 * 4 * R + 2048) + 512)); // 256 records per staging round
+            const int per_cu = std::min(8, (160 * 1024) / (kWavesPerBlock * (kTileRows * 4 * R + 2048 + 16 * 128) + 512)); // a tile of records + transpose + parked lines per wave
             grid = clamp_grid_api((q->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, 256 * per_cu);
         }
         // A select chain that is ONE tile pass also reduces its count in the kernel (one relaxed atomic per work-group): no
@@ -1324,7 +1325,7 @@ static int run_select(imm3_query *q, bool overlap_total) {
         // bitmap lines parked in LDS and stored in bursts: no staging (whose LDS and 2048 work-groups
         // leave no room for 32 KiB more per group); tuning variant 12 switches it off
         // (64 lines = 32 KiB per work-group at <= 4 groups per CU; 16 lines = 8 KiB for the 1536-group narrow-column kernels)
-        a.defer_lines = (!q->stage_written && ctx->filter_variant != 12) ? (grid <= 1024 ? kDeferLines : 16) : 0;
+        a.defer_lines = ctx->filter_variant == 12 ? 0 : (q->stage_written ? 16 : (grid <= 1024 ? kDeferLines : 16));
         if (a.stamps) { ctx->stamp_grids.push_back(grid); ++ctx->stamp_used; }
         LaunchTimer t(ctx, 0);
         if (!launch_filter_tile(a, grid, s, t.start, t.stop)) return fail(IMM3_ERR_ARG, "internal: no tile kernel for this column combination");
@@ -1385,7 +1386,8 @@ static int run_select(imm3_query *q, bool overlap_total) {
         gi += take;
         ++pass;
     }
-    if (!count_done) { // the last pass's per-workgroup partials -> selected-row count (+ rows ProjectOp will emit)
+    q->count_pending_scan = !count_done && count_in_scan;
+    if (!count_done && !count_in_scan) { // the last pass's per-workgroup partials -> selected-row count (+ rows ProjectOp will emit)
         TotalArgs ta;
         std::memset(&ta, 0, sizeof(ta));
         ta.block_partials = q->d_block_partials;
@@ -1513,6 +1515,7 @@ static int run_project(imm3_query *q) {
         sa.tile_offsets = q->d_tile_offsets;
         sa.chunk_sums = q->d_chunk_sums;
         sa.n_tiles = q->n_tiles;
+        sa.finish = q->count_pending_scan ? q->d_total : nullptr;
         {
             LaunchTimer t(ctx, 1);
             launch_scan(sa, s, t.start, t.stop);
@@ -1562,7 +1565,7 @@ extern "C" int imm3_query_run(imm3_query *q) {
     // per step: the cross-queue event packets cost more than the two same-queue launch gaps they remove), so the
     // default keeps the reduce on the main stream.
     const bool select_only = q->proj.empty() && !q->is_agg && q->ctx->filter_variant == 2;
-    int rc = run_select(q, select_only);
+    int rc = run_select(q, select_only, !q->proj.empty() && q->n_tiles > 0 && !q->always_false && q->ctx->filter_variant != 7);
     if (rc) return rc;
     if (!q->proj.empty()) rc = run_project(q);
     if (!rc && q->is_agg) rc = run_agg(q);

@@ -73,6 +73,19 @@ __device__ __forceinline__ void count_log_append(unsigned long long *finish, uns
 // to re-read, no ordering between two atomics, and no release/acquire fence (a device-scope fence writes back and
 // invalidates the XCD's L2: one per work-group made the scan 25 % slower).  One atomic per work-group, spread over the
 // kernel's tail, unlike the per-wave atomics of finding 1.
+// one thread per work-group: add this work-group's survivors; the last arrival publishes the total
+__device__ __forceinline__ void finish_add(unsigned long long *finish, unsigned long long t) {
+    const unsigned long long prev = __hip_atomic_fetch_add(finish + 4, t | (1ULL << 40), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((prev >> 40) == (unsigned long long)gridDim.x - 1) {
+        const unsigned long long total = (prev & ((1ULL << 40) - 1)) + t;
+        const long long limit = (long long)finish[3];
+        finish[0] = total;
+        finish[1] = (limit > 0 && total > (unsigned long long)limit) ? (unsigned long long)limit : total;
+        count_log_append(finish, total);
+        __hip_atomic_store(finish + 4, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
+    }
+}
+
 __device__ __forceinline__ void block_partial_finish(unsigned long long *finish, uint32_t wave_total, int lane, int wave) {
     __shared__ uint32_t s_part[kWavesPerBlock];
     if (lane == 0) s_part[wave] = wave_total;
@@ -81,15 +94,7 @@ __device__ __forceinline__ void block_partial_finish(unsigned long long *finish,
         unsigned long long t = 0;
 #pragma unroll
         for (int i = 0; i < kWavesPerBlock; ++i) t += s_part[i];
-        const unsigned long long prev = __hip_atomic_fetch_add(finish + 4, t | (1ULL << 40), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((prev >> 40) == (unsigned long long)gridDim.x - 1) {
-            const unsigned long long total = (prev & ((1ULL << 40) - 1)) + t;
-            const long long limit = (long long)finish[3];
-            finish[0] = total;
-            finish[1] = (limit > 0 && total > (unsigned long long)limit) ? (unsigned long long)limit : total;
-            count_log_append(finish, total);
-            __hip_atomic_store(finish + 4, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
-        }
+        finish_add(finish, t);
     }
 }
 

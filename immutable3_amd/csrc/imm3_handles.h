@@ -181,6 +181,7 @@ struct imm3_query {
     int32_t stage_kinds[imm3::kMaxTileCols] = {imm3::TK_NONE, imm3::TK_NONE, imm3::TK_NONE}; // of the staged launch, in its column order
     int32_t stage_seg_col[imm3::kMaxTileCols] = {-1, -1, -1};                                 // segment column of each
     bool stage_written = false;   // the last select run filled the records
+    bool count_pending_scan = false; // the last select run left the count to the projection's offsets scan
 };
 
 

@@ -162,6 +162,7 @@ struct ScanArgs {
     uint32_t *tile_offsets;      // exclusive prefix of the per-tile survivor counts WITHIN its chunk
     uint32_t *chunk_sums;        // selected rows per chunk of kChunkTiles tiles
     int64_t n_tiles;
+    unsigned long long *finish;  // the query's {total, n_emit, status, limit, tally, log ...} block when THIS kernel publishes the count, else null
 };
 
 struct ProjCol {

@@ -46,7 +46,7 @@ namespace imm3 {
 // = 2 per CU = 8 waves/CU (more waves add DRAM page conflicts, fewer starve the memory pipeline).
 // ---------------------------------------------------------------------------------------------
 constexpr int kXposeBytes = 2048; // per wave: one tile of the widest transposed kind (2-byte strings)
-constexpr int kStageRecs = 256;   // survivor records a wave's LDS staging buffer holds
+constexpr int kStageRecs = kTileRows; // survivor records a wave's LDS staging buffer holds: one tile
 
 // LDS hand-off between the lanes of ONE wave needs no wait at all: a wave's LDS instructions execute in order, so a
 // ds_read issued after a ds_write sees it.  Only the compiler must not reorder them.
@@ -55,6 +55,7 @@ __device__ __forceinline__ void lds_wave_order() { asm volatile("" ::: "memory")
 template <int KIND>
 struct ColRegs { // TK_NONE: no column
     __device__ __forceinline__ void load(const void *, int64_t, int) {}
+    __device__ __forceinline__ void touch() {}
     __device__ __forceinline__ void eval(const TileCol &, uint64_t (&)[kTileWords], int, uint8_t *) {}
     __device__ __forceinline__ bool row(const void *, const TileCol &, int64_t) { return true; }
     __device__ __forceinline__ uint32_t value(int) const { return 0u; }
@@ -69,6 +70,11 @@ struct ColRegs<TK_I32> {
 #pragma unroll
         for (int j = 0; j < kTileWords; ++j) v[j] = __builtin_nontemporal_load(p + 64 * j);
     }
+    // "the loaded registers are needed HERE": pins the compiler's s_waitcnt for these loads to this point (see k_filter_tile)
+    __device__ __forceinline__ void touch() {
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) asm volatile("" : "+v"(v[j]));
+    }
     __device__ __forceinline__ void eval(const TileCol &c, uint64_t (&acc)[kTileWords], int, uint8_t *) {
 #pragma unroll
         for (int j = 0; j < kTileWords; ++j) acc[j] &= ballot64(in_closed(v[j], c.lo, c.hi));
@@ -81,21 +87,22 @@ struct ColRegs<TK_I32> {
 template <>
 struct ColRegs<TK_I8> {
     v4i raw;
-    int32_t v[kTileWords]; // after eval(): row 64j + lane, sign-extended
+    uint32_t v[kTileWords]; // after eval(): the byte of row 64j + lane, zero-extended (what a survivor record carries)
     __device__ __forceinline__ void load(const void *data, int64_t row0, int lane) {
         raw = __builtin_nontemporal_load((const v4i *)((const int8_t *)data + row0) + lane);
     }
+    __device__ __forceinline__ void touch() { asm volatile("" : "+v"(raw)); }
     __device__ __forceinline__ void eval(const TileCol &c, uint64_t (&acc)[kTileWords], int lane, uint8_t *xp) {
         *(v4i *)(xp + 16 * lane) = raw; // the tile's 1024 bytes in row order
         lds_wave_order();
 #pragma unroll
-        for (int j = 0; j < kTileWords; ++j) v[j] = (int32_t)((const int8_t *)xp)[64 * j + lane];
+        for (int j = 0; j < kTileWords; ++j) v[j] = ((const uint8_t *)xp)[64 * j + lane];
         lds_wave_order();
 #pragma unroll
-        for (int j = 0; j < kTileWords; ++j) acc[j] &= ballot64(in_closed(v[j], c.lo, c.hi));
+        for (int j = 0; j < kTileWords; ++j) acc[j] &= ballot64(in_closed((int32_t)(int8_t)v[j], c.lo, c.hi)); // (sign extension folds into the subtract: SDWA)
     }
     __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return in_closed((int32_t)((const int8_t *)data)[r], c.lo, c.hi); }
-    __device__ __forceinline__ uint32_t value(int j) const { return (uint32_t)v[j] & 0xFFu; }
+    __device__ __forceinline__ uint32_t value(int j) const { return v[j]; }
     __device__ __forceinline__ uint32_t rowval(const void *data, int64_t r) const { return ((const uint8_t *)data)[r]; }
 };
 
@@ -107,6 +114,10 @@ struct ColRegs<TK_S2> {
         const v4i *p = (const v4i *)((const uint16_t *)data + row0) + lane;
         raw[0] = __builtin_nontemporal_load(p);
         raw[1] = __builtin_nontemporal_load(p + 64);
+    }
+    __device__ __forceinline__ void touch() {
+        asm volatile("" : "+v"(raw[0]));
+        asm volatile("" : "+v"(raw[1]));
     }
     __device__ __forceinline__ bool hit(const TileCol &c, uint32_t x) {
         bool f = false;
@@ -175,49 +186,64 @@ struct Rec {
     }
 };
 
+// The records of the tile a wave compacted last wait in its LDS buffer; they are copied to the tile's slots LATER -- in the
+// pipelined loop right after the next group's loads have been issued -- so that their write acknowledgement never sits
+// in front of a wait for loads: vmcnt retires in issue order, and the loop's one wait (vmcnt(0), before the prefetch)
+// then only ever sees stores that have had a whole iteration to complete (C3 filter: 107 -> 8x us).
+struct PendingRecords {
+    void *out = nullptr; // the tile's first slot, or null: nothing waiting
+    uint32_t n = 0;
+};
+
+template <int R>
+__device__ __forceinline__ void flush_records(const TileArgs &a, PendingRecords &p, const uint8_t *lds, int lane) {
+    typedef typename RecVec<R>::type vec;
+    if (!p.out) return; // wave-uniform
+    const vec *l = (const vec *)lds;
+    vec *out = (vec *)p.out;
+    lds_wave_order();
+    if (a.debug != 20) // (ablation: records compacted in LDS but not stored)
+        for (uint32_t i = lane; i < p.n; i += 64) out[i] = l[i];
+    lds_wave_order();
+    p.out = nullptr;
+}
+
 template <int K0, int K1, int K2>
 __device__ __forceinline__ void stage_full_tile(const TileArgs &a, int64_t tile, int lane, const ColRegs<K0> &c0, const ColRegs<K1> &c1,
-                                                const ColRegs<K2> &c2, const uint64_t (&acc)[kTileWords], uint8_t *lds) {
+                                                const ColRegs<K2> &c2, const uint64_t (&acc)[kTileWords], uint8_t *lds, PendingRecords &pend) {
     typedef Rec<K0, K1, K2> L;
     typedef typename L::vec vec;
+    flush_records<L::R>(a, pend, lds, lane); // the buffer holds one tile
     vec *l = (vec *)lds;
-    vec *out = (vec *)a.stage_rec + tile * kTileRows;
-    // The wave's LDS buffer holds kStageRecs records: it is flushed to the tile's slots whenever the next word's survivors
-    // might not fit -- once per tile at <= 25 % selectivity, more often above -- so the LDS a wave needs stays small and 8
-    // work-groups fit a CU.
-    uint32_t base = 0; // wave-uniform: records in the buffer
-    auto flush = [&]() {
-        lds_wave_order();
-        if (a.debug != 20) // (ablation: records compacted in LDS but not stored)
-            for (uint32_t i = lane; i < base; i += 64) out[i] = l[i];
-        lds_wave_order();
-        out += base;
-        base = 0;
-    };
+    // The wave's LDS buffer holds a whole tile of records, so the 16 words go in back to back -- no capacity checks.
+    uint32_t base = 0; // wave-uniform: records so far
 #pragma unroll
     for (int j = 0; j < kTileWords; ++j) {
         const uint64_t m = acc[j];
-        const uint32_t pc = (uint32_t)__popcll(m);
-        if (base + pc > (uint32_t)kStageRecs) flush(); // wave-uniform
         uint32_t rec[4] = {(uint32_t)(64 * j) | (uint32_t)lane, 0u, 0u, 0u};
         L::template put<0>(rec, c0.value(j));
         L::template put<1>(rec, c1.value(j));
         L::template put<2>(rec, c2.value(j));
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
-        if (__builtin_amdgcn_inverse_ballot_w64(m)) l[rank] = L::pack(rec); // exec = the word itself
-        base += pc;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (__builtin_amdgcn_inverse_ballot_w64(m)) (l + base)[rank] = L::pack(rec); // exec = the word itself; `base` stays scalar
+        base += (uint32_t)__popcll(m);
     }
-    if (base) flush();
+    pend.out = (vec *)a.stage_rec + tile * kTileRows;
+    pend.n = base;
 }
 
-// AND the per-kind results of one FULL tile (registers already loaded), store / park its bitmap line, stage its
-// survivors' records where asked, return in lanes 0..15 the popcount of the words they own.
+// `earlier`: the tile's words from an earlier pass when the caller has loaded them already (pipelined loop), else null and
+// they are loaded here.  A staging launch is the only pass of its chain: it never ANDs.
 template <int K0, int K1, int K2, bool STAGE>
 __device__ __forceinline__ uint32_t finish_full_tile(const TileArgs &a, int64_t tile, int lane, ColRegs<K0> &c0,
-                                                     ColRegs<K1> &c1, ColRegs<K2> &c2, uint8_t *xp, uint8_t *lds, uint64_t *park = nullptr) {
+                                                     ColRegs<K1> &c1, ColRegs<K2> &c2, uint8_t *xp, uint8_t *lds, PendingRecords &pend,
+                                                     uint64_t *park = nullptr, const uint64_t *earlier = nullptr) {
     const int64_t w = tile * kTileWords + lane; // lane j < 16 owns bitmap word j of the tile
     uint64_t mine = ~0ULL;
-    if (a.and_existing) mine = lane < kTileWords ? a.bitmap[w] : 0ULL;
+    if constexpr (!STAGE) {
+        if (earlier) mine = *earlier;
+        else if (a.and_existing) mine = lane < kTileWords ? a.bitmap[w] : 0ULL;
+    }
     uint64_t acc[kTileWords]; // wave-uniform words (SGPR pairs)
 #pragma unroll
     for (int j = 0; j < kTileWords; ++j) acc[j] = ~0ULL;
@@ -231,7 +257,7 @@ __device__ __forceinline__ uint32_t finish_full_tile(const TileArgs &a, int64_t 
         else __builtin_nontemporal_store(mine, a.bitmap + w);
     }
     if constexpr (STAGE)
-        if (a.debug != 21) stage_full_tile<K0, K1, K2>(a, tile, lane, c0, c1, c2, acc, lds); // (a staging launch never ANDs into an existing bitmap; 21: ablation)
+        if (a.debug != 21) stage_full_tile<K0, K1, K2>(a, tile, lane, c0, c1, c2, acc, lds, pend); // (21: ablation)
     return (uint32_t)__popcll(mine);
 }
 
@@ -274,7 +300,7 @@ __device__ __forceinline__ uint32_t partial_tile(const TileArgs &a, int64_t tile
 // loads in flight (8 waves/CU x 4 KiB is what saturates HBM, see the header comment).
 // TABLE selects the tile-table walk (table queries) at compile time, so the single-segment kernel carries none of it.
 // DEFER (compile time, like TABLE): the bitmap lines of a wave's tiles are parked in LDS and written in bursts.
-// STAGE: the survivors' records are compacted and stored per tile (projecting queries; never with DEFER).
+// STAGE: the survivors' records are compacted and stored per tile (projecting queries).
 template <int K0, int K1, int K2, int T, bool TABLE, bool DEFER, bool STAGE>
 __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a) {
     constexpr bool kXpose = K0 == TK_I8 || K0 == TK_S2 || K1 == TK_I8 || K1 == TK_S2 || K2 == TK_I8 || K2 == TK_S2;
@@ -296,6 +322,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
     uint64_t *park = DEFER ? s_park + (size_t)wave * a.defer_lines * kTileWords : nullptr;
     if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x] = wall_clock64(); // instrumented pass of bench.py only
     uint32_t lane_total = 0; // lanes 0..15: survivors in the words they stored
+    PendingRecords pend;
+    constexpr int kRecDwords = Rec<K0, K1, K2>::R;
     const int64_t wave_id = (int64_t)blockIdx.x * kWavesPerBlock + wave;
     const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
 
@@ -322,7 +350,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
                 c0.load(d0, 0, lane);
                 c1.load(d1, 0, lane);
                 c2.load(d2, 0, lane);
-                lane_total += finish_full_tile<K0, K1, K2, STAGE>(a, tile, lane, c0, c1, c2, xp, lds, DEFER ? park + parked * kTileWords : nullptr);
+                lane_total += finish_full_tile<K0, K1, K2, STAGE>(a, tile, lane, c0, c1, c2, xp, lds, pend, DEFER ? park + parked * kTileWords : nullptr);
                 if (DEFER) {
                     if (lane == 0) pidx[parked] = (uint64_t)tile;
                     if (++parked == a.defer_lines) flush(); // wave-uniform
@@ -332,6 +360,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
             }
         }
         if (DEFER && parked) flush();
+        if constexpr (STAGE) flush_records<kRecDwords>(a, pend, lds, lane);
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) lane_total += __shfl_xor(lane_total, d);
         if (a.finish) block_partial_finish(a.finish, lane_total, lane, wave);
@@ -370,21 +399,38 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
         ColRegs<K0> c0[T];
         ColRegs<K1> c1[T];
         ColRegs<K2> c2[T];
+        uint64_t earlier[T];
         if constexpr (kPipe) {
+            // Software pipeline, and where its one wait sits.  vmcnt retires in ISSUE ORDER, so the wait for this group's loads
+            // (issued an iteration ago) must come BEFORE the next group's loads are issued -- a wait placed after them would be
+            // vmcnt(their count) and cover everything older, including the previous tile's record stores, whose write
+            // acknowledgement then sits on the critical path of every tile (measured: C3 filter 82 -> 107 us).  touch() pins the
+            // wait here, where the only younger operations are those stores: s_waitcnt vmcnt(2).
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 c0[t] = n0[t];
                 c1[t] = n1[t];
                 c2[t] = n2[t];
+                c0[t].touch();
+                c1[t].touch();
+                c2[t].touch();
             }
-            if (grp + n_waves < n_groups) load_group(n0, n1, n2, grp + n_waves); // wave-uniform
+            if constexpr (!STAGE) { // a later pass of a multi-pass chain: this group's words so far, ahead of the prefetch
+#pragma unroll
+                for (int t = 0; t < T; ++t) earlier[t] = (a.and_existing && lane < kTileWords) ? a.bitmap[(grp * T + t) * kTileWords + lane] : (a.and_existing ? 0ULL : ~0ULL);
+            }
+            // unconditional (the last iteration re-reads its own group): a load the compiler sees on every path is a load its
+            // s_waitcnt can count past
+            load_group(n0, n1, n2, grp + n_waves < n_groups ? grp + n_waves : grp);
+            if constexpr (STAGE) flush_records<kRecDwords>(a, pend, lds, lane); // the previous tile's records: behind the prefetch
         } else {
             load_group(c0, c1, c2, grp);
         }
         if (DEFER && parked == 0) first_grp = grp;
 #pragma unroll
         for (int t = 0; t < T; ++t)
-            lane_total += finish_full_tile<K0, K1, K2, STAGE>(a, grp * T + t, lane, c0[t], c1[t], c2[t], xp, lds, DEFER ? park + (parked + t) * kTileWords : nullptr);
+            lane_total += finish_full_tile<K0, K1, K2, STAGE>(a, grp * T + t, lane, c0[t], c1[t], c2[t], xp, lds, pend, DEFER ? park + (parked + t) * kTileWords : nullptr,
+                                                              (kPipe && !STAGE) ? &earlier[t] : nullptr);
         if (DEFER) {
             parked += T;
             if (parked + T > a.defer_lines) flush(); // wave-uniform
@@ -401,11 +447,12 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
             c0.load(a.cols[0].data, row0, lane);
             c1.load(a.cols[1].data, row0, lane);
             c2.load(a.cols[2].data, row0, lane);
-            lane_total += finish_full_tile<K0, K1, K2, STAGE>(a, tile, lane, c0, c1, c2, xp, lds);
+            lane_total += finish_full_tile<K0, K1, K2, STAGE>(a, tile, lane, c0, c1, c2, xp, lds, pend);
         } else { // rolled, bounds-checked
             lane_total += partial_tile<K0, K1, K2, STAGE>(a, tile, lane, a.cols[0].data, a.cols[1].data, a.cols[2].data, row0, a.n_rows - row0, c0, c1, c2);
         }
     }
+    if constexpr (STAGE) flush_records<kRecDwords>(a, pend, lds, lane);
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) lane_total += __shfl_xor(lane_total, d); // lanes 0..15 -> lane 0
     if (a.finish) block_partial_finish(a.finish, lane_total, lane, wave); // the last pass also reduces the count
@@ -556,7 +603,12 @@ __global__ __launch_bounds__(kChunkTiles) void k_scan(const ScanArgs a) {
     for (int i = 0; i < wave; ++i) wave_prefix += s_wave[i];
     incl += wave_prefix;
     if (tile < a.n_tiles) a.tile_offsets[tile] = incl - c;
-    if (t == kChunkTiles - 1) a.chunk_sums[blockIdx.x] = incl;
+    if (t == kChunkTiles - 1) {
+        a.chunk_sums[blockIdx.x] = incl;
+        // A projecting run takes the selected-row count from here instead of a k_total launch: the chunk sums meet in one
+        // relaxed packed atomic (arrivals in the high bits, the running count in the low 40), the last chunk publishes.
+        if (a.finish) finish_add(a.finish, incl);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -891,6 +943,8 @@ int filter_grid(int64_t units, bool generic, bool any_i32, int grid_blocks) {
 #define IMM3_TILE_CASE(k0, k1, k2, T)                                                           \
     if (a.kinds[0] == k0 && a.kinds[1] == k1 && a.kinds[2] == k2) {                             \
         if (a.stage_rec && a.tile_rows) IMM3_LAUNCH((k_filter_tile<k0, k1, k2, 1, true, false, true>), grid, kBlockThreads, s, ev0, ev1, a); \
+        else if (a.stage_rec && a.defer_lines) IMM3_LAUNCH_LDS((k_filter_tile<k0, k1, k2, T, false, true, true>), grid, kBlockThreads, \
+                             (size_t)kWavesPerBlock * (size_t)a.defer_lines * kTileWords * sizeof(uint64_t), s, ev0, ev1, a); \
         else if (a.stage_rec) IMM3_LAUNCH((k_filter_tile<k0, k1, k2, T, false, false, true>), grid, kBlockThreads, s, ev0, ev1, a); \
         else if (a.tile_rows && a.defer_lines) IMM3_LAUNCH_LDS((k_filter_tile<k0, k1, k2, 1, true, true, false>), grid, kBlockThreads, \
                              (size_t)kWavesPerBlock * (size_t)a.defer_lines * (kTileWords + 1) * sizeof(uint64_t), s, ev0, ev1, a); \
