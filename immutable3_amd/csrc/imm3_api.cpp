@@ -667,6 +667,7 @@ static void query_free(imm3_query *q) {
     for (auto p : q->d_proj) pool_release(ctx, p);
     for (auto &p : q->preds) pool_release(ctx, p.d_blob);
     pool_release(ctx, q->d_stage_rec);
+    pool_release(ctx, q->d_tile_start);
     pool_release(ctx, q->d_akeys); pool_release(ctx, q->d_acounts); pool_release(ctx, q->d_okeys); pool_release(ctx, q->d_ocounts);
     pool_release(ctx, q->d_afirst); pool_release(ctx, q->d_ofirst); pool_release(ctx, q->d_ameta);
     pool_release(ctx, q->d_avals); pool_release(ctx, q->d_ovals);
@@ -1009,10 +1010,28 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
                 q->stage_kinds[k] = tile_kind(*order[k]);
                 q->stage_seg_col[k] = order[k]->seg_col;
             }
+            // Every wave of the staging launch writes its records to its own arena, so the launch geometry is fixed here:
+            // 768 work-groups (3 per CU: an 8 KiB record buffer per wave), grid-stride over groups of T tiles.
             const int R = rec_layout(q->stage_kinds, -1).dwords;
-            void *d = nullptr;
-            HIPCHK(pool_alloc(ctx, &d, (size_t)q->n_tiles * kTileRows * 4 * (size_t)R + 256));
-            q->d_stage_rec = (uint8_t *)d;
+            const int T = filter_tile_group(q->stage_kinds);
+            const int cap = ctx->grid_blocks > 0 ? std::min(ctx->grid_blocks, kMaxFilterGrid) : 768; // 3 per CU: ~52 KiB of LDS each
+            const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((q->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, cap));
+            const int64_t n_waves = grid * kWavesPerBlock;
+            const int64_t n_groups = T > 0 ? (q->n_rows / kTileRows) / T : 0;
+            const int64_t main_tiles = n_groups * T;
+            const int64_t max_slots = ((n_groups + n_waves - 1) / n_waves) * T + (q->n_tiles - main_tiles + n_waves - 1) / n_waves;
+            if (T > 0 && max_slots <= kMaxArenaSlots) {
+                q->stage_grid = (int32_t)grid;
+                q->stage_T = T;
+                q->stage_max_slots = (int32_t)std::max<int64_t>(max_slots, 1);
+                q->stage_wave_cap = (int64_t)q->stage_max_slots * kTileRows;
+                q->stage_main_tiles = main_tiles;
+                void *d = nullptr;
+                HIPCHK(pool_alloc(ctx, &d, (size_t)n_waves * (size_t)q->stage_wave_cap * 4 * (size_t)R + 256));
+                q->d_stage_rec = (uint8_t *)d;
+                HIPCHK(pool_alloc(ctx, &d, (size_t)n_waves * (size_t)q->stage_max_slots * sizeof(uint32_t) + 256));
+                q->d_tile_start = (uint32_t *)d;
+            }
         }
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1187,8 +1206,6 @@ extern "C" int imm3_query_reserve_rows(imm3_query *q, uint64_t rows) {
 // ---------------------------------------------------------------------------------------------
 // execution
 // ---------------------------------------------------------------------------------------------
-static int clamp_grid_api(int64_t want, int cap);
-
 static void fill_colpred(const imm3_query *q, const FoldedPred &fp, ColPred &cp) {
     std::memset(&cp, 0, sizeof(cp));
     const SegCol &sc = q->seg->cols[(size_t)fp.seg_col];
@@ -1294,9 +1311,12 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
             for (int k = 0; k < kMaxTileCols; ++k) same = same && a.kinds[k] == q->stage_kinds[k] && (k >= n || take[(size_t)k]->seg_col == q->stage_seg_col[k]);
             if (!same) return fail(IMM3_ERR_ARG, "internal: staged record layout does not match the tile launch");
             a.stage_rec = q->d_stage_rec;
+            a.tile_start = q->d_tile_start;
+            a.wave_cap = q->stage_wave_cap;
+            a.max_slots = q->stage_max_slots;
             q->stage_written = true;
         }
-        a.debug = (ctx->filter_variant == 20 || ctx->filter_variant == 21) ? ctx->filter_variant : 0;
+        a.debug = (ctx->filter_variant >= 20 && ctx->filter_variant <= 22) ? ctx->filter_variant : 0;
         a.and_existing = pass > 0;
         a.n_rows = q->n_rows;
         a.n_words = q->n_words;
@@ -1308,13 +1328,7 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
         for (int k = 0; k < kMaxTileCols; ++k) any_i32 |= (a.kinds[k] == TK_I32);
         if (ctx->d_stamps && ctx->stamp_used < ctx->stamp_slots) a.stamps = ctx->d_stamps + (size_t)ctx->stamp_used * kMaxFilterGrid * 2;
         grid = filter_grid(q->n_tiles, false, any_i32 || n == 0, ctx->grid_blocks);
-        // a staging launch keeps one tile of records per wave in LDS (4 KiB x R) next to the transpose buffers: as many
-        // work-groups per CU as that leaves room for, up to 8
-        if (q->stage_written && ctx->grid_blocks <= 0) {
-            const int R = rec_layout(q->stage_kinds, -1).dwords;
-            const int per_cu = std::min(8, (160 * 1024) / (kWavesPerBlock * (kTileRows * 4 * R + 2048 + 16 * 128) + 512)); // a tile of records + transpose + parked lines per wave
-            grid = clamp_grid_api((q->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, 256 * per_cu);
-        }
+        if (q->stage_written) grid = q->stage_grid; // fixed at creation: the arena layout depends on it
         // A select chain that is ONE tile pass also reduces its count in the kernel (one relaxed atomic per work-group): no
         // k_total launch.  Only at <= 512 work-groups: same-address atomics serialise at ~12 ns each, and 1536-2048 of them
         // at the tail of a short kernel cost more than the launch they save (int8: 32 vs 25 + 4 us).  Variant 7 = never.
@@ -1422,14 +1436,18 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
     return IMM3_OK;
 }
 
-static int clamp_grid_api(int64_t want, int cap) { return (int)std::max<int64_t>(1, std::min<int64_t>(want, cap)); }
-
 // ProjectOp from the survivor records the select launch staged
 static int launch_emit_records(imm3_query *q) {
     imm3_ctx *ctx = q->ctx;
     EmitArgs e;
     std::memset(&e, 0, sizeof(e));
     e.stage = q->d_stage_rec;
+    e.tile_start = q->d_tile_start;
+    e.wave_cap = q->stage_wave_cap;
+    e.n_waves = (int64_t)q->stage_grid * kWavesPerBlock;
+    e.main_tiles = q->stage_main_tiles;
+    e.max_slots = q->stage_max_slots;
+    e.T = q->stage_T;
     e.tile_offsets = q->d_tile_offsets;
     e.chunk_sums = q->d_chunk_sums;
     e.n_tiles = q->n_tiles;

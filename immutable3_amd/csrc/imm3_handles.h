@@ -180,6 +180,10 @@ struct imm3_query {
     uint8_t *d_stage_rec = nullptr;
     int32_t stage_kinds[imm3::kMaxTileCols] = {imm3::TK_NONE, imm3::TK_NONE, imm3::TK_NONE}; // of the staged launch, in its column order
     int32_t stage_seg_col[imm3::kMaxTileCols] = {-1, -1, -1};                                 // segment column of each
+    // the staging launch's geometry (fixed at creation: the arena layout depends on it)
+    uint32_t *d_tile_start = nullptr;
+    int32_t stage_grid = 0, stage_T = 1, stage_max_slots = 0;
+    int64_t stage_wave_cap = 0, stage_main_tiles = 0;
     bool stage_written = false;   // the last select run filled the records
     bool count_pending_scan = false; // the last select run left the count to the projection's offsets scan
 };

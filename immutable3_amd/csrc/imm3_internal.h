@@ -44,6 +44,7 @@ enum TileKind : int32_t { TK_I32 = 0, TK_I8 = 1, TK_S2 = 2, TK_NONE = 3 };
 constexpr int kMaxTileCols = 3;
 constexpr int kDeferLines = 64;     // bitmap lines a wave parks in LDS between store bursts (32 KiB per work-group)
 constexpr int kMaxTileMatch = 8;
+constexpr int kMaxArenaSlots = 256; // tiles per wave of a staging launch (the wave's start table sits in LDS)
 
 struct TileCol {
     const void *data;               // flat column in HBM, 16-byte aligned
@@ -63,7 +64,11 @@ struct TileArgs {
     uint64_t *bitmap;
     uint32_t *block_partials;
     unsigned long long *finish;     // {total, n_emit, status, limit, tally, log, log index, log capacity}: the count is reduced in the kernel (block_partial_finish); null = k_total does
-    void *stage_rec;                // survivor records, 1024 slots of rec_layout(kinds).dwords dwords per tile, or null
+    void *stage_rec;                // survivor records (rec_layout(kinds).dwords dwords each): one arena of wave_cap records per wave, or null
+    uint32_t *tile_start;           // [wave * max_slots + i]: where in its arena the wave's i-th staged tile starts
+    int64_t wave_cap;               // records per arena
+    int32_t max_slots;              // tiles a wave stages at most (<= kMaxArenaSlots)
+    int32_t pad1;
     unsigned long long *stamps;     // diagnostics only: per work-group {start, end} of the 100 MHz device clock, or null
     // table queries (imm3_table): the tile table replaces cols[k].data / n_rows.  Tile t holds tile_rows[t] valid rows
     // (1024 except the last tile of each segment) starting at tile_ptrs[k][t] in column k.  Null for one segment.
@@ -121,7 +126,10 @@ struct EmitCol {
     int32_t pad;
 };
 struct EmitArgs {
-    const void *stage;              // records, 1024 slots of R dwords per tile
+    const void *stage;              // records, R dwords each: one arena per wave of the filter launch that staged them
+    const uint32_t *tile_start;     // [wave * max_slots + i]
+    int64_t wave_cap, n_waves, main_tiles; // arena size in records; waves of the filter launch; tiles its main loop covered (the rest: leftovers)
+    int32_t max_slots, T;           // T: tiles per wave iteration of that launch
     const uint32_t *tile_offsets;
     const uint32_t *chunk_sums;
     int64_t n_tiles;
@@ -290,6 +298,7 @@ struct SumCountsArgs {
 void launch_sum_counts(const SumCountsArgs &a, hipStream_t s);
 
 bool launch_filter_tile(const TileArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+int filter_tile_group(const int32_t *kinds); // tiles per wave iteration of the instance for these kinds (0: none)
 void launch_filter_generic(const FilterArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 void launch_total(const TotalArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 void launch_read_stream(const int32_t *data, int64_t n_tiles, int32_t *sink, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);

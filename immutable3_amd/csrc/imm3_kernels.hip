@@ -46,7 +46,6 @@ namespace imm3 {
 // = 2 per CU = 8 waves/CU (more waves add DRAM page conflicts, fewer starve the memory pipeline).
 // ---------------------------------------------------------------------------------------------
 constexpr int kXposeBytes = 2048; // per wave: one tile of the widest transposed kind (2-byte strings)
-constexpr int kStageRecs = kTileRows; // survivor records a wave's LDS staging buffer holds: one tile
 
 // LDS hand-off between the lanes of ONE wave needs no wait at all: a wave's LDS instructions execute in order, so a
 // ds_read issued after a ds_write sees it.  Only the compiler must not reorder them.
@@ -159,10 +158,15 @@ struct ColRegs<TK_S2> {
 // ---- survivor records ---------------------------------------------------------------------------------------
 // A projecting query whose select chain is ONE tile launch compacts, per tile, one RECORD per survivor -- its position
 // in the tile and the value of every predicate column, all of which are in registers here -- through a per-wave LDS
-// buffer and stores the tile's records DENSELY at stage[(tile * 1024 + rank) * R] (rank = set bits below the row:
-// s_bcnt1 of the earlier words + v_mbcnt on the row's own word).  k_emit then produces ProjectOp's rows from the
-// records alone: no second look at the bitmap, and no second read of a predicate column (at 10 % selectivity a gather
-// would touch nearly every 64-byte sector of the column again).  Layout: rec_layout() in imm3_internal.h.
+// buffer (rank = set bits below the row: s_bcnt1 of the earlier words + v_mbcnt on the row's own word).  The buffer
+// holds SEVERAL tiles; when the next tile might not fit it is written out in one piece to the wave's own ARENA -- a
+// contiguous region of the staging area -- so the record stores are few, large and sequential per wave (~8-16 KiB at
+// a time) instead of one ~800-byte piece per tile at an 8 KiB stride: scattered small writes in between the streaming
+// loads ran at ~3.5 GB/ms (C3: 22 us for 78 MB; with the records aimed at an L2-resident region the cost vanished, so
+// it is the HBM write pattern, not instruction issue).  Where each tile's records start in the arena goes into a small
+// per-wave table (LDS, written once at the end).  k_emit then produces ProjectOp's rows from the records alone: no
+// second look at the bitmap, and no second read of a predicate column (at 10 % selectivity a gather would touch nearly
+// every 64-byte sector of the column again).  Layout: rec_layout() in imm3_internal.h.
 template <int R> struct RecVec;
 template <> struct RecVec<1> { typedef uint32_t type; };
 template <> struct RecVec<2> { typedef uint2 type; };
@@ -186,37 +190,51 @@ struct Rec {
     }
 };
 
-// The records of the tile a wave compacted last wait in its LDS buffer; they are copied to the tile's slots LATER -- in the
-// pipelined loop right after the next group's loads have been issued -- so that their write acknowledgement never sits
-// in front of a wait for loads: vmcnt retires in issue order, and the loop's one wait (vmcnt(0), before the prefetch)
-// then only ever sees stores that have had a whole iteration to complete (C3 filter: 107 -> 8x us).
-struct PendingRecords {
-    void *out = nullptr; // the tile's first slot, or null: nothing waiting
-    uint32_t n = 0;
+// The wave's staging state.  Records wait in the LDS buffer until arena_flush(); the flush itself is issued LATER than
+// the decision to flush -- in the pipelined loop right after the next group's loads -- so that the stores' write
+// acknowledgement never sits in front of a wait for loads: vmcnt retires in issue order, and the loop's one wait
+// (before the prefetch) then only ever sees stores that have had a whole iteration to complete.
+struct Arena {
+    uint32_t buf_n = 0;   // records waiting in the LDS buffer
+    uint32_t arena_n = 0; // records this wave has written to its arena
+    uint32_t slot = 0;    // tiles this wave has staged
+    uint32_t last = 0;    // records of the tile staged last (the guess for the next one)
 };
+constexpr int kArenaBufBytes = 8 * 1024; // LDS record buffer per wave: one tile at worst, ~10 tiles at 10 % selectivity
+constexpr int kArenaSlots = kMaxArenaSlots; // tiles per wave the start table holds
 
 template <int R>
-__device__ __forceinline__ void flush_records(const TileArgs &a, PendingRecords &p, const uint8_t *lds, int lane) {
+__device__ __forceinline__ void arena_flush(const TileArgs &a, Arena &A, const uint8_t *lds, int64_t wave_id, int lane) {
     typedef typename RecVec<R>::type vec;
-    if (!p.out) return; // wave-uniform
+    if (!A.buf_n) return; // wave-uniform
     const vec *l = (const vec *)lds;
-    vec *out = (vec *)p.out;
+    vec *out = (vec *)a.stage_rec + wave_id * a.wave_cap + A.arena_n;
     lds_wave_order();
     if (a.debug != 20) // (ablation: records compacted in LDS but not stored)
-        for (uint32_t i = lane; i < p.n; i += 64) out[i] = l[i];
+        for (uint32_t i = lane; i < A.buf_n; i += 64) out[i] = l[i];
     lds_wave_order();
-    p.out = nullptr;
+    A.arena_n += A.buf_n;
+    A.buf_n = 0;
 }
 
+// would `n` more records overflow the buffer?
+template <int R>
+__device__ __forceinline__ bool arena_full(const Arena &A, uint32_t n) { return A.buf_n + n > (uint32_t)(kArenaBufBytes / (4 * R)); }
+
 template <int K0, int K1, int K2>
-__device__ __forceinline__ void stage_full_tile(const TileArgs &a, int64_t tile, int lane, const ColRegs<K0> &c0, const ColRegs<K1> &c1,
-                                                const ColRegs<K2> &c2, const uint64_t (&acc)[kTileWords], uint8_t *lds, PendingRecords &pend) {
+__device__ __forceinline__ void stage_full_tile(const TileArgs &a, int lane, const ColRegs<K0> &c0, const ColRegs<K1> &c1, const ColRegs<K2> &c2,
+                                                const uint64_t (&acc)[kTileWords], uint8_t *lds, uint32_t *tstart, Arena &A, int64_t wave_id) {
     typedef Rec<K0, K1, K2> L;
     typedef typename L::vec vec;
-    flush_records<L::R>(a, pend, lds, lane); // the buffer holds one tile
-    vec *l = (vec *)lds;
-    // The wave's LDS buffer holds a whole tile of records, so the 16 words go in back to back -- no capacity checks.
-    uint32_t base = 0; // wave-uniform: records so far
+    uint32_t cnt = 0; // wave-uniform
+#pragma unroll
+    for (int j = 0; j < kTileWords; ++j) cnt += (uint32_t)__popcll(acc[j]);
+    if (arena_full<L::R>(A, cnt)) arena_flush<L::R>(a, A, lds, wave_id, lane); // (the pipelined loop has normally seen it coming)
+    A.last = cnt;
+    if (lane == 0) tstart[A.slot] = A.arena_n + A.buf_n;
+    ++A.slot;
+    vec *l = (vec *)lds + A.buf_n;
+    uint32_t base = 0; // wave-uniform: this tile's records so far
 #pragma unroll
     for (int j = 0; j < kTileWords; ++j) {
         const uint64_t m = acc[j];
@@ -228,16 +246,15 @@ __device__ __forceinline__ void stage_full_tile(const TileArgs &a, int64_t tile,
         if (__builtin_amdgcn_inverse_ballot_w64(m)) (l + base)[rank] = L::pack(rec); // exec = the word itself; `base` stays scalar
         base += (uint32_t)__popcll(m);
     }
-    pend.out = (vec *)a.stage_rec + tile * kTileRows;
-    pend.n = base;
+    A.buf_n += base;
 }
 
 // `earlier`: the tile's words from an earlier pass when the caller has loaded them already (pipelined loop), else null and
 // they are loaded here.  A staging launch is the only pass of its chain: it never ANDs.
 template <int K0, int K1, int K2, bool STAGE>
 __device__ __forceinline__ uint32_t finish_full_tile(const TileArgs &a, int64_t tile, int lane, ColRegs<K0> &c0,
-                                                     ColRegs<K1> &c1, ColRegs<K2> &c2, uint8_t *xp, uint8_t *lds, PendingRecords &pend,
-                                                     uint64_t *park = nullptr, const uint64_t *earlier = nullptr) {
+                                                     ColRegs<K1> &c1, ColRegs<K2> &c2, uint8_t *xp, uint8_t *lds, uint32_t *tstart, Arena &A,
+                                                     int64_t wave_id, uint64_t *park = nullptr, const uint64_t *earlier = nullptr) {
     const int64_t w = tile * kTileWords + lane; // lane j < 16 owns bitmap word j of the tile
     uint64_t mine = ~0ULL;
     if constexpr (!STAGE) {
@@ -257,7 +274,7 @@ __device__ __forceinline__ uint32_t finish_full_tile(const TileArgs &a, int64_t 
         else __builtin_nontemporal_store(mine, a.bitmap + w);
     }
     if constexpr (STAGE)
-        if (a.debug != 21) stage_full_tile<K0, K1, K2>(a, tile, lane, c0, c1, c2, acc, lds, pend); // (21: ablation)
+        if (a.debug != 21) stage_full_tile<K0, K1, K2>(a, lane, c0, c1, c2, acc, lds, tstart, A, wave_id); // (21: ablation)
     return (uint32_t)__popcll(mine);
 }
 
@@ -265,12 +282,20 @@ __device__ __forceinline__ uint32_t finish_full_tile(const TileArgs &a, int64_t 
 // `valid_rows` rows starting at element `row0` of each column pointer.
 template <int K0, int K1, int K2, bool STAGE>
 __device__ __forceinline__ uint32_t partial_tile(const TileArgs &a, int64_t tile, int lane, const void *d0, const void *d1, const void *d2,
-                                                 int64_t row0, int64_t valid_rows, ColRegs<K0> &c0, ColRegs<K1> &c1, ColRegs<K2> &c2) {
+                                                 int64_t row0, int64_t valid_rows, ColRegs<K0> &c0, ColRegs<K1> &c1, ColRegs<K2> &c2,
+                                                 uint8_t *lds, uint32_t *tstart, Arena &A, int64_t wave_id) {
     typedef Rec<K0, K1, K2> L;
     const int64_t w = tile * kTileWords + lane;
     uint64_t mine = ~0ULL;
     if (a.and_existing) mine = (lane < kTileWords && w < a.n_words) ? a.bitmap[w] : 0ULL;
     uint32_t base = 0;
+    typename L::vec *arena_out = nullptr;
+    if constexpr (STAGE) { // one tile per segment: its records go straight to the arena, behind everything buffered so far
+        arena_flush<L::R>(a, A, lds, wave_id, lane);
+        if (lane == 0) tstart[A.slot] = A.arena_n;
+        ++A.slot;
+        arena_out = (typename L::vec *)a.stage_rec + wave_id * a.wave_cap + A.arena_n;
+    }
 #pragma unroll 1
     for (int j = 0; j < kTileWords; ++j) {
         const int64_t i = 64 * j + lane;
@@ -280,16 +305,17 @@ __device__ __forceinline__ uint32_t partial_tile(const TileArgs &a, int64_t tile
         if (valid) keep = c0.row(d0, a.cols[0], r) && c1.row(d1, a.cols[1], r) && c2.row(d2, a.cols[2], r);
         const uint64_t m = ballot64(keep);
         if (lane == j) mine &= m;
-        if constexpr (STAGE) { // one tile per segment: its records go straight to memory
+        if constexpr (STAGE) {
             uint32_t rec[4] = {(uint32_t)i, 0u, 0u, 0u};
             L::template put<0>(rec, c0.rowval(d0, r));
             L::template put<1>(rec, c1.rowval(d1, r));
             L::template put<2>(rec, c2.rowval(d2, r));
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
-            if (keep) ((typename L::vec *)a.stage_rec + tile * kTileRows)[rank] = L::pack(rec);
+            if (keep) arena_out[rank] = L::pack(rec);
             base += (uint32_t)__popcll(m);
         }
     }
+    if constexpr (STAGE) A.arena_n += base;
     mine &= low_mask(valid_rows - 64 * (int64_t)lane); // rows past the end are not rows
     if (lane >= kTileWords) mine = 0;
     if (lane < kTileWords && w < a.n_words) a.bitmap[w] = mine;
@@ -304,12 +330,13 @@ __device__ __forceinline__ uint32_t partial_tile(const TileArgs &a, int64_t tile
 template <int K0, int K1, int K2, int T, bool TABLE, bool DEFER, bool STAGE>
 __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a) {
     constexpr bool kXpose = K0 == TK_I8 || K0 == TK_S2 || K1 == TK_I8 || K1 == TK_S2 || K2 == TK_I8 || K2 == TK_S2;
-    constexpr int kStage = STAGE ? kStageRecs * 4 * Rec<K0, K1, K2>::R : 16;
+    constexpr int kStage = STAGE ? kArenaBufBytes : 16;
     // narrow-only kernels spend longer on a tile (LDS transpose) than its loads take to issue: the next group's loads go
     // out BEFORE the current group is evaluated.  (With an int32 column the same pipeline measured slower: DESIGN.md finding 8.)
     constexpr bool kPipe = STAGE || (kXpose && K0 != TK_I32 && K1 != TK_I32 && K2 != TK_I32);
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[kWavesPerBlock][kStage];
     __shared__ __attribute__((aligned(16))) uint8_t s_xpose[kWavesPerBlock][kXpose ? kXposeBytes : 16];
+    __shared__ uint32_t s_tstart[kWavesPerBlock][STAGE ? kArenaSlots : 1]; // where each staged tile's records start in the wave's arena
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint8_t *lds = s_stage[wave];
@@ -322,7 +349,8 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
     uint64_t *park = DEFER ? s_park + (size_t)wave * a.defer_lines * kTileWords : nullptr;
     if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x] = wall_clock64(); // instrumented pass of bench.py only
     uint32_t lane_total = 0; // lanes 0..15: survivors in the words they stored
-    PendingRecords pend;
+    Arena A;
+    uint32_t *tstart = s_tstart[wave];
     constexpr int kRecDwords = Rec<K0, K1, K2>::R;
     const int64_t wave_id = (int64_t)blockIdx.x * kWavesPerBlock + wave;
     const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
@@ -350,17 +378,20 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
                 c0.load(d0, 0, lane);
                 c1.load(d1, 0, lane);
                 c2.load(d2, 0, lane);
-                lane_total += finish_full_tile<K0, K1, K2, STAGE>(a, tile, lane, c0, c1, c2, xp, lds, pend, DEFER ? park + parked * kTileWords : nullptr);
+                lane_total += finish_full_tile<K0, K1, K2, STAGE>(a, tile, lane, c0, c1, c2, xp, lds, tstart, A, wave_id, DEFER ? park + parked * kTileWords : nullptr);
                 if (DEFER) {
                     if (lane == 0) pidx[parked] = (uint64_t)tile;
                     if (++parked == a.defer_lines) flush(); // wave-uniform
                 }
             } else {
-                lane_total += partial_tile<K0, K1, K2, STAGE>(a, tile, lane, d0, d1, d2, 0, rows_here, c0, c1, c2);
+                lane_total += partial_tile<K0, K1, K2, STAGE>(a, tile, lane, d0, d1, d2, 0, rows_here, c0, c1, c2, lds, tstart, A, wave_id);
             }
         }
         if (DEFER && parked) flush();
-        if constexpr (STAGE) flush_records<kRecDwords>(a, pend, lds, lane);
+        if constexpr (STAGE) {
+            arena_flush<kRecDwords>(a, A, lds, wave_id, lane);
+            for (uint32_t i = lane; i < A.slot; i += 64) a.tile_start[wave_id * a.max_slots + i] = tstart[i];
+        }
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) lane_total += __shfl_xor(lane_total, d);
         if (a.finish) block_partial_finish(a.finish, lane_total, lane, wave);
@@ -422,14 +453,15 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
             // unconditional (the last iteration re-reads its own group): a load the compiler sees on every path is a load its
             // s_waitcnt can count past
             load_group(n0, n1, n2, grp + n_waves < n_groups ? grp + n_waves : grp);
-            if constexpr (STAGE) flush_records<kRecDwords>(a, pend, lds, lane); // the previous tile's records: behind the prefetch
+            if constexpr (STAGE)
+                if (arena_full<kRecDwords>(A, 2 * A.last)) arena_flush<kRecDwords>(a, A, lds, wave_id, lane); // the next tile will probably not fit: the buffered records go out here, behind the prefetch
         } else {
             load_group(c0, c1, c2, grp);
         }
         if (DEFER && parked == 0) first_grp = grp;
 #pragma unroll
         for (int t = 0; t < T; ++t)
-            lane_total += finish_full_tile<K0, K1, K2, STAGE>(a, grp * T + t, lane, c0[t], c1[t], c2[t], xp, lds, pend, DEFER ? park + (parked + t) * kTileWords : nullptr,
+            lane_total += finish_full_tile<K0, K1, K2, STAGE>(a, grp * T + t, lane, c0[t], c1[t], c2[t], xp, lds, tstart, A, wave_id, DEFER ? park + (parked + t) * kTileWords : nullptr,
                                                               (kPipe && !STAGE) ? &earlier[t] : nullptr);
         if (DEFER) {
             parked += T;
@@ -447,12 +479,15 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a)
             c0.load(a.cols[0].data, row0, lane);
             c1.load(a.cols[1].data, row0, lane);
             c2.load(a.cols[2].data, row0, lane);
-            lane_total += finish_full_tile<K0, K1, K2, STAGE>(a, tile, lane, c0, c1, c2, xp, lds, pend);
+            lane_total += finish_full_tile<K0, K1, K2, STAGE>(a, tile, lane, c0, c1, c2, xp, lds, tstart, A, wave_id);
         } else { // rolled, bounds-checked
-            lane_total += partial_tile<K0, K1, K2, STAGE>(a, tile, lane, a.cols[0].data, a.cols[1].data, a.cols[2].data, row0, a.n_rows - row0, c0, c1, c2);
+            lane_total += partial_tile<K0, K1, K2, STAGE>(a, tile, lane, a.cols[0].data, a.cols[1].data, a.cols[2].data, row0, a.n_rows - row0, c0, c1, c2, lds, tstart, A, wave_id);
         }
     }
-    if constexpr (STAGE) flush_records<kRecDwords>(a, pend, lds, lane);
+    if constexpr (STAGE) {
+        arena_flush<kRecDwords>(a, A, lds, wave_id, lane);
+        for (uint32_t i = lane; i < A.slot; i += 64) a.tile_start[wave_id * a.max_slots + i] = tstart[i];
+    }
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) lane_total += __shfl_xor(lane_total, d); // lanes 0..15 -> lane 0
     if (a.finish) block_partial_finish(a.finish, lane_total, lane, wave); // the last pass also reduces the count
@@ -819,6 +854,7 @@ template <int R, int NG>
 __global__ __launch_bounds__(kBlockThreads) void k_emit(const EmitArgs a) {
     typedef typename RecVec<R>::type vec;
     __shared__ uint32_t s_off[kEmitTiles + 1];
+    __shared__ unsigned long long s_addr[kEmitTiles]; // first record of each tile in the staging area
     __shared__ unsigned long long s_base;
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -829,6 +865,19 @@ __global__ __launch_bounds__(kBlockThreads) void k_emit(const EmitArgs a) {
         if (t <= kEmitTiles) {
             const int64_t tile = tile0 + t;
             s_off[t] = (tile < a.n_tiles && tile / kChunkTiles == chunk) ? a.tile_offsets[tile] : a.chunk_sums[chunk];
+            if (t < kEmitTiles && tile < a.n_tiles) { // which wave of the filter launch staged this tile, and as its how-manieth
+                int64_t w, slot;
+                if (tile < a.main_tiles) {
+                    const int64_t g = tile / a.T;
+                    w = g % a.n_waves;
+                    slot = (g / a.n_waves) * a.T + tile % a.T;
+                } else {
+                    const int64_t idx = tile - a.main_tiles, n_groups = a.main_tiles / a.T;
+                    w = idx % a.n_waves;
+                    slot = (w < n_groups ? ((n_groups - 1 - w) / a.n_waves + 1) * a.T : 0) + idx / a.n_waves;
+                }
+                s_addr[t] = (unsigned long long)(w * a.wave_cap) + a.tile_start[w * a.max_slots + slot];
+            }
         } else if (t >= 128 && t < 192) { // one wave: survivors of the chunks before this one
             unsigned long long part = 0;
             for (int64_t i = lane; i < chunk; i += 64) part += a.chunk_sums[i];
@@ -854,7 +903,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_emit(const EmitArgs a) {
                     if (s_off[lo + step] - o0 <= k) lo += step; // the LAST tile whose first survivor is <= k: the one that holds row k
                 const int64_t tile = tile0 + lo;
                 const uint32_t j = k - (s_off[lo] - o0);
-                rec[u] = ((const vec *)a.stage)[tile * kTileRows + j];
+                rec[u] = ((const vec *)a.stage)[s_addr[lo] + j];
                 rowv[u] = (uint32_t)tile; // (position added once the record is here)
             }
 #pragma unroll
@@ -942,7 +991,7 @@ int filter_grid(int64_t units, bool generic, bool any_i32, int grid_blocks) {
 
 #define IMM3_TILE_CASE(k0, k1, k2, T)                                                           \
     if (a.kinds[0] == k0 && a.kinds[1] == k1 && a.kinds[2] == k2) {                             \
-        if (a.stage_rec && a.tile_rows) IMM3_LAUNCH((k_filter_tile<k0, k1, k2, 1, true, false, true>), grid, kBlockThreads, s, ev0, ev1, a); \
+        if (a.stage_rec && a.tile_rows) return false; /* (table queries do not stage) */                 \
         else if (a.stage_rec && a.defer_lines) IMM3_LAUNCH_LDS((k_filter_tile<k0, k1, k2, T, false, true, true>), grid, kBlockThreads, \
                              (size_t)kWavesPerBlock * (size_t)a.defer_lines * kTileWords * sizeof(uint64_t), s, ev0, ev1, a); \
         else if (a.stage_rec) IMM3_LAUNCH((k_filter_tile<k0, k1, k2, T, false, false, true>), grid, kBlockThreads, s, ev0, ev1, a); \
@@ -957,24 +1006,26 @@ int filter_grid(int64_t units, bool generic, bool any_i32, int grid_blocks) {
 
 // kinds must be sorted ascending with TK_NONE (= 3) last; at most one TK_S2 column per launch.
 // T (tiles per wave iteration) is chosen so a wave has >= 4 KiB in flight: bytes/row x 1024 x T.
+#define IMM3_TILE_KINDS(X)                                                                          \
+    X(TK_NONE, TK_NONE, TK_NONE, 1)                                                                 \
+    X(TK_I32, TK_NONE, TK_NONE, 1) X(TK_I8, TK_NONE, TK_NONE, 4) X(TK_S2, TK_NONE, TK_NONE, 2)       \
+    X(TK_I32, TK_I32, TK_NONE, 1) X(TK_I32, TK_I8, TK_NONE, 1) X(TK_I8, TK_I8, TK_NONE, 2)           \
+    X(TK_I32, TK_S2, TK_NONE, 1) X(TK_I8, TK_S2, TK_NONE, 2)                                         \
+    X(TK_I32, TK_I32, TK_I32, 1) X(TK_I32, TK_I32, TK_I8, 1) X(TK_I32, TK_I8, TK_I8, 1)              \
+    X(TK_I8, TK_I8, TK_I8, 2) X(TK_I32, TK_I32, TK_S2, 1) X(TK_I32, TK_I8, TK_S2, 1) X(TK_I8, TK_I8, TK_S2, 1)
+
 bool launch_filter_tile(const TileArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    IMM3_TILE_CASE(TK_NONE, TK_NONE, TK_NONE, 1)
-    IMM3_TILE_CASE(TK_I32, TK_NONE, TK_NONE, 1)
-    IMM3_TILE_CASE(TK_I8, TK_NONE, TK_NONE, 4)
-    IMM3_TILE_CASE(TK_S2, TK_NONE, TK_NONE, 2)
-    IMM3_TILE_CASE(TK_I32, TK_I32, TK_NONE, 1)
-    IMM3_TILE_CASE(TK_I32, TK_I8, TK_NONE, 1)
-    IMM3_TILE_CASE(TK_I8, TK_I8, TK_NONE, 2)
-    IMM3_TILE_CASE(TK_I32, TK_S2, TK_NONE, 1)
-    IMM3_TILE_CASE(TK_I8, TK_S2, TK_NONE, 2)
-    IMM3_TILE_CASE(TK_I32, TK_I32, TK_I32, 1)
-    IMM3_TILE_CASE(TK_I32, TK_I32, TK_I8, 1)
-    IMM3_TILE_CASE(TK_I32, TK_I8, TK_I8, 1)
-    IMM3_TILE_CASE(TK_I8, TK_I8, TK_I8, 2)
-    IMM3_TILE_CASE(TK_I32, TK_I32, TK_S2, 1)
-    IMM3_TILE_CASE(TK_I32, TK_I8, TK_S2, 1)
-    IMM3_TILE_CASE(TK_I8, TK_I8, TK_S2, 1)
+    IMM3_TILE_KINDS(IMM3_TILE_CASE)
     return false;
+}
+
+// tiles per wave iteration of the instance launch_filter_tile picks for these kinds (0: no such instance)
+int filter_tile_group(const int32_t *kinds) {
+#define IMM3_TILE_T(k0, k1, k2, T) \
+    if (kinds[0] == k0 && kinds[1] == k1 && kinds[2] == k2) return T;
+    IMM3_TILE_KINDS(IMM3_TILE_T)
+#undef IMM3_TILE_T
+    return 0;
 }
 
 void launch_filter_generic(const FilterArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
