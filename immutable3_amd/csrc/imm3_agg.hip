@@ -291,6 +291,164 @@ __global__ __launch_bounds__(kAggThreads) void k_group_agg(const AggArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_group_agg_tile: the fast form -- one uniform segment, group key <= 4 bytes (one or two columns of 1 / 2 / 4
+// bytes), aggregates count / min / max over int32 / int8 columns or max over strings of <= 4 bytes: keys, values and
+// table entries are all 32-bit.  One wave per 1024-row tile, every column ROW-STRIDED like in the filter kernel
+// (narrow columns transposed through LDS), so bitmap word j is the exec mask of register j and a selected row costs one
+// probe read plus one LDS atomic per aggregate: ds_add (count), ds_min (first-seen row), ds_min / ds_max (values) --
+// no guards, no 64-bit arithmetic, no per-row branches.  The general kernel above did ~250 vector + ~240 scalar
+// instructions per 256 rows (hashing 64-bit keys, probing with CAS, guarded atomics on i64 values).
+// A work-group whose 1024-slot table fills up raises overflow = 2 and the host re-runs the general kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFastSlots = 1024;
+constexpr uint32_t kEmpty32 = 0xFFFFFFFFu;
+
+// column `data` (width 1 / 2 / 4), tile `tile` -> v[j] = raw little-endian value of row 64j + lane, zero-extended
+__device__ __forceinline__ void load_tile_rows(const void *data, int width, int64_t tile, int lane, uint8_t *xp, uint32_t (&v)[kTileWords]) {
+    typedef int v4i_ __attribute__((ext_vector_type(4)));
+    if (width == 4) {
+        const uint32_t *p = (const uint32_t *)data + tile * kTileRows + lane;
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) v[j] = __builtin_nontemporal_load(p + 64 * j);
+    } else if (width == 2) {
+        const v4i_ *p = (const v4i_ *)((const uint16_t *)data + tile * kTileRows) + lane;
+        const v4i_ r0 = __builtin_nontemporal_load(p), r1 = __builtin_nontemporal_load(p + 64);
+        *(v4i_ *)(xp + 16 * lane) = r0;
+        *(v4i_ *)(xp + 1024 + 16 * lane) = r1;
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) v[j] = ((const uint16_t *)xp)[64 * j + lane];
+        asm volatile("" ::: "memory");
+    } else {
+        const v4i_ r0 = __builtin_nontemporal_load((const v4i_ *)((const uint8_t *)data + tile * kTileRows) + lane);
+        *(v4i_ *)(xp + 16 * lane) = r0;
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) v[j] = ((const uint8_t *)xp)[64 * j + lane];
+        asm volatile("" ::: "memory");
+    }
+}
+
+// Table layout: one array per field, each striding by ONE element per slot.  Every update is an UNCONDITIONAL LDS atomic:
+// guarding the first-seen row and the extremes with a read (update only when the row improves them -- the general kernel's
+// trick) measured SLOWER here, 331-354 us against 263 per 100 M rows: each guard is one more dependent LDS round trip and
+// one more divergent branch per word, and those, not the atomics (~30 us for the count and first-seen pair), are what
+// this kernel's time is made of.  Ablation (100 M rows, group by state: count(id), max(age)): value phase 80 us, count +
+// first-seen atomics 30 us, flush 11 us, key load + probe loop the rest -- 16 serialised probe round trips per tile.
+
+__global__ __launch_bounds__(kBlockThreads) void k_group_agg_tile(const AggArgs a) {
+    __shared__ uint32_t s_keys[kFastSlots + 1];
+    __shared__ uint32_t s_first[kFastSlots + 1];              // first-seen (lowest) selected row
+    __shared__ uint32_t s_count[kFastSlots + 1];
+    __shared__ uint32_t s_vals[kMaxAggs][kFastSlots + 1];     // per aggregate
+    __shared__ __attribute__((aligned(16))) uint8_t s_xp[kWavesPerBlock][2048];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    uint8_t *xp = s_xp[wave];
+    for (int i = t; i <= kFastSlots; i += kBlockThreads) {
+        s_keys[i] = kEmpty32;
+        s_first[i] = 0xFFFFFFFFu;
+        s_count[i] = 0;
+        for (int j = 0; j < kMaxAggs; ++j) {
+            const int kind = j < a.n_agg ? a.aggs[j].kind : AGG_COUNT;
+            const bool str = j < a.n_agg && a.aggs[j].is_str;
+            s_vals[j][i] = kind == AGG_MIN ? (uint32_t)INT32_MAX : (str ? 0u : (uint32_t)INT32_MIN);
+        }
+    }
+    __syncthreads();
+
+    for (int64_t tile = (int64_t)blockIdx.x * kWavesPerBlock + wave; tile < a.n_tiles; tile += (int64_t)gridDim.x * kWavesPerBlock) {
+        uint64_t m[kTileWords]; // the tile's bitmap words: wave-uniform
+        uint64_t any = 0;
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) {
+            m[j] = a.bitmap[tile * kTileWords + j];
+            any |= m[j];
+        }
+        if (!any) continue; // nothing selected in these 1024 rows
+        uint32_t key[kTileWords];
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) key[j] = 0;
+        for (int g = 0; g < a.n_group; ++g) {
+            uint32_t v[kTileWords];
+            load_tile_rows(a.groups[g].data, a.groups[g].width, tile, lane, xp, v);
+            const int sh = 8 * a.groups[g].shift;
+#pragma unroll
+            for (int j = 0; j < kTileWords; ++j) key[j] |= v[j] << sh;
+        }
+        uint32_t slot[kTileWords];
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) {
+            slot[j] = kFastSlots;
+            if (__builtin_amdgcn_inverse_ballot_w64(m[j])) { // exec = the bitmap word: only selected rows run this
+                const uint32_t k = key[j];
+                const uint32_t row = (uint32_t)(tile * kTileRows + 64 * j + lane);
+                uint32_t s = kFastSlots; // the all-ones key has a slot of its own (all-ones marks an empty slot)
+                if (k != kEmpty32) {
+                    s = (k * 0x9E3779B1u) >> 22;
+                    int probes = 0;
+                    for (;; ++probes) {
+                        uint32_t cur = s_keys[s]; // plain read first: after warm-up the key is there
+                        if (cur == kEmpty32) cur = atomicCAS(&s_keys[s], kEmpty32, k);
+                        if (cur == kEmpty32 || cur == k) break;
+                        if (probes == 64) { // crowded table: the host re-runs the general kernel
+                            *a.overflow = 2;
+                            s = kFastSlots;
+                            break;
+                        }
+                        s = (s + 1) & (kFastSlots - 1);
+                    }
+                }
+                slot[j] = s;
+                if (a.debug != 12) { // (ablation)
+                    atomicAdd(&s_count[s], 1u);
+                    atomicMin(&s_first[s], row);
+                }
+            }
+        }
+        for (int q = 0; q < a.n_agg; ++q) {
+            const int kind = a.aggs[q].kind;
+            if (kind == AGG_COUNT || a.debug == 13) continue; // (13: ablation)
+            uint32_t v[kTileWords];
+            load_tile_rows(a.aggs[q].data, a.aggs[q].width, tile, lane, xp, v);
+            const int w = a.aggs[q].width;
+            const bool str = a.aggs[q].is_str;
+#pragma unroll
+            for (int j = 0; j < kTileWords; ++j) {
+                if (__builtin_amdgcn_inverse_ballot_w64(m[j])) {
+                    uint32_t *p = &s_vals[q][slot[j]];
+                    if (str) { // big-endian pack: integer order == byte-lexicographic order
+                        const uint32_t be = w == 4 ? __builtin_bswap32(v[j]) : (w == 2 ? (uint32_t)__builtin_bswap16((uint16_t)v[j]) : v[j]);
+                        atomicMax(p, be);
+                    } else {
+                        const int32_t x = w == 4 ? (int32_t)v[j] : (int32_t)(int8_t)v[j];
+                        if (kind == AGG_MIN) atomicMin((int32_t *)p, x);
+                        else atomicMax((int32_t *)p, x);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // flush: one atomic set per (work-group, group), widened to what the global table holds
+    if (a.debug == 14) return; // (ablation)
+    for (int i = t; i <= kFastSlots; i += kBlockThreads) {
+        if (s_count[i] == 0) continue;
+        const unsigned long long key = i == kFastSlots ? (unsigned long long)kEmpty32 : (unsigned long long)s_keys[i];
+        const uint32_t g = global_slot(a, key);
+        if (g == 0xFFFFFFFFu) continue;
+        long long vals[kMaxAggs];
+        for (int j = 0; j < kMaxAggs; ++j) {
+            const bool str = j < a.n_agg && a.aggs[j].is_str;
+            vals[j] = str ? (long long)(unsigned long long)s_vals[j][i] : (long long)(int32_t)s_vals[j][i];
+        }
+        agg_update_global(a, g, s_first[i], (unsigned long long)s_count[i], vals);
+    }
+}
+
 // occupied entries of the global table -> dense arrays (order irrelevant: the host sorts by first_row)
 __global__ __launch_bounds__(kBlockThreads) void k_group_collect(const AggArgs a) {
     const int lane = threadIdx.x & 63;
@@ -334,10 +492,35 @@ __global__ __launch_bounds__(kBlockThreads) void k_group_init(const AggArgs a) {
     }
 }
 
+// Can the fast form take this aggregation?  (uniform single segment; 32-bit keys and values)
+bool group_agg_fast_ok(const AggArgs &a) {
+    if (a.word_row_base || a.n_group > 2) return false;
+    int key_bytes = 0;
+    for (int g = 0; g < a.n_group; ++g) {
+        const int w = a.groups[g].width;
+        if (a.groups[g].tile_ptrs || (w != 1 && w != 2 && w != 4)) return false;
+        key_bytes += w;
+    }
+    if (key_bytes > 4) return false;
+    for (int q = 0; q < a.n_agg; ++q) {
+        if (a.aggs[q].tile_ptrs) return false;
+        if (a.aggs[q].kind == AGG_COUNT) continue;
+        const int w = a.aggs[q].width;
+        if (a.aggs[q].is_str ? (w != 1 && w != 2 && w != 4) : (w != 1 && w != 4)) return false;
+    }
+    return true;
+}
+
 void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     const int64_t n = (int64_t)a.mask + 2;
     const int init_grid = (int)std::min<int64_t>((n + kBlockThreads - 1) / kBlockThreads, 2048);
     hipLaunchKernelGGL(k_group_init, dim3(init_grid), dim3(kBlockThreads), 0, s, a);
+    if (a.debug != 9 && group_agg_fast_ok(a)) { // (debug 9: force the general kernel -- also what the host does after an overflow = 2)
+        const int64_t want = (a.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, 768)); // ~41 KiB of LDS: 3 per CU
+        hipExtLaunchKernelGGL(k_group_agg_tile, dim3(grid), dim3(kBlockThreads), 0, s, ev0, ev1, 0, a);
+        return;
+    }
     const int64_t want = ((a.n_words + 3) / 4 + kAggWaves - 1) / kAggWaves;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, 768)); // 512-thread work-groups, 48 KiB LDS: 3 per CU
     hipExtLaunchKernelGGL(k_group_agg, dim3(grid), dim3(kAggThreads), 0, s, ev0, ev1, 0, a);

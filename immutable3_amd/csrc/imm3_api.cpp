@@ -1875,7 +1875,7 @@ static int settle_groups(imm3_query *q, uint32_t *n_groups) {
     imm3_ctx *ctx = q->ctx;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = 0; attempt < 3; ++attempt) {
         AggArgs a;
         fill_agg_args(q, a);
         HIPCHK(hipMemsetAsync(q->d_ameta, 0, sizeof(uint32_t), s)); // n_groups only; keep the overflow flag
@@ -1884,6 +1884,14 @@ static int settle_groups(imm3_query *q, uint32_t *n_groups) {
         uint32_t meta[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(meta, q->d_ameta, sizeof(meta), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        if (meta[1] == 2) { // the fast kernel's per-work-group table filled up: aggregate again with the general kernel
+            AggArgs g;
+            fill_agg_args(q, g);
+            g.debug = 9;
+            launch_group_agg(g, s, nullptr, nullptr);
+            HIPCHK(hipGetLastError());
+            continue;
+        }
         if (meta[1]) return fail(IMM3_ERR_LAYOUT, "more distinct groups than the aggregation table holds (2^27)");
         if (meta[0] <= q->out_cap) { *n_groups = meta[0]; return IMM3_OK; }
         pool_release(ctx, q->d_okeys); pool_release(ctx, q->d_ofirst); pool_release(ctx, q->d_ocounts); pool_release(ctx, q->d_ovals);

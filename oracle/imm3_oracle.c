@@ -9,6 +9,7 @@
  */
 #include "imm3_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -465,4 +466,136 @@ int64_t imm3o_project(const imm3o_column *cols, int32_t ncols,
     free(vecs);
     free(its);
     return rc < 0 ? rc : total;
+}
+
+/* ===========================================================================================
+ * ProjectAggOp.ProjectAggIterator.runAggs -- engine/engine/operator/ProjectAggregate.scala:115-227
+ * (the C twin of oracle_np.project_agg: group-by aggregation is checked by two restatements).
+ *
+ *   for every batch, for every selected position ascending (:158-159):
+ *       groupKey = group column values mkString "_"                          (:144, :160-164)
+ *       resultMap.getOrElseUpdate(groupKey, fresh aggregators)               (:177, LinkedHashMap: first-seen order, :126)
+ *       CountAggr.add            counter += 1                                (:22-24)
+ *       Max/MinDoubleAggr.add    value.toDouble, started at -/+Double.MaxValue (:36-39, :49-52)
+ *       MaxStringAggr.add        "" = unset, else String.compareTo           (:78-83)
+ *   a String vector only takes CountAggr / MaxStringAggr ("bad aggregator for this data type", :205-209).
+ * =========================================================================================== */
+typedef struct agg_group {
+    char *key;
+    int64_t *counts;   /* per aggregate */
+    double *nums;
+    char *strs;        /* per aggregate, str_stride bytes, NUL-terminated ("" = unset) */
+    struct agg_group *next_in_bucket;
+} agg_group;
+
+static uint64_t fnv1a(const char *s) {
+    uint64_t h = 1469598103934665603ULL;
+    for (; *s; ++s) { h ^= (uint8_t)*s; h *= 1099511628211ULL; }
+    return h;
+}
+
+int64_t imm3o_project_agg(const imm3o_column *cols, int32_t ncols, const int32_t *group, int32_t ngroup,
+                          const imm3o_aggregate *aggs, int32_t naggs, const uint64_t *words,
+                          char *keys_out, int32_t key_stride, int64_t *count_out, double *num_out,
+                          char *str_out, int32_t str_stride, int64_t max_groups, char *msg) {
+    if (msg) msg[0] = 0;
+    if (ncols <= 0 || naggs <= 0 || ngroup < 0) return -IMM3O_ERR_ARG;
+    for (int32_t g = 0; g < ngroup; g++) if (group[g] < 0 || group[g] >= ncols) return -IMM3O_ERR_ARG;
+    for (int32_t a = 0; a < naggs; a++) if (aggs[a].column < 0 || aggs[a].column >= ncols || aggs[a].kind < 0 || aggs[a].kind > 2) return -IMM3O_ERR_ARG;
+    const int64_t n_buckets = 1 << 16;
+    agg_group **buckets = (agg_group **)calloc((size_t)n_buckets, sizeof(agg_group *));
+    agg_group **order = 0; /* first-seen order */
+    int64_t n_groups = 0, cap_groups = 0;
+    block_iter *its = (block_iter *)malloc(sizeof(block_iter) * (size_t)ncols);
+    colvec *vecs = (colvec *)calloc((size_t)ncols, sizeof(colvec));
+    for (int32_t c = 0; c < ncols; c++) block_iter_init(&its[c], &cols[c]);
+    int64_t woff = 0, rc = 0;
+    char *keybuf = (char *)malloc((size_t)key_stride + 64);
+    while (block_iter_has_next(&its[0]) && rc == 0) {
+        const uint8_t *blk0 = 0;
+        int64_t len0 = block_iter_peek(&its[0], &blk0);
+        if (len0 < 0) { rc = -IMM3O_ERR_INDEX; break; }
+        const int32_t size = (int32_t)n_values(len0, cols[0].width);
+        const int64_t nw = ((int64_t)size + 63) / 64;
+        const uint64_t *sel = words + woff;
+        for (int32_t c = 0; c < ncols; c++) {
+            if (!block_iter_has_next(&its[c])) { rc = -IMM3O_ERR_INDEX; break; }
+            const uint8_t *blk = 0;
+            int64_t len = block_iter_peek(&its[c], &blk);
+            if (len < 0) { rc = -IMM3O_ERR_INDEX; break; }
+            if (decode_tight(blk, len, cols[c].codec, cols[c].width, &vecs[c])) { rc = -IMM3O_ERR_ARG; break; }
+            block_iter_advance(&its[c], len);
+        }
+        for (int32_t pos = 0; pos < size && rc == 0; pos++) {
+            if (!bitset_contains(sel, pos)) continue; /* for (currVecBatchPos <- currVecBatch.selected), ascending */
+            /* groupKey: values mkString "_" */
+            int32_t kl = 0;
+            for (int32_t g = 0; g < ngroup && rc == 0; g++) {
+                const colvec *cv = &vecs[group[g]];
+                if (pos >= cv->n) { rc = -IMM3O_ERR_INDEX; break; }
+                if (g) keybuf[kl++] = '_';
+                const uint8_t *p = cv->data + (int64_t)pos * cv->width;
+                if (cols[group[g]].codec == IMM3O_DENSE_INT) kl += snprintf(keybuf + kl, 16, "%d", imm3o_bytes_to_int(p));
+                else if (cols[group[g]].codec == IMM3O_DENSE_TINYINT) kl += snprintf(keybuf + kl, 8, "%d", (int)(int8_t)p[0]);
+                else { memcpy(keybuf + kl, p, (size_t)cv->width); kl += cv->width; } /* new String(bytes), DataType.scala:70 */
+                if (kl + 24 + 256 > key_stride + 64 && kl >= key_stride) { rc = -IMM3O_ERR_ARG; break; }
+            }
+            if (rc) break;
+            keybuf[kl] = 0;
+            if (kl >= key_stride) { rc = -IMM3O_ERR_ARG; break; }
+            const uint64_t h = fnv1a(keybuf) & (uint64_t)(n_buckets - 1);
+            agg_group *G = buckets[h];
+            while (G && strcmp(G->key, keybuf)) G = G->next_in_bucket;
+            if (!G) { /* getOrElseUpdate(groupKey, getNewAggs(aggsMap)) */
+                if (n_groups >= max_groups) { rc = -IMM3O_ERR_ARG; break; }
+                G = (agg_group *)calloc(1, sizeof(agg_group));
+                G->key = (char *)malloc((size_t)kl + 1);
+                memcpy(G->key, keybuf, (size_t)kl + 1);
+                G->counts = (int64_t *)calloc((size_t)naggs, sizeof(int64_t));
+                G->nums = (double *)calloc((size_t)naggs, sizeof(double));
+                G->strs = (char *)calloc((size_t)naggs, (size_t)str_stride);
+                for (int32_t a = 0; a < naggs; a++) G->nums[a] = aggs[a].kind == 2 ? -DBL_MAX : DBL_MAX; /* Double.MinValue / Double.MaxValue */
+                G->next_in_bucket = buckets[h];
+                buckets[h] = G;
+                if (n_groups == cap_groups) {
+                    cap_groups = cap_groups ? 2 * cap_groups : 256;
+                    order = (agg_group **)realloc(order, (size_t)cap_groups * sizeof(agg_group *));
+                }
+                order[n_groups++] = G;
+            }
+            for (int32_t a = 0; a < naggs && rc == 0; a++) {
+                const int32_t c = aggs[a].column;
+                const colvec *cv = &vecs[c];
+                if (pos >= cv->n) { rc = -IMM3O_ERR_INDEX; break; }
+                const uint8_t *p = cv->data + (int64_t)pos * cv->width;
+                if (aggs[a].kind == 0) { G->counts[a] += 1; continue; } /* CountAggr.add(value) */
+                if (cols[c].codec == IMM3O_DENSE_STRING) {
+                    if (aggs[a].kind != 2) { if (msg) snprintf(msg, 128, "bad aggregator for this data type"); rc = -IMM3O_ERR_UNSUPPORTED_VECTOR; break; }
+                    if (cv->width + 1 > str_stride) { rc = -IMM3O_ERR_ARG; break; }
+                    char *cur = G->strs + (size_t)a * (size_t)str_stride;
+                    /* MaxStringAggr.add: if (max == "") max = v else if (v > max) max = v  (String.compareTo: UTF-16 order;
+                     * byte order for ASCII) */
+                    if (cur[0] == 0 || memcmp(p, cur, (size_t)cv->width) > 0) { memcpy(cur, p, (size_t)cv->width); cur[cv->width] = 0; }
+                } else {
+                    const double v = cols[c].codec == IMM3O_DENSE_INT ? (double)imm3o_bytes_to_int(p) : (double)(int8_t)p[0]; /* value.toDouble */
+                    if (aggs[a].kind == 2) { if (v > G->nums[a]) G->nums[a] = v; }
+                    else if (v < G->nums[a]) G->nums[a] = v;
+                }
+            }
+        }
+        for (int32_t c = 0; c < ncols; c++) { free(vecs[c].data); vecs[c].data = 0; }
+        woff += nw;
+    }
+    if (rc == 0) {
+        for (int64_t g = 0; g < n_groups; g++) {
+            snprintf(keys_out + g * key_stride, (size_t)key_stride, "%s", order[g]->key);
+            memcpy(count_out + g * naggs, order[g]->counts, (size_t)naggs * sizeof(int64_t));
+            memcpy(num_out + g * naggs, order[g]->nums, (size_t)naggs * sizeof(double));
+            memcpy(str_out + g * naggs * str_stride, order[g]->strs, (size_t)naggs * (size_t)str_stride);
+        }
+    }
+    for (int64_t g = 0; g < n_groups; g++) { free(order[g]->key); free(order[g]->counts); free(order[g]->nums); free(order[g]->strs); free(order[g]); }
+    for (int32_t c = 0; c < ncols; c++) free(vecs[c].data);
+    free(order); free(buckets); free(vecs); free(its); free(keybuf);
+    return rc < 0 ? rc : n_groups;
 }

@@ -116,6 +116,25 @@ int64_t imm3o_project(const imm3o_column *cols, int32_t ncols,
                       int32_t *out_batch, int32_t *out_pos, uint8_t *const *out_vals,
                       int64_t cap_rows, int32_t *would_throw);
 
+/*
+ * ProjectAggOp (engine/engine/operator/ProjectAggregate.scala:115-227) over the batches produced above: count / min /
+ * max per group, groups in first-seen order (LinkedHashMap).  The C twin of oracle_np.project_agg.
+ *   group[0..ngroup)  indices into cols[] of the group-by columns, in the order their values are joined with "_"
+ *   aggs[0..naggs)    {kind: 0 count, 1 min, 2 max; column: index into cols[]}
+ *   keys_out          group g's key string at keys_out + g * key_stride (NUL-terminated)
+ *   count_out / num_out / str_out   [g * naggs + a]: CountAggr counter / Min-MaxDoubleAggr value (-/+Double.MaxValue when
+ *                     untouched) / MaxStringAggr value at str_out + (g * naggs + a) * str_stride ("" = unset)
+ * Returns the number of groups, or -(error code) (msg receives the reference's exception text).
+ */
+typedef struct {
+    int32_t kind;
+    int32_t column;
+} imm3o_aggregate;
+int64_t imm3o_project_agg(const imm3o_column *cols, int32_t ncols, const int32_t *group, int32_t ngroup,
+                          const imm3o_aggregate *aggs, int32_t naggs, const uint64_t *words,
+                          char *keys_out, int32_t key_stride, int64_t *count_out, double *num_out,
+                          char *str_out, int32_t str_stride, int64_t max_groups, char *msg);
+
 /* ---- PFOR_INT block codec (imm3_oracle_pfor.c; core/codec/PFORCodec.scala:19-31 + JavaFastPFOR 0.1.10) ----
  * The block format is defined by the reference's ENCODER; the reference's decoder is broken (PFORCodec.scala:43-50),
  * so decode is the inverse the encoder implies.  Parity unpinned (third-party library, no vectors offline). */

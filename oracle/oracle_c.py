@@ -91,6 +91,9 @@ def lib():
             C.POINTER(_CColumn), C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p,
             C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int64, C.POINTER(C.c_int32),
         ]
+        L.imm3o_project_agg.restype = C.c_int64
+        L.imm3o_project_agg.argtypes = [C.POINTER(_CColumn), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                        C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_char_p]
         L.imm3o_pfor_encode_bound.restype = C.c_int64
         L.imm3o_pfor_encode_bound.argtypes = [C.c_int32]
         L.imm3o_pfor_encode_block.restype = C.c_int64
@@ -239,6 +242,49 @@ def project(cols: Sequence[OColumn], proj: Sequence[int], limit: int, block_size
 
 
 # ---- PFOR_INT block codec (imm3_oracle_pfor.c) ----------------------------------------------------------------
+AGG_KIND = {"count": 0, "min": 1, "max": 2}
+DOUBLE_MAX = 1.7976931348623157e308
+
+
+def project_agg(cols: Sequence[OColumn], group: Sequence[int], aggs, words: np.ndarray, max_groups: int = 1 << 20):
+    """ProjectAggOp over one segment (the C twin of oracle_np.project_agg).  aggs: [(kind in {'count','min','max'}, column)].
+    Returns the same insertion-ordered dict: groupKey -> [int (count) | float (min / max) | str (MaxStringAggr)]."""
+    words = np.ascontiguousarray(words, dtype=np.uint64)
+    na = len(aggs)
+    key_stride, str_stride = 96, 40
+    garr = np.array(list(group) or [0], dtype=np.int32)
+    aarr = np.array([[AGG_KIND[k], c] for k, c in aggs], dtype=np.int32)
+    cap = max_groups
+    while True:
+        keys = np.zeros(cap * key_stride, dtype=np.uint8)
+        counts = np.zeros(cap * na, dtype=np.int64)
+        nums = np.zeros(cap * na, dtype=np.float64)
+        strs = np.zeros(cap * na * str_stride, dtype=np.uint8)
+        msg = C.create_string_buffer(256)
+        cc = _ccols(cols)
+        n = lib().imm3o_project_agg(cc, len(cols), garr.ctypes.data, len(group), aarr.ctypes.data, na,
+                                    words.ctypes.data if words.size else None, keys.ctypes.data, key_stride, counts.ctypes.data,
+                                    nums.ctypes.data, strs.ctypes.data, str_stride, cap, msg)
+        if n < 0:
+            raise OracleError(int(-n), msg.value.decode() or "project_agg failed")
+        break
+    out = {}
+    for g in range(int(n)):
+        kb = keys[g * key_stride:(g + 1) * key_stride].tobytes()
+        key = kb[:kb.index(b"\0")].decode("utf-8", errors="replace")
+        st = []
+        for a, (kind, c) in enumerate(aggs):
+            if kind == "count":
+                st.append(int(counts[g * na + a]))
+            elif cols[c].codec == DENSE_STRING:
+                sb = strs[(g * na + a) * str_stride:(g * na + a + 1) * str_stride].tobytes()
+                st.append(sb[:sb.index(b"\0")].decode("utf-8", errors="replace"))
+            else:
+                st.append(float(nums[g * na + a]))
+        out[key] = st
+    return out
+
+
 def pfor_encode_block(vals: np.ndarray) -> bytes:
     """PFORCodecInt.encode of one block of int32 values (PFORCodec.scala:19-31)."""
     v = np.ascontiguousarray(vals, dtype=np.int32)

@@ -8,7 +8,7 @@ import pytest
 from conftest import DENSE_INT, DENSE_STRING, DENSE_TINYINT, EQ, GT, LT, MATCH, RawColumn, blocks_of
 from immutable3_amd import Count, GT as QGT, LT as QLT, And, Match, Max, Min, NoSelect, ProjectAgg, Query, Select, Sum
 from immutable3_amd import native, synth
-from oracle import oracle_np
+from oracle import oracle_c, oracle_np
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -37,6 +37,10 @@ def check(ctx, cols, used, sels, group, aggs, block_size=1024):
     ucols = [cols[i] for i in used]
     _, _, masks = oracle_np.scan_select([c.npcol() for c in ucols], sels, block_size)
     expect = oracle_np.project_agg([c.npcol() for c in ucols], group, aggs, masks)
+    if all(hasattr(c, "ocol") for c in ucols):      # ... and the C twin: two restatements must agree before they grade the GPU
+        words, _ = oracle_c.scan_select([c.ocol() for c in ucols], sels, block_size)
+        twin = oracle_c.project_agg([c.ocol() for c in ucols], group, aggs, words)
+        assert list(twin.items()) == list(expect.items())
     keys, first, counts, vals = gpu_groups(ctx, cols, used, sels, group, aggs, block_size)
     assert keys.shape[0] == len(expect)
     got = []

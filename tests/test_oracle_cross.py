@@ -120,3 +120,31 @@ def test_zero_batches_errors():
         oracle_np.scan_select([(np.zeros(0, np.uint8), np.array([0], np.int32), DENSE_STRING, 2)], [(0, 1, [b"CA"])], 1024)
     wn, cn, _ = oracle_np.scan_select([(np.zeros(0, np.uint8), np.array([0], np.int32), DENSE_STRING, 2)], [(0, GT, 1.0)], 1024)
     assert cn == 0
+
+
+def test_project_agg_c_twin_agrees_with_numpy(oracle):
+    """Group-by aggregation is restated twice (C: imm3o_project_agg, numpy: oracle_np.project_agg): same groups, same
+    first-seen order, same counts / extremes on random tables, layouts, group columns and aggregate lists."""
+    from oracle import oracle_np
+    rng = np.random.default_rng(77)
+    codes = [b"CA", b"NY", b"TX", b"WA", b"VA", b"DC", b"CT", b"a_", b"_b"]
+    for trial in range(30):
+        n = int(rng.integers(1, 700))
+        block = int(rng.choice([64, 100, 128, 1024]))
+        br = blocks_of(n, block)
+        ids = rng.integers(-40, 40, size=n).astype(np.int32)
+        age = rng.integers(-128, 128, size=n).astype(np.int8)
+        st = np.array([list(codes[i]) for i in rng.integers(0, len(codes), size=n)], dtype=np.uint8).reshape(n, 2)
+        cols = [RawColumn(DENSE_INT, 4, ids, br), RawColumn(DENSE_TINYINT, 1, age, br), RawColumn(DENSE_STRING, 2, st, br)]
+        sels = [] if trial % 3 == 0 else [(0, GT, float(rng.integers(-40, 20)))]
+        words, _ = oracle.scan_select([c.ocol() for c in cols], sels, block)
+        _, _, masks = oracle_np.scan_select([c.npcol() for c in cols], sels, block)
+        group = [int(g) for g in rng.permutation(3)[: int(rng.integers(0, 3))]]
+        pool = [("count", 0), ("count", 2), ("max", 0), ("min", 0), ("max", 1), ("min", 1), ("max", 2)]
+        aggs = [pool[i] for i in rng.permutation(len(pool))[: int(rng.integers(1, 5))]]
+        a = oracle.project_agg([c.ocol() for c in cols], group, aggs, words)
+        b = oracle_np.project_agg([c.npcol() for c in cols], group, aggs, masks)
+        assert list(a.items()) == list(b.items()), (trial, group, aggs)
+    # a String vector only takes CountAggr / MaxStringAggr
+    with pytest.raises(oracle.OracleError, match="bad aggregator"):
+        oracle.project_agg([c.ocol() for c in cols], [0], [("min", 2)], oracle.scan_select([c.ocol() for c in cols], [], block)[0])
