@@ -556,11 +556,31 @@ def extra_workloads(env: Env, steps: int = 20):
                      "frac": algo / (sum(v for v in k.values() if v) * 1e-3) / 1e9 / HBM_PEAK_GBS}
         q.close()
     seg.close()
-    # host -> HBM staging of one 400 MB column (the step before the path)
+    # host -> HBM staging of 400 MB columns (the step before the path): synchronous create, and three asynchronous creates on
+    # the context's copy stream while the query stream keeps scanning (what SegmentManager's start-up looks like here)
+    off4 = synth.block_offsets(n, 4)
     t0 = time.perf_counter()
-    s2 = native.DeviceSegment(ctx, [(native.DENSE_INT, 4, ids.view(np.uint8), n * 4, synth.block_offsets(n, 4))])
+    s2 = native.DeviceSegment(ctx, [(native.DENSE_INT, 4, ids.view(np.uint8), n * 4, off4)])
     dt = time.perf_counter() - t0
-    out["staging_400MB"] = {"seconds": dt, "GBps": n * 4 / dt / 1e9, "note": "imm3_segment_create from pageable host memory"}
+    q = native.DeviceQuery(ctx, s2, [0], [(0, native.GT, lo), (0, native.LT, hi)])
+    scan_s = env.timed_steps(lambda i: q.run_select(), 20, 3) / 20
+    t0 = time.perf_counter()
+    more = [native.DeviceSegment(ctx, [(native.DENSE_INT, 4, ids.view(np.uint8), n * 4, off4)], async_copy=True) for _ in range(3)]
+    scans = 0
+    while time.perf_counter() - t0 < 3 * dt * 0.9:      # keep the query stream busy for about as long as the copies take
+        q.run_select()
+        scans += 1
+    for m in more:
+        m.wait()
+    env.sync()
+    dta = time.perf_counter() - t0
+    out["staging_400MB"] = {"seconds": dt, "GBps": n * 4 / dt / 1e9, "note": "imm3_segment_create from pageable host memory, copy stream; PCIe link rate on this "
+                            "platform is 55-56 GB/s for pageable, pinned and registered memory alike (tools/h2d_probe.py)",
+                            "async_3_segments": {"seconds": dta, "GBps": 3 * n * 4 / dta / 1e9, "scans_on_the_query_stream_meanwhile": scans,
+                                                 "scan_ms_alone": scan_s * 1e3}}
+    q.close()
+    for m in more:
+        m.close()
     s2.close()
     # PFOR_INT: the id column as PFORCodecInt.encode writes it; the range predicate is evaluated on the
     # compressed blocks (k_filter_pfor), HBM traffic = compressed bytes.  VALU-bound, not HBM-bound.

@@ -181,6 +181,7 @@ extern "C" int imm3_ctx_destroy(imm3_ctx *ctx) {
     ctx->used = 0;
     ctx->timing = false;
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); ctx->aux = nullptr; }
+    if (ctx->copy) { (void)hipStreamSynchronize(ctx->copy); (void)hipStreamDestroy(ctx->copy); ctx->copy = nullptr; }
     (void)hipFree(ctx->d_stamps);
     ctx->d_stamps = nullptr;
     ctx->stamp_slots = 0;
@@ -365,6 +366,8 @@ static void segment_free(imm3_segment *seg) {
         if (c.d_row_base) (void)hipFree(c.d_row_base);
         if (c.d_dense) (void)hipFree(c.d_dense);
     }
+    for (void *p : seg->registered) (void)hipHostUnregister(p);
+    if (seg->ready) (void)hipEventDestroy(seg->ready);
     if (seg->ctx) ctx_release(seg->ctx);
     delete seg;
 }
@@ -574,7 +577,18 @@ static int ensure_dense(imm3_ctx *ctx, const imm3_segment *cseg, int32_t col) {
     return IMM3_OK;
 }
 
-static int segment_build(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, bool wrap, imm3_segment **out) {
+// the query stream must not touch a segment's columns before their copies have landed
+static int segment_await(imm3_ctx *ctx, const imm3_segment *seg) {
+    if (seg->ready_pending.load(std::memory_order_acquire)) HIPCHK(hipStreamWaitEvent(ctx->stream, seg->ready, 0));
+    return IMM3_OK;
+}
+
+// Staging: the columns are copied on the context's COPY stream (pageable host memory goes over PCIe at the link rate on
+// this platform -- 55-56 GB/s, the same as pinned or registered memory: tools/h2d_probe.py -- so there is nothing to gain
+// from bounce buffers; what matters is that staging never occupies or synchronises the query stream).  async = false:
+// returns when the host buffers have been consumed; async = true: returns at once, imm3_segment_wait() ends the
+// caller's obligation to keep them mapped.
+static int segment_build(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, bool wrap, imm3_segment **out, bool async = false) {
     if (!out) return fail(IMM3_ERR_ARG, "null argument");
     *out = nullptr;
     CTX_LIVE(ctx);
@@ -584,6 +598,9 @@ static int segment_build(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, 
     seg->ctx = ctx;
     ctx_retain(ctx);
     seg->cols.resize((size_t)ncols);
+    if (!wrap && !ctx->copy) HIPCHK(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
+    bool any_compressed = false;
+    for (int32_t i = 0; i < ncols; ++i) any_compressed |= is_compressed(cols[i].codec);
     for (int32_t i = 0; i < ncols; ++i) {
         const imm3_column &c = cols[i];
         SegCol &s = seg->cols[(size_t)i];
@@ -605,11 +622,27 @@ static int segment_build(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, 
             s.d_data = (uint8_t *)p;
             s.owned = true;
             seg->device_bytes += c.dat_bytes + kPad;
-            if (c.dat_bytes) HIPCHK(hipMemcpyAsync(s.d_data, c.dat, c.dat_bytes, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(hipMemsetAsync(s.d_data + c.dat_bytes, 0, kPad, ctx->stream));
+            if (c.dat_bytes && async && !any_compressed) {
+                // hipMemcpyAsync from pageable memory blocks the host for the whole copy; pinned IN PLACE (~4 ms per 400 MB,
+                // against 7 ms for the copy itself) it returns at once.  A range that cannot be pinned is copied the blocking way.
+                hipError_t re = hipHostRegister((void *)c.dat, c.dat_bytes, hipHostRegisterDefault);
+                if (re != hipSuccess) { (void)hipGetLastError(); re = hipHostRegister((void *)c.dat, c.dat_bytes, hipHostRegisterReadOnly); }
+                if (re == hipSuccess) seg->registered.push_back((void *)c.dat);
+                else (void)hipGetLastError();
+            }
+            if (c.dat_bytes) HIPCHK(hipMemcpyAsync(s.d_data, c.dat, c.dat_bytes, hipMemcpyHostToDevice, ctx->copy));
+            HIPCHK(hipMemsetAsync(s.d_data + c.dat_bytes, 0, kPad, ctx->copy));
         }
     }
-    HIPCHK(hipStreamSynchronize(ctx->stream)); // host buffers may be unmapped after we return
+    if (!wrap) {
+        HIPCHK(hipEventCreateWithFlags(&seg->ready, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(seg->ready, ctx->copy));
+        seg->ready_pending.store(true, std::memory_order_release);
+        if (!async || any_compressed) { // host buffers may be unmapped after we return: wait for the COPY stream only
+            HIPCHK(hipStreamSynchronize(ctx->copy));
+            seg->ready_pending.store(false, std::memory_order_release);
+        }
+    }
     for (auto &sc : seg->cols) {
         if (!is_compressed(sc.codec)) continue;
         const int rc = sc.codec == IMM3_PFOR_INT ? pfor_index(ctx, seg.get(), sc) : snappy_index(ctx, seg.get(), sc);
@@ -625,6 +658,20 @@ extern "C" int imm3_segment_create(imm3_ctx *ctx, const imm3_column *cols, int32
 extern "C" int imm3_segment_wrap_device(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, imm3_segment **out) {
     return segment_build(ctx, cols, ncols, true, out);
 }
+extern "C" int imm3_segment_create_async(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, imm3_segment **out) {
+    return segment_build(ctx, cols, ncols, false, out, true);
+}
+extern "C" int imm3_segment_wait(imm3_segment *seg) {
+    if (!seg) return fail(IMM3_ERR_ARG, "segment is null");
+    if (seg->ready_pending.load(std::memory_order_acquire)) {
+        HIPCHK(hipSetDevice(seg->ctx->device));
+        HIPCHK(hipEventSynchronize(seg->ready));
+        seg->ready_pending.store(false, std::memory_order_release);
+    }
+    for (void *p : seg->registered) (void)hipHostUnregister(p);
+    seg->registered.clear();
+    return IMM3_OK;
+}
 
 extern "C" int imm3_segment_destroy(imm3_segment *seg) {
     if (!seg) return IMM3_OK;
@@ -632,8 +679,11 @@ extern "C" int imm3_segment_destroy(imm3_segment *seg) {
     seg->closed = true;
     if (!seg->ctx->closed) { // (a destroyed context has already drained its streams)
         (void)hipSetDevice(seg->ctx->device);
+        if (seg->ready_pending.load()) (void)hipEventSynchronize(seg->ready);
         (void)hipStreamSynchronize(seg->ctx->stream);
     }
+    for (void *p : seg->registered) (void)hipHostUnregister(p); // the caller may unmap its buffers after destroy
+    seg->registered.clear();
     segment_release(seg); // tables / queries built on it keep the columns alive until they are destroyed
     return IMM3_OK;
 }
@@ -786,6 +836,12 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
     for (int32_t i = 0; i < n_proj; ++i)
         if (proj[i] < 0 || proj[i] >= n_used) return fail(IMM3_ERR_ARG, "project column is not among the used columns");
     HIPCHK(hipSetDevice(ctx->device));
+    if (table) {
+        for (const imm3_segment *sg : table->segs) { const int wrc = segment_await(ctx, sg); if (wrc) return wrc; }
+    } else {
+        const int wrc = segment_await(ctx, seg);
+        if (wrc) return wrc;
+    }
 
     // (1) SelectOp.iterator (Select.scala:17-23) rejects NotMatch / NoOp when the chain is built,
     //     whether or not the segment has any block.

@@ -48,6 +48,7 @@ struct imm3_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t aux = nullptr;      // count reduce of select-only runs: overlaps the next scan on `stream`
+    hipStream_t copy = nullptr;     // host -> HBM staging of segments: never on the query stream, so staging overlaps queries
     int filter_variant = 0;
     int grid_blocks = 0;
     bool timing = false;
@@ -101,6 +102,9 @@ struct imm3_segment {
     imm3_ctx *ctx = nullptr;
     std::vector<SegCol> cols;
     uint64_t device_bytes = 0;
+    std::vector<void *> registered;    // host ranges pinned in place for an asynchronous create (unpinned by imm3_segment_wait)
+    hipEvent_t ready = nullptr;        // recorded on the context's copy stream behind the last column's copy
+    std::atomic<bool> ready_pending{false}; // the copies may still be in flight: consumers make their stream wait for `ready`
     std::mutex decode_mu;              // guards the lazy d_dense of PFOR_INT columns
 };
 

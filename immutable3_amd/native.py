@@ -29,7 +29,7 @@ ERR_UNSUPPORTED_CONDITION, ERR_UNSUPPORTED_VECTOR, ERR_NO_CODEC, ERR_LAYOUT, ERR
 EXPORTS = [
     "imm3_abi_version", "imm3_last_error", "imm3_device_count",
     "imm3_ctx_create", "imm3_ctx_destroy", "imm3_ctx_sync", "imm3_ctx_stream",
-    "imm3_segment_create", "imm3_segment_wrap_device", "imm3_segment_destroy", "imm3_segment_bytes",
+    "imm3_segment_create", "imm3_segment_create_async", "imm3_segment_wait", "imm3_segment_wrap_device", "imm3_segment_destroy", "imm3_segment_bytes",
     "imm3_table_create", "imm3_table_destroy", "imm3_query_create_table", "imm3_query_create_table_agg",
     "imm3_query_segment_starts", "imm3_query_locate_rows",
     "imm3_query_create", "imm3_query_create_agg", "imm3_query_group_count", "imm3_query_fetch_groups",
@@ -121,6 +121,8 @@ def load() -> C.CDLL:
     L.imm3_ctx_stream.argtypes = [vp, P(vp)]
     L.imm3_segment_create.argtypes = [vp, P(CColumn), i32, P(vp)]
     L.imm3_segment_wrap_device.argtypes = [vp, P(CColumn), i32, P(vp)]
+    L.imm3_segment_create_async.argtypes = [vp, P(CColumn), i32, P(vp)]
+    L.imm3_segment_wait.argtypes = [vp]
     L.imm3_segment_destroy.argtypes = [vp]
     L.imm3_segment_bytes.argtypes = [vp, P(u64)]
     L.imm3_query_create.argtypes = [vp, vp, vp, i32, P(CSelect), i32, vp, i32, i64, i32, P(vp)]
@@ -329,15 +331,17 @@ def _ccolumns(cols):
 class DeviceSegment:
     """imm3_segment: all columns of one segment id, resident in HBM."""
 
-    def __init__(self, ctx: Context, cols, wrap_device: bool = False):
+    def __init__(self, ctx: Context, cols, wrap_device: bool = False, async_copy: bool = False):
+        """async_copy: imm3_segment_create_async -- returns once the copies are enqueued on the context's copy stream; the
+        host arrays are kept alive here until wait() (or the first close)."""
         self.ctx = ctx
         self.ncols = len(cols)
         arr, keep = _ccolumns(cols)
         self._h = C.c_void_p()
-        fn = load().imm3_segment_wrap_device if wrap_device else load().imm3_segment_create
+        fn = load().imm3_segment_wrap_device if wrap_device else (load().imm3_segment_create_async if async_copy else load().imm3_segment_create)
         _check(fn(ctx._h, arr, len(cols), C.byref(self._h)))
         ctx._adopt(self)
-        self._keep = keep if wrap_device else None
+        self._keep = keep if (wrap_device or async_copy) else None
         self.widths = [c[1] for c in cols]
         self.codecs = [c[0] for c in cols]
 
@@ -346,6 +350,10 @@ class DeviceSegment:
         n = C.c_uint64(0)
         _check(load().imm3_segment_bytes(self._h, C.byref(n)))
         return n.value
+
+    def wait(self):
+        """The copies of an async_copy segment have consumed the host buffers."""
+        _check(load().imm3_segment_wait(self._h))
 
     def close(self):
         if self._h:

@@ -136,6 +136,17 @@ def load_rows(dataDir: str, table: Table, rows: Sequence[Sequence[str]], segment
         seg.close()
 
 
+def java_split_comma(line: str):
+    """`line.split(",")` as java.lang.String.split does it (LoaderCli.scala:136): trailing empty strings are dropped
+    BEFORE the fields are trimmed ("1,CA," -> ["1", "CA"]; ",," -> []), a line without a comma is returned whole
+    ("" -> [""]).  Python's str.split keeps the trailing empties."""
+    vals = line.split(",")
+    if len(vals) > 1:
+        while vals and vals[-1] == "":
+            vals.pop()
+    return vals
+
+
 def load_csv(dataDir: str, table: Table, csv_path: str, segmentSize: int):
     """LoaderCli: the first line is a header and is skipped (:115-116); fields split on ',' and trimmed (:136)."""
     def gen():
@@ -143,7 +154,7 @@ def load_csv(dataDir: str, table: Table, csv_path: str, segmentSize: int):
             next(f, None)
             for line in f:
                 line = line.rstrip("\n").rstrip("\r")
-                yield [v.strip() for v in line.split(",")]
+                yield [v.strip() for v in java_split_comma(line)]
     load_rows(dataDir, table, gen(), segmentSize)
 
 

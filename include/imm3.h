@@ -120,6 +120,12 @@ int imm3_segment_create(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, i
  * readable for 16 KiB past dat_bytes: the partial last tile of a column is read as a whole tile (1024 rows x width),
  * and the aggregation / gather kernels fetch the aligned dword around a narrow value. */
 int imm3_segment_wrap_device(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, imm3_segment **out);
+/* Asynchronous staging: returns as soon as the copies are enqueued on the context's copy stream (never the query stream:
+ * staging a segment overlaps queries on the others); the host buffers must stay mapped until imm3_segment_wait()
+ * returns (the reference's mmaps live as long as the SegmentManager).  Queries created on the segment order
+ * themselves behind the copies by themselves. */
+int imm3_segment_create_async(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, imm3_segment **out);
+int imm3_segment_wait(imm3_segment *seg);
 int imm3_segment_destroy(imm3_segment *seg);
 int imm3_segment_bytes(const imm3_segment *seg, uint64_t *device_bytes);
 

@@ -6,8 +6,10 @@
  * non-zero statuses become java.lang.Exception(msg), the reference's error convention (Scan.scala:49,
  * Select.scala:22,41,80).
  *
- * NOT COMPILED IN THIS REPOSITORY'S PIPELINE: the build image has no JDK (no jni.h, no libjvm).  The guard
- * below makes the translation unit empty there.  Build on a host with a JDK:
+ * NOT COMPILED AGAINST A JDK IN THIS REPOSITORY'S PIPELINE: the build image has no JDK (no jni.h, no libjvm).  The guard
+ * below makes the translation unit empty there; tests/test_host.py only SYNTAX-checks it against a minimal stand-in for
+ * jni.h (tests/jni_stub/jni.h: the handful of JNIEnv entries used here) -- it has never been linked or run.  UNVERIFIED.
+ * Build on a host with a JDK:
  *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude \
  *       integration/jni/imm3_jni.c -Limmutable3_amd/lib -limm3 -o libimm3_jni.so
  */
@@ -60,11 +62,15 @@ JNIEXPORT jlong JNICALL Java_immutabledb_gpu_Native_00024_segmentCreate(JNIEnv *
         cols[i].dat_bytes = (uint64_t)(*env)->GetDirectBufferCapacity(env, buf);
         cols[i].block_offsets = (const int32_t *)offPtrs[i];
         cols[i].n_offsets = (int32_t)(*env)->GetArrayLength(env, offArrs[i]);
+        (*env)->DeleteLocalRef(env, buf); /* one local ref per column otherwise: a wide table would exhaust the frame */
     }
     CHECKED(imm3_segment_create((imm3_ctx *)(intptr_t)ctx, cols, (int32_t)n, &seg));
 done:
     for (jsize i = 0; i < n; i++)
-        if (offPtrs[i]) (*env)->ReleaseIntArrayElements(env, offArrs[i], offPtrs[i], JNI_ABORT);
+        if (offPtrs[i]) {
+            (*env)->ReleaseIntArrayElements(env, offArrs[i], offPtrs[i], JNI_ABORT);
+            (*env)->DeleteLocalRef(env, offArrs[i]);
+        }
     (*env)->ReleaseIntArrayElements(env, codecs, cd, JNI_ABORT);
     (*env)->ReleaseIntArrayElements(env, widths, wd, JNI_ABORT);
     free(offPtrs); free(offArrs); free(cols);
@@ -104,6 +110,7 @@ JNIEXPORT jlong JNICALL Java_immutabledb_gpu_Native_00024_queryCreate(JNIEnv *en
                 jbyteArray b = (jbyteArray)(*env)->GetObjectArrayElement(env, vals, m);
                 lens[i][m] = (int32_t)(*env)->GetArrayLength(env, b);
                 total += (size_t)lens[i][m];
+                (*env)->DeleteLocalRef(env, b); /* (an IN-list can be long: do not accumulate local refs) */
             }
             blobs[i] = (uint8_t *)malloc(total ? total : 1);
             size_t off = 0;
@@ -111,10 +118,12 @@ JNIEXPORT jlong JNICALL Java_immutabledb_gpu_Native_00024_queryCreate(JNIEnv *en
                 jbyteArray b = (jbyteArray)(*env)->GetObjectArrayElement(env, vals, m);
                 (*env)->GetByteArrayRegion(env, b, 0, lens[i][m], (jbyte *)(blobs[i] + off));
                 off += (size_t)lens[i][m];
+                (*env)->DeleteLocalRef(env, b);
             }
             sels[i].match_bytes = blobs[i];
             sels[i].match_lens = lens[i];
             sels[i].n_match = (int32_t)nv;
+            (*env)->DeleteLocalRef(env, vals);
         }
     }
     CHECKED(imm3_query_create((imm3_ctx *)(intptr_t)ctx, (imm3_segment *)(intptr_t)seg, (const int32_t *)used, (int32_t)nUsed,
@@ -191,9 +200,62 @@ JNIEXPORT void JNICALL Java_immutabledb_gpu_Native_00024_queryFetchRows(JNIEnv *
         jobject rowIndex, jobjectArray cols, jlong maxRows) {
     jsize n = (*env)->GetArrayLength(env, cols);
     void **ptrs = (void **)calloc((size_t)(n > 0 ? n : 1), sizeof(void *));
-    for (jsize j = 0; j < n; j++) ptrs[j] = (*env)->GetDirectBufferAddress(env, (*env)->GetObjectArrayElement(env, cols, j));
+    for (jsize j = 0; j < n; j++) {
+        jobject b = (*env)->GetObjectArrayElement(env, cols, j);
+        ptrs[j] = (*env)->GetDirectBufferAddress(env, b);
+        (*env)->DeleteLocalRef(env, b);
+    }
     uint32_t *idx = rowIndex ? (uint32_t *)(*env)->GetDirectBufferAddress(env, rowIndex) : NULL;
     if (imm3_query_fetch_rows((imm3_query *)(intptr_t)q, idx, ptrs, (uint64_t)maxRows) != IMM3_OK) throw_last(env);
     free(ptrs);
+}
+
+/* ---- multi-GPU (one JVM, G devices): one imm3_ctx per device, one communicator per context (ncclCommInitAll) ---- */
+JNIEXPORT jlongArray JNICALL Java_immutabledb_gpu_Native_00024_commCreateAll(JNIEnv *env, jobject self, jlongArray ctxs) {
+    jsize n = (*env)->GetArrayLength(env, ctxs);
+    jlong *ch = (*env)->GetLongArrayElements(env, ctxs, NULL);
+    imm3_ctx **cs = (imm3_ctx **)calloc((size_t)n, sizeof(imm3_ctx *));
+    imm3_comm **comms = (imm3_comm **)calloc((size_t)n, sizeof(imm3_comm *));
+    jlongArray out = NULL;
+    for (jsize i = 0; i < n; i++) cs[i] = (imm3_ctx *)(intptr_t)ch[i];
+    CHECKED(imm3_comm_create_all(cs, (int32_t)n, comms));
+    out = (*env)->NewLongArray(env, n);
+    for (jsize i = 0; i < n; i++) { jlong h = (jlong)(intptr_t)comms[i]; (*env)->SetLongArrayRegion(env, out, i, 1, &h); }
+done:
+    (*env)->ReleaseLongArrayElements(env, ctxs, ch, JNI_ABORT);
+    free(cs); free(comms);
+    return out;
+}
+
+JNIEXPORT void JNICALL Java_immutabledb_gpu_Native_00024_commDestroy(JNIEnv *env, jobject self, jlong c) {
+    imm3_comm_destroy((imm3_comm *)(intptr_t)c);
+}
+
+/* queries(i): the queries device i ran in this pass (each already run); returns the selected-row count over all devices:
+ * per device a sum kernel, then ONE ncclAllReduce(sum, uint64, 1) per device inside a group (the only collective of the path) */
+JNIEXPORT jlong JNICALL Java_immutabledb_gpu_Native_00024_commAllreduceCountAll(JNIEnv *env, jobject self, jlongArray comms, jobjectArray queries) {
+    jsize n = (*env)->GetArrayLength(env, comms);
+    jlong *ch = (*env)->GetLongArrayElements(env, comms, NULL);
+    imm3_comm **cs = (imm3_comm **)calloc((size_t)n, sizeof(imm3_comm *));
+    imm3_query ***qs = (imm3_query ***)calloc((size_t)n, sizeof(imm3_query **));
+    int32_t *nq = (int32_t *)calloc((size_t)n, sizeof(int32_t));
+    uint64_t total = 0;
+    for (jsize i = 0; i < n; i++) {
+        jlongArray qa = (jlongArray)(*env)->GetObjectArrayElement(env, queries, i);
+        jsize m = (*env)->GetArrayLength(env, qa);
+        jlong *qh = (*env)->GetLongArrayElements(env, qa, NULL);
+        cs[i] = (imm3_comm *)(intptr_t)ch[i];
+        nq[i] = (int32_t)m;
+        qs[i] = (imm3_query **)calloc((size_t)(m > 0 ? m : 1), sizeof(imm3_query *));
+        for (jsize k = 0; k < m; k++) qs[i][k] = (imm3_query *)(intptr_t)qh[k];
+        (*env)->ReleaseLongArrayElements(env, qa, qh, JNI_ABORT);
+        (*env)->DeleteLocalRef(env, qa);
+    }
+    CHECKED(imm3_comm_allreduce_count_all(cs, (int32_t)n, (imm3_query *const *const *)qs, nq, &total));
+done:
+    for (jsize i = 0; i < n; i++) free(qs[i]);
+    (*env)->ReleaseLongArrayElements(env, comms, ch, JNI_ABORT);
+    free(qs); free(cs); free(nq);
+    return (jlong)total;
 }
 #endif /* IMM3_HAVE_JNI */

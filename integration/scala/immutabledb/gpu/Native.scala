@@ -8,7 +8,7 @@ import java.nio.ByteBuffer
   * library reports a non-zero status -- the same convention as the CPU operators
   * (engine/.../operator/Scan.scala:49, Select.scala:22,41,80).
   *
-  * Written against the reference at v0; NOT compiled in this repository (no JDK / sbt in the build image).
+  * Written against the reference at v0; NOT compiled in this repository (no JDK / sbt in the build image): UNVERIFIED.
   */
 object Native {
   System.loadLibrary("imm3_jni") // which links libimm3.so
@@ -39,4 +39,11 @@ object Native {
   @native def queryCount(q: Long): Long
   @native def queryRowCount(q: Long): Long
   @native def queryFetchRows(q: Long, rowIndex: ByteBuffer, cols: Array[ByteBuffer], maxRows: Long): Unit
+
+  // ---- multi-GPU: one context per device, one communicator per context (imm3_comm_create_all = ncclCommInitAll) ----
+  @native def commCreateAll(ctxs: Array[Long]): Array[Long]
+  @native def commDestroy(comm: Long): Unit
+  /** queries(i): the queries device i ran in this pass.  Selected-row count over all devices: ONE 8-byte
+    * ncclAllReduce(sum) per device over RCCL / xGMI -- the only collective of the path (imm3_comm_allreduce_count_all). */
+  @native def commAllreduceCountAll(comms: Array[Long], queries: Array[Array[Long]]): Long
 }

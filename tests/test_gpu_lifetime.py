@@ -199,3 +199,30 @@ def test_rccl_count_reduce_one_rank_both_flavours():
     for s in segs:
         s.close()
     ctx.close()
+
+
+def test_async_staging_orders_queries_behind_the_copies():
+    """imm3_segment_create_async: the copies run on the context's copy stream; a query created right away waits for them on
+    the query stream (stream side) and sees the whole column."""
+    ctx = native.Context(0)
+    n = 3_000_000
+    segs, wants = [], []
+    cols = [synth.uniform_int30(60 + s, n) for s in range(3)]
+    for v in cols:
+        segs.append(native.DeviceSegment(ctx, [RawColumn(DENSE_INT, 4, v, blocks_of(n, 1024)).native()], async_copy=True))
+        wants.append(int(((v > 2 ** 28) & (v < 3 * 2 ** 28)).sum()))
+    qs = [native.DeviceQuery(ctx, s, [0], [(0, GT, float(2 ** 28)), (0, LT, float(3 * 2 ** 28))], [0], 0) for s in segs]
+    for q in qs:
+        q.run()
+    for q, v, want in zip(qs, cols, wants):
+        assert q.count() == want
+        idx, vals = q.fetch_rows()
+        keep = np.flatnonzero((v > 2 ** 28) & (v < 3 * 2 ** 28))
+        assert (idx == keep).all() and (vals[0].view("<i4").reshape(-1) == v[keep]).all()
+    for s in segs:
+        s.wait()
+    for q in qs:
+        q.close()
+    for s in segs:
+        s.close()
+    ctx.close()

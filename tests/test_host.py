@@ -29,6 +29,25 @@ def test_library_loads_and_exports_every_header_symbol():
     assert isinstance(native.device_count(), int)
 
 
+def test_jni_shim_syntax_checks_against_a_stub_header():
+    """integration/jni/imm3_jni.c cannot be built here (no JDK); at least its C parses and type-checks against include/imm3.h
+    with a minimal stand-in for jni.h (tests/jni_stub/jni.h).  Never linked, never run: the shim stays UNVERIFIED."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    p = subprocess.run([gcc, "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-DIMM3_HAVE_JNI=1",
+                        "-I" + os.path.join(ROOT, "tests", "jni_stub"), "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "integration", "jni", "imm3_jni.c")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    # every @native method of Native.scala has its Java_immutabledb_gpu_Native_00024_<name> in the shim
+    scala = open(os.path.join(ROOT, "integration", "scala", "immutabledb", "gpu", "Native.scala")).read()
+    shim = open(os.path.join(ROOT, "integration", "jni", "imm3_jni.c")).read()
+    natives = re.findall(r"@native def (\w+)", scala)
+    assert natives and all(f"Java_immutabledb_gpu_Native_00024_{n}(" in shim for n in natives), [n for n in natives if f"_{n}(" not in shim]
+
+
 def test_no_gpu_fails_loudly_not_silently():
     """Without a HIP device the product path raises; it never falls back to a CPU evaluation."""
     if native.device_count() > 0:
@@ -54,6 +73,22 @@ def test_table_meta_roundtrip(tmp_path):
     assert t2 == t and t2.getColumn("state").width == 2 and t2.getColumn("id").width == 4
     with pytest.raises(Exception, match="does not exist"):
         t2.getColumn("nope")
+
+
+def test_loader_split_drops_trailing_empty_fields_like_java(tmp_path):
+    """LoaderCli splits with java.lang.String.split (LoaderCli.scala:136): "1,CA," binds two fields, not three."""
+    from immutable3_amd.storage import java_split_comma
+    assert java_split_comma("1,CA,") == ["1", "CA"] and java_split_comma(",,") == [] and java_split_comma("") == [""]
+    assert java_split_comma("1,,3") == ["1", "", "3"] and java_split_comma("1,CA, ") == ["1", "CA", " "]
+    t = Table("tr", [Column.make("id", CodecType.DENSE_INT), Column.make("state", CodecType.DENSE_STRING, {"size": "2"}),
+                     Column.make("age", CodecType.DENSE_TINYINT)], 4)
+    csv = tmp_path / "in.csv"
+    csv.write_text("id,state,age\n1,CA,5\n2,NY,\n3,TX,7,\n")     # row 2 has no age: the reference writes nothing for it
+    load_csv(str(tmp_path), t, str(csv), 10)
+    sm = SegmentManager(str(tmp_path))
+    ids = np.asarray(sm.getSegment(0, "tr", "id").segmentData).view("<i4")
+    ages = np.asarray(sm.getSegment(0, "tr", "age").segmentData).view(np.int8)
+    assert ids.tolist() == [1, 2, 3] and ages.tolist() == [5, 7]        # the age column silently falls one row short, as in the reference
 
 
 def test_loader_csv_and_lexicographic_segment_order(tmp_path):
