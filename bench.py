@@ -564,8 +564,9 @@ def extra_workloads(env: Env, steps: int = 20):
     dt = time.perf_counter() - t0
     q = native.DeviceQuery(ctx, s2, [0], [(0, native.GT, lo), (0, native.LT, hi)])
     scan_s = env.timed_steps(lambda i: q.run_select(), 20, 3) / 20
+    hosts = [ids, ids + 1, ids + 2]                     # three distinct host buffers, as SegmentManager's mmaps are
     t0 = time.perf_counter()
-    more = [native.DeviceSegment(ctx, [(native.DENSE_INT, 4, ids.view(np.uint8), n * 4, off4)], async_copy=True) for _ in range(3)]
+    more = [native.DeviceSegment(ctx, [(native.DENSE_INT, 4, h.view(np.uint8), n * 4, off4)], async_copy=True) for h in hosts]
     scans = 0
     while time.perf_counter() - t0 < 3 * dt * 0.9:      # keep the query stream busy for about as long as the copies take
         q.run_select()
@@ -610,6 +611,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the extra block (C3, C4, aggregation, C5 at G = 1)")
     ap.add_argument("--no-c2-weak", action="store_true", help="N > 1: skip the weak-scaling C2 leg")
+    ap.add_argument("--no-c5", action="store_true", help="N = 1: leave the C5-at-G=1 leg out of the extra block (profiling runs: its kernels are C3's instances)")
     ap.add_argument("--extra", action="store_true", help="(kept for compatibility: the extra block is on by default)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--grid", type=int, default=0)
@@ -633,9 +635,10 @@ def main():
         result["cpu_baseline"] = c2.get("cpu_baseline")
         if not args.no_extra:
             extra = extra_workloads(env)
-            c5 = measure_c5(env, max(3, min(args.steps, 10)), 2)
-            extra["c5_g1"] = {k: c5[k] for k in ("value", "ms_per_step", "global_selected_rows_per_pass", "count_allreduce", "config", "roofline")}
-            extra["c5_g1"]["note"] = "the G = 1 point of the C5 strong-scaling curve whose G > 1 points are the `value` of the --gpus N lines"
+            if not args.no_c5:
+                c5 = measure_c5(env, max(3, min(args.steps, 10)), 2)
+                extra["c5_g1"] = {k: c5[k] for k in ("value", "ms_per_step", "global_selected_rows_per_pass", "count_allreduce", "config", "roofline")}
+                extra["c5_g1"]["note"] = "the G = 1 point of the C5 strong-scaling curve whose G > 1 points are the `value` of the --gpus N lines"
             result["extra"] = extra
         result["scaling_note"] = ("N = 1: value = C2 (headline).  N > 1: value = C5 aggregate (strong scaling, 8e8 rows per pass); its G = 1 point is "
                                   "extra.c5_g1.value; the like-for-like weak-scaling curve of the headline workload is c2_weak.value at N > 1")

@@ -356,6 +356,29 @@ struct LaunchTimer {
 // ---------------------------------------------------------------------------------------------
 static constexpr uint64_t kPad = 16384; // readable slack past every column: a partial last tile is read as a whole (1024 rows x <= 16 B)
 
+// Host ranges pinned in place for asynchronous staging are counted per context: two segments staged from the same buffer
+// share one registration, and the range stays pinned until the last of them has finished with it (unpinning it under a
+// copy still in flight is an error the runtime reports much later, on an unrelated call).
+static bool pin_range(imm3_ctx *ctx, void *p, size_t bytes) {
+    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    auto it = ctx->pinned.find(p);
+    if (it != ctx->pinned.end()) { ++it->second; return true; }
+    hipError_t re = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (re != hipSuccess) { (void)hipGetLastError(); re = hipHostRegister(p, bytes, hipHostRegisterReadOnly); }
+    if (re != hipSuccess) { (void)hipGetLastError(); return false; }
+    ctx->pinned[p] = 1;
+    return true;
+}
+static void unpin_range(imm3_ctx *ctx, void *p) {
+    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    auto it = ctx->pinned.find(p);
+    if (it == ctx->pinned.end()) return;
+    if (--it->second == 0) {
+        if (hipHostUnregister(p) != hipSuccess) (void)hipGetLastError();
+        ctx->pinned.erase(it);
+    }
+}
+
 // last reference gone: free the columns (hipFree waits for the device by itself) and let go of the context
 static void segment_free(imm3_segment *seg) {
     if (!seg) return;
@@ -366,7 +389,7 @@ static void segment_free(imm3_segment *seg) {
         if (c.d_row_base) (void)hipFree(c.d_row_base);
         if (c.d_dense) (void)hipFree(c.d_dense);
     }
-    for (void *p : seg->registered) (void)hipHostUnregister(p);
+    if (seg->ctx) for (void *p : seg->registered) unpin_range(seg->ctx, p);
     if (seg->ready) (void)hipEventDestroy(seg->ready);
     if (seg->ctx) ctx_release(seg->ctx);
     delete seg;
@@ -625,10 +648,7 @@ static int segment_build(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, 
             if (c.dat_bytes && async && !any_compressed) {
                 // hipMemcpyAsync from pageable memory blocks the host for the whole copy; pinned IN PLACE (~4 ms per 400 MB,
                 // against 7 ms for the copy itself) it returns at once.  A range that cannot be pinned is copied the blocking way.
-                hipError_t re = hipHostRegister((void *)c.dat, c.dat_bytes, hipHostRegisterDefault);
-                if (re != hipSuccess) { (void)hipGetLastError(); re = hipHostRegister((void *)c.dat, c.dat_bytes, hipHostRegisterReadOnly); }
-                if (re == hipSuccess) seg->registered.push_back((void *)c.dat);
-                else (void)hipGetLastError();
+                if (pin_range(ctx, (void *)c.dat, c.dat_bytes)) seg->registered.push_back((void *)c.dat);
             }
             if (c.dat_bytes) HIPCHK(hipMemcpyAsync(s.d_data, c.dat, c.dat_bytes, hipMemcpyHostToDevice, ctx->copy));
             HIPCHK(hipMemsetAsync(s.d_data + c.dat_bytes, 0, kPad, ctx->copy));
@@ -668,7 +688,7 @@ extern "C" int imm3_segment_wait(imm3_segment *seg) {
         HIPCHK(hipEventSynchronize(seg->ready));
         seg->ready_pending.store(false, std::memory_order_release);
     }
-    for (void *p : seg->registered) (void)hipHostUnregister(p);
+    for (void *p : seg->registered) unpin_range(seg->ctx, p);
     seg->registered.clear();
     return IMM3_OK;
 }
@@ -682,7 +702,7 @@ extern "C" int imm3_segment_destroy(imm3_segment *seg) {
         if (seg->ready_pending.load()) (void)hipEventSynchronize(seg->ready);
         (void)hipStreamSynchronize(seg->ctx->stream);
     }
-    for (void *p : seg->registered) (void)hipHostUnregister(p); // the caller may unmap its buffers after destroy
+    for (void *p : seg->registered) unpin_range(seg->ctx, p); // the caller may unmap its buffers after destroy
     seg->registered.clear();
     segment_release(seg); // tables / queries built on it keep the columns alive until they are destroyed
     return IMM3_OK;
@@ -1383,7 +1403,7 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
         bool any_i32 = false;
         for (int k = 0; k < kMaxTileCols; ++k) any_i32 |= (a.kinds[k] == TK_I32);
         if (ctx->d_stamps && ctx->stamp_used < ctx->stamp_slots) a.stamps = ctx->d_stamps + (size_t)ctx->stamp_used * kMaxFilterGrid * 2;
-        grid = filter_grid(q->n_tiles, false, any_i32 || n == 0, ctx->grid_blocks);
+        grid = filter_grid(q->n_tiles, false, any_i32, ctx->grid_blocks); // (no column at all: the store-only kernel also likes 1536 groups, 9.9 vs 17.2 us)
         if (q->stage_written) grid = q->stage_grid; // fixed at creation: the arena layout depends on it
         // A select chain that is ONE tile pass also reduces its count in the kernel (one relaxed atomic per work-group): no
         // k_total launch.  Only at <= 512 work-groups: same-address atomics serialise at ~12 ns each, and 1536-2048 of them

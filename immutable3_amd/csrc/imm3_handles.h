@@ -49,6 +49,7 @@ struct imm3_ctx {
     bool own_stream = false;
     hipStream_t aux = nullptr;      // count reduce of select-only runs: overlaps the next scan on `stream`
     hipStream_t copy = nullptr;     // host -> HBM staging of segments: never on the query stream, so staging overlaps queries
+    std::map<void *, int> pinned;   // host ranges pinned in place for asynchronous staging, by start address, with a use count (pool_mu)
     int filter_variant = 0;
     int grid_blocks = 0;
     bool timing = false;

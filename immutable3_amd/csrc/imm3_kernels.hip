@@ -1008,8 +1008,8 @@ int filter_grid(int64_t units, bool generic, bool any_i32, int grid_blocks) {
 // T (tiles per wave iteration) is chosen so a wave has >= 4 KiB in flight: bytes/row x 1024 x T.
 #define IMM3_TILE_KINDS(X)                                                                          \
     X(TK_NONE, TK_NONE, TK_NONE, 1)                                                                 \
-    X(TK_I32, TK_NONE, TK_NONE, 1) X(TK_I8, TK_NONE, TK_NONE, 4) X(TK_S2, TK_NONE, TK_NONE, 2)       \
-    X(TK_I32, TK_I32, TK_NONE, 1) X(TK_I32, TK_I8, TK_NONE, 1) X(TK_I8, TK_I8, TK_NONE, 2)           \
+    X(TK_I32, TK_NONE, TK_NONE, 1) X(TK_I8, TK_NONE, TK_NONE, 2) X(TK_S2, TK_NONE, TK_NONE, 1)       \
+    X(TK_I32, TK_I32, TK_NONE, 1) X(TK_I32, TK_I8, TK_NONE, 1) X(TK_I8, TK_I8, TK_NONE, 1)           \
     X(TK_I32, TK_S2, TK_NONE, 1) X(TK_I8, TK_S2, TK_NONE, 2)                                         \
     X(TK_I32, TK_I32, TK_I32, 1) X(TK_I32, TK_I32, TK_I8, 1) X(TK_I32, TK_I8, TK_I8, 1)              \
     X(TK_I8, TK_I8, TK_I8, 2) X(TK_I32, TK_I32, TK_S2, 1) X(TK_I32, TK_I8, TK_S2, 1) X(TK_I8, TK_I8, TK_S2, 1)

@@ -85,7 +85,9 @@ _lib = None
 
 
 def load() -> C.CDLL:
-    """Load libimm3.so; fail loudly when the HIP extension has not been built."""
+    """Load libimm3.so; fail loudly when the HIP extension has not been built.
+    Note for hosts that also use PyTorch-ROCm in the same process: import torch BEFORE the first call of this function.
+    torch bundles its own HIP runtime; the runtime loaded first serves the process, a second instance sees no GPU."""
     global _lib
     if _lib is not None:
         return _lib

@@ -4,6 +4,15 @@ import sys
 import numpy as np
 import pytest
 
+# PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so); libimm3.so links the system one.  Whichever is
+# loaded FIRST serves the whole process -- a second runtime instance finds no GPU ("No HIP GPUs are available").  Tests
+# that use torch for device memory next to the library therefore need torch loaded before the first native.load(),
+# whatever order the test files run in: load it here, once, for every session.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
