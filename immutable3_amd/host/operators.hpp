@@ -17,6 +17,7 @@
 
 #include "../../include/imm3.h"
 #include "storage.hpp"
+#include "scala_sets.hpp"
 
 namespace immutabledb {
 
@@ -565,22 +566,26 @@ class Engine {
   public:
     explicit Engine(GpuSegmentManager &sm) : sm_(sm) {}
 
-    // Engine.getColumns (:85-106): (selectColumnsSet.toList ++ projectColumns).toSet.toList.  Scala's Set1..Set4 keep
-    // insertion order, so for <= 4 distinct columns this is first-seen order (SURVEY A.1 rule 3).
+    // Engine.getColumns (:85-106): (rec(query.select).toList ++ projectColumns).toSet.toList.  Scala's Set1..Set4 keep
+    // insertion order, so for <= 4 distinct columns this is first-seen order (SURVEY A.1 rule 3); from the fifth distinct
+    // column on, the set is an immutable.HashSet and the order is its hash trie's (scala_sets.hpp).
     static std::vector<Column> getColumns(const Query &q, const Table &table) {
-        std::vector<Column> out;
-        auto add = [&](const Column &c) { for (const auto &x : out) if (x == c) return; out.push_back(c); };
-        std::function<void(const SelectADT &)> rec = [&](const SelectADT &s) {
-            if (s.kind == SelectADT::And || s.kind == SelectADT::Or) { rec(*s.op1); rec(*s.op2); }
-            else if (s.kind == SelectADT::Select) add(table.getColumn(s.col));
+        std::function<scalasets::ColumnSet(const SelectADT &)> rec = [&](const SelectADT &s) {
+            scalasets::ColumnSet out;
+            if (s.kind == SelectADT::And || s.kind == SelectADT::Or) { // rec(a) ++ rec(b): b's elements, in b's order, added to a
+                out = rec(*s.op1);
+                for (const auto &c : rec(*s.op2).toList()) out.add(c);
+            } else if (s.kind == SelectADT::Select) out.add(table.getColumn(s.col));
+            return out;
         };
-        rec(*q.select);
-        if (q.project.kind == ProjectADT::Project) for (const auto &c : q.project.cols) add(table.getColumn(c));
+        scalasets::ColumnSet all;
+        for (const auto &c : rec(*q.select).toList()) all.add(c);
+        if (q.project.kind == ProjectADT::Project) for (const auto &c : q.project.cols) all.add(table.getColumn(c));
         else if (q.project.kind == ProjectADT::ProjectAgg) {
-            for (const auto &a : q.project.aggs) add(table.getColumn(a.col));
-            for (const auto &g : q.project.groupBy) add(table.getColumn(g));
+            for (const auto &a : q.project.aggs) all.add(table.getColumn(a.col));
+            for (const auto &g : q.project.groupBy) all.add(table.getColumn(g));
         }
-        return out;
+        return all.toList();
     }
     // resolveSelectOps + runOps (:108-128, :237-245): left-to-right fold, AND/OR tag ignored
     static std::vector<Leaf> resolveSelectOps(const Query &q) {

@@ -604,38 +604,44 @@ def _rows_from_columns(cols: List[np.ndarray]) -> Iterator[Row]:
 # ------------------------------------------------------------------------------------------
 # Engine (the caller of the hot path; only what the path needs: planning + per-segment fan-out)
 # ------------------------------------------------------------------------------------------
-def getColumns(query: Query, table: Table) -> List[Column]:
-    """Engine.getColumns (Engine.scala:85-106): (selectColumnsSet.toList ++ projectColumns).toSet.toList.
-    Scala's Set1..Set4 keep insertion order, so for <= 4 distinct columns the order is first-seen order
-    (SURVEY A.1 rule 3).  Beyond 4 the reference's order is a HashSet's; first-seen order is used here and
-    is NOT pinned to the reference (it only decides which column is 'first', i.e. defines the batches)."""
-    def rec(sel: SelectADT) -> List[Column]:
-        if isinstance(sel, (And, Or)):
-            out = rec(sel.op1)
-            for c in rec(sel.op2):
-                if c not in out:
-                    out.append(c)
-            return out
-        if isinstance(sel, Select):
-            return [table.getColumn(sel.col)]
-        return []
+def _column_hash(c: Column) -> int:
+    from . import scala_sets
+    codec_id = CodecType.id_of(c.codec)
+    return scala_sets.product_hash([scala_sets.java_string_hash(c.name), scala_sets.COLUMN_TYPE_ID[c.columnType], codec_id,
+                                    scala_sets.map_hash(dict(c.dtypeAttrs))])
 
-    cols = rec(query.select)
+
+def getColumns(query: Query, table: Table) -> List[Column]:
+    """Engine.getColumns (Engine.scala:85-106): (rec(query.select).toList ++ projectColumns).toSet.toList.
+    Scala's Set1..Set4 keep insertion order, so for <= 4 distinct columns the order is first-seen order
+    (SURVEY A.1 rule 3).  From the fifth distinct column on the set is an immutable.HashSet and the order is its hash
+    trie's: restated in scala_sets.py (scala-library 2.12.11; unpinned at the reference boundary, pinned against the
+    library's well-known Set(1 to 10) order).  The first column of the result defines the batches (Scan.scala:55); for
+    aggregations the order also decides how the group key is joined (ProjectAggregate.scala:135-156)."""
+    from .scala_sets import ScalaSet
+
+    def rec(sel: SelectADT) -> ScalaSet:
+        out = ScalaSet()
+        if isinstance(sel, (And, Or)):                 # rec(a) ++ rec(b): b's elements, in b's order, added to a
+            out = rec(sel.op1)
+            for c in rec(sel.op2).to_list():
+                out.add(c, _column_hash(c))
+        elif isinstance(sel, Select):
+            c = table.getColumn(sel.col)
+            out.add(c, _column_hash(c))
+        return out
+
+    cols = ScalaSet()
+    for c in rec(query.select).to_list():
+        cols.add(c, _column_hash(c))
     if isinstance(query.project, Project):
-        for name in query.project.cols:
-            c = table.getColumn(name)
-            if c not in cols:
-                cols.append(c)
+        names = list(query.project.cols)
     else:                                              # ProjectAgg: aggsCols ++ groupCols (Engine.scala:96-100)
-        for a in query.project.aggs:
-            c = table.getColumn(a.col)
-            if c not in cols:
-                cols.append(c)
-        for name in query.project.groupBy:
-            c = table.getColumn(name)
-            if c not in cols:
-                cols.append(c)
-    return cols
+        names = [a.col for a in query.project.aggs] + list(query.project.groupBy)
+    for name in names:
+        c = table.getColumn(name)
+        cols.add(c, _column_hash(c))
+    return cols.to_list()
 
 
 def resolveSelectOps(query: Query) -> List[Callable[[ColumnVectorOperator], ColumnVectorOperator]]:

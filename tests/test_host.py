@@ -209,3 +209,55 @@ def test_snappy_writer_is_readable_by_the_oracle_and_google_snappy(tmp_path):
     dat = open(tmp_path / "a" / "sn" / "v_0.dat", "rb").read()
     got = b"".join(oracle_c.snappy_block_decode(dat[offs[k]:offs[k + 1]]) for k in range(len(offs) - 1))
     assert np.frombuffer(got, dtype="<i4").tolist() == [int(v) for v in vals]
+
+
+def test_scala_set_order_building_blocks_are_pinned():
+    """Engine.getColumns' order beyond 4 distinct columns is a Scala 2.12 immutable.HashSet's (Engine.scala:105).  The
+    restatement (immutable3_amd/scala_sets.py) is pinned where it can be: MurmurHash3's mix / finalizeHash against an
+    independent murmur3_32 (sklearn), String.hashCode against known values, and the hash-trie iteration order against
+    scala-library 2.12's well-known outputs Set(1 to 5) -> (5, 1, 2, 3, 4) and Set(1 to 10) -> (5, 10, 1, 6, 9, 2, 7, 3, 8, 4)."""
+    import struct
+    from immutable3_amd import scala_sets as S
+    assert S.java_string_hash("Map") == 77116 and S.java_string_hash("hello") == 99162322 and S.java_string_hash("") == 0
+    try:
+        from sklearn.utils import murmurhash3_32
+    except Exception:
+        murmurhash3_32 = None
+    if murmurhash3_32 is not None:
+        for seed in (0, 1, 0xcafebabe, 77116):
+            for k in (0, 1, 0x87654321, 0xffffffff, 12345):
+                assert murmurhash3_32(struct.pack("<I", k), seed=seed, positive=True) == S.finalize_hash(S.mix(seed, k), 4)
+                assert murmurhash3_32(struct.pack("<II", k, k ^ 0x5bd1e995), seed=seed, positive=True) == \
+                    S.finalize_hash(S.mix(S.mix(seed, k), k ^ 0x5bd1e995), 8)
+    for n, want in ((4, [1, 2, 3, 4]), (5, [5, 1, 2, 3, 4]), (10, [5, 10, 1, 6, 9, 2, 7, 3, 8, 4])):
+        st = S.ScalaSet()
+        for i in range(1, n + 1):
+            st.add(i, i)                   # Int.## is the int itself
+        st.add(1, 1)                       # adding an element again changes nothing
+        assert st.to_list() == want
+
+
+def test_get_columns_order_small_sets_and_hash_sets(tmp_path):
+    """<= 4 distinct columns: first-seen order (Set1..Set4).  >= 5: the HashSet's order -- the Python and the C++ planner
+    must agree on it, and it is NOT first-seen order."""
+    import subprocess
+    from immutable3_amd.build import build_native
+    names = ["id", "state", "age", "zip", "score", "flag", "tag"]
+    cols = [Column.make("id", CodecType.DENSE_INT), Column.make("state", CodecType.DENSE_STRING, {"size": "2"}),
+            Column.make("age", CodecType.DENSE_TINYINT), Column.make("zip", CodecType.DENSE_INT), Column.make("score", CodecType.DENSE_TINYINT),
+            Column.make("flag", CodecType.DENSE_TINYINT), Column.make("tag", CodecType.DENSE_STRING, {"size": "3"})]
+    t = Table("wide", cols, 1024)
+    TableIO.store(str(tmp_path), t)
+    small = Query("wide", And(Select("age", GT(1.0)), Select("zip", LT(5.0))), Project(["id", "age"], 0))
+    assert [c.name for c in getColumns(small, t)] == ["age", "zip", "id"]
+    big = Query("wide", And(And(Select("age", GT(1.0)), Select("zip", LT(5.0))), Select("state", Match(["CA"]))),
+                Project(["id", "score", "flag", "tag", "age"], 0))
+    order = [c.name for c in getColumns(big, t)]
+    assert sorted(order) == sorted(names) and order != ["age", "zip", "state", "id", "score", "flag", "tag"]
+    build_native()
+    sql = "select id, score, flag, tag, age from wide where ((age > 1 and zip < 5) and state = 'CA')"
+    p = subprocess.run([os.path.join(ROOT, "immutable3_amd", "bin", "imm3_sql"), "--parse-only", "-q", sql, "-d", str(tmp_path)],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    used = [l for l in p.stdout.splitlines() if l.startswith("usedColumns:")][0].split()[1:]
+    assert used == order, (used, order)
