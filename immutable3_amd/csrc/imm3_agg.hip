@@ -13,6 +13,7 @@
 // Numeric min/max stay int32 (exact); the host converts to Double like value.toDouble.  String max compares the
 // value bytes big-endian-packed into a u64 == lexicographic byte order == String.compareTo for ASCII.
 #include "imm3_internal.h"
+#include "imm3_device.h"
 #include <hip/hip_ext.h>
 
 namespace imm3 {
@@ -449,6 +450,169 @@ __global__ __launch_bounds__(kBlockThreads) void k_group_agg_tile(const AggArgs 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_group_agg_direct: group key <= 2 bytes.  The key indexes a byte map in LDS (256 B or 64 KiB) that names the group's
+// dense slot (<= 254 distinct keys per work-group, assigned on first sight), so a row's slot costs ONE ds_read_u8 with no
+// key compare, no probing and no branch -- and all 16 words of a tile issue their map reads back to back, then their
+// count / first-seen / value atomics back to back: three LDS waits per TILE instead of two per WORD (k_group_agg_tile's
+// 16 serialised probe round trips per tile were what its time was made of).  One 1024-thread work-group per CU shares the
+// map and the tables (16 waves), which also keeps the flush small: groups x work-groups global atomics on a few hot
+// addresses serialise at ~12 ns each.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDirectThreads = 1024;
+constexpr int kDirectWaves = kDirectThreads / 64;
+constexpr int kDirectSlots = 256; // slot 255 = "not assigned yet" in the map
+
+__global__ __launch_bounds__(kDirectThreads) void k_group_agg_direct(const AggArgs a, const int map_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_map[]; // [map_bytes] key -> slot
+    __shared__ uint32_t s_slotkey[kDirectSlots];
+    __shared__ uint32_t s_first[kDirectSlots];
+    __shared__ uint32_t s_count[kDirectSlots];
+    __shared__ uint32_t s_vals[kMaxAggs][kDirectSlots];
+    __shared__ uint32_t s_nslots;
+    __shared__ __attribute__((aligned(16))) uint8_t s_xp[kDirectWaves][2048];
+    // LDS atomics retire ~1.4 lanes per cycle per CU whatever the addresses (measured: each atomic per row costs ~115 us per
+    // 100 M rows), so they are the budget.  The first-seen row needs none after warm-up: a wave walks its tiles in ascending
+    // order, so only its FIRST rows of a slot can lower the minimum -- a per-wave byte map remembers which slots it has seen
+    // (plain read per row, plain write on first sight).
+    __shared__ uint8_t s_seen[kDirectWaves][kDirectSlots];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    uint8_t *xp = s_xp[wave];
+    uint8_t *seen = s_seen[wave];
+    for (int i = t; i < kDirectWaves * kDirectSlots / 4; i += kDirectThreads) ((uint32_t *)s_seen)[i] = 0u;
+    for (int i = t; i < map_bytes / 4; i += kDirectThreads) ((uint32_t *)s_map)[i] = 0xFFFFFFFFu;
+    for (int i = t; i < kDirectSlots; i += kDirectThreads) {
+        s_first[i] = 0xFFFFFFFFu;
+        s_count[i] = 0;
+        for (int j = 0; j < kMaxAggs; ++j) {
+            const int kind = j < a.n_agg ? a.aggs[j].kind : AGG_COUNT;
+            const bool str = j < a.n_agg && a.aggs[j].is_str;
+            s_vals[j][i] = kind == AGG_MIN ? (uint32_t)INT32_MAX : (str ? 0u : (uint32_t)INT32_MIN);
+        }
+    }
+    if (t == 0) s_nslots = 0;
+    __syncthreads();
+
+    for (int64_t tile = (int64_t)blockIdx.x * kDirectWaves + wave; tile < a.n_tiles; tile += (int64_t)gridDim.x * kDirectWaves) {
+        uint64_t m[kTileWords]; // the tile's bitmap words: wave-uniform
+        uint64_t any = 0;
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) {
+            m[j] = a.bitmap[tile * kTileWords + j];
+            any |= m[j];
+        }
+        if (!any) continue; // nothing selected in these 1024 rows
+        uint32_t key[kTileWords];
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) key[j] = 0;
+        for (int g = 0; g < a.n_group; ++g) {
+            uint32_t v[kTileWords];
+            load_tile_rows(a.groups[g].data, a.groups[g].width, tile, lane, xp, v);
+            const int sh = 8 * a.groups[g].shift;
+#pragma unroll
+            for (int j = 0; j < kTileWords; ++j) key[j] |= v[j] << sh;
+        }
+        // slots: 16 map reads back to back
+        uint32_t sid[kTileWords];
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) {
+            sid[j] = 0;
+            if (__builtin_amdgcn_inverse_ballot_w64(m[j])) sid[j] = s_map[key[j]];
+        }
+        uint64_t bad = 0;
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) bad |= m[j] & ballot64(sid[j] == 255u);
+        if (bad) { // wave-uniform, warm-up only: give every unseen key of this tile a slot, one distinct key at a time
+#pragma unroll
+            for (int j = 0; j < kTileWords; ++j) { // (unrolled: a run-time index would push key[] / sid[] into scratch memory)
+                uint64_t todo = m[j] & ballot64(sid[j] == 255u);
+                while (todo) {
+                    const int leader = __builtin_ctzll(todo);
+                    const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key[j], leader);
+                    uint32_t id = 255u;
+                    if (lane == 0) {
+                        uint32_t *w32 = (uint32_t *)s_map + (k >> 2);
+                        const int sh = 8 * (int)(k & 3u);
+                        for (int tries = 0; tries < 64 && id == 255u; ++tries) {
+                            const uint32_t cur = *(volatile uint32_t *)w32;
+                            const uint32_t b = (cur >> sh) & 0xFFu;
+                            if (b != 255u) { id = b; break; }
+                            const uint32_t mine = atomicAdd(&s_nslots, 1u);
+                            if (mine >= 255u) { *a.overflow = 2; id = 0; break; } // too many distinct keys for this form: the host re-runs the general kernel
+                            const uint32_t want = cur ^ ((255u ^ mine) << sh);
+                            if (atomicCAS(w32, cur, want) == cur) { id = mine; s_slotkey[mine] = k; }
+                            // else: another wave changed this dword meanwhile (the slot number `mine` is simply not used)
+                        }
+                        if (id == 255u) { *a.overflow = 2; id = 0; }
+                    }
+                    id = (uint32_t)__builtin_amdgcn_readfirstlane((int)id);
+                    const uint64_t same = ballot64(key[j] == k) & todo;
+                    if ((same >> lane) & 1ULL) sid[j] = id;
+                    todo &= ~same;
+                }
+            }
+        }
+        // count: 16 atomics back to back; first-seen row: 16 plain reads of the wave's seen map, atomics only on first sight
+        uint32_t was[kTileWords];
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) {
+            was[j] = 1u;
+            if (__builtin_amdgcn_inverse_ballot_w64(m[j])) {
+                atomicAdd(&s_count[sid[j]], 1u);
+                was[j] = seen[sid[j]];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) {
+            if (was[j] == 0u) { // (all lanes of this word that meet the slot for the first time: the atomic keeps the lowest row)
+                atomicMin(&s_first[sid[j]], (uint32_t)(tile * kTileRows + 64 * j + lane));
+                seen[sid[j]] = 1;
+            }
+        }
+        // values
+        for (int q = 0; q < a.n_agg; ++q) {
+            const int kind = a.aggs[q].kind;
+            if (kind == AGG_COUNT) continue;
+            uint32_t late[kTileWords];
+            load_tile_rows(a.aggs[q].data, a.aggs[q].width, tile, lane, xp, late);
+            const int w = a.aggs[q].width;
+            const bool str = a.aggs[q].is_str;
+#pragma unroll
+            for (int j = 0; j < kTileWords; ++j) {
+                if (__builtin_amdgcn_inverse_ballot_w64(m[j])) {
+                    const uint32_t raw = late[j];
+                    uint32_t *p = &s_vals[q][sid[j]];
+                    if (str) { // big-endian pack: integer order == byte-lexicographic order
+                        const uint32_t be = w == 4 ? __builtin_bswap32(raw) : (w == 2 ? (uint32_t)__builtin_bswap16((uint16_t)raw) : raw);
+                        atomicMax(p, be);
+                    } else {
+                        const int32_t x = w == 4 ? (int32_t)raw : (int32_t)(int8_t)raw;
+                        if (kind == AGG_MIN) atomicMin((int32_t *)p, x);
+                        else atomicMax((int32_t *)p, x);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // flush: one atomic set per (work-group, group), widened to what the global table holds
+    const uint32_t n_slots = s_nslots < 255u ? s_nslots : 255u;
+    for (uint32_t i = t; i < n_slots; i += kDirectThreads) {
+        if (s_count[i] == 0) continue;
+        const uint32_t g = global_slot(a, (unsigned long long)s_slotkey[i]);
+        if (g == 0xFFFFFFFFu) continue;
+        long long vals[kMaxAggs];
+        for (int j = 0; j < kMaxAggs; ++j) {
+            const bool str = j < a.n_agg && a.aggs[j].is_str;
+            vals[j] = str ? (long long)(unsigned long long)s_vals[j][i] : (long long)(int32_t)s_vals[j][i];
+        }
+        agg_update_global(a, g, s_first[i], (unsigned long long)s_count[i], vals);
+    }
+}
+
 // occupied entries of the global table -> dense arrays (order irrelevant: the host sorts by first_row)
 __global__ __launch_bounds__(kBlockThreads) void k_group_collect(const AggArgs a) {
     const int lane = threadIdx.x & 63;
@@ -515,6 +679,15 @@ void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_
     const int64_t n = (int64_t)a.mask + 2;
     const int init_grid = (int)std::min<int64_t>((n + kBlockThreads - 1) / kBlockThreads, 2048);
     hipLaunchKernelGGL(k_group_init, dim3(init_grid), dim3(kBlockThreads), 0, s, a);
+    int key_bytes = 0;
+    for (int g = 0; g < a.n_group; ++g) key_bytes += a.groups[g].width;
+    if (a.debug != 9 && a.debug != 8 && group_agg_fast_ok(a) && key_bytes <= 2) { // the key indexes a slot map directly (debug 8: skip this form)
+        const int map_bytes = key_bytes <= 1 ? 256 : 65536;
+        const int64_t want = (a.n_tiles + kDirectWaves - 1) / kDirectWaves;
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, 256)); // one 1024-thread work-group per CU
+        hipExtLaunchKernelGGL(k_group_agg_direct, dim3(grid), dim3(kDirectThreads), (size_t)map_bytes, s, ev0, ev1, 0, a, map_bytes);
+        return;
+    }
     if (a.debug != 9 && group_agg_fast_ok(a)) { // (debug 9: force the general kernel -- also what the host does after an overflow = 2)
         const int64_t want = (a.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, 768)); // ~41 KiB of LDS: 3 per CU
