@@ -1100,7 +1100,7 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
                 q->stage_grid = (int32_t)grid;
                 q->stage_T = T;
                 q->stage_max_slots = (int32_t)std::max<int64_t>(max_slots, 1);
-                q->stage_wave_cap = (int64_t)q->stage_max_slots * kTileRows;
+                q->stage_wave_cap = (int64_t)q->stage_max_slots * kTileRows; // (skewing the arena bases off their 128 KiB-aligned stride changed nothing)
                 q->stage_main_tiles = main_tiles;
                 void *d = nullptr;
                 HIPCHK(pool_alloc(ctx, &d, (size_t)n_waves * (size_t)q->stage_wave_cap * 4 * (size_t)R + 256));
@@ -1524,6 +1524,7 @@ static int launch_emit_records(imm3_query *q) {
     e.main_tiles = q->stage_main_tiles;
     e.max_slots = q->stage_max_slots;
     e.T = q->stage_T;
+    e.debug = (ctx->filter_variant >= 31 && ctx->filter_variant <= 33) ? ctx->filter_variant : 0;
     e.tile_offsets = q->d_tile_offsets;
     e.chunk_sums = q->d_chunk_sums;
     e.n_tiles = q->n_tiles;

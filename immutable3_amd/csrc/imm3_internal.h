@@ -130,6 +130,7 @@ struct EmitArgs {
     const uint32_t *tile_start;     // [wave * max_slots + i]
     int64_t wave_cap, n_waves, main_tiles; // arena size in records; waves of the filter launch; tiles its main loop covered (the rest: leftovers)
     int32_t max_slots, T;           // T: tiles per wave iteration of that launch
+    int32_t debug, pad;             // ablation switch for experiments (0 in production)
     const uint32_t *tile_offsets;
     const uint32_t *chunk_sums;
     int64_t n_tiles;

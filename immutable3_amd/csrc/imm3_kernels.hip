@@ -903,7 +903,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_emit(const EmitArgs a) {
                     if (s_off[lo + step] - o0 <= k) lo += step; // the LAST tile whose first survivor is <= k: the one that holds row k
                 const int64_t tile = tile0 + lo;
                 const uint32_t j = k - (s_off[lo] - o0);
-                rec[u] = ((const vec *)a.stage)[s_addr[lo] + j];
+                rec[u] = ((const vec *)a.stage)[a.debug == 31 ? (unsigned long long)((k0 + u * kBlockThreads) & 0xFFFF) : s_addr[lo] + j]; // (31: ablation -- records from an L2-resident region)
                 rowv[u] = (uint32_t)tile; // (position added once the record is here)
             }
 #pragma unroll
@@ -923,7 +923,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_emit(const EmitArgs a) {
                 const uint32_t k = k0 + u * kBlockThreads;
                 if (k < n_here) {
                     const unsigned long long out = base + k;
-                    if (a.row_index) a.row_index[out] = rowv[u];
+                    if (a.row_index && a.debug != 33) a.row_index[out] = rowv[u]; // (33: ablation -- no row index)
 #pragma unroll
                     for (int c = 0; c < NG; ++c) store_value_rt(a.cols[c].dst, a.cols[c].width, out, gv[u][c]);
                     uint32_t rw[4];
@@ -931,6 +931,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_emit(const EmitArgs a) {
                     else if constexpr (R == 2) { rw[0] = rec[u].x; rw[1] = rec[u].y; rw[2] = rw[3] = 0u; }
                     else { rw[0] = rec[u].x; rw[1] = rec[u].y; rw[2] = rec[u].z; rw[3] = rec[u].w; }
                     for (int c = NG; c < a.n_cols; ++c) { // staged columns: already in the record
+                        if (a.debug == 32 && a.cols[c].width == 1) continue; // (32: ablation -- no byte stores)
                         const int d = a.cols[c].rec_dword;
                         const uint32_t word = d == 0 ? rw[0] : (d == 1 ? rw[1] : (d == 2 ? rw[2] : rw[3]));
                         store_value_rt(a.cols[c].dst, a.cols[c].width, out, word >> a.cols[c].rec_shift);
