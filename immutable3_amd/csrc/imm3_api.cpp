@@ -1524,7 +1524,7 @@ static int launch_emit_records(imm3_query *q) {
     e.main_tiles = q->stage_main_tiles;
     e.max_slots = q->stage_max_slots;
     e.T = q->stage_T;
-    e.debug = (ctx->filter_variant >= 31 && ctx->filter_variant <= 33) ? ctx->filter_variant : 0;
+    e.debug = (ctx->filter_variant >= 31 && ctx->filter_variant <= 34) ? ctx->filter_variant : 0;
     e.tile_offsets = q->d_tile_offsets;
     e.chunk_sums = q->d_chunk_sums;
     e.n_tiles = q->n_tiles;

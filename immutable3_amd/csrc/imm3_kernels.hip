@@ -943,6 +943,110 @@ __global__ __launch_bounds__(kBlockThreads) void k_emit(const EmitArgs a) {
     }
 }
 
+// k_emit_wide<R>: k_emit for the case that needs no gathers (every SELECT-list column is a predicate column: C3, C5).
+// k_emit is bound by vector-memory ISSUE, not bytes: with one output row per lane every store instruction moves 256 B
+// (64 B for an int8 column), and each of its three store streams cost the same ~7 us on C3 whatever its width.  Here a
+// lane owns FOUR consecutive output rows -- an aligned quad of the global output index -- and stores 16 / 8 / 4 bytes
+// per column: a quarter of the store instructions.  The quads that straddle the group's first and last row are written
+// row by row (the neighbouring group writes the rest of them).
+template <int R>
+__global__ __launch_bounds__(kBlockThreads) void k_emit_wide(const EmitArgs a) {
+    typedef typename RecVec<R>::type vec;
+    __shared__ uint32_t s_off[kEmitTiles + 1];
+    __shared__ unsigned long long s_addr[kEmitTiles]; // first record of each tile in the staging area
+    __shared__ unsigned long long s_base;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int64_t n_groups = (a.n_tiles + kEmitTiles - 1) / kEmitTiles;
+    for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) { // block-uniform trip count
+        const int64_t tile0 = g * kEmitTiles;
+        const int64_t chunk = tile0 / kChunkTiles; // kChunkTiles % kEmitTiles == 0: a group never straddles chunks
+        if (t <= kEmitTiles) {
+            const int64_t tile = tile0 + t;
+            s_off[t] = (tile < a.n_tiles && tile / kChunkTiles == chunk) ? a.tile_offsets[tile] : a.chunk_sums[chunk];
+            if (t < kEmitTiles && tile < a.n_tiles) { // which wave of the filter launch staged this tile, and as its how-manieth
+                int64_t w, slot;
+                if (tile < a.main_tiles) {
+                    const int64_t gi = tile / a.T;
+                    w = gi % a.n_waves;
+                    slot = (gi / a.n_waves) * a.T + tile % a.T;
+                } else {
+                    const int64_t idx = tile - a.main_tiles, ng = a.main_tiles / a.T;
+                    w = idx % a.n_waves;
+                    slot = (w < ng ? ((ng - 1 - w) / a.n_waves + 1) * a.T : 0) + idx / a.n_waves;
+                }
+                s_addr[t] = (unsigned long long)(w * a.wave_cap) + a.tile_start[w * a.max_slots + slot];
+            }
+        } else if (t >= 128 && t < 192) { // one wave: survivors of the chunks before this one
+            unsigned long long part = 0;
+            for (int64_t i = lane; i < chunk; i += 64) part += a.chunk_sums[i];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+            if (lane == 0) s_base = part;
+        }
+        __syncthreads();
+        const uint32_t o0 = s_off[0];
+        const unsigned long long base = s_base + o0;
+        uint32_t n_here = s_off[kEmitTiles] - o0;
+        if (base + n_here > a.cap_rows) n_here = base >= a.cap_rows ? 0u : (uint32_t)(a.cap_rows - base); // block-uniform
+        const unsigned long long q0 = base >> 2;                                     // first quad that holds a row of this group
+        const uint32_t n_quads = n_here ? (uint32_t)(((base + n_here + 3) >> 2) - q0) : 0u;
+        for (uint32_t qi = t; qi < n_quads; qi += kBlockThreads) {
+            const unsigned long long out0 = (q0 + qi) << 2;
+            vec rec[4];
+            uint32_t rowv[4];
+            bool ok[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { // four independent searches + record loads (a row outside the group re-reads row 0: no branch)
+                const unsigned long long o = out0 + e;
+                ok[e] = o >= base && o < base + n_here;
+                const uint32_t k = ok[e] ? (uint32_t)(o - base) : 0u;
+                int lo = 0;
+#pragma unroll
+                for (int step = kEmitTiles / 2; step >= 1; step >>= 1)
+                    if (s_off[lo + step] - o0 <= k) lo += step; // the LAST tile whose first survivor is <= k: the one that holds row k
+                const uint32_t j = k - (s_off[lo] - o0);
+                rec[e] = ((const vec *)a.stage)[s_addr[lo] + j];
+                rowv[e] = (uint32_t)(tile0 + lo);
+            }
+            uint32_t rw[4][4]; // [row][record dword]
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (R == 1) { rw[e][0] = rec[e]; rw[e][1] = rw[e][2] = rw[e][3] = 0u; }
+                else if constexpr (R == 2) { rw[e][0] = rec[e].x; rw[e][1] = rec[e].y; rw[e][2] = rw[e][3] = 0u; }
+                else { rw[e][0] = rec[e].x; rw[e][1] = rec[e].y; rw[e][2] = rec[e].z; rw[e][3] = rec[e].w; }
+                rowv[e] = rowv[e] * (uint32_t)kTileRows + (rw[e][0] & (uint32_t)(kTileRows - 1));
+            }
+            const bool whole = ok[0] && ok[3]; // (the group's rows are contiguous: first and last in => all four in)
+            if (whole) {
+                if (a.row_index) *(uint4 *)(a.row_index + out0) = make_uint4(rowv[0], rowv[1], rowv[2], rowv[3]);
+                for (int c = 0; c < a.n_cols; ++c) {
+                    const int d = a.cols[c].rec_dword, sh = a.cols[c].rec_shift, w = a.cols[c].width;
+                    uint32_t v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (d == 0 ? rw[e][0] : (d == 1 ? rw[e][1] : (d == 2 ? rw[e][2] : rw[e][3]))) >> sh;
+                    if (w == 4) *(uint4 *)((uint32_t *)a.cols[c].dst + out0) = make_uint4(v[0], v[1], v[2], v[3]);
+                    else if (w == 2) *(uint2 *)((uint16_t *)a.cols[c].dst + out0) = make_uint2((v[0] & 0xFFFFu) | (v[1] << 16), (v[2] & 0xFFFFu) | (v[3] << 16));
+                    else *(uint32_t *)((uint8_t *)a.cols[c].dst + out0) = (v[0] & 0xFFu) | ((v[1] & 0xFFu) << 8) | ((v[2] & 0xFFu) << 16) | (v[3] << 24);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (!ok[e]) continue;
+                    const unsigned long long out = out0 + e;
+                    if (a.row_index) a.row_index[out] = rowv[e];
+                    for (int c = 0; c < a.n_cols; ++c) {
+                        const int d = a.cols[c].rec_dword;
+                        const uint32_t word = d == 0 ? rw[e][0] : (d == 1 ? rw[e][1] : (d == 2 ? rw[e][2] : rw[e][3]));
+                        store_value_rt(a.cols[c].dst, a.cols[c].width, out, word >> a.cols[c].rec_shift);
+                    }
+                }
+            }
+        }
+        __syncthreads(); // s_off / s_base are reused by the next group
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_read_stream: read-only ceiling probe (same tiling, loads and grid as k_filter_tile<I32>, no compares, no stores)
 // ---------------------------------------------------------------------------------------------
@@ -1093,6 +1197,12 @@ static void launch_emit_r(const EmitArgs &a, int n_gather, int grid, hipStream_t
 void launch_emit(const EmitArgs &a, int n_gather, int grid_blocks, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     const int64_t n_groups = (a.n_tiles + kEmitTiles - 1) / kEmitTiles;
     const int grid = clamp_grid(n_groups, grid_blocks > 0 ? grid_blocks : 2048);
+    if (n_gather == 0 && a.debug != 34) { // (34: ablation -- one row per lane)
+        if (a.R == 1) IMM3_LAUNCH((k_emit_wide<1>), grid, kBlockThreads, s, ev0, ev1, a);
+        else if (a.R == 2) IMM3_LAUNCH((k_emit_wide<2>), grid, kBlockThreads, s, ev0, ev1, a);
+        else IMM3_LAUNCH((k_emit_wide<4>), grid, kBlockThreads, s, ev0, ev1, a);
+        return;
+    }
     if (a.R == 1) launch_emit_r<1>(a, n_gather, grid, s, ev0, ev1);
     else if (a.R == 2) launch_emit_r<2>(a, n_gather, grid, s, ev0, ev1);
     else launch_emit_r<4>(a, n_gather, grid, s, ev0, ev1);
