@@ -613,6 +613,322 @@ __global__ __launch_bounds__(kDirectThreads) void k_group_agg_direct(const AggAr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_group_agg_lanes: group key <= 2 bytes, at most 63 distinct keys, at most one min / max aggregate -- NO ATOMICS on the
+// row path.  LDS atomics retire ~1.4 lanes per cycle per CU on this chip whatever the addresses, which made two atomics
+// per row (count + max) 230 us per 100 M rows in k_group_agg_direct.  Here every LANE owns a private table
+// [slot][lane] in LDS, so an update is a plain ds_read + ds_write at full LDS rate that never conflicts (lane l always
+// hits bank l).  What that needs:
+//   * a lane takes 16 CONSECUTIVE rows of a tile (16 / 32 / 64 contiguous bytes per column, no transposition through
+//     LDS; its 16 bitmap bits are one u16), in batches of four: four entries read, duplicates among the four folded in
+//     registers (six compares), four writes IN ORDER -- LDS executes one wave's operations in order, so the next
+//     batch's reads see them without a wait;
+//   * rows that are not selected update a trash slot instead of branching;
+//   * values are mapped to an "unsigned max" domain on load (sign bit flipped, complemented for MIN, strings packed
+//     big-endian), so the update is always v_max_u32 and tables start at zero.  Values of <= 2 bytes share a dword with
+//     the count (count low, value high: one read + one write per row); 4-byte values have an array of their own;
+//   * key -> slot through a two-level byte map (first key byte -> page, page[second byte] -> slot): exact like the 64 KiB
+//     map of the direct form at 1/8 of the LDS, which is what lets 9 waves' tables fit beside it.  New keys are placed
+//     lock-free by the lanes that meet them (claim the map byte with a CAS, take the next slot, publish);
+//   * the first-seen row: a wave remembers the slots it has met in one 64-bit scalar; while that differs from the slots
+//     handed out so far (warm-up, or a key this wave has not met) its rows of new slots do an atomic min.
+// Too many keys / pages raises overflow = 3 and the host re-runs k_group_agg_direct.
+// ---------------------------------------------------------------------------------------------
+constexpr int kLaneSlots = 64;  // per-lane table rows; the last one is the trash slot
+constexpr int kLanePages = 30;
+constexpr int kLaneTrash = kLaneSlots - 1;
+constexpr uint32_t kMapFree = 255u, kMapClaimed = 254u, kMapFull = 253u; // map bytes that are not a page / slot number
+
+struct LanesShared { // fixed part of the dynamic LDS; [l1 .. first] start as all-ones, the rest as zero
+    uint8_t l1[256];
+    uint8_t l2[kLanePages * 256];
+    uint32_t first[kLaneSlots];
+    uint32_t slotkey[kLaneSlots];
+    uint32_t count[kLaneSlots];
+    uint32_t val[kLaneSlots];
+    uint32_t nslots, npages, pad[2];
+};
+constexpr int kLanesOnesBytes = 256 + kLanePages * 256 + kLaneSlots * 4;
+constexpr int kLanesFixedBytes = (int)((sizeof(LanesShared) + 255) / 256 * 256);
+constexpr int lanes_wave_bytes(int vw) { return kLaneSlots * 64 * (vw == 4 ? 2 + 4 : 4); }
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+// rows 16 * lane .. 16 * lane + 15 of tile `tile` of a W-byte column: W contiguous 16-byte pieces per lane
+template <int W>
+__device__ __forceinline__ void load_lane_rows(const void *data, int64_t tile, int lane, v4i_t (&r)[W == 4 ? 4 : (W == 2 ? 2 : 1)]) {
+    constexpr int N = W == 4 ? 4 : (W == 2 ? 2 : 1);
+    const v4i_t *p = (const v4i_t *)((const uint8_t *)data + tile * (int64_t)(kTileRows * W)) + lane * N;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = __builtin_nontemporal_load(p + i);
+}
+template <int W>
+__device__ __forceinline__ uint32_t lane_row_value(const v4i_t (&r)[W == 4 ? 4 : (W == 2 ? 2 : 1)], int i) { // i: compile time after unrolling
+    if constexpr (W == 4) return (uint32_t)r[i >> 2][i & 3];
+    else if constexpr (W == 2) return ((uint32_t)r[i >> 3][(i >> 1) & 3] >> (16 * (i & 1))) & 0xFFFFu;
+    else return ((uint32_t)r[0][i >> 2] >> (8 * (i & 3))) & 0xFFu;
+}
+
+// one byte of a map: its value, or -- when it is free -- an attempt to claim it and fill it from *counter (values >= limit
+// become `full` and raise the overflow flag).  Returns kMapFree when the byte is being filled by someone else right now
+// (or the CAS lost against a neighbour byte): ask again.  Straight-line between claim and publish, so lanes of one wave
+// cannot wait on each other.
+__device__ __forceinline__ uint32_t map_byte(uint8_t *map, uint32_t idx, uint32_t *counter, uint32_t limit, uint32_t full, uint32_t *overflow, bool &placed) {
+    uint32_t *w = (uint32_t *)map + (idx >> 2);
+    const int sh = 8 * (int)(idx & 3u);
+    const uint32_t cur = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (not `volatile`: that turns an LDS access into a flat one, which waits for every global load in flight)
+    uint32_t b = (cur >> sh) & 0xFFu;
+    placed = false;
+    if (b == kMapFree) {
+        if (atomicCAS(w, cur, cur ^ (1u << sh)) != cur) return kMapFree; // 255 -> 254: claimed
+        uint32_t n = atomicAdd(counter, 1u);
+        if (n >= limit) {
+            n = full;
+            *overflow = 3;
+        } else placed = true;
+        atomicXor(w, (kMapClaimed ^ n) << sh);
+        b = n;
+    }
+    return b == kMapClaimed ? kMapFree : b;
+}
+
+// slot of key k: 0 .. 62, kLaneTrash when the form is full, kMapFree: not placed yet, ask again
+template <int KS>
+__device__ __forceinline__ uint32_t lanes_slot(LanesShared &S, uint32_t k, uint32_t *overflow) {
+    uint32_t pg = 0;
+    bool placed;
+    if constexpr (KS != 0) {
+        pg = map_byte(S.l1, k & 0xFFu, &S.npages, (uint32_t)kLanePages, kMapFull, overflow, placed);
+        if (pg == kMapFree) return kMapFree;
+        if (pg == kMapFull) return kLaneTrash;
+    }
+    const uint32_t id = map_byte(S.l2, (pg << 8) | (KS == 0 ? (k & 0xFFu) : (k >> 8)), &S.nslots, (uint32_t)kLaneTrash, (uint32_t)kLaneTrash, overflow, placed);
+    if (placed) S.slotkey[id] = k; // (read after the work-group barrier that precedes the flush)
+    return id;
+}
+
+__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo |= (uint32_t)__shfl_xor((int)lo, d);
+        hi |= (uint32_t)__shfl_xor((int)hi, d);
+    }
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+}
+
+// KS: key shape -- 0: one 1-byte column, 1: one 2-byte column, 2: two 1-byte columns.  VW: bytes of the aggregated column (0: counts only)
+template <int KS, int VW>
+__global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const int vq) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    LanesShared &S = *(LanesShared *)s_dyn;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int n_waves = (int)(blockDim.x >> 6);
+    constexpr int kWaveBytes = lanes_wave_bytes(VW);
+    constexpr int NV = VW == 4 ? 4 : (VW == 2 ? 2 : 1);
+    constexpr bool kPacked = VW != 4; // count (low 16) and value (high 16) in one dword
+    uint8_t *wbase = s_dyn + kLanesFixedBytes + wave * kWaveBytes;
+    uint32_t *tab = (uint32_t *)wbase + lane;                               // packed: [slot * 64]
+    uint16_t *cnt = (uint16_t *)wbase + lane;                               // VW == 4: counts [slot * 64] ...
+    uint32_t *val = (uint32_t *)(wbase + kLaneSlots * 64 * 2) + lane;       // ... and values [slot * 64]
+    {
+        const int n_dw = (kLanesFixedBytes + n_waves * kWaveBytes) / 4;
+        for (int i = t; i < n_dw; i += (int)blockDim.x) ((uint32_t *)s_dyn)[i] = i < kLanesOnesBytes / 4 ? 0xFFFFFFFFu : 0u;
+    }
+    __syncthreads();
+
+    uint32_t vflip = 0, vmask = 0;
+    bool vstr = false;
+    if constexpr (VW != 0) {
+        vmask = VW == 4 ? 0xFFFFFFFFu : ((1u << (8 * VW)) - 1u);
+        vstr = a.aggs[vq].is_str != 0;
+        vflip = (vstr ? 0u : (1u << (8 * VW - 1))) ^ (a.aggs[vq].kind == AGG_MIN ? vmask : 0u);
+    }
+    const int sh0 = 8 * a.groups[0].shift, sh1 = KS == 2 ? 8 * a.groups[1].shift : 0;
+    uint64_t seen = 0; // slots this wave has met (wave-uniform)
+
+    // Software pipeline, kDepth tiles deep: with one read + one wait per tile a wave spent its time in two dependent HBM round
+    // trips per tile (bitmap, then columns: 128 of the first version's 173 us).  Every register set is re-loaded right
+    // after its tile is done and used kDepth tiles later; loads past the wave's last tile re-read the last tile (no branch).
+    struct TileRegs {
+        uint32_t bits; // rows 16 * lane ..: bits 16 * lane .. of the tile's 1024
+        v4i_t kr0[KS == 1 ? 2 : 1], kr1[1], vr[NV];
+    };
+    constexpr int kDepth = VW == 4 ? 2 : 3;
+    const int64_t stride = (int64_t)gridDim.x * n_waves;
+    const int64_t first_tile = (int64_t)blockIdx.x * n_waves + wave;
+    auto issue = [&](TileRegs &r, int64_t tile) {
+        if (tile >= a.n_tiles) tile = a.n_tiles - 1;
+        r.bits = ((const uint16_t *)a.bitmap)[tile * 64 + lane];
+        load_lane_rows<(KS == 1 ? 2 : 1)>(a.groups[0].data, tile, lane, r.kr0);
+        if constexpr (KS == 2) load_lane_rows<1>(a.groups[1].data, tile, lane, r.kr1);
+        if constexpr (VW != 0) load_lane_rows<(VW ? VW : 1)>(a.aggs[vq].data, tile, lane, r.vr);
+    };
+    auto process = [&](const TileRegs &r, const int64_t tile) {
+        const uint32_t bits = r.bits;
+        if (!ballot64(bits != 0u)) return; // nothing selected in these 1024 rows
+        const auto &kr0 = r.kr0;
+        const auto &kr1 = r.kr1;
+        const auto &vr = r.vr;
+        uint32_t key[16], sid[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            key[i] = lane_row_value<(KS == 1 ? 2 : 1)>(kr0, i);
+            if constexpr (KS == 2) key[i] = (key[i] << sh0) | (lane_row_value<1>(kr1, i) << sh1);
+        }
+        // slots: all first-level reads, then all second-level reads (values >= 253: no slot yet)
+        if constexpr (KS == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sid[i] = S.l2[key[i]];
+        } else {
+            uint32_t pg[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pg[i] = S.l1[key[i] & 0xFFu];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const bool none = pg[i] >= kMapFull;
+                const uint32_t s2 = S.l2[((none ? 0u : pg[i]) << 8) | (key[i] >> 8)];
+                sid[i] = none ? kMapFree : s2;
+            }
+        }
+        uint32_t unseen = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) unseen |= (sid[i] >= (uint32_t)kLaneSlots ? 1u : 0u) << i;
+        unseen &= bits;
+        if (ballot64(unseen != 0u)) { // wave-uniform, warm-up only: every lane places (or looks up again) its own new keys
+            uint32_t pend = unseen;    // this lane's rows that still need a slot
+            for (int rounds = 0; rounds < 1024 && ballot64(pend != 0u); ++rounds) {
+                if (pend) {
+                    const int first = __builtin_ctz(pend);
+                    uint32_t mine = key[0];
+#pragma unroll
+                    for (int i = 1; i < 16; ++i) mine = first == i ? key[i] : mine; // (a run-time index would push key[] into scratch memory)
+                    const uint32_t id = lanes_slot<KS>(S, mine, a.overflow);
+                    if (id != kMapFree) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            if (key[i] == mine) {
+                                sid[i] = id;
+                                pend &= ~(1u << i);
+                            }
+                    }
+                }
+            }
+            if (ballot64(pend != 0u)) *a.overflow = 3; // (never seen: a claimed byte is published a few instructions later)
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sid[i] = (((bits >> i) & 1u) && sid[i] < (uint32_t)kLaneSlots) ? sid[i] : (uint32_t)kLaneTrash; // rows that are not selected: the trash slot
+        const uint32_t row0 = (uint32_t)(tile * kTileRows + 16 * lane);
+        // first-seen rows
+        {
+            const uint32_t ns = __hip_atomic_load(&S.nslots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint64_t all = ns >= 63u ? 0x7FFFFFFFFFFFFFFFULL : ((1ULL << ns) - 1ULL);
+            if ((seen & all) != all) { // wave-uniform: warm-up, or a key some other wave met and this one has not yet
+                uint64_t here = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (((bits >> i) & 1u) && !((seen >> sid[i]) & 1ULL)) atomicMin(&S.first[sid[i]], row0 + i);
+                    here |= ((bits >> i) & 1u) ? (1ULL << sid[i]) : 0ULL;
+                }
+                seen |= wave_or64(here);
+            }
+        }
+        // updates, four rows at a time
+#pragma unroll
+        for (int b = 0; b < (a.debug == 42 ? 0 : 4); ++b) { // (42: ablation)
+            uint32_t s[4], x[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = 4 * b + k;
+                s[k] = sid[i];
+                x[k] = 0;
+                if constexpr (VW != 0) {
+                    uint32_t raw = lane_row_value<(VW ? VW : 1)>(vr, i);
+                    if (vstr) raw = VW == 4 ? __builtin_bswap32(raw) : (VW == 2 ? (uint32_t)__builtin_bswap16((uint16_t)raw) : raw); // big-endian pack: integer order == byte order
+                    x[k] = (raw ^ vflip) & vmask;
+                }
+            }
+            const bool e01 = s[0] == s[1], e02 = s[0] == s[2], e12 = s[1] == s[2], e03 = s[0] == s[3], e13 = s[1] == s[3], e23 = s[2] == s[3];
+            const uint32_t c[4] = {1u, 1u + e01, 1u + e02 + e12, 1u + e03 + e13 + e23}; // this row and the batch's earlier rows in the same slot
+            uint32_t m[4]; // value of this row and of those earlier rows
+            m[0] = x[0];
+            m[1] = max(x[1], e01 ? x[0] : 0u);
+            m[2] = max(x[2], max(e02 ? x[0] : 0u, e12 ? x[1] : 0u));
+            m[3] = max(max(x[3], e03 ? x[0] : 0u), max(e13 ? x[1] : 0u, e23 ? x[2] : 0u));
+            if constexpr (kPacked) {
+                uint32_t old[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) old[k] = tab[s[k] * 64];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { // in order: of two rows in one slot the later write (the larger total) lands last
+                    if constexpr (VW == 0) tab[s[k] * 64] = old[k] + c[k];
+                    else tab[s[k] * 64] = ((old[k] + c[k]) & 0xFFFFu) | (max(old[k], m[k] << 16) & 0xFFFF0000u); // (a lane's count stays below 2^16: lanes_plan)
+                }
+            } else {
+                uint32_t oc[4], ov[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    oc[k] = cnt[s[k] * 64];
+                    ov[k] = val[s[k] * 64];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    cnt[s[k] * 64] = (uint16_t)(oc[k] + c[k]);
+                    val[s[k] * 64] = max(ov[k], m[k]);
+                }
+            }
+        }
+    };
+    TileRegs R[kDepth];
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) issue(R[d], first_tile + d * stride);
+    for (int64_t base = first_tile; base < a.n_tiles; base += kDepth * stride) {
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) {
+            const int64_t tile = base + d * stride;
+            if (tile < a.n_tiles) process(R[d], tile); // wave-uniform
+            issue(R[d], tile + kDepth * stride);
+        }
+    }
+    __syncthreads();
+
+    // fold: lane = slot; it sums / maxes its slot over the 64 lanes' private entries (rotated so that lanes hit different banks)
+    {
+        uint32_t c = 0, m = 0;
+        for (int l = 0; l < 64; ++l) {
+            const int src = (l + lane) & 63;
+            if constexpr (kPacked) {
+                const uint32_t e = ((const uint32_t *)wbase)[lane * 64 + src];
+                c += VW == 0 ? e : (e & 0xFFFFu);
+                m = max(m, e >> 16);
+            } else {
+                c += ((const uint16_t *)wbase)[lane * 64 + src];
+                m = max(m, ((const uint32_t *)(wbase + kLaneSlots * 64 * 2))[lane * 64 + src]);
+            }
+        }
+        if (lane < kLaneTrash && c) {
+            atomicAdd(&S.count[lane], c);
+            if constexpr (VW != 0) atomicMax(&S.val[lane], m);
+        }
+    }
+    __syncthreads();
+    // flush: one atomic set per (work-group, group), widened to what the global table holds
+    const uint32_t n_slots = S.nslots < (uint32_t)kLaneTrash ? S.nslots : (uint32_t)kLaneTrash;
+    if ((uint32_t)t < n_slots && S.count[t]) {
+        const uint32_t g = global_slot(a, (unsigned long long)S.slotkey[t]);
+        if (g != 0xFFFFFFFFu) {
+            long long vals[kMaxAggs] = {0, 0, 0, 0};
+            if constexpr (VW != 0) {
+                const uint32_t u = (S.val[t] ^ vflip) & vmask;
+                vals[vq] = vstr ? (long long)(unsigned long long)u : (VW == 4 ? (long long)(int32_t)u : (VW == 2 ? (long long)(int16_t)u : (long long)(int8_t)u));
+            }
+            agg_update_global(a, g, S.first[t], (unsigned long long)S.count[t], vals);
+        }
+    }
+}
+
 // occupied entries of the global table -> dense arrays (order irrelevant: the host sorts by first_row)
 __global__ __launch_bounds__(kBlockThreads) void k_group_collect(const AggArgs a) {
     const int lane = threadIdx.x & 63;
@@ -675,12 +991,58 @@ bool group_agg_fast_ok(const AggArgs &a) {
     return true;
 }
 
+// which form of k_group_agg_lanes takes this aggregation (false: none).  waves: as many as the LDS holds.
+struct LanesPlan { int ks, vw, vq, waves, lds_bytes; };
+static bool lanes_plan(const AggArgs &a, LanesPlan &p) {
+    if (!group_agg_fast_ok(a)) return false;
+    if (a.n_group == 1 && a.groups[0].width == 1) p.ks = 0;
+    else if (a.n_group == 1 && a.groups[0].width == 2) p.ks = 1;
+    else if (a.n_group == 2 && a.groups[0].width == 1 && a.groups[1].width == 1 && a.groups[0].shift + a.groups[1].shift == 1) p.ks = 2;
+    else return false;
+    p.vw = 0;
+    p.vq = 0;
+    int n_val = 0;
+    for (int q = 0; q < a.n_agg; ++q)
+        if (a.aggs[q].kind != AGG_COUNT) {
+            ++n_val;
+            p.vq = q;
+            p.vw = a.aggs[q].width;
+        }
+    if (n_val > 1) return false;
+    const int per_wave = lanes_wave_bytes(p.vw);
+    p.waves = std::min(16, (160 * 1024 - kLanesFixedBytes) / per_wave);
+    const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((a.n_tiles + p.waves - 1) / p.waves, 256));
+    const int64_t tiles_per_wave = (a.n_tiles + grid * p.waves - 1) / (grid * p.waves);
+    if (tiles_per_wave * 16 >= 65536) return false; // a lane's u16 count of one slot must hold all its rows
+    p.lds_bytes = kLanesFixedBytes + p.waves * per_wave;
+    return true;
+}
+
+template <int KS, int VW>
+static void launch_lanes(const AggArgs &a, const LanesPlan &p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    static bool raised = false; // (the limit is per kernel function, process wide)
+    if (!raised) {
+        (void)hipFuncSetAttribute((const void *)k_group_agg_lanes<KS, VW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        raised = true;
+    }
+    const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((a.n_tiles + p.waves - 1) / p.waves, 256)); // one work-group per CU
+    hipExtLaunchKernelGGL((k_group_agg_lanes<KS, VW>), dim3((unsigned)grid), dim3(p.waves * 64), (size_t)p.lds_bytes, s, ev0, ev1, 0, a, p.vq);
+}
+
 void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     const int64_t n = (int64_t)a.mask + 2;
     const int init_grid = (int)std::min<int64_t>((n + kBlockThreads - 1) / kBlockThreads, 2048);
     hipLaunchKernelGGL(k_group_init, dim3(init_grid), dim3(kBlockThreads), 0, s, a);
     int key_bytes = 0;
     for (int g = 0; g < a.n_group; ++g) key_bytes += a.groups[g].width;
+    LanesPlan lp;
+    if ((a.debug == 0 || a.debug >= 40) && lanes_plan(a, lp)) { // private per-lane tables, no atomics (debug 7: skip -- also what the host does after an overflow = 3)
+#define IMM3_LANES(KS, VW) if (lp.ks == KS && lp.vw == VW) { launch_lanes<KS, VW>(a, lp, s, ev0, ev1); return; }
+        IMM3_LANES(0, 0) IMM3_LANES(0, 1) IMM3_LANES(0, 2) IMM3_LANES(0, 4)
+        IMM3_LANES(1, 0) IMM3_LANES(1, 1) IMM3_LANES(1, 2) IMM3_LANES(1, 4)
+        IMM3_LANES(2, 0) IMM3_LANES(2, 1) IMM3_LANES(2, 2) IMM3_LANES(2, 4)
+#undef IMM3_LANES
+    }
     if (a.debug != 9 && a.debug != 8 && group_agg_fast_ok(a) && key_bytes <= 2) { // the key indexes a slot map directly (debug 8: skip this form)
         const int map_bytes = key_bytes <= 1 ? 256 : 65536;
         const int64_t want = (a.n_tiles + kDirectWaves - 1) / kDirectWaves;

@@ -1524,7 +1524,7 @@ static int launch_emit_records(imm3_query *q) {
     e.main_tiles = q->stage_main_tiles;
     e.max_slots = q->stage_max_slots;
     e.T = q->stage_T;
-    e.debug = (ctx->filter_variant >= 31 && ctx->filter_variant <= 34) ? ctx->filter_variant : 0;
+    e.debug = (ctx->filter_variant >= 34 && ctx->filter_variant <= 35) ? ctx->filter_variant : 0;
     e.tile_offsets = q->d_tile_offsets;
     e.chunk_sums = q->d_chunk_sums;
     e.n_tiles = q->n_tiles;
@@ -1937,7 +1937,7 @@ static int run_agg(imm3_query *q) {
     imm3_ctx *ctx = q->ctx;
     AggArgs a;
     fill_agg_args(q, a);
-    a.debug = ctx->filter_variant >= 100 ? ctx->filter_variant - 100 : 0;
+    a.debug = ctx->filter_variant >= 100 ? ctx->filter_variant - 100 : q->agg_skip; // (agg_skip: forms this query's keys overflowed before)
     LaunchTimer t(ctx, 4);
     launch_group_agg(a, ctx->stream, t.start, t.stop);
     HIPCHK(hipGetLastError());
@@ -1952,7 +1952,7 @@ static int settle_groups(imm3_query *q, uint32_t *n_groups) {
     imm3_ctx *ctx = q->ctx;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
         AggArgs a;
         fill_agg_args(q, a);
         HIPCHK(hipMemsetAsync(q->d_ameta, 0, sizeof(uint32_t), s)); // n_groups only; keep the overflow flag
@@ -1961,10 +1961,10 @@ static int settle_groups(imm3_query *q, uint32_t *n_groups) {
         uint32_t meta[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(meta, q->d_ameta, sizeof(meta), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        if (meta[1] == 2) { // the fast kernel's per-work-group table filled up: aggregate again with the general kernel
-            AggArgs g;
+        if (meta[1] == 2 || meta[1] == 3) { // a fast form's per-work-group table filled up: aggregate again with the next form
+            AggArgs g;                       // (3: k_group_agg_lanes -> k_group_agg_direct; 2: -> the general kernel)
             fill_agg_args(q, g);
-            g.debug = 9;
+            g.debug = q->agg_skip = meta[1] == 3 ? 7 : 9;
             launch_group_agg(g, s, nullptr, nullptr);
             HIPCHK(hipGetLastError());
             continue;

@@ -177,6 +177,7 @@ struct imm3_query {
     long long *d_avals = nullptr, *d_ovals = nullptr;
     uint32_t out_cap = 0;
     bool ran_agg = false;
+    int agg_skip = 0;              // 0, or the launch_group_agg debug value that skips the forms this query overflowed (7, 9)
     // select-only runs: the count reduce goes to ctx->aux, fenced by these events
     hipEvent_t ev_filter_done = nullptr, ev_total_done = nullptr;
     bool total_on_aux = false;

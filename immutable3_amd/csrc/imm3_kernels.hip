@@ -849,7 +849,22 @@ __global__ __launch_bounds__(kBlockThreads) void k_gather_plain(const GatherArgs
 // ~100 at 10 %), every thread independent of every other.
 // ---------------------------------------------------------------------------------------------
 constexpr int kEmitUnroll = 2;
+constexpr uint32_t kEmitQuadMinRows = kEmitTiles * kTileRows / 20; // gathers present: quads from 5 % survivors up
 
+// four consecutive output rows of one column, out0 % 4 == 0: one 16-, 8- or 4-byte store
+__device__ __forceinline__ void store_quad(void *dst, int width, unsigned long long out0, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+    if (width == 4) *(uint4 *)((uint32_t *)dst + out0) = make_uint4(v0, v1, v2, v3);
+    else if (width == 2) *(uint2 *)((uint16_t *)dst + out0) = make_uint2((v0 & 0xFFFFu) | (v1 << 16), (v2 & 0xFFFFu) | (v3 << 16));
+    else *(uint32_t *)((uint8_t *)dst + out0) = (v0 & 0xFFu) | ((v1 & 0xFFu) << 8) | ((v2 & 0xFFu) << 16) | (v3 << 24);
+}
+
+// One output row per lane is bound by vector-memory ISSUE, not bytes: every store instruction moves 256 B (64 B for an
+// int8 column), and each of C3's three store streams cost the same ~7 us whatever its width.  So a lane owns FOUR
+// consecutive output rows -- an aligned quad of the global output index -- and stores 16 / 8 / 4 bytes per column: a
+// quarter of the store instructions (C3 42 -> 36 us, 50 % survivors 264 -> 168 us).  The quads that straddle the
+// group's first and last row are written row by row (the neighbouring group writes the rest of them).  With gathers
+// and few survivors (C4: 20 a tile) the row-per-lane form is the faster one -- the group is one dependent chain
+// offsets -> record -> gather -> store, and four searches per lane lengthen it -- so the form is chosen per group.
 template <int R, int NG>
 __global__ __launch_bounds__(kBlockThreads) void k_emit(const EmitArgs a) {
     typedef typename RecVec<R>::type vec;
@@ -890,155 +905,116 @@ __global__ __launch_bounds__(kBlockThreads) void k_emit(const EmitArgs a) {
         const unsigned long long base = s_base + o0;
         uint32_t n_here = s_off[kEmitTiles] - o0;
         if (base + n_here > a.cap_rows) n_here = base >= a.cap_rows ? 0u : (uint32_t)(a.cap_rows - base); // block-uniform
-        for (uint32_t k0 = t; k0 < n_here; k0 += kEmitUnroll * kBlockThreads) {
-            vec rec[kEmitUnroll];
-            uint32_t rowv[kEmitUnroll];
-            uint32_t gv[kEmitUnroll][NG > 0 ? NG : 1];
+        const bool quads = a.debug == 35 || (a.debug != 34 && (NG == 0 || n_here >= kEmitQuadMinRows)); // block-uniform (34 / 35: ablation)
+        if (quads) {
+            const unsigned long long q0 = base >> 2;                                     // first quad that holds a row of this group
+            const uint32_t n_quads = n_here ? (uint32_t)(((base + n_here + 3) >> 2) - q0) : 0u;
+            for (uint32_t qi = t; qi < n_quads; qi += kBlockThreads) {
+                const unsigned long long out0 = (q0 + qi) << 2;
+                vec rec[4];
+                uint32_t rowv[4];
+                bool ok[4];
 #pragma unroll
-            for (int u = 0; u < kEmitUnroll; ++u) { // the records of the step (an out-of-range row re-reads row k0: no branch)
-                const uint32_t k = k0 + u * kBlockThreads < n_here ? k0 + u * kBlockThreads : k0;
-                int lo = 0;
+                for (int e = 0; e < 4; ++e) { // four independent searches + record loads (a row outside the group re-reads row 0: no branch)
+                    const unsigned long long o = out0 + e;
+                    ok[e] = o >= base && o < base + n_here;
+                    const uint32_t k = ok[e] ? (uint32_t)(o - base) : 0u;
+                    int lo = 0;
 #pragma unroll
-                for (int step = kEmitTiles / 2; step >= 1; step >>= 1)
-                    if (s_off[lo + step] - o0 <= k) lo += step; // the LAST tile whose first survivor is <= k: the one that holds row k
-                const int64_t tile = tile0 + lo;
-                const uint32_t j = k - (s_off[lo] - o0);
-                rec[u] = ((const vec *)a.stage)[a.debug == 31 ? (unsigned long long)((k0 + u * kBlockThreads) & 0xFFFF) : s_addr[lo] + j]; // (31: ablation -- records from an L2-resident region)
-                rowv[u] = (uint32_t)tile; // (position added once the record is here)
-            }
-#pragma unroll
-            for (int u = 0; u < kEmitUnroll; ++u) { // every gather of the step before the first store
-                uint32_t r0;
-                if constexpr (R == 1) r0 = rec[u];
-                else r0 = rec[u].x;
-                rowv[u] = rowv[u] * (uint32_t)kTileRows + (r0 & (uint32_t)(kTileRows - 1));
-#pragma unroll
-                for (int c = 0; c < NG; ++c) { // the launcher puts the gathered columns first
-                    const int64_t byte = (int64_t)rowv[u] * a.cols[c].width;
-                    gv[u][c] = ((const uint32_t *)a.cols[c].src)[byte >> 2] >> (8 * ((uint32_t)byte & 3u));
+                    for (int step = kEmitTiles / 2; step >= 1; step >>= 1)
+                        if (s_off[lo + step] - o0 <= k) lo += step; // the LAST tile whose first survivor is <= k: the one that holds row k
+                    const uint32_t j = k - (s_off[lo] - o0);
+                    rec[e] = ((const vec *)a.stage)[s_addr[lo] + j];
+                    rowv[e] = (uint32_t)(tile0 + lo);
                 }
-            }
+                uint32_t rw[4][4]; // [row][record dword]
+                uint32_t gv[4][NG > 0 ? NG : 1];
 #pragma unroll
-            for (int u = 0; u < kEmitUnroll; ++u) {
-                const uint32_t k = k0 + u * kBlockThreads;
-                if (k < n_here) {
-                    const unsigned long long out = base + k;
-                    if (a.row_index && a.debug != 33) a.row_index[out] = rowv[u]; // (33: ablation -- no row index)
+                for (int e = 0; e < 4; ++e) { // every gather of the quad before the first store
+                    if constexpr (R == 1) { rw[e][0] = rec[e]; rw[e][1] = rw[e][2] = rw[e][3] = 0u; }
+                    else if constexpr (R == 2) { rw[e][0] = rec[e].x; rw[e][1] = rec[e].y; rw[e][2] = rw[e][3] = 0u; }
+                    else { rw[e][0] = rec[e].x; rw[e][1] = rec[e].y; rw[e][2] = rec[e].z; rw[e][3] = rec[e].w; }
+                    rowv[e] = rowv[e] * (uint32_t)kTileRows + (rw[e][0] & (uint32_t)(kTileRows - 1));
 #pragma unroll
-                    for (int c = 0; c < NG; ++c) store_value_rt(a.cols[c].dst, a.cols[c].width, out, gv[u][c]);
-                    uint32_t rw[4];
-                    if constexpr (R == 1) { rw[0] = rec[u]; rw[1] = rw[2] = rw[3] = 0u; }
-                    else if constexpr (R == 2) { rw[0] = rec[u].x; rw[1] = rec[u].y; rw[2] = rw[3] = 0u; }
-                    else { rw[0] = rec[u].x; rw[1] = rec[u].y; rw[2] = rec[u].z; rw[3] = rec[u].w; }
-                    for (int c = NG; c < a.n_cols; ++c) { // staged columns: already in the record
-                        if (a.debug == 32 && a.cols[c].width == 1) continue; // (32: ablation -- no byte stores)
-                        const int d = a.cols[c].rec_dword;
-                        const uint32_t word = d == 0 ? rw[0] : (d == 1 ? rw[1] : (d == 2 ? rw[2] : rw[3]));
-                        store_value_rt(a.cols[c].dst, a.cols[c].width, out, word >> a.cols[c].rec_shift);
+                    for (int c = 0; c < NG; ++c) { // the launcher puts the gathered columns first
+                        const int64_t byte = (int64_t)rowv[e] * a.cols[c].width;
+                        gv[e][c] = ((const uint32_t *)a.cols[c].src)[byte >> 2] >> (8 * ((uint32_t)byte & 3u));
+                    }
+                }
+                const bool whole = ok[0] && ok[3]; // (the group's rows are contiguous: first and last in => all four in)
+                if (whole) {
+                    if (a.row_index) *(uint4 *)(a.row_index + out0) = make_uint4(rowv[0], rowv[1], rowv[2], rowv[3]);
+#pragma unroll
+                    for (int c = 0; c < NG; ++c) store_quad(a.cols[c].dst, a.cols[c].width, out0, gv[0][c], gv[1][c], gv[2][c], gv[3][c]);
+                    for (int c = NG; c < a.n_cols; ++c) {
+                        const int d = a.cols[c].rec_dword, sh = a.cols[c].rec_shift, w = a.cols[c].width;
+                        uint32_t v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (d == 0 ? rw[e][0] : (d == 1 ? rw[e][1] : (d == 2 ? rw[e][2] : rw[e][3]))) >> sh;
+                        store_quad(a.cols[c].dst, w, out0, v[0], v[1], v[2], v[3]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (!ok[e]) continue;
+                        const unsigned long long out = out0 + e;
+                        if (a.row_index) a.row_index[out] = rowv[e];
+#pragma unroll
+                        for (int c = 0; c < NG; ++c) store_value_rt(a.cols[c].dst, a.cols[c].width, out, gv[e][c]);
+                        for (int c = NG; c < a.n_cols; ++c) {
+                            const int d = a.cols[c].rec_dword;
+                            const uint32_t word = d == 0 ? rw[e][0] : (d == 1 ? rw[e][1] : (d == 2 ? rw[e][2] : rw[e][3]));
+                            store_value_rt(a.cols[c].dst, a.cols[c].width, out, word >> a.cols[c].rec_shift);
+                        }
                     }
                 }
             }
-        }
-        __syncthreads(); // s_off / s_base are reused by the next group
-    }
-}
-
-// k_emit_wide<R>: k_emit for the case that needs no gathers (every SELECT-list column is a predicate column: C3, C5).
-// k_emit is bound by vector-memory ISSUE, not bytes: with one output row per lane every store instruction moves 256 B
-// (64 B for an int8 column), and each of its three store streams cost the same ~7 us on C3 whatever its width.  Here a
-// lane owns FOUR consecutive output rows -- an aligned quad of the global output index -- and stores 16 / 8 / 4 bytes
-// per column: a quarter of the store instructions.  The quads that straddle the group's first and last row are written
-// row by row (the neighbouring group writes the rest of them).
-template <int R>
-__global__ __launch_bounds__(kBlockThreads) void k_emit_wide(const EmitArgs a) {
-    typedef typename RecVec<R>::type vec;
-    __shared__ uint32_t s_off[kEmitTiles + 1];
-    __shared__ unsigned long long s_addr[kEmitTiles]; // first record of each tile in the staging area
-    __shared__ unsigned long long s_base;
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int64_t n_groups = (a.n_tiles + kEmitTiles - 1) / kEmitTiles;
-    for (int64_t g = blockIdx.x; g < n_groups; g += gridDim.x) { // block-uniform trip count
-        const int64_t tile0 = g * kEmitTiles;
-        const int64_t chunk = tile0 / kChunkTiles; // kChunkTiles % kEmitTiles == 0: a group never straddles chunks
-        if (t <= kEmitTiles) {
-            const int64_t tile = tile0 + t;
-            s_off[t] = (tile < a.n_tiles && tile / kChunkTiles == chunk) ? a.tile_offsets[tile] : a.chunk_sums[chunk];
-            if (t < kEmitTiles && tile < a.n_tiles) { // which wave of the filter launch staged this tile, and as its how-manieth
-                int64_t w, slot;
-                if (tile < a.main_tiles) {
-                    const int64_t gi = tile / a.T;
-                    w = gi % a.n_waves;
-                    slot = (gi / a.n_waves) * a.T + tile % a.T;
-                } else {
-                    const int64_t idx = tile - a.main_tiles, ng = a.main_tiles / a.T;
-                    w = idx % a.n_waves;
-                    slot = (w < ng ? ((ng - 1 - w) / a.n_waves + 1) * a.T : 0) + idx / a.n_waves;
+        } else {
+            for (uint32_t k0 = t; k0 < n_here; k0 += kEmitUnroll * kBlockThreads) {
+                vec rec[kEmitUnroll];
+                uint32_t rowv[kEmitUnroll];
+                uint32_t gv[kEmitUnroll][NG > 0 ? NG : 1];
+#pragma unroll
+                for (int u = 0; u < kEmitUnroll; ++u) { // the records of the step (an out-of-range row re-reads row k0: no branch)
+                    const uint32_t k = k0 + u * kBlockThreads < n_here ? k0 + u * kBlockThreads : k0;
+                    int lo = 0;
+#pragma unroll
+                    for (int step = kEmitTiles / 2; step >= 1; step >>= 1)
+                        if (s_off[lo + step] - o0 <= k) lo += step; // the LAST tile whose first survivor is <= k: the one that holds row k
+                    const int64_t tile = tile0 + lo;
+                    const uint32_t j = k - (s_off[lo] - o0);
+                    rec[u] = ((const vec *)a.stage)[s_addr[lo] + j];
+                    rowv[u] = (uint32_t)tile; // (position added once the record is here)
                 }
-                s_addr[t] = (unsigned long long)(w * a.wave_cap) + a.tile_start[w * a.max_slots + slot];
-            }
-        } else if (t >= 128 && t < 192) { // one wave: survivors of the chunks before this one
-            unsigned long long part = 0;
-            for (int64_t i = lane; i < chunk; i += 64) part += a.chunk_sums[i];
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
-            if (lane == 0) s_base = part;
-        }
-        __syncthreads();
-        const uint32_t o0 = s_off[0];
-        const unsigned long long base = s_base + o0;
-        uint32_t n_here = s_off[kEmitTiles] - o0;
-        if (base + n_here > a.cap_rows) n_here = base >= a.cap_rows ? 0u : (uint32_t)(a.cap_rows - base); // block-uniform
-        const unsigned long long q0 = base >> 2;                                     // first quad that holds a row of this group
-        const uint32_t n_quads = n_here ? (uint32_t)(((base + n_here + 3) >> 2) - q0) : 0u;
-        for (uint32_t qi = t; qi < n_quads; qi += kBlockThreads) {
-            const unsigned long long out0 = (q0 + qi) << 2;
-            vec rec[4];
-            uint32_t rowv[4];
-            bool ok[4];
+                for (int u = 0; u < kEmitUnroll; ++u) { // every gather of the step before the first store
+                    uint32_t r0;
+                    if constexpr (R == 1) r0 = rec[u];
+                    else r0 = rec[u].x;
+                    rowv[u] = rowv[u] * (uint32_t)kTileRows + (r0 & (uint32_t)(kTileRows - 1));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { // four independent searches + record loads (a row outside the group re-reads row 0: no branch)
-                const unsigned long long o = out0 + e;
-                ok[e] = o >= base && o < base + n_here;
-                const uint32_t k = ok[e] ? (uint32_t)(o - base) : 0u;
-                int lo = 0;
-#pragma unroll
-                for (int step = kEmitTiles / 2; step >= 1; step >>= 1)
-                    if (s_off[lo + step] - o0 <= k) lo += step; // the LAST tile whose first survivor is <= k: the one that holds row k
-                const uint32_t j = k - (s_off[lo] - o0);
-                rec[e] = ((const vec *)a.stage)[s_addr[lo] + j];
-                rowv[e] = (uint32_t)(tile0 + lo);
-            }
-            uint32_t rw[4][4]; // [row][record dword]
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if constexpr (R == 1) { rw[e][0] = rec[e]; rw[e][1] = rw[e][2] = rw[e][3] = 0u; }
-                else if constexpr (R == 2) { rw[e][0] = rec[e].x; rw[e][1] = rec[e].y; rw[e][2] = rw[e][3] = 0u; }
-                else { rw[e][0] = rec[e].x; rw[e][1] = rec[e].y; rw[e][2] = rec[e].z; rw[e][3] = rec[e].w; }
-                rowv[e] = rowv[e] * (uint32_t)kTileRows + (rw[e][0] & (uint32_t)(kTileRows - 1));
-            }
-            const bool whole = ok[0] && ok[3]; // (the group's rows are contiguous: first and last in => all four in)
-            if (whole) {
-                if (a.row_index) *(uint4 *)(a.row_index + out0) = make_uint4(rowv[0], rowv[1], rowv[2], rowv[3]);
-                for (int c = 0; c < a.n_cols; ++c) {
-                    const int d = a.cols[c].rec_dword, sh = a.cols[c].rec_shift, w = a.cols[c].width;
-                    uint32_t v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (d == 0 ? rw[e][0] : (d == 1 ? rw[e][1] : (d == 2 ? rw[e][2] : rw[e][3]))) >> sh;
-                    if (w == 4) *(uint4 *)((uint32_t *)a.cols[c].dst + out0) = make_uint4(v[0], v[1], v[2], v[3]);
-                    else if (w == 2) *(uint2 *)((uint16_t *)a.cols[c].dst + out0) = make_uint2((v[0] & 0xFFFFu) | (v[1] << 16), (v[2] & 0xFFFFu) | (v[3] << 16));
-                    else *(uint32_t *)((uint8_t *)a.cols[c].dst + out0) = (v[0] & 0xFFu) | ((v[1] & 0xFFu) << 8) | ((v[2] & 0xFFu) << 16) | (v[3] << 24);
+                    for (int c = 0; c < NG; ++c) { // the launcher puts the gathered columns first
+                        const int64_t byte = (int64_t)rowv[u] * a.cols[c].width;
+                        gv[u][c] = ((const uint32_t *)a.cols[c].src)[byte >> 2] >> (8 * ((uint32_t)byte & 3u));
+                    }
                 }
-            } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (!ok[e]) continue;
-                    const unsigned long long out = out0 + e;
-                    if (a.row_index) a.row_index[out] = rowv[e];
-                    for (int c = 0; c < a.n_cols; ++c) {
-                        const int d = a.cols[c].rec_dword;
-                        const uint32_t word = d == 0 ? rw[e][0] : (d == 1 ? rw[e][1] : (d == 2 ? rw[e][2] : rw[e][3]));
-                        store_value_rt(a.cols[c].dst, a.cols[c].width, out, word >> a.cols[c].rec_shift);
+                for (int u = 0; u < kEmitUnroll; ++u) {
+                    const uint32_t k = k0 + u * kBlockThreads;
+                    if (k < n_here) {
+                        const unsigned long long out = base + k;
+                        if (a.row_index) a.row_index[out] = rowv[u];
+#pragma unroll
+                        for (int c = 0; c < NG; ++c) store_value_rt(a.cols[c].dst, a.cols[c].width, out, gv[u][c]);
+                        uint32_t rw[4];
+                        if constexpr (R == 1) { rw[0] = rec[u]; rw[1] = rw[2] = rw[3] = 0u; }
+                        else if constexpr (R == 2) { rw[0] = rec[u].x; rw[1] = rec[u].y; rw[2] = rw[3] = 0u; }
+                        else { rw[0] = rec[u].x; rw[1] = rec[u].y; rw[2] = rec[u].z; rw[3] = rec[u].w; }
+                        for (int c = NG; c < a.n_cols; ++c) { // staged columns: already in the record
+                            const int d = a.cols[c].rec_dword;
+                            const uint32_t word = d == 0 ? rw[0] : (d == 1 ? rw[1] : (d == 2 ? rw[2] : rw[3]));
+                            store_value_rt(a.cols[c].dst, a.cols[c].width, out, word >> a.cols[c].rec_shift);
+                        }
                     }
                 }
             }
@@ -1197,12 +1173,6 @@ static void launch_emit_r(const EmitArgs &a, int n_gather, int grid, hipStream_t
 void launch_emit(const EmitArgs &a, int n_gather, int grid_blocks, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     const int64_t n_groups = (a.n_tiles + kEmitTiles - 1) / kEmitTiles;
     const int grid = clamp_grid(n_groups, grid_blocks > 0 ? grid_blocks : 2048);
-    if (n_gather == 0 && a.debug != 34) { // (34: ablation -- one row per lane)
-        if (a.R == 1) IMM3_LAUNCH((k_emit_wide<1>), grid, kBlockThreads, s, ev0, ev1, a);
-        else if (a.R == 2) IMM3_LAUNCH((k_emit_wide<2>), grid, kBlockThreads, s, ev0, ev1, a);
-        else IMM3_LAUNCH((k_emit_wide<4>), grid, kBlockThreads, s, ev0, ev1, a);
-        return;
-    }
     if (a.R == 1) launch_emit_r<1>(a, n_gather, grid, s, ev0, ev1);
     else if (a.R == 2) launch_emit_r<2>(a, n_gather, grid, s, ev0, ev1);
     else launch_emit_r<4>(a, n_gather, grid, s, ev0, ev1);
