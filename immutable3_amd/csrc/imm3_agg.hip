@@ -635,20 +635,22 @@ __global__ __launch_bounds__(kDirectThreads) void k_group_agg_direct(const AggAr
 // Too many keys / pages raises overflow = 3 and the host re-runs k_group_agg_direct.
 // ---------------------------------------------------------------------------------------------
 constexpr int kLaneSlots = 64;  // per-lane table rows; the last one is the trash slot
-constexpr int kLanePages = 30;
+constexpr int kLanePages = 30;  // second-level pages: 0 is the null page (every first byte starts there: all entries free), 1 .. 29 real
 constexpr int kLaneTrash = kLaneSlots - 1;
-constexpr uint32_t kMapFree = 255u, kMapClaimed = 254u, kMapFull = 253u; // map bytes that are not a page / slot number
+constexpr uint32_t kMapFree = 255u, kMapClaimed = 254u, kMapFull = 253u; // second-level bytes that are not a slot number
+// first-level bytes: 0 = free (the null page), 1 .. 29 = page, 254 / 253 = claimed / full -- a lookup clamps those to page
+// kLanePages, a second null page, so that the row path needs no compare
 
-struct LanesShared { // fixed part of the dynamic LDS; [l1 .. first] start as all-ones, the rest as zero
-    uint8_t l1[256];
-    uint8_t l2[kLanePages * 256];
+struct LanesShared { // fixed part of the dynamic LDS; [l2 .. first] start as all-ones, the rest as zero
+    uint8_t l2[(kLanePages + 1) * 256];
     uint32_t first[kLaneSlots];
+    uint8_t l1[256];
     uint32_t slotkey[kLaneSlots];
     uint32_t count[kLaneSlots];
     uint32_t val[kLaneSlots];
     uint32_t nslots, npages, pad[2];
 };
-constexpr int kLanesOnesBytes = 256 + kLanePages * 256 + kLaneSlots * 4;
+constexpr int kLanesOnesBytes = (kLanePages + 1) * 256 + kLaneSlots * 4;
 constexpr int kLanesFixedBytes = (int)((sizeof(LanesShared) + 255) / 256 * 256);
 constexpr int lanes_wave_bytes(int vw) { return kLaneSlots * 64 * (vw == 4 ? 2 + 4 : 4); }
 
@@ -670,17 +672,17 @@ __device__ __forceinline__ uint32_t lane_row_value(const v4i_t (&r)[W == 4 ? 4 :
 }
 
 // one byte of a map: its value, or -- when it is free -- an attempt to claim it and fill it from *counter (values >= limit
-// become `full` and raise the overflow flag).  Returns kMapFree when the byte is being filled by someone else right now
-// (or the CAS lost against a neighbour byte): ask again.  Straight-line between claim and publish, so lanes of one wave
+// become `full` and raise the overflow flag).  Returns `free` when the byte is being filled by someone else right now (or
+// the CAS lost against a neighbour byte): ask again.  Straight-line between claim and publish, so lanes of one wave
 // cannot wait on each other.
-__device__ __forceinline__ uint32_t map_byte(uint8_t *map, uint32_t idx, uint32_t *counter, uint32_t limit, uint32_t full, uint32_t *overflow, bool &placed) {
+__device__ __forceinline__ uint32_t map_byte(uint8_t *map, uint32_t idx, uint32_t free, uint32_t *counter, uint32_t limit, uint32_t full, uint32_t *overflow, bool &placed) {
     uint32_t *w = (uint32_t *)map + (idx >> 2);
     const int sh = 8 * (int)(idx & 3u);
     const uint32_t cur = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (not `volatile`: that turns an LDS access into a flat one, which waits for every global load in flight)
     uint32_t b = (cur >> sh) & 0xFFu;
     placed = false;
-    if (b == kMapFree) {
-        if (atomicCAS(w, cur, cur ^ (1u << sh)) != cur) return kMapFree; // 255 -> 254: claimed
+    if (b == free) {
+        if (atomicCAS(w, cur, cur ^ ((free ^ kMapClaimed) << sh)) != cur) return free;
         uint32_t n = atomicAdd(counter, 1u);
         if (n >= limit) {
             n = full;
@@ -689,20 +691,20 @@ __device__ __forceinline__ uint32_t map_byte(uint8_t *map, uint32_t idx, uint32_
         atomicXor(w, (kMapClaimed ^ n) << sh);
         b = n;
     }
-    return b == kMapClaimed ? kMapFree : b;
+    return b == kMapClaimed ? free : b;
 }
 
 // slot of key k: 0 .. 62, kLaneTrash when the form is full, kMapFree: not placed yet, ask again
 template <int KS>
 __device__ __forceinline__ uint32_t lanes_slot(LanesShared &S, uint32_t k, uint32_t *overflow) {
-    uint32_t pg = 0;
+    uint32_t pg = 1; // one-byte keys: page 1, no first level
     bool placed;
     if constexpr (KS != 0) {
-        pg = map_byte(S.l1, k & 0xFFu, &S.npages, (uint32_t)kLanePages, kMapFull, overflow, placed);
-        if (pg == kMapFree) return kMapFree;
+        pg = map_byte(S.l1, k & 0xFFu, 0u, &S.npages, (uint32_t)kLanePages, kMapFull, overflow, placed); // (npages starts at 1)
+        if (pg == 0u) return kMapFree;
         if (pg == kMapFull) return kLaneTrash;
     }
-    const uint32_t id = map_byte(S.l2, (pg << 8) | (KS == 0 ? (k & 0xFFu) : (k >> 8)), &S.nslots, (uint32_t)kLaneTrash, (uint32_t)kLaneTrash, overflow, placed);
+    const uint32_t id = map_byte(S.l2, (pg << 8) | (KS == 0 ? (k & 0xFFu) : (k >> 8)), kMapFree, &S.nslots, (uint32_t)kLaneTrash, (uint32_t)kLaneTrash, overflow, placed);
     if (placed) S.slotkey[id] = k; // (read after the work-group barrier that precedes the flush)
     return id;
 }
@@ -735,8 +737,10 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
     uint32_t *val = (uint32_t *)(wbase + kLaneSlots * 64 * 2) + lane;       // ... and values [slot * 64]
     {
         const int n_dw = (kLanesFixedBytes + n_waves * kWaveBytes) / 4;
-        for (int i = t; i < n_dw; i += (int)blockDim.x) ((uint32_t *)s_dyn)[i] = i < kLanesOnesBytes / 4 ? 0xFFFFFFFFu : 0u;
+        for (int i = t; i < n_dw; i += (int)blockDim.x) ((uint32_t *)s_dyn)[i] = i < kLanesOnesBytes / 4 ? 0xFFFFFFFFu : 0u; // l2 + first: ones
     }
+    __syncthreads();
+    if (t == 0) S.npages = 1; // page 0 is the null page
     __syncthreads();
 
     uint32_t vflip = 0, vmask = 0;
@@ -781,24 +785,22 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
         // slots: all first-level reads, then all second-level reads (values >= 253: no slot yet)
         if constexpr (KS == 0) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sid[i] = S.l2[key[i]];
+            for (int i = 0; i < 16; ++i) sid[i] = S.l2[256 + key[i]];
         } else {
             uint32_t pg[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) pg[i] = S.l1[key[i] & 0xFFu];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const bool none = pg[i] >= kMapFull;
-                const uint32_t s2 = S.l2[((none ? 0u : pg[i]) << 8) | (key[i] >> 8)];
-                sid[i] = none ? kMapFree : s2;
-            }
+            for (int i = 0; i < 16; ++i) sid[i] = S.l2[(min(pg[i], (uint32_t)kLanePages) << 8) | (key[i] >> 8)];
         }
-        uint32_t unseen = 0;
+        uint32_t top = 0; // any row, selected or not, without a slot?  (valid slots < 64 <= the map's markers)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) unseen |= (sid[i] >= (uint32_t)kLaneSlots ? 1u : 0u) << i;
-        unseen &= bits;
-        if (ballot64(unseen != 0u)) { // wave-uniform, warm-up only: every lane places (or looks up again) its own new keys
-            uint32_t pend = unseen;    // this lane's rows that still need a slot
+        for (int i = 0; i < 16; ++i) top = max(top, sid[i]);
+        if (ballot64(top >= (uint32_t)kLaneSlots)) { // wave-uniform, warm-up only: every lane places (or looks up again) its own new keys
+            uint32_t pend = 0;                        // this lane's selected rows that need a slot
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pend |= (sid[i] >= (uint32_t)kLaneSlots ? 1u : 0u) << i;
+            pend &= bits;
             for (int rounds = 0; rounds < 1024 && ballot64(pend != 0u); ++rounds) {
                 if (pend) {
                     const int first = __builtin_ctz(pend);
@@ -817,9 +819,13 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
                 }
             }
             if (ballot64(pend != 0u)) *a.overflow = 3; // (never seen: a claimed byte is published a few instructions later)
-        }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sid[i] = (((bits >> i) & 1u) && sid[i] < (uint32_t)kLaneSlots) ? sid[i] : (uint32_t)kLaneTrash; // rows that are not selected: the trash slot
+            for (int i = 0; i < 16; ++i) sid[i] = sid[i] < (uint32_t)kLaneSlots ? sid[i] : (uint32_t)kLaneTrash; // keys of rows that are not selected stay unplaced
+        }
+        if (ballot64(bits != 0xFFFFu)) { // wave-uniform: rows that are not selected update the trash slot
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sid[i] = ((bits >> i) & 1u) ? sid[i] : (uint32_t)kLaneTrash;
+        }
         const uint32_t row0 = (uint32_t)(tile * kTileRows + 16 * lane);
         // first-seen rows
         {

@@ -181,3 +181,91 @@ def test_engine_agg_over_segments_and_double_repr():
     from immutable3_amd.operators import java_double_to_string
     assert [java_double_to_string(v) for v in (0.0, 89.0, -5.0, 9999999.0, 1e7, 12345678.0, 2147483647.0, -2147483648.0)] == \
         ["0.0", "89.0", "-5.0", "9999999.0", "1.0E7", "1.2345678E7", "2.147483647E9", "-2.147483648E9"]
+
+
+# ---- k_group_agg_lanes (key <= 2 bytes, <= 63 keys, <= 1 min/max aggregate): every key shape x value width ----
+def _codes(rng, n, k, first_bytes=None):
+    """n two-byte codes drawn from k distinct ones; `first_bytes` distinct first characters."""
+    first_bytes = first_bytes or k
+    pool = np.array([[65 + (i % first_bytes), 97 + (i // first_bytes)] for i in range(k)], dtype=np.uint8)
+    return pool[rng.integers(0, k, size=n)]
+
+
+LANES_CASES = [
+    # (key columns, aggregates) over columns [id i32, age i8, state s2, flag i8, code s2]
+    ([2], [("count", 0)]),                                   # KS 1, VW 0
+    ([2], [("count", 0), ("max", 1)]),                       # KS 1, VW 1 (the bench query)
+    ([2], [("min", 1), ("count", 1), ("count", 0)]),         # KS 1, VW 1, MIN over signed bytes
+    ([2], [("max", 4)]),                                     # KS 1, VW 2: max over a string column
+    ([2], [("count", 2), ("min", 0)]),                       # KS 1, VW 4
+    ([2], [("max", 0)]),                                     # KS 1, VW 4
+    ([3], [("count", 0), ("max", 1)]),                       # KS 0
+    ([3], [("min", 0)]),                                     # KS 0, VW 4
+    ([3, 1], [("count", 0), ("max", 4)]),                    # KS 2 (two byte columns), VW 2
+    ([1, 3], [("min", 1)]),                                  # KS 2, other column order
+]
+
+
+def _lanes_cols(rng, n, n_codes=51, age_values=4, first_bytes=19):
+    br = blocks_of(n, 1024)
+    ids = rng.integers(-2**31, 2**31, size=n, dtype=np.int64).astype(np.int32)
+    age = (rng.integers(0, age_values, size=n) * 37 - 60).astype(np.int8)       # few distinct values, both signs
+    st = _codes(rng, n, n_codes, first_bytes)
+    flag = rng.integers(-3, 4, size=n).astype(np.int8)                            # 7 values
+    code = _codes(rng, n, 40)
+    return [RawColumn(DENSE_INT, 4, ids, br), RawColumn(DENSE_TINYINT, 1, age, br), RawColumn(DENSE_STRING, 2, st, br),
+            RawColumn(DENSE_TINYINT, 1, flag, br), RawColumn(DENSE_STRING, 2, code, br)]
+
+
+@pytest.mark.parametrize("group,aggs", LANES_CASES)
+def test_lanes_form_every_shape(ctx, group, aggs):
+    rng = np.random.default_rng(len(group) * 100 + len(aggs))
+    cols = _lanes_cols(rng, 300_000)
+    used = [0, 1, 2, 3, 4]
+    check(ctx, cols, used, [], group, aggs)                                       # every row
+    check(ctx, cols, used, [(0, GT, 0.0), (3, LT, 2.0)], group, aggs)             # a selection: rows that are not selected go to the trash slot
+    check(ctx, cols, used, [(0, GT, 2.0 ** 31 - 4096)], group, aggs)              # nearly nothing selected: most tiles skipped
+
+
+def test_lanes_form_pipeline_depth_and_rare_keys(ctx):
+    """7.2 M rows = 7032 tiles: more than 3 tiles per wave (the prefetch ring wraps), plus keys that appear once, late."""
+    rng = np.random.default_rng(99)
+    n = 7_200_000
+    br = blocks_of(n, 1024)
+    st = _codes(rng, n, 51, 19)
+    st[n - 5] = [90, 90]                                                          # "ZZ" once, in the last tile
+    st[3_333_333] = [90, 65]                                                      # "ZA" once, mid-way
+    age = rng.integers(-128, 128, size=n).astype(np.int8)
+    ids = np.arange(n, dtype=np.int32)
+    cols = [RawColumn(DENSE_INT, 4, ids, br), RawColumn(DENSE_STRING, 2, st, br), RawColumn(DENSE_TINYINT, 1, age, br)]
+    got = check(ctx, cols, [0, 1, 2], [], [1], [("count", 0), ("max", 2)])
+    assert [k for k, _ in got][-2:] == ["ZA", "ZZ"] and got[-1][1][0] == 1
+    check(ctx, cols, [0, 1, 2], [(2, GT, 18.0), (2, LT, 30.0)], [1], [("count", 0), ("min", 2)])
+
+
+def test_lanes_form_overflows_into_the_next_form(ctx):
+    """More than 63 keys, or more than 29 distinct first key bytes: overflow = 3, the host re-runs k_group_agg_direct
+    (and the general kernel after that when even 254 slots do not do); a second run of the same query starts there."""
+    rng = np.random.default_rng(7)
+    n = 200_000
+    br = blocks_of(n, 1024)
+    ids = rng.integers(-1000, 1000, size=n).astype(np.int32)
+    byte_key = rng.integers(-100, 100, size=n).astype(np.int8)                    # 200 keys of one byte
+    many = _codes(rng, n, 64, 8)                                                  # 64 keys: one too many
+    pages = _codes(rng, n, 40, 40)                                                # 40 keys, 40 distinct first bytes
+    wide = _codes(rng, n, 600, 25)                                                # 600 keys: past the direct form as well
+    for key in (byte_key, many, pages, wide):
+        kc = RawColumn(DENSE_TINYINT, 1, key, br) if key.dtype == np.int8 else RawColumn(DENSE_STRING, 2, key, br)
+        cols = [RawColumn(DENSE_INT, 4, ids, br), kc]
+        check(ctx, cols, [0, 1], [], [1], [("count", 0), ("max", 0)])
+        check(ctx, cols, [0, 1], [(0, GT, 0.0)], [1], [("count", 0), ("max", 0)])
+    # the same query handle run twice: the second run skips the form that overflowed
+    seg = native.DeviceSegment(ctx, [RawColumn(DENSE_INT, 4, ids, br).native(), RawColumn(DENSE_STRING, 2, many, br).native()])
+    q = native.DeviceQuery(ctx, seg, [0, 1], [], (), 0, 1024, group_cols=[1], aggs=[(native.AGG_COUNT, 0)])
+    q.run()
+    k1, f1, c1, _ = q.fetch_groups()
+    q.run()
+    k2, f2, c2, _ = q.fetch_groups()
+    assert k1.size == 64 and (k1 == k2).all() and (f1 == f2).all() and (c1 == c2).all() and int(c1.sum()) == n
+    q.close()
+    seg.close()
