@@ -652,7 +652,7 @@ struct LanesShared { // fixed part of the dynamic LDS; [l2 .. first] start as al
 };
 constexpr int kLanesOnesBytes = (kLanePages + 1) * 256 + kLaneSlots * 4;
 constexpr int kLanesFixedBytes = (int)((sizeof(LanesShared) + 255) / 256 * 256);
-constexpr int lanes_wave_bytes(int vw) { return kLaneSlots * 64 * (vw == 4 ? 2 + 4 : 4); }
+constexpr int lanes_wave_bytes(int vw) { return vw <= 1 ? kLaneSlots * 64 * 2 + kLaneSlots * 4 : kLaneSlots * 64 * (vw == 4 ? 2 + 4 : 4); }
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 
@@ -730,8 +730,14 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
     const int n_waves = (int)(blockDim.x >> 6);
     constexpr int kWaveBytes = lanes_wave_bytes(VW);
     constexpr int NV = VW == 4 ? 4 : (VW == 2 ? 2 : 1);
-    constexpr bool kPacked = VW != 4; // count (low 16) and value (high 16) in one dword
+    // entry of one (slot, lane):  VW 0: u16 count.  VW 1: u16 = value << 8 | count, the 8-bit counts folded into a per-wave
+    // u32 table every 15 tiles (a lane adds at most 16 per tile).  VW 2: u32 = value << 16 | count.  VW 4: u16 count + u32 value.
+    // The 16-bit forms halve the tables, which is what doubles the waves per CU (16): the row path is latency-bound.
+    constexpr bool kE16 = VW <= 1;
+    constexpr bool kPacked = VW == 2;
     uint8_t *wbase = s_dyn + kLanesFixedBytes + wave * kWaveBytes;
+    uint16_t *t16 = (uint16_t *)wbase + (lane & 31) * 2 + (lane >> 5);      // 16-bit: [slot * 64]; lanes l and l + 32 share a dword, so each half-wave hits 32 banks
+    uint32_t *wcnt = (uint32_t *)(wbase + kLaneSlots * 64 * 2);             // VW 1: [slot] counts folded so far (owned by lane = slot)
     uint32_t *tab = (uint32_t *)wbase + lane;                               // packed: [slot * 64]
     uint16_t *cnt = (uint16_t *)wbase + lane;                               // VW == 4: counts [slot * 64] ...
     uint32_t *val = (uint32_t *)(wbase + kLaneSlots * 64 * 2) + lane;       // ... and values [slot * 64]
@@ -760,7 +766,7 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
         uint32_t bits; // rows 16 * lane ..: bits 16 * lane .. of the tile's 1024
         v4i_t kr0[KS == 1 ? 2 : 1], kr1[1], vr[NV];
     };
-    constexpr int kDepth = VW == 4 ? 2 : 3;
+    constexpr int kDepth = VW == 2 ? 3 : 2; // (16-bit entries: 16 waves per CU, two tiles ahead suffice; VW 4: registers)
     const int64_t stride = (int64_t)gridDim.x * n_waves;
     const int64_t first_tile = (int64_t)blockIdx.x * n_waves + wave;
     auto issue = [&](TileRegs &r, int64_t tile) {
@@ -770,12 +776,29 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
         if constexpr (KS == 2) load_lane_rows<1>(a.groups[1].data, tile, lane, r.kr1);
         if constexpr (VW != 0) load_lane_rows<(VW ? VW : 1)>(a.aggs[vq].data, tile, lane, r.vr);
     };
+    int since_fold = 0; // VW 1: tiles since the 8-bit counts were folded (wave-uniform)
+    auto fold_counts = [&]() { // lane = slot: move the 64 lanes' 8-bit counts of its slot into wcnt (rotated: lanes on different banks)
+        uint16_t *row = (uint16_t *)wbase + lane * 64;
+        uint32_t c = 0;
+#pragma unroll 4
+        for (int j = 0; j < 64; ++j) {
+            const int idx = (j + lane) & 63;
+            const uint32_t e = row[idx];
+            c += e & 0xFFu;
+            row[idx] = (uint16_t)(e & 0xFF00u);
+        }
+        wcnt[lane] += c;
+    };
     auto process = [&](const TileRegs &r, const int64_t tile) {
         const uint32_t bits = r.bits;
         if (!ballot64(bits != 0u)) return; // nothing selected in these 1024 rows
         const auto &kr0 = r.kr0;
         const auto &kr1 = r.kr1;
         const auto &vr = r.vr;
+        if (a.debug == 44) { // (ablation: loads only)
+            asm volatile("" ::"v"(kr0[0]), "v"(kr0[KS == 1 ? 1 : 0]), "v"(vr[0]), "v"(vr[NV - 1]));
+            return;
+        }
         uint32_t key[16], sid[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -863,14 +886,22 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
             m[1] = max(x[1], e01 ? x[0] : 0u);
             m[2] = max(x[2], max(e02 ? x[0] : 0u, e12 ? x[1] : 0u));
             m[3] = max(max(x[3], e03 ? x[0] : 0u), max(e13 ? x[1] : 0u, e23 ? x[2] : 0u));
-            if constexpr (kPacked) {
+            if constexpr (kE16) {
+                uint32_t old[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) old[k] = t16[s[k] * 64];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { // in order: of two rows in one slot the later write (the larger total) lands last
+                    if constexpr (VW == 0) t16[s[k] * 64] = (uint16_t)(old[k] + c[k]); // (a lane's count stays below 2^16: lanes_plan)
+                    else t16[s[k] * 64] = (uint16_t)(((old[k] + c[k]) & 0xFFu) | (max(old[k], m[k] << 8) & 0xFF00u));
+                }
+            } else if constexpr (kPacked) {
                 uint32_t old[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) old[k] = tab[s[k] * 64];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { // in order: of two rows in one slot the later write (the larger total) lands last
-                    if constexpr (VW == 0) tab[s[k] * 64] = old[k] + c[k];
-                    else tab[s[k] * 64] = ((old[k] + c[k]) & 0xFFFFu) | (max(old[k], m[k] << 16) & 0xFFFF0000u); // (a lane's count stays below 2^16: lanes_plan)
+                    tab[s[k] * 64] = ((old[k] + c[k]) & 0xFFFFu) | (max(old[k], m[k] << 16) & 0xFFFF0000u); // (a lane's count stays below 2^16: lanes_plan)
                 }
             } else {
                 uint32_t oc[4], ov[4];
@@ -897,17 +928,32 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
             if (tile < a.n_tiles) process(R[d], tile); // wave-uniform
             issue(R[d], tile + kDepth * stride);
         }
+        if constexpr (VW == 1) {
+            since_fold += kDepth;
+            if (since_fold + kDepth > 15) { // 15 x 16 rows: the 8-bit counts are still below 256
+                fold_counts();
+                since_fold = 0;
+            }
+        }
     }
     __syncthreads();
 
     // fold: lane = slot; it sums / maxes its slot over the 64 lanes' private entries (rotated so that lanes hit different banks)
     {
         uint32_t c = 0, m = 0;
+        if constexpr (VW == 1) {
+            fold_counts();
+            c = wcnt[lane];
+        }
         for (int l = 0; l < 64; ++l) {
             const int src = (l + lane) & 63;
-            if constexpr (kPacked) {
+            if constexpr (kE16) {
+                const uint32_t e = ((const uint16_t *)wbase)[lane * 64 + src];
+                if constexpr (VW == 0) c += e;
+                else m = max(m, e >> 8);
+            } else if constexpr (kPacked) {
                 const uint32_t e = ((const uint32_t *)wbase)[lane * 64 + src];
-                c += VW == 0 ? e : (e & 0xFFFFu);
+                c += e & 0xFFFFu;
                 m = max(m, e >> 16);
             } else {
                 c += ((const uint16_t *)wbase)[lane * 64 + src];
