@@ -1078,7 +1078,7 @@ static void launch_lanes(const AggArgs &a, const LanesPlan &p, hipStream_t s, hi
         raised = true;
     }
     const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((a.n_tiles + p.waves - 1) / p.waves, 256)); // one work-group per CU
-    hipExtLaunchKernelGGL((k_group_agg_lanes<KS, VW>), dim3((unsigned)grid), dim3(p.waves * 64), (size_t)p.lds_bytes, s, ev0, ev1, 0, a, p.vq);
+    IMM3_LAUNCH_LDS((k_group_agg_lanes<KS, VW>), (unsigned)grid, p.waves * 64, (size_t)p.lds_bytes, s, ev0, ev1, a, p.vq);
 }
 
 void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
@@ -1099,18 +1099,18 @@ void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_
         const int map_bytes = key_bytes <= 1 ? 256 : 65536;
         const int64_t want = (a.n_tiles + kDirectWaves - 1) / kDirectWaves;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, 256)); // one 1024-thread work-group per CU
-        hipExtLaunchKernelGGL(k_group_agg_direct, dim3(grid), dim3(kDirectThreads), (size_t)map_bytes, s, ev0, ev1, 0, a, map_bytes);
+        IMM3_LAUNCH_LDS(k_group_agg_direct, grid, kDirectThreads, (size_t)map_bytes, s, ev0, ev1, a, map_bytes);
         return;
     }
     if (a.debug != 9 && group_agg_fast_ok(a)) { // (debug 9: force the general kernel -- also what the host does after an overflow = 2)
         const int64_t want = (a.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, 768)); // ~41 KiB of LDS: 3 per CU
-        hipExtLaunchKernelGGL(k_group_agg_tile, dim3(grid), dim3(kBlockThreads), 0, s, ev0, ev1, 0, a);
+        IMM3_LAUNCH(k_group_agg_tile, grid, kBlockThreads, s, ev0, ev1, a);
         return;
     }
     const int64_t want = ((a.n_words + 3) / 4 + kAggWaves - 1) / kAggWaves;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, 768)); // 512-thread work-groups, 48 KiB LDS: 3 per CU
-    hipExtLaunchKernelGGL(k_group_agg, dim3(grid), dim3(kAggThreads), 0, s, ev0, ev1, 0, a);
+    IMM3_LAUNCH(k_group_agg, grid, kAggThreads, s, ev0, ev1, a);
 }
 
 void launch_group_collect(const AggArgs &a, hipStream_t s) {

@@ -32,10 +32,16 @@ int imm3::fail(int code, const std::string &msg) {
     return code;
 }
 
-#define CTX_LIVE(c)                                                                                   \
+#define CTX_LIVE_RUN(c)                                                                               \
     do {                                                                                              \
         if (!(c)) return fail(IMM3_ERR_ARG, "ctx is null");                                           \
         if ((c)->closed) return fail(IMM3_ERR_STATE, "the context of this handle has been destroyed"); \
+    } while (0)
+// every entry point but the run calls: not while a graph capture is open (most of them synchronise or allocate)
+#define CTX_LIVE(c)                                                                                   \
+    do {                                                                                              \
+        CTX_LIVE_RUN(c);                                                                              \
+        if ((c)->capture) return fail(IMM3_ERR_STATE, "a graph capture is open on this context: only imm3_query_run / imm3_query_run_select and imm3_ctx_capture_end are accepted"); \
     } while (0)
 
 // ---------------------------------------------------------------------------------------------
@@ -172,7 +178,24 @@ extern "C" int imm3_ctx_destroy(imm3_ctx *ctx) {
     if (!ctx) return IMM3_OK;
     if (ctx->closed) return fail(IMM3_ERR_STATE, "context destroyed twice");
     (void)hipSetDevice(ctx->device);
+    if (ctx->capture) { // an abandoned capture: end it and drop what it recorded
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(ctx->stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        ctx->capture->stale = true;
+        ctx->graphs.push_back(ctx->capture); // (so that it is released below like the others)
+        ctx->capture = nullptr;
+    }
     (void)hipStreamSynchronize(ctx->stream);
+    for (imm3_graph *g : ctx->graphs) { // the handles stay valid (imm3_graph_destroy frees them); what they recorded is gone
+        if (g->exec) (void)hipGraphExecDestroy(g->exec);
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        g->exec = nullptr;
+        g->graph = nullptr;
+        g->stale = true;
+    }
+    ctx->graphs.clear();
     for (auto &r : ctx->pool) {
         (void)hipEventDestroy(r.start);
         (void)hipEventDestroy(r.stop);
@@ -200,6 +223,72 @@ extern "C" int imm3_ctx_sync(imm3_ctx *ctx) {
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->aux) HIPCHK(hipStreamSynchronize(ctx->aux));
+    return IMM3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// graphs: a recorded sequence of query runs, enqueued with one call (hipGraph)
+// ---------------------------------------------------------------------------------------------
+extern "C" int imm3_ctx_capture_begin(imm3_ctx *ctx) {
+    CTX_LIVE(ctx);
+    HIPCHK(hipSetDevice(ctx->device));
+    imm3_graph *g = new imm3_graph();
+    g->ctx = ctx;
+    const hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) {
+        delete g;
+        (void)hipGetLastError();
+        return fail(IMM3_ERR_DEVICE, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e));
+    }
+    ctx_retain(ctx);
+    ctx->capture = g;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_ctx_capture_end(imm3_ctx *ctx, imm3_graph **out) {
+    if (!out) return fail(IMM3_ERR_ARG, "null argument");
+    CTX_LIVE_RUN(ctx);
+    if (!ctx->capture) return fail(IMM3_ERR_STATE, "no capture is open on this context");
+    imm3_graph *g = ctx->capture;
+    ctx->capture = nullptr;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipError_t e = hipStreamEndCapture(ctx->stream, &g->graph);
+    if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        delete g;
+        ctx_release(ctx);
+        return fail(IMM3_ERR_DEVICE, std::string("graph capture failed: ") + hipGetErrorString(e));
+    }
+    ctx->graphs.push_back(g);
+    *out = g;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_graph_launch(imm3_graph *g) {
+    if (!g) return fail(IMM3_ERR_ARG, "graph is null");
+    CTX_LIVE(g->ctx);
+    if (g->stale || !g->exec) return fail(IMM3_ERR_STATE, "a query recorded in this graph has been destroyed");
+    HIPCHK(hipSetDevice(g->ctx->device));
+    HIPCHK(hipGraphLaunch(g->exec, g->ctx->stream));
+    return IMM3_OK;
+}
+
+extern "C" int imm3_graph_destroy(imm3_graph *g) {
+    if (!g) return IMM3_OK;
+    imm3_ctx *ctx = g->ctx;
+    if (!ctx->closed) {
+        if (ctx->capture) return fail(IMM3_ERR_STATE, "a graph capture is open on this context");
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream); // a launch may still be running
+        auto &gs = ctx->graphs;
+        gs.erase(std::remove(gs.begin(), gs.end(), g), gs.end());
+    }
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    ctx_release(ctx);
     return IMM3_OK;
 }
 
@@ -341,7 +430,7 @@ namespace {
 struct LaunchTimer {
     hipEvent_t start = nullptr, stop = nullptr;
     LaunchTimer(imm3_ctx *ctx, int32_t id) {
-        if (ctx->timing && ((ctx->timing_mask >> id) & 1u) && ctx->used < ctx->pool.size()) {
+        if (ctx->timing && !ctx->capture && ((ctx->timing_mask >> id) & 1u) && ctx->used < ctx->pool.size()) {
             TimingRecord &rec = ctx->pool[ctx->used++];
             rec.kernel_id = id;
             start = rec.start;
@@ -1265,6 +1354,11 @@ extern "C" int imm3_query_locate_rows(const imm3_query *q, const uint32_t *row_i
 }
 
 extern "C" int imm3_query_destroy(imm3_query *q) {
+    if (q && q->ctx && !q->ctx->closed) {
+        if (q->ctx->capture) return fail(IMM3_ERR_STATE, "a graph capture is open on this context");
+        for (imm3_graph *g : q->ctx->graphs) // a graph that recorded this query's runs points into its buffers
+            if (std::find(g->queries.begin(), g->queries.end(), q) != g->queries.end()) g->stale = true;
+    }
     query_free(q);
     return IMM3_OK;
 }
@@ -1638,9 +1732,24 @@ static int run_project(imm3_query *q) {
 
 static int run_agg(imm3_query *q);
 
+// a run recorded into an open capture: nothing in it may synchronise, allocate or use a second stream
+static int capture_admit(imm3_query *q) {
+    imm3_ctx *ctx = q->ctx;
+    if (!ctx->capture) return IMM3_OK;
+    if (ctx->filter_variant == 2) return fail(IMM3_ERR_STATE, "tuning variant 2 (count reduce on the aux stream) cannot be captured");
+    if (!q->proj.empty() && !(q->limit > 0) && !q->reserved)
+        return fail(IMM3_ERR_STATE, "an unlimited projection sizes its output from the count (a synchronisation): call imm3_query_reserve_rows before capturing it");
+    if (!q->proj.empty() && !q->d_row_index) return fail(IMM3_ERR_STATE, "run the query once (or reserve rows) before capturing it: its output buffers are allocated on first use");
+    auto &qs = ctx->capture->queries;
+    if (std::find(qs.begin(), qs.end(), q) == qs.end()) qs.push_back(q);
+    return IMM3_OK;
+}
+
 extern "C" int imm3_query_run_select(imm3_query *q) {
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
-    CTX_LIVE(q->ctx);
+    CTX_LIVE_RUN(q->ctx);
+    const int ca = capture_admit(q);
+    if (ca) return ca;
     q->ran_project = false;
     return run_select(q, q->ctx->filter_variant == 2);
 }
@@ -1654,7 +1763,9 @@ extern "C" int imm3_query_join_count(imm3_query *q) {
 
 extern "C" int imm3_query_run(imm3_query *q) {
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
-    CTX_LIVE(q->ctx);
+    CTX_LIVE_RUN(q->ctx);
+    const int ca = capture_admit(q);
+    if (ca) return ca;
     q->ran_project = false;
     // Reducing the count on the aux stream (tuning variant 2) measured SLOWER on MI355X / ROCm 7.2 (75.6 vs 67.1 us
     // per step: the cross-queue event packets cost more than the two same-queue launch gaps they remove), so the

@@ -345,11 +345,11 @@ void launch_pfor_counts(const uint8_t *data, const uint32_t *block_off, int64_t 
 }
 
 void launch_filter_pfor(const PforArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    hipExtLaunchKernelGGL(k_filter_pfor, dim3(grid), dim3(kBlockThreads), 0, s, ev0, ev1, 0, a);
+    IMM3_LAUNCH(k_filter_pfor, grid, kBlockThreads, s, ev0, ev1, a);
 }
 
 void launch_pfor_decode(const PforArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    hipExtLaunchKernelGGL(k_pfor_decode, dim3(grid), dim3(kBlockThreads), 0, s, ev0, ev1, 0, a);
+    IMM3_LAUNCH(k_pfor_decode, grid, kBlockThreads, s, ev0, ev1, a);
 }
 
 } // namespace imm3

@@ -41,6 +41,7 @@ struct TimingRecord {
 // the last dependant is destroyed, so handles may be destroyed in ANY order (a JVM finalizer or a Python __del__ run
 // by the garbage collector gives no order).  Work submitted through a handle whose context has been destroyed fails
 // with IMM3_ERR_STATE; destroying the same handle twice while dependants keep it alive does too.
+struct imm3_graph;
 struct imm3_ctx {
     std::atomic<int> refs{1};
     bool closed = false;            // imm3_ctx_destroy has run: streams, events and the buffer pool are gone
@@ -68,6 +69,17 @@ struct imm3_ctx {
     int32_t stamp_slots = 0, stamp_used = 0;
     std::vector<int32_t> stamp_grids;
     uint32_t *d_xpow8 = nullptr;    // snappy CRC-32C check: x^(8 n) mod P for n = 0 .. 32768
+    imm3_graph *capture = nullptr;  // open stream capture (imm3_ctx_capture_begin .. _end), else null
+    std::vector<imm3_graph *> graphs; // graphs recorded on this context that have not been destroyed yet
+};
+
+// A recorded sequence of query runs (hipGraph): launching it enqueues every kernel of those runs with one call.
+struct imm3_graph {
+    imm3_ctx *ctx = nullptr;              // retained
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<imm3_query *> queries;    // the queries whose runs were recorded (not retained: destroying one makes the graph stale)
+    bool stale = false;
 };
 
 static inline bool is_snappy(int32_t c) { return c == IMM3_SNAPPY_INT || c == IMM3_SNAPPY_TINYINT || c == IMM3_SNAPPY_STRING; }

@@ -307,3 +307,16 @@ void launch_scan(const ScanArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev
 void launch_gather(const GatherArgs &a, int grid_blocks, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 
 } // namespace imm3
+
+#ifdef __HIPCC__
+#include <hip/hip_ext.h>
+// Kernel launch with optional start / stop events stamped by the launch itself (hipExtLaunchKernelGGL); the plain launch
+// when there are none: that is the one a stream capture (imm3_ctx_capture_begin) records.
+#define IMM3_LAUNCH_LDS(kern, grid, block, lds, s, ev0, ev1, ...)                                                \
+    do {                                                                                                         \
+        if (ev0 || ev1) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, ev0, ev1, 0, __VA_ARGS__);  \
+        else hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, __VA_ARGS__);                             \
+    } while (0)
+#define IMM3_LAUNCH(kern, grid, block, s, ev0, ev1, ...) IMM3_LAUNCH_LDS(kern, grid, block, 0, s, ev0, ev1, __VA_ARGS__)
+#endif
+

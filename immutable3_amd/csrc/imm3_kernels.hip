@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_read_stream(const int32_t *da
 }
 
 void launch_read_stream(const int32_t *data, int64_t n_tiles, int32_t *sink, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    hipExtLaunchKernelGGL(k_read_stream, dim3(512), dim3(kBlockThreads), 0, s, ev0, ev1, 0, data, n_tiles, sink);
+    IMM3_LAUNCH(k_read_stream, 512, kBlockThreads, s, ev0, ev1, data, n_tiles, sink);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1065,10 +1065,6 @@ int filter_grid(int64_t units, bool generic, bool any_i32, int grid_blocks) {
 
 // With ev0/ev1 set, hipExtLaunchKernelGGL stamps them with the kernel's own start and end, so the elapsed
 // time is the kernel's duration (what rocprofv3 reports), not launch-to-launch.
-#define IMM3_LAUNCH(kern, grid, block, s, ev0, ev1, args) \
-    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, s, ev0, ev1, 0, args)
-#define IMM3_LAUNCH_LDS(kern, grid, block, lds, s, ev0, ev1, args) \
-    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, ev0, ev1, 0, args)
 
 #define IMM3_TILE_CASE(k0, k1, k2, T)                                                           \
     if (a.kinds[0] == k0 && a.kinds[1] == k1 && a.kinds[2] == k2) {                             \

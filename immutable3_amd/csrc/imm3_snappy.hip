@@ -259,7 +259,7 @@ void launch_snappy_sizes(const uint8_t *data, const uint32_t *block_off, int64_t
 
 void launch_snappy_decode(const SnappyArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     const size_t lds = 1024 + (size_t)a.in_cap + (size_t)a.out_cap;
-    hipExtLaunchKernelGGL(k_snappy_decode, dim3(grid), dim3(64), lds, s, ev0, ev1, 0, a);
+    IMM3_LAUNCH_LDS(k_snappy_decode, grid, 64, lds, s, ev0, ev1, a);
 }
 
 } // namespace imm3

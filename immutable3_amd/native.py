@@ -29,6 +29,7 @@ ERR_UNSUPPORTED_CONDITION, ERR_UNSUPPORTED_VECTOR, ERR_NO_CODEC, ERR_LAYOUT, ERR
 EXPORTS = [
     "imm3_abi_version", "imm3_last_error", "imm3_device_count",
     "imm3_ctx_create", "imm3_ctx_destroy", "imm3_ctx_sync", "imm3_ctx_stream",
+    "imm3_ctx_capture_begin", "imm3_ctx_capture_end", "imm3_graph_launch", "imm3_graph_destroy",
     "imm3_segment_create", "imm3_segment_create_async", "imm3_segment_wait", "imm3_segment_wrap_device", "imm3_segment_destroy", "imm3_segment_bytes",
     "imm3_table_create", "imm3_table_destroy", "imm3_query_create_table", "imm3_query_create_table_agg",
     "imm3_query_segment_starts", "imm3_query_locate_rows",
@@ -121,6 +122,10 @@ def load() -> C.CDLL:
     L.imm3_ctx_destroy.argtypes = [vp]
     L.imm3_ctx_sync.argtypes = [vp]
     L.imm3_ctx_stream.argtypes = [vp, P(vp)]
+    L.imm3_ctx_capture_begin.argtypes = [vp]
+    L.imm3_ctx_capture_end.argtypes = [vp, P(vp)]
+    L.imm3_graph_launch.argtypes = [vp]
+    L.imm3_graph_destroy.argtypes = [vp]
     L.imm3_segment_create.argtypes = [vp, P(CColumn), i32, P(vp)]
     L.imm3_segment_wrap_device.argtypes = [vp, P(CColumn), i32, P(vp)]
     L.imm3_segment_create_async.argtypes = [vp, P(CColumn), i32, P(vp)]
@@ -258,6 +263,11 @@ class Context:
         _check(load().imm3_ctx_stream(self._h, C.byref(s)))
         return s.value or 0
 
+    def capture(self) -> "_Capture":
+        """`with ctx.capture() as cap: q0.run(); q1.run()` records the runs (nothing executes); `cap.graph.launch()`
+        then enqueues all of their kernels with one call (imm3_ctx_capture_begin / _end, a hipGraph)."""
+        return _Capture(self)
+
     def set_tuning(self, filter_variant: int = 0, grid_blocks: int = 0):
         _check(load().imm3_ctx_set_tuning(self._h, filter_variant, grid_blocks))
 
@@ -295,7 +305,7 @@ class Context:
             # The C ABI allows any destruction order (handles are reference counted); closing dependants first simply
             # returns their device memory now instead of when the garbage collector gets to them.
             kids = list(self._children)
-            for kind in (Comm, DeviceQuery, DeviceTable, DeviceSegment):   # comms, queries -> tables -> segments
+            for kind in (Graph, Comm, DeviceQuery, DeviceTable, DeviceSegment):   # graphs, comms, queries -> tables -> segments
                 for k in kids:
                     if isinstance(k, kind):
                         k.close()
@@ -307,6 +317,49 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+class Graph:
+    """imm3_graph: a recorded sequence of query runs."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx = ctx
+        self._h = handle
+        ctx._adopt(self)
+
+    def launch(self):
+        _check(load().imm3_graph_launch(self._h))
+
+    def close(self):
+        if self._h:
+            load().imm3_graph_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _Capture:
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.graph: Optional[Graph] = None
+
+    def __enter__(self):
+        _check(load().imm3_ctx_capture_begin(self.ctx._h))
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        h = C.c_void_p()
+        rc = load().imm3_ctx_capture_end(self.ctx._h, C.byref(h))
+        if exc_type is None:
+            _check(rc)
+            self.graph = Graph(self.ctx, h)
+        elif rc == OK:                       # the body failed: drop what was recorded, let its exception through
+            load().imm3_graph_destroy(h)
+        return False
 
 
 def _ccolumns(cols):

@@ -67,6 +67,7 @@ typedef struct imm3_ctx imm3_ctx;         /* device + stream + scratch          
 typedef struct imm3_segment imm3_segment; /* one segment's columns resident in HBM (SegmentManager role) */
 typedef struct imm3_table imm3_table;     /* all resident segments of one table: scanned by ONE launch    */
 typedef struct imm3_query imm3_query;     /* one PipelineThread: ScanOp -> SelectOp* -> ProjectOp        */
+typedef struct imm3_graph imm3_graph;     /* a recorded sequence of query runs (hipGraph)                */
 
 /* One column of one segment as the reference stores it: `<col>_<id>.dat` bytes + the
  * `blockOffset` array of `<col>_<id>.meta` (core/storage/Segment.scala:33-58, 154-181;
@@ -110,6 +111,22 @@ int imm3_ctx_create(int device, void *stream, imm3_ctx **out);
 int imm3_ctx_destroy(imm3_ctx *ctx);
 int imm3_ctx_sync(imm3_ctx *ctx);
 int imm3_ctx_stream(imm3_ctx *ctx, void **stream_out);
+
+/* ---- graphs: the reference's Engine starts one PipelineThread per segment for every query it executes
+ * (Engine.scala:176-196); here a host that runs the same set of queries again and again -- the segments of a table, pass
+ * after pass -- records their runs once and replays them with ONE call: a hipGraph of every kernel of those runs, which
+ * removes the per-launch host cost and the gaps between the kernels.
+ *   imm3_ctx_capture_begin(ctx); imm3_query_run(q0); imm3_query_run(q1); ...; imm3_ctx_capture_end(ctx, &g);
+ *   imm3_graph_launch(g);   -- asynchronous on the context's stream, like the runs it stands for; results are read
+ *                              through the queries as after imm3_query_run
+ * Between begin and end the context accepts only imm3_query_run / imm3_query_run_select (nothing executes then: the
+ * runs are recorded) -- every other call returns IMM3_ERR_STATE.  A recorded run must not need the host: an unlimited
+ * projection has to have rows reserved (imm3_query_reserve_rows), and every recorded query must have run once before (its
+ * buffers are allocated on first use).  Destroying a recorded query makes the graph stale (launch: IMM3_ERR_STATE). */
+int imm3_ctx_capture_begin(imm3_ctx *ctx);
+int imm3_ctx_capture_end(imm3_ctx *ctx, imm3_graph **out);
+int imm3_graph_launch(imm3_graph *g);
+int imm3_graph_destroy(imm3_graph *g);
 
 /* ---- segment: what SegmentManager.getSegment(id, table, col) hands to ScanOp, for every column
  * of one segment id, staged into HBM once and kept resident (the reference keeps the mmaps for the

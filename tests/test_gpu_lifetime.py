@@ -226,3 +226,58 @@ def test_async_staging_orders_queries_behind_the_copies():
     for s in segs:
         s.close()
     ctx.close()
+
+
+def test_graph_capture_replays_runs_of_several_queries():
+    """imm3_ctx_capture_begin / _end: the runs of three queries (select-only, projection, aggregation) recorded once and
+    replayed with one call; results through the queries as after imm3_query_run; the misuse cases fail with ERR_STATE."""
+    import torch
+    ctx = native.Context(0)
+    n = 400_000
+    br = blocks_of(n, 1024)
+    v = synth.uniform_int30(70, n)
+    age = synth.uniform_below(71, n, 100, np.int8)
+    st = synth.state_codes(72, n)
+    seg = native.DeviceSegment(ctx, [RawColumn(DENSE_INT, 4, v, br).native(), RawColumn(2, 1, age, br).native(), RawColumn(3, 2, st, br).native()])
+    sels = [(0, GT, float(2 ** 28)), (0, LT, float(3 * 2 ** 28))]
+    keep = np.flatnonzero((v > 2 ** 28) & (v < 3 * 2 ** 28))
+    q_sel = native.DeviceQuery(ctx, seg, [0], sels)
+    q_prj = native.DeviceQuery(ctx, seg, [0, 1], sels, [1, 0], 0)
+    q_agg = native.DeviceQuery(ctx, seg, [0, 1, 2], sels, (), 0, 1024, group_cols=[2], aggs=[(native.AGG_COUNT, 0), (native.AGG_MAX, 1)])
+    log = torch.zeros(8, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    q_sel.log_counts(log.data_ptr(), 8)
+    with pytest.raises(native.Imm3Error) as e:      # an unlimited projection that has never run: its size needs the host
+        with ctx.capture():
+            q_prj.run()
+    assert e.value.code == native.ERR_STATE
+    for q in (q_sel, q_prj, q_agg):
+        q.run()
+    assert q_prj.row_count() == keep.size
+    q_prj.reserve_rows(keep.size + 16)
+    k0, f0, c0, v0 = q_agg.fetch_groups()
+    with ctx.capture() as cap:
+        q_sel.run_select()
+        q_prj.run()
+        q_agg.run()
+        with pytest.raises(native.Imm3Error) as e:  # nothing but runs while a capture is open
+            q_sel.count()
+        assert e.value.code == native.ERR_STATE
+    g = cap.graph
+    ctx.sync()
+    assert log.tolist()[:2] == [keep.size, 0]       # recording executed nothing
+    for _ in range(3):
+        g.launch()
+    ctx.sync()
+    assert log.tolist()[:5] == [keep.size] * 4 + [0]
+    assert q_sel.count() == keep.size
+    idx, vals = q_prj.fetch_rows()
+    assert (idx == keep).all() and (vals[0].view(np.int8).reshape(-1) == age[keep]).all() and (vals[1].view("<i4").reshape(-1) == v[keep]).all()
+    k1, f1, c1, v1 = q_agg.fetch_groups()
+    assert (k1 == k0).all() and (f1 == f0).all() and (c1 == c0).all() and (v1 == v0).all() and int(c1.sum()) == keep.size
+    q_prj.close()                                   # a recorded query goes away: the graph is stale, not dangling
+    with pytest.raises(native.Imm3Error) as e:
+        g.launch()
+    assert e.value.code == native.ERR_STATE
+    g.close()
+    q_sel.close(); q_agg.close(); seg.close(); ctx.close()
