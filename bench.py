@@ -398,7 +398,7 @@ def measure_c2(env: Env, steps: int, warmup: int, with_cpu_baseline: bool):
 C5_ID_LO, C5_ID_HI = 1.0e6, 7.9e8        # the C3 id range stretched over the 8-segment id space [0, 8e8)
 
 
-def measure_c5(env: Env, steps: int, warmup: int):
+def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True):
     torch, native, synth, ctx, args = env.torch, env.native, env.synth, env.ctx, env.args
     from immutable3_amd.distributed import owned_segments
     n = args.rows
@@ -434,9 +434,21 @@ def measure_c5(env: Env, steps: int, warmup: int):
     env.sync()
     host_counts = []
 
-    def step(i: int):
-        for q in queries:
-            q.run()                                     # scan+select(+stage) -> offsets scan -> compact+gather, per owned segment
+    # One pass = the runs of every owned segment's query.  They are recorded once (imm3_ctx_capture_begin / _end: a hipGraph of
+    # 3 kernels per segment) and replayed with one call per pass; `--no-graph` issues the runs one by one instead.
+    graph = None
+    if use_graph:
+        with ctx.capture() as cap:
+            for q in queries:
+                q.run()
+        graph = cap.graph
+
+    def step(i: int, graphed: bool = True):
+        if graph is not None and graphed:
+            graph.launch()
+        else:
+            for q in queries:
+                q.run()                                 # scan+select(+stage) -> offsets scan -> compact+gather, per owned segment
         if env.comm is not None:
             env.comm.allreduce_count(queries, device_out=log.data_ptr() + 8 * i, wait=False)
         else:                                           # rehearsal on one device: host counts over gloo
@@ -445,6 +457,11 @@ def measure_c5(env: Env, steps: int, warmup: int):
     elapsed = env.timed_steps(step, steps, warmup)
     got = log[:steps].tolist() if env.comm is not None else host_counts[-steps:]
     assert all(g == expect_total for g in got), (got[:4], expect_total)
+    elapsed_plain = None
+    if graph is not None:                               # the same passes launched kernel by kernel, for the record
+        elapsed_plain = env.timed_steps(lambda i: step(i, graphed=False), steps, min(warmup, 2))
+        got = log[:steps].tolist() if env.comm is not None else host_counts[-steps:]
+        assert all(g == expect_total for g in got), (got[:4], expect_total)
 
     # per-kernel durations of one pass over this rank's segments (second, event-bracketed pass)
     def one_pass():
@@ -463,6 +480,9 @@ def measure_c5(env: Env, steps: int, warmup: int):
         out = {
             "value": float(n) * C5_SEGMENTS * steps / elapsed,
             "ms_per_step": elapsed / steps * 1e3,
+            "launch": (f"one hipGraph launch per pass ({3 * len(queries)} kernels, imm3_graph_launch) + the count all-reduce"
+                       if graph is not None else "kernel by kernel (--no-graph)"),
+            "ms_per_step_kernel_by_kernel": elapsed_plain / steps * 1e3 if elapsed_plain is not None else None,
             "global_selected_rows_per_pass": int(expect_total),
             "count_allreduce": {"collective": env.count_reduce, "checked": f"all {steps} per-pass global counts == {expect_total} (numpy, summed over ranks via gloo)"},
             "config": {
@@ -483,6 +503,8 @@ def measure_c5(env: Env, steps: int, warmup: int):
             "staging": {"host_to_hbm_s_per_segment": stage_s / max(len(mine), 1), "note": "incl. synthetic generation and the parity gate; never part of value"},
             "per_rank": per_rank,
         }
+    if graph is not None:
+        graph.close()
     for q in queries:
         q.close()
     for s in segs:
@@ -612,6 +634,7 @@ def main():
     ap.add_argument("--segments", type=int, default=3, help="distinct resident C2 segments rotated per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the extra block (C3, C4, aggregation, C5 at G = 1)")
+    ap.add_argument("--no-graph", action="store_true", help="C5: launch every pass kernel by kernel instead of replaying the recorded hipGraph")
     ap.add_argument("--no-c2-weak", action="store_true", help="N > 1: skip the weak-scaling C2 leg")
     ap.add_argument("--no-c5", action="store_true", help="N = 1: leave the C5-at-G=1 leg out of the extra block (profiling runs: its kernels are C3's instances)")
     ap.add_argument("--extra", action="store_true", help="(kept for compatibility: the extra block is on by default)")
@@ -638,14 +661,14 @@ def main():
         if not args.no_extra:
             extra = extra_workloads(env)
             if not args.no_c5:
-                c5 = measure_c5(env, max(3, min(args.steps, 10)), 2)
-                extra["c5_g1"] = {k: c5[k] for k in ("value", "ms_per_step", "global_selected_rows_per_pass", "count_allreduce", "config", "roofline")}
+                c5 = measure_c5(env, max(3, min(args.steps, 10)), 2, use_graph=not args.no_graph)
+                extra["c5_g1"] = {k: c5[k] for k in ("value", "ms_per_step", "launch", "ms_per_step_kernel_by_kernel", "global_selected_rows_per_pass", "count_allreduce", "config", "roofline")}
                 extra["c5_g1"]["note"] = "the G = 1 point of the C5 strong-scaling curve whose G > 1 points are the `value` of the --gpus N lines"
             result["extra"] = extra
         result["scaling_note"] = ("N = 1: value = C2 (headline).  N > 1: value = C5 aggregate (strong scaling, 8e8 rows per pass); its G = 1 point is "
                                   "extra.c5_g1.value; the like-for-like weak-scaling curve of the headline workload is c2_weak.value at N > 1")
     else:
-        c5 = measure_c5(env, args.steps, args.warmup)
+        c5 = measure_c5(env, args.steps, args.warmup, use_graph=not args.no_graph)
         c2 = None if args.no_c2_weak else measure_c2(env, max(10, min(args.steps, 50)), 5, with_cpu_baseline=False)
         if env.rank == 0:
             result = dict(base, scaling="strong", dtype="i32/i8", **c5)

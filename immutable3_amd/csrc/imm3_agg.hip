@@ -620,9 +620,8 @@ __global__ __launch_bounds__(kDirectThreads) void k_group_agg_direct(const AggAr
 // [slot][lane] in LDS, so an update is a plain ds_read + ds_write at full LDS rate that never conflicts (lane l always
 // hits bank l).  What that needs:
 //   * a lane takes 16 CONSECUTIVE rows of a tile (16 / 32 / 64 contiguous bytes per column, no transposition through
-//     LDS; its 16 bitmap bits are one u16), in batches of four: four entries read, duplicates among the four folded in
-//     registers (six compares), four writes IN ORDER -- LDS executes one wave's operations in order, so the next
-//     batch's reads see them without a wait;
+//     LDS; its 16 bitmap bits are one u16) and updates its entries row after row: read, modify, write -- LDS executes one
+//     wave's operations in order, so the next row's read sees the write without a wait;
 //   * rows that are not selected update a trash slot instead of branching;
 //   * values are mapped to an "unsigned max" domain on load (sign bit flipped, complemented for MIN, strings packed
 //     big-endian), so the update is always v_max_u32 and tables start at zero.  Values of <= 2 bytes share a dword with
@@ -722,8 +721,8 @@ __device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
 // KS: key shape -- 0: one 1-byte column, 1: one 2-byte column, 2: two 1-byte columns.  VW: bytes of the aggregated column (0: counts only)
 template <int KS, int VW>
 __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const int vq) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
-    LanesShared &S = *(LanesShared *)s_dyn;
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[]; // the waves' private tables
+    __shared__ LanesShared S; // (static: its addresses fold into the LDS instructions' offset fields)
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -735,16 +734,14 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
     // The 16-bit forms halve the tables, which is what doubles the waves per CU (16): the row path is latency-bound.
     constexpr bool kE16 = VW <= 1;
     constexpr bool kPacked = VW == 2;
-    uint8_t *wbase = s_dyn + kLanesFixedBytes + wave * kWaveBytes;
+    uint8_t *wbase = s_dyn + wave * kWaveBytes;
     uint16_t *t16 = (uint16_t *)wbase + (lane & 31) * 2 + (lane >> 5);      // 16-bit: [slot * 64]; lanes l and l + 32 share a dword, so each half-wave hits 32 banks
     uint32_t *wcnt = (uint32_t *)(wbase + kLaneSlots * 64 * 2);             // VW 1: [slot] counts folded so far (owned by lane = slot)
     uint32_t *tab = (uint32_t *)wbase + lane;                               // packed: [slot * 64]
     uint16_t *cnt = (uint16_t *)wbase + lane;                               // VW == 4: counts [slot * 64] ...
     uint32_t *val = (uint32_t *)(wbase + kLaneSlots * 64 * 2) + lane;       // ... and values [slot * 64]
-    {
-        const int n_dw = (kLanesFixedBytes + n_waves * kWaveBytes) / 4;
-        for (int i = t; i < n_dw; i += (int)blockDim.x) ((uint32_t *)s_dyn)[i] = i < kLanesOnesBytes / 4 ? 0xFFFFFFFFu : 0u; // l2 + first: ones
-    }
+    for (int i = t; i < (int)(sizeof(LanesShared) / 4); i += (int)blockDim.x) ((uint32_t *)&S)[i] = i < kLanesOnesBytes / 4 ? 0xFFFFFFFFu : 0u; // l2 + first: ones
+    for (int i = t; i < n_waves * kWaveBytes / 4; i += (int)blockDim.x) ((uint32_t *)s_dyn)[i] = 0u;
     __syncthreads();
     if (t == 0) S.npages = 1; // page 0 is the null page
     __syncthreads();
@@ -816,10 +813,10 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
 #pragma unroll
             for (int i = 0; i < 16; ++i) sid[i] = S.l2[(min(pg[i], (uint32_t)kLanePages) << 8) | (key[i] >> 8)];
         }
-        uint32_t top = 0; // any row, selected or not, without a slot?  (valid slots < 64 <= the map's markers)
+        uint32_t any = 0; // any row, selected or not, without a slot?  (valid slots < 64; the map's markers 253 .. 255 have bits 6 and 7 set)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) top = max(top, sid[i]);
-        if (ballot64(top >= (uint32_t)kLaneSlots)) { // wave-uniform, warm-up only: every lane places (or looks up again) its own new keys
+        for (int i = 0; i < 16; ++i) any |= sid[i];
+        if (ballot64((any & 0xC0u) != 0u)) { // wave-uniform, warm-up only: every lane places (or looks up again) its own new keys
             uint32_t pend = 0;                        // this lane's selected rows that need a slot
 #pragma unroll
             for (int i = 0; i < 16; ++i) pend |= (sid[i] >= (uint32_t)kLaneSlots ? 1u : 0u) << i;
@@ -864,57 +861,30 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
                 seen |= wave_or64(here);
             }
         }
-        // updates, four rows at a time
+        // updates: one row after the other, read -> modify -> write.  LDS executes one wave's operations in order, so a row
+        // sees the write of the row before it without a wait in between; the 16 waves hide the round trips.  (Batches of
+        // 4 or 2 reads with duplicate slots folded in registers measured slower: 109 / 100 us against 97 -- the fold is
+        // vector work, which is what this kernel is short of.)
 #pragma unroll
-        for (int b = 0; b < (a.debug == 42 ? 0 : 4); ++b) { // (42: ablation)
-            uint32_t s[4], x[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = 4 * b + k;
-                s[k] = sid[i];
-                x[k] = 0;
-                if constexpr (VW != 0) {
-                    uint32_t raw = lane_row_value<(VW ? VW : 1)>(vr, i);
-                    if (vstr) raw = VW == 4 ? __builtin_bswap32(raw) : (VW == 2 ? (uint32_t)__builtin_bswap16((uint16_t)raw) : raw); // big-endian pack: integer order == byte order
-                    x[k] = (raw ^ vflip) & vmask;
-                }
+        for (int i = 0; i < (a.debug == 42 ? 0 : 16); ++i) { // (42: ablation)
+            const uint32_t s = sid[i];
+            uint32_t x = 0;
+            if constexpr (VW != 0) {
+                uint32_t raw = lane_row_value<(VW ? VW : 1)>(vr, i);
+                if (vstr) raw = VW == 4 ? __builtin_bswap32(raw) : (VW == 2 ? (uint32_t)__builtin_bswap16((uint16_t)raw) : raw); // big-endian pack: integer order == byte order
+                x = (raw ^ vflip) & vmask;
             }
-            const bool e01 = s[0] == s[1], e02 = s[0] == s[2], e12 = s[1] == s[2], e03 = s[0] == s[3], e13 = s[1] == s[3], e23 = s[2] == s[3];
-            const uint32_t c[4] = {1u, 1u + e01, 1u + e02 + e12, 1u + e03 + e13 + e23}; // this row and the batch's earlier rows in the same slot
-            uint32_t m[4]; // value of this row and of those earlier rows
-            m[0] = x[0];
-            m[1] = max(x[1], e01 ? x[0] : 0u);
-            m[2] = max(x[2], max(e02 ? x[0] : 0u, e12 ? x[1] : 0u));
-            m[3] = max(max(x[3], e03 ? x[0] : 0u), max(e13 ? x[1] : 0u, e23 ? x[2] : 0u));
             if constexpr (kE16) {
-                uint32_t old[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) old[k] = t16[s[k] * 64];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { // in order: of two rows in one slot the later write (the larger total) lands last
-                    if constexpr (VW == 0) t16[s[k] * 64] = (uint16_t)(old[k] + c[k]); // (a lane's count stays below 2^16: lanes_plan)
-                    else t16[s[k] * 64] = (uint16_t)(((old[k] + c[k]) & 0xFFu) | (max(old[k], m[k] << 8) & 0xFF00u));
-                }
+                const uint32_t old = t16[s * 64];
+                if constexpr (VW == 0) t16[s * 64] = (uint16_t)(old + 1u); // (a lane's count stays below 2^16: lanes_plan)
+                else t16[s * 64] = (uint16_t)(((old + 1u) & 0xFFu) | (max(old, x << 8) & 0xFF00u));
             } else if constexpr (kPacked) {
-                uint32_t old[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) old[k] = tab[s[k] * 64];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { // in order: of two rows in one slot the later write (the larger total) lands last
-                    tab[s[k] * 64] = ((old[k] + c[k]) & 0xFFFFu) | (max(old[k], m[k] << 16) & 0xFFFF0000u); // (a lane's count stays below 2^16: lanes_plan)
-                }
+                const uint32_t old = tab[s * 64];
+                tab[s * 64] = ((old + 1u) & 0xFFFFu) | (max(old, x << 16) & 0xFFFF0000u); // (a lane's count stays below 2^16: lanes_plan)
             } else {
-                uint32_t oc[4], ov[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    oc[k] = cnt[s[k] * 64];
-                    ov[k] = val[s[k] * 64];
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    cnt[s[k] * 64] = (uint16_t)(oc[k] + c[k]);
-                    val[s[k] * 64] = max(ov[k], m[k]);
-                }
+                const uint32_t oc = cnt[s * 64], ov = val[s * 64];
+                cnt[s * 64] = (uint16_t)(oc + 1u);
+                val[s * 64] = max(ov, x);
             }
         }
     };
@@ -1066,7 +1036,7 @@ static bool lanes_plan(const AggArgs &a, LanesPlan &p) {
     const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((a.n_tiles + p.waves - 1) / p.waves, 256));
     const int64_t tiles_per_wave = (a.n_tiles + grid * p.waves - 1) / (grid * p.waves);
     if (tiles_per_wave * 16 >= 65536) return false; // a lane's u16 count of one slot must hold all its rows
-    p.lds_bytes = kLanesFixedBytes + p.waves * per_wave;
+    p.lds_bytes = p.waves * per_wave; // dynamic part; the maps are static
     return true;
 }
 
@@ -1074,7 +1044,7 @@ template <int KS, int VW>
 static void launch_lanes(const AggArgs &a, const LanesPlan &p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     static bool raised = false; // (the limit is per kernel function, process wide)
     if (!raised) {
-        (void)hipFuncSetAttribute((const void *)k_group_agg_lanes<KS, VW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_group_agg_lanes<KS, VW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - kLanesFixedBytes);
         raised = true;
     }
     const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((a.n_tiles + p.waves - 1) / p.waves, 256)); // one work-group per CU

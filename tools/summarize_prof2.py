@@ -52,7 +52,8 @@ for name in ("fetch", "write"):
 
 
 def kernel(sub):
-    ks = [k for k in stats if sub in k]
+    parts = sub.split("*")   # "a*b": a name that contains a, then b
+    ks = [k for k in stats if all(x in k for x in parts) and k.find(parts[0]) <= k.find(parts[-1])]
     if len(ks) != 1:
         raise SystemExit(f"kernel '{sub}': {ks}")
     k = ks[0]
@@ -71,7 +72,7 @@ summary["c2_headline"] = dict(head, algorithmic_bytes=412.5e6, frac=412.5e6 / (h
                               traffic_ratio=head["hbm_bytes_fetch_x2"] / 412.5e6 if head["hbm_bytes_fetch_x2"] else None)
 summary["fetch_x2_calibration"] = dict(calib, known_bytes=400.0e6, ratio=calib["hbm_bytes_fetch_x2"] / 400.0e6 if calib["hbm_bytes_fetch_x2"] else None)
 cfgs = {"c3_range_age_id_project": ("k_filter_tile<0, 1, 3, 1, false, true, true>", "k_emit<2, 0>"),
-        "c4_match_state_project": ("k_filter_tile<2, 3, 3, 2, false, true, true>", "k_emit<1, 2>")}
+        "c4_match_state_project": ("k_filter_tile<2, 3, 3, *, false, true, true>", "k_emit<1, 2>")}
 scan = kernel("k_scan")
 for name, (fk, ek) in cfgs.items():
     f, e = kernel(fk), kernel(ek)
@@ -83,6 +84,10 @@ for name, (fk, ek) in cfgs.items():
                      "hbm_bytes_sum_fetch_x2": traffic, "traffic_ratio": traffic / algo if traffic and algo else None,
                      "bench_line_frac": line["extra"][name]["frac"] if line else None,
                      "bench_line_kernel_ms": line["extra"][name]["kernel_ms"] if line else None}
+agg = kernel("k_group_agg_lanes<1, 1>")   # both aggregation configs of the extra block run this kernel (all rows / sigma = 0.11): same cost per tile
+summary["agg_group_by_state"] = dict(agg, algorithmic_bytes_all_rows=312.5e6, frac_all_rows=312.5e6 / (agg["avg_us"] * 1e-6) / 8e12,
+                                     traffic_ratio_all_rows=agg["hbm_bytes_fetch_x2"] / 312.5e6 if agg["hbm_bytes_fetch_x2"] else None,
+                                     bench_line={k: line["extra"][k]["kernel_ms"] for k in ("agg_group_by_state_all_rows", "agg_group_by_state_range_age")} if line else None)
 json.dump(summary, open(os.path.join(out, f"{tag}_summary.json"), "w"), indent=1)
 t = summary["c2_headline"]
 json.dump({"workload": "range_filter_i32", "rows": 100_000_000, "kernel": t["kernel"], "tag": tag,
