@@ -227,6 +227,25 @@ done:
     return out;
 }
 
+/* ---- graphs: record the runs of a set of queries once, replay them with one call per execution ---- */
+JNIEXPORT void JNICALL Java_immutabledb_gpu_Native_00024_captureBegin(JNIEnv *env, jobject self, jlong ctx) {
+    if (imm3_ctx_capture_begin((imm3_ctx *)(intptr_t)ctx) != IMM3_OK) throw_last(env);
+}
+
+JNIEXPORT jlong JNICALL Java_immutabledb_gpu_Native_00024_captureEnd(JNIEnv *env, jobject self, jlong ctx) {
+    imm3_graph *g = NULL;
+    if (imm3_ctx_capture_end((imm3_ctx *)(intptr_t)ctx, &g) != IMM3_OK) throw_last(env);
+    return (jlong)(intptr_t)g;
+}
+
+JNIEXPORT void JNICALL Java_immutabledb_gpu_Native_00024_graphLaunch(JNIEnv *env, jobject self, jlong g) {
+    if (imm3_graph_launch((imm3_graph *)(intptr_t)g) != IMM3_OK) throw_last(env);
+}
+
+JNIEXPORT void JNICALL Java_immutabledb_gpu_Native_00024_graphDestroy(JNIEnv *env, jobject self, jlong g) {
+    imm3_graph_destroy((imm3_graph *)(intptr_t)g);
+}
+
 JNIEXPORT void JNICALL Java_immutabledb_gpu_Native_00024_commDestroy(JNIEnv *env, jobject self, jlong c) {
     imm3_comm_destroy((imm3_comm *)(intptr_t)c);
 }

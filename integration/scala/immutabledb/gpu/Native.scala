@@ -40,6 +40,12 @@ object Native {
   @native def queryRowCount(q: Long): Long
   @native def queryFetchRows(q: Long, rowIndex: ByteBuffer, cols: Array[ByteBuffer], maxRows: Long): Unit
 
+  // ---- graphs: between captureBegin and captureEnd, queryRun records instead of executing; graphLaunch replays the lot ----
+  @native def captureBegin(ctx: Long): Unit
+  @native def captureEnd(ctx: Long): Long
+  @native def graphLaunch(graph: Long): Unit
+  @native def graphDestroy(graph: Long): Unit
+
   // ---- multi-GPU: one context per device, one communicator per context (imm3_comm_create_all = ncclCommInitAll) ----
   @native def commCreateAll(ctxs: Array[Long]): Array[Long]
   @native def commDestroy(comm: Long): Unit
