@@ -33,6 +33,9 @@ cases = {
 import os
 VARIANT = int(os.environ.get("IMM3_VARIANT", "0"))
 grids = [int(g) for g in sys.argv[1:]] or [0]
+ONLY = [c for c in os.environ.get("IMM3_KINDS", "").split(",") if c]
+if ONLY:
+    cases = {k: v for k, v in cases.items() if k in ONLY}
 print(f"{'kinds':12s} {'grid':>6s} {'us':>8s} {'GB/s (cols + bitmap)':>22s} {'% of 8 TB/s':>12s}")
 for name, (used, sels, bpr) in [(k, v) for k, v in cases.items() for _ in grids]:
     pass
