@@ -116,7 +116,7 @@ constexpr RecField rec_layout(const int (&kinds)[kMaxTileCols], int col) {
 }
 
 // k_emit: ProjectOp from the staged records
-constexpr int kEmitTiles = 64;      // tiles per emit work-group (kChunkTiles % kEmitTiles == 0)
+constexpr int kEmitTiles = 32;      // tiles per emit work-group (kChunkTiles % kEmitTiles == 0).  32 beat 64 on C3 (34 -> 31 us) and on clustered survivors (2 % contiguous: 77 -> 40 us), lost on 50 % contiguous (167 -> 196 us); 16 lost on C4 (50 -> 60 us)
 constexpr int kMaxEmitGather = 4;   // SELECT-list columns that are not predicate columns: gathered at the record's position
 struct EmitCol {
     void *dst;                      // packed output, width bytes per emitted row

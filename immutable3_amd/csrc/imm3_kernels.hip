@@ -843,7 +843,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_gather_plain(const GatherArgs
 // ---------------------------------------------------------------------------------------------
 // k_emit: ProjectOp over the survivor records the filter kernel staged (one uniform segment, unlimited projection).
 // One work-group per group of kEmitTiles tiles; the group's tile offsets sit in LDS and every THREAD owns one output
-// row: it finds the row's tile by binary search in LDS (6 steps), loads the row's record, takes the staged columns
+// row: it finds the row's tile by binary search in LDS (log2 kEmitTiles steps), loads the row's record, takes the staged columns
 // out of it, gathers the others at the record's position -- all NG gathers of all kEmitUnroll rows in flight
 // together -- and stores.  No bitmap expansion, no per-tile lane waste (a tile has ~20 survivors at 2 % selectivity,
 // ~100 at 10 %), every thread independent of every other.
