@@ -1109,8 +1109,9 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
     q->d_chunk_sums = (uint32_t *)p;
     HIPCHK(pool_alloc(ctx, &p, kMaxFilterGrid * sizeof(uint32_t)));
     q->d_block_partials = (uint32_t *)p;
-    HIPCHK(pool_alloc(ctx, &p, 8 * sizeof(unsigned long long))); // {total, n_emit, status, limit, tally, log, log index, log capacity}
+    HIPCHK(pool_alloc(ctx, &p, kFinishWords * sizeof(unsigned long long))); // {total, n_emit, status, limit, tally, log, log index, log capacity}, then the sub-tallies (imm3_device.h)
     q->d_total = (unsigned long long *)p;
+    HIPCHK(hipMemsetAsync(q->d_total, 0, kFinishWords * sizeof(unsigned long long), ctx->stream));
     q->d_n_emit = q->d_total + 1;
     std::memset(q->h_init, 0, sizeof(q->h_init)); // lives as long as the query; creation ends with a stream sync anyway
     q->h_init[3] = (unsigned long long)limit;
@@ -1499,10 +1500,10 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
         if (ctx->d_stamps && ctx->stamp_used < ctx->stamp_slots) a.stamps = ctx->d_stamps + (size_t)ctx->stamp_used * kMaxFilterGrid * 2;
         grid = filter_grid(q->n_tiles, false, any_i32, ctx->grid_blocks); // (no column at all: the store-only kernel also likes 1536 groups, 9.9 vs 17.2 us)
         if (q->stage_written) grid = q->stage_grid; // fixed at creation: the arena layout depends on it
-        // A select chain that is ONE tile pass also reduces its count in the kernel (one relaxed atomic per work-group): no
-        // k_total launch.  Only at <= 512 work-groups: same-address atomics serialise at ~12 ns each, and 1536-2048 of them
-        // at the tail of a short kernel cost more than the launch they save (int8: 32 vs 25 + 4 us).  Variant 7 = never.
-        if (single_tile_pass && !overlap_total && ctx->filter_variant != 7 && (grid <= 512 || ctx->filter_variant == 11)) {
+        // A select chain that is ONE tile pass also reduces its count in the kernel (one relaxed atomic per work-group into a
+        // two-level tally, finish_add): no k_total launch.  Variant 7 = never; variant 13 = only at <= 512 work-groups (what
+        // round 1 did: with a single tally the 1536 atomics of a narrow-column launch cost more than the launch they saved).
+        if (single_tile_pass && !overlap_total && ctx->filter_variant != 7 && (grid <= 512 || ctx->filter_variant != 13)) {
             a.finish = q->d_total;
             count_done = true;
         }

@@ -73,10 +73,23 @@ __device__ __forceinline__ void count_log_append(unsigned long long *finish, uns
 // to re-read, no ordering between two atomics, and no release/acquire fence (a device-scope fence writes back and
 // invalidates the XCD's L2: one per work-group made the scan 25 % slower).  One atomic per work-group, spread over the
 // kernel's tail, unlike the per-wave atomics of finding 1.
+// Work-groups of one launch are equally long and end together, so with a single tally their atomics arrive back to back
+// at one address: ~12 ns each, 1536 of them were 7 us of serial tail on a 20 us kernel (which is why round 1 reduced the
+// counts of such launches in a k_total launch of its own instead).  The tally is therefore two-level: work-group b adds
+// to sub-tally b % kSubTallies (each on a 128-byte line of its own), the last arrival there carries the sub-total to the
+// top tally, the last arrival there publishes.  Serial depth grid / 32 + 32 instead of grid.
 // one thread per work-group: add this work-group's survivors; the last arrival publishes the total
 __device__ __forceinline__ void finish_add(unsigned long long *finish, unsigned long long t) {
-    const unsigned long long prev = __hip_atomic_fetch_add(finish + 4, t | (1ULL << 40), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((prev >> 40) == (unsigned long long)gridDim.x - 1) {
+    const unsigned int grid = gridDim.x, sub = blockIdx.x % kSubTallies;
+    const unsigned int peers = (grid - sub + kSubTallies - 1) / kSubTallies; // work-groups b < grid with b % kSubTallies == sub
+    unsigned long long *st = finish + 16 + 16 * sub;
+    unsigned long long prev = __hip_atomic_fetch_add(st, t | (1ULL << 40), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((prev >> 40) != (unsigned long long)peers - 1) return;
+    t += prev & ((1ULL << 40) - 1);
+    __hip_atomic_store(st, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
+    const unsigned int tops = grid < (unsigned int)kSubTallies ? grid : (unsigned int)kSubTallies;
+    prev = __hip_atomic_fetch_add(finish + 4, t | (1ULL << 40), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((prev >> 40) == (unsigned long long)tops - 1) {
         const unsigned long long total = (prev & ((1ULL << 40) - 1)) + t;
         const long long limit = (long long)finish[3];
         finish[0] = total;

@@ -249,6 +249,8 @@ struct AggArgs {
 void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 void launch_group_collect(const AggArgs &a, hipStream_t s);
 
+constexpr int kSubTallies = 32;                       // in-kernel count reduce: sub-tallies (finish_add, imm3_device.h)
+constexpr int kFinishWords = 16 + kSubTallies * 16;   // u64 words of a query's `finish` block: header (8, padded to a 128-byte line) + one line per sub-tally
 constexpr int kMaxFilterGrid = 4096; // capacity of block_partials
 int filter_grid(int64_t units, bool generic, bool any_i32, int grid_blocks);
 // ev0/ev1: optional events stamped with the kernel's own start/end (hipExtLaunchKernelGGL), else null

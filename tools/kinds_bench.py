@@ -52,6 +52,11 @@ for name, (used, sels, bpr) in cases.items():
     ctx.sync()
     ms = float(np.median(ctx.timing_collect(0)))
     ctx.timing_enable(0)
+    import time
+    ctx.sync(); t0 = time.perf_counter()
+    for _ in range(200):
+        q.run_select()
+    ctx.sync(); step_us = (time.perf_counter() - t0) / 200 * 1e6   # whole select: kernel(s) + count reduce, back to back
     gbs = (bpr + 0.125) * n / (ms * 1e-3) / 1e9
-    print(f"{name:12s} {grid:6d} {ms * 1e3:8.1f} {gbs:22.0f} {gbs / 80:11.1f}%")
+    print(f"{name:12s} {grid:6d} {ms * 1e3:8.1f} {gbs:22.0f} {gbs / 80:11.1f}%   step {step_us:6.1f} us")
     q.close()
