@@ -156,3 +156,29 @@ def test_headline_kernel_meets_the_north_star_roofline_target(big):
     q.close()
     gbps = 4.125 * N / (ms * 1e-3) / 1e9
     assert gbps >= 0.60 * 8000.0, f"scan+select kernel at {gbps:.0f} GB/s ({ms * 1e3:.1f} us)"
+
+
+def test_group_by_state_100m(big):
+    """Group-by aggregation at the bench's size (k_group_agg_lanes), all rows and under a range predicate, against a numpy
+    evaluation: group keys in first-seen order, counts, max / min of the int8 column, first rows."""
+    from immutable3_amd import native
+    ctx, seg, ids, age, st = big
+    code = st.view("<u2").reshape(-1)                           # the two bytes of a state, little-endian
+    for sels, keep in (([], None), ([(1, GT, 18.0), (1, LT, 30.0)], (age > 18) & (age < 30))):
+        for kind, red in ((native.AGG_MAX, np.maximum), (native.AGG_MIN, np.minimum)):
+            q = native.DeviceQuery(ctx, seg, [0, 1, 2], sels, (), 0, 1024, group_cols=[2], aggs=[(native.AGG_COUNT, 0), (kind, 1)])
+            q.run()
+            keys, first, counts, vals = q.fetch_groups()
+            q.close()
+            rows = np.arange(N) if keep is None else np.flatnonzero(keep)
+            c, a = code[rows], age[rows]
+            uniq, first_pos = np.unique(c, return_index=True)
+            order = np.argsort(first_pos)                       # first-seen order
+            want_keys = uniq[order]
+            assert keys.astype(np.uint64).tolist() == want_keys.astype(np.uint64).tolist()
+            assert first.tolist() == rows[first_pos[order]].tolist()
+            cnt = np.bincount(c, minlength=65536)
+            assert counts.tolist() == cnt[want_keys].tolist() and int(counts.sum()) == rows.size
+            ext = np.full(65536, -128 if kind == native.AGG_MAX else 127, np.int8)
+            red.at(ext, c, a)
+            assert vals[:, 1].tolist() == ext[want_keys].astype(np.int64).tolist()
