@@ -614,8 +614,8 @@ __global__ __launch_bounds__(kDirectThreads) void k_group_agg_direct(const AggAr
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_group_agg_lanes: group key <= 2 bytes, at most 63 distinct keys, at most one min / max aggregate -- NO ATOMICS on the
-// row path.  LDS atomics retire ~1.4 lanes per cycle per CU on this chip whatever the addresses, which made two atomics
+// k_group_agg_lanes: group key <= 2 bytes, at most 63 distinct keys, one min / max aggregate (or two over 1-byte columns) and
+// any number of counts -- NO ATOMICS on the row path.  LDS atomics retire ~1.4 lanes per cycle per CU on this chip whatever the addresses, which made two atomics
 // per row (count + max) 230 us per 100 M rows in k_group_agg_direct.  Here every LANE owns a private table
 // [slot][lane] in LDS, so an update is a plain ds_read + ds_write at full LDS rate that never conflicts (lane l always
 // hits bank l).  What that needs:
@@ -647,11 +647,14 @@ struct LanesShared { // fixed part of the dynamic LDS; [l2 .. first] start as al
     uint32_t slotkey[kLaneSlots];
     uint32_t count[kLaneSlots];
     uint32_t val[kLaneSlots];
+    uint32_t val2[kLaneSlots];
     uint32_t nslots, npages, pad[2];
 };
 constexpr int kLanesOnesBytes = (kLanePages + 1) * 256 + kLaneSlots * 4;
 constexpr int kLanesFixedBytes = (int)((sizeof(LanesShared) + 255) / 256 * 256);
-constexpr int lanes_wave_bytes(int vw) { return vw <= 1 ? kLaneSlots * 64 * 2 + kLaneSlots * 4 : kLaneSlots * 64 * (vw == 4 ? 2 + 4 : 4); }
+constexpr int lanes_wave_bytes(int vw, bool v2 = false) {
+    return v2 ? kLaneSlots * 64 * 4 + kLaneSlots * 4 : (vw <= 1 ? kLaneSlots * 64 * 2 + kLaneSlots * 4 : kLaneSlots * 64 * (vw == 4 ? 2 + 4 : 4));
+}
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 
@@ -718,25 +721,28 @@ __device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
 }
 
-// KS: key shape -- 0: one 1-byte column, 1: one 2-byte column, 2: two 1-byte columns.  VW: bytes of the aggregated column (0: counts only)
-template <int KS, int VW>
-__global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const int vq) {
+// KS: key shape -- 0: one 1-byte column, 1: one 2-byte column, 2: two 1-byte columns.  VW: bytes of the aggregated column (0: counts only).
+// V2: a second min / max aggregate, both over 1-byte columns (e.g. max(age), min(age)).
+template <int KS, int VW, bool V2>
+__global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const int vq, const int vq2) {
+    static_assert(!V2 || VW == 1, "two value aggregates: 1-byte columns only");
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[]; // the waves' private tables
     __shared__ LanesShared S; // (static: its addresses fold into the LDS instructions' offset fields)
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int n_waves = (int)(blockDim.x >> 6);
-    constexpr int kWaveBytes = lanes_wave_bytes(VW);
+    constexpr int kWaveBytes = lanes_wave_bytes(VW, V2);
     constexpr int NV = VW == 4 ? 4 : (VW == 2 ? 2 : 1);
     // entry of one (slot, lane):  VW 0: u16 count.  VW 1: u16 = value << 8 | count, the 8-bit counts folded into a per-wave
     // u32 table every 15 tiles (a lane adds at most 16 per tile).  VW 2: u32 = value << 16 | count.  VW 4: u16 count + u32 value.
     // The 16-bit forms halve the tables, which is what doubles the waves per CU (16): the row path is latency-bound.
-    constexpr bool kE16 = VW <= 1;
+    // V2: u32 = value2 << 16 | value << 8 | count, counts folded like VW 1.
+    constexpr bool kE16 = VW <= 1 && !V2;
     constexpr bool kPacked = VW == 2;
     uint8_t *wbase = s_dyn + wave * kWaveBytes;
     uint16_t *t16 = (uint16_t *)wbase + (lane & 31) * 2 + (lane >> 5);      // 16-bit: [slot * 64]; lanes l and l + 32 share a dword, so each half-wave hits 32 banks
-    uint32_t *wcnt = (uint32_t *)(wbase + kLaneSlots * 64 * 2);             // VW 1: [slot] counts folded so far (owned by lane = slot)
+    uint32_t *wcnt = (uint32_t *)(wbase + kLaneSlots * 64 * (V2 ? 4 : 2));  // VW 1: [slot] counts folded so far (owned by lane = slot)
     uint32_t *tab = (uint32_t *)wbase + lane;                               // packed: [slot * 64]
     uint16_t *cnt = (uint16_t *)wbase + lane;                               // VW == 4: counts [slot * 64] ...
     uint32_t *val = (uint32_t *)(wbase + kLaneSlots * 64 * 2) + lane;       // ... and values [slot * 64]
@@ -753,6 +759,13 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
         vstr = a.aggs[vq].is_str != 0;
         vflip = (vstr ? 0u : (1u << (8 * VW - 1))) ^ (a.aggs[vq].kind == AGG_MIN ? vmask : 0u);
     }
+    uint32_t vflip2 = 0;
+    bool vstr2 = false, same2 = false;
+    if constexpr (V2) {
+        vstr2 = a.aggs[vq2].is_str != 0;
+        vflip2 = (vstr2 ? 0u : 0x80u) ^ (a.aggs[vq2].kind == AGG_MIN ? 0xFFu : 0u);
+        same2 = a.aggs[vq2].data == a.aggs[vq].data; // e.g. max(age), min(age): one load serves both
+    }
     const int sh0 = 8 * a.groups[0].shift, sh1 = KS == 2 ? 8 * a.groups[1].shift : 0;
     uint64_t seen = 0; // slots this wave has met (wave-uniform)
 
@@ -761,7 +774,7 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
     // after its tile is done and used kDepth tiles later; loads past the wave's last tile re-read the last tile (no branch).
     struct TileRegs {
         uint32_t bits; // rows 16 * lane ..: bits 16 * lane .. of the tile's 1024
-        v4i_t kr0[KS == 1 ? 2 : 1], kr1[1], vr[NV];
+        v4i_t kr0[KS == 1 ? 2 : 1], kr1[1], vr[NV], vr2[1];
     };
     constexpr int kDepth = VW == 2 ? 3 : 2; // (16-bit entries: 16 waves per CU, two tiles ahead suffice; VW 4: registers)
     const int64_t stride = (int64_t)gridDim.x * n_waves;
@@ -772,17 +785,31 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
         load_lane_rows<(KS == 1 ? 2 : 1)>(a.groups[0].data, tile, lane, r.kr0);
         if constexpr (KS == 2) load_lane_rows<1>(a.groups[1].data, tile, lane, r.kr1);
         if constexpr (VW != 0) load_lane_rows<(VW ? VW : 1)>(a.aggs[vq].data, tile, lane, r.vr);
+        if constexpr (V2) {
+            if (!same2) load_lane_rows<1>(a.aggs[vq2].data, tile, lane, r.vr2); // wave-uniform
+        }
     };
     int since_fold = 0; // VW 1: tiles since the 8-bit counts were folded (wave-uniform)
     auto fold_counts = [&]() { // lane = slot: move the 64 lanes' 8-bit counts of its slot into wcnt (rotated: lanes on different banks)
-        uint16_t *row = (uint16_t *)wbase + lane * 64;
         uint32_t c = 0;
+        if constexpr (V2) {
+            uint32_t *row = (uint32_t *)wbase + lane * 64;
 #pragma unroll 4
-        for (int j = 0; j < 64; ++j) {
-            const int idx = (j + lane) & 63;
-            const uint32_t e = row[idx];
-            c += e & 0xFFu;
-            row[idx] = (uint16_t)(e & 0xFF00u);
+            for (int j = 0; j < 64; ++j) {
+                const int idx = (j + lane) & 63;
+                const uint32_t e = row[idx];
+                c += e & 0xFFu;
+                row[idx] = e & ~0xFFu;
+            }
+        } else {
+            uint16_t *row = (uint16_t *)wbase + lane * 64;
+#pragma unroll 4
+            for (int j = 0; j < 64; ++j) {
+                const int idx = (j + lane) & 63;
+                const uint32_t e = row[idx];
+                c += e & 0xFFu;
+                row[idx] = (uint16_t)(e & 0xFF00u);
+            }
         }
         wcnt[lane] += c;
     };
@@ -792,6 +819,7 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
         const auto &kr0 = r.kr0;
         const auto &kr1 = r.kr1;
         const auto &vr = r.vr;
+        const auto &vr2 = r.vr2;
         if (a.debug == 44) { // (ablation: loads only)
             asm volatile("" ::"v"(kr0[0]), "v"(kr0[KS == 1 ? 1 : 0]), "v"(vr[0]), "v"(vr[NV - 1]));
             return;
@@ -874,7 +902,13 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
                 if (vstr) raw = VW == 4 ? __builtin_bswap32(raw) : (VW == 2 ? (uint32_t)__builtin_bswap16((uint16_t)raw) : raw); // big-endian pack: integer order == byte order
                 x = (raw ^ vflip) & vmask;
             }
-            if constexpr (kE16) {
+            if constexpr (V2) {
+                uint32_t raw2 = lane_row_value<1>(vr2, i);
+                raw2 = same2 ? lane_row_value<1>(vr, i) : raw2;
+                const uint32_t x2 = (raw2 ^ vflip2) & 0xFFu; // (1-byte strings need no byte swap)
+                const uint32_t old = tab[s * 64];
+                tab[s * 64] = ((old + 1u) & 0xFFu) | max(old & 0xFF00u, x << 8) | max(old & 0xFF0000u, x2 << 16);
+            } else if constexpr (kE16) {
                 const uint32_t old = t16[s * 64];
                 if constexpr (VW == 0) t16[s * 64] = (uint16_t)(old + 1u); // (a lane's count stays below 2^16: lanes_plan)
                 else t16[s * 64] = (uint16_t)(((old + 1u) & 0xFFu) | (max(old, x << 8) & 0xFF00u));
@@ -898,7 +932,7 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
             if (tile < a.n_tiles) process(R[d], tile); // wave-uniform
             issue(R[d], tile + kDepth * stride);
         }
-        if constexpr (VW == 1) {
+        if constexpr (VW == 1) { // (with or without a second value)
             since_fold += kDepth;
             if (since_fold + kDepth > 15) { // 15 x 16 rows: the 8-bit counts are still below 256
                 fold_counts();
@@ -910,14 +944,18 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
 
     // fold: lane = slot; it sums / maxes its slot over the 64 lanes' private entries (rotated so that lanes hit different banks)
     {
-        uint32_t c = 0, m = 0;
+        uint32_t c = 0, m = 0, m2 = 0;
         if constexpr (VW == 1) {
             fold_counts();
             c = wcnt[lane];
         }
         for (int l = 0; l < 64; ++l) {
             const int src = (l + lane) & 63;
-            if constexpr (kE16) {
+            if constexpr (V2) {
+                const uint32_t e = ((const uint32_t *)wbase)[lane * 64 + src];
+                m = max(m, (e >> 8) & 0xFFu);
+                m2 = max(m2, (e >> 16) & 0xFFu);
+            } else if constexpr (kE16) {
                 const uint32_t e = ((const uint16_t *)wbase)[lane * 64 + src];
                 if constexpr (VW == 0) c += e;
                 else m = max(m, e >> 8);
@@ -933,6 +971,7 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
         if (lane < kLaneTrash && c) {
             atomicAdd(&S.count[lane], c);
             if constexpr (VW != 0) atomicMax(&S.val[lane], m);
+            if constexpr (V2) atomicMax(&S.val2[lane], m2);
         }
     }
     __syncthreads();
@@ -945,6 +984,10 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
             if constexpr (VW != 0) {
                 const uint32_t u = (S.val[t] ^ vflip) & vmask;
                 vals[vq] = vstr ? (long long)(unsigned long long)u : (VW == 4 ? (long long)(int32_t)u : (VW == 2 ? (long long)(int16_t)u : (long long)(int8_t)u));
+            }
+            if constexpr (V2) {
+                const uint32_t u2 = (S.val2[t] ^ vflip2) & 0xFFu;
+                vals[vq2] = vstr2 ? (long long)(unsigned long long)u2 : (long long)(int8_t)u2;
             }
             agg_update_global(a, g, S.first[t], (unsigned long long)S.count[t], vals);
         }
@@ -1014,7 +1057,7 @@ bool group_agg_fast_ok(const AggArgs &a) {
 }
 
 // which form of k_group_agg_lanes takes this aggregation (false: none).  waves: as many as the LDS holds.
-struct LanesPlan { int ks, vw, vq, waves, lds_bytes; };
+struct LanesPlan { int ks, vw, vq, vq2, v2, waves, lds_bytes; };
 static bool lanes_plan(const AggArgs &a, LanesPlan &p) {
     if (!group_agg_fast_ok(a)) return false;
     if (a.n_group == 1 && a.groups[0].width == 1) p.ks = 0;
@@ -1022,16 +1065,23 @@ static bool lanes_plan(const AggArgs &a, LanesPlan &p) {
     else if (a.n_group == 2 && a.groups[0].width == 1 && a.groups[1].width == 1 && a.groups[0].shift + a.groups[1].shift == 1) p.ks = 2;
     else return false;
     p.vw = 0;
-    p.vq = 0;
+    p.vq = p.vq2 = 0;
+    p.v2 = 0;
     int n_val = 0;
     for (int q = 0; q < a.n_agg; ++q)
         if (a.aggs[q].kind != AGG_COUNT) {
+            if (n_val == 0) {
+                p.vq = q;
+                p.vw = a.aggs[q].width;
+            } else p.vq2 = q;
             ++n_val;
-            p.vq = q;
-            p.vw = a.aggs[q].width;
         }
-    if (n_val > 1) return false;
-    const int per_wave = lanes_wave_bytes(p.vw);
+    if (n_val > 2) return false;
+    if (n_val == 2) { // two min / max aggregates: both over 1-byte columns
+        if (p.vw != 1 || a.aggs[p.vq2].width != 1) return false;
+        p.v2 = 1;
+    }
+    const int per_wave = lanes_wave_bytes(p.vw, p.v2 != 0);
     p.waves = std::min(16, (160 * 1024 - kLanesFixedBytes) / per_wave);
     const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((a.n_tiles + p.waves - 1) / p.waves, 256));
     const int64_t tiles_per_wave = (a.n_tiles + grid * p.waves - 1) / (grid * p.waves);
@@ -1040,15 +1090,15 @@ static bool lanes_plan(const AggArgs &a, LanesPlan &p) {
     return true;
 }
 
-template <int KS, int VW>
+template <int KS, int VW, bool V2>
 static void launch_lanes(const AggArgs &a, const LanesPlan &p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     static bool raised = false; // (the limit is per kernel function, process wide)
     if (!raised) {
-        (void)hipFuncSetAttribute((const void *)k_group_agg_lanes<KS, VW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - kLanesFixedBytes);
+        (void)hipFuncSetAttribute((const void *)k_group_agg_lanes<KS, VW, V2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - kLanesFixedBytes);
         raised = true;
     }
     const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((a.n_tiles + p.waves - 1) / p.waves, 256)); // one work-group per CU
-    IMM3_LAUNCH_LDS((k_group_agg_lanes<KS, VW>), (unsigned)grid, p.waves * 64, (size_t)p.lds_bytes, s, ev0, ev1, a, p.vq);
+    IMM3_LAUNCH_LDS((k_group_agg_lanes<KS, VW, V2>), (unsigned)grid, p.waves * 64, (size_t)p.lds_bytes, s, ev0, ev1, a, p.vq, p.vq2);
 }
 
 void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
@@ -1059,7 +1109,13 @@ void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_
     for (int g = 0; g < a.n_group; ++g) key_bytes += a.groups[g].width;
     LanesPlan lp;
     if ((a.debug == 0 || a.debug >= 40) && lanes_plan(a, lp)) { // private per-lane tables, no atomics (debug 7: skip -- also what the host does after an overflow = 3)
-#define IMM3_LANES(KS, VW) if (lp.ks == KS && lp.vw == VW) { launch_lanes<KS, VW>(a, lp, s, ev0, ev1); return; }
+#define IMM3_LANES(KS, VW) if (lp.ks == KS && lp.vw == VW && !lp.v2) { launch_lanes<KS, VW, false>(a, lp, s, ev0, ev1); return; }
+        if (lp.v2) {
+            if (lp.ks == 0) launch_lanes<0, 1, true>(a, lp, s, ev0, ev1);
+            else if (lp.ks == 1) launch_lanes<1, 1, true>(a, lp, s, ev0, ev1);
+            else launch_lanes<2, 1, true>(a, lp, s, ev0, ev1);
+            return;
+        }
         IMM3_LANES(0, 0) IMM3_LANES(0, 1) IMM3_LANES(0, 2) IMM3_LANES(0, 4)
         IMM3_LANES(1, 0) IMM3_LANES(1, 1) IMM3_LANES(1, 2) IMM3_LANES(1, 4)
         IMM3_LANES(2, 0) IMM3_LANES(2, 1) IMM3_LANES(2, 2) IMM3_LANES(2, 4)

@@ -203,6 +203,11 @@ LANES_CASES = [
     ([3], [("min", 0)]),                                     # KS 0, VW 4
     ([3, 1], [("count", 0), ("max", 4)]),                    # KS 2 (two byte columns), VW 2
     ([1, 3], [("min", 1)]),                                  # KS 2, other column order
+    ([2], [("max", 1), ("min", 1), ("count", 0)]),           # two value aggregates over the same 1-byte column
+    ([2], [("min", 3), ("count", 2), ("max", 1)]),           # ... over two 1-byte columns
+    ([3], [("max", 1), ("min", 3)]),                         # ... KS 0
+    ([3, 1], [("min", 1), ("max", 1)]),                      # ... KS 2
+    ([2], [("max", 0), ("max", 1)]),                         # 4 + 1 bytes: not a lanes shape (k_group_agg_direct), same answers
 ]
 
 
