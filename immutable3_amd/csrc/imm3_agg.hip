@@ -633,9 +633,8 @@ __global__ __launch_bounds__(kDirectThreads) void k_group_agg_direct(const AggAr
 //     handed out so far (warm-up, or a key this wave has not met) its rows of new slots do an atomic min.
 // Too many keys / pages raises overflow = 3 and the host re-runs k_group_agg_direct.
 // ---------------------------------------------------------------------------------------------
-constexpr int kLaneSlots = 64;  // per-lane table rows; the last one is the trash slot
+constexpr int kLaneSlots = 128; // most per-lane table rows of any instance (template parameter NS: 64 or 128); the last row is the trash slot
 constexpr int kLanePages = 30;  // second-level pages: 0 is the null page (every first byte starts there: all entries free), 1 .. 29 real
-constexpr int kLaneTrash = kLaneSlots - 1;
 constexpr uint32_t kMapFree = 255u, kMapClaimed = 254u, kMapFull = 253u; // second-level bytes that are not a slot number
 // first-level bytes: 0 = free (the null page), 1 .. 29 = page, 254 / 253 = claimed / full -- a lookup clamps those to page
 // kLanePages, a second null page, so that the row path needs no compare
@@ -652,8 +651,8 @@ struct LanesShared { // fixed part of the dynamic LDS; [l2 .. first] start as al
 };
 constexpr int kLanesOnesBytes = (kLanePages + 1) * 256 + kLaneSlots * 4;
 constexpr int kLanesFixedBytes = (int)((sizeof(LanesShared) + 255) / 256 * 256);
-constexpr int lanes_wave_bytes(int vw, bool v2 = false) {
-    return v2 ? kLaneSlots * 64 * 4 + kLaneSlots * 4 : (vw <= 1 ? kLaneSlots * 64 * 2 + kLaneSlots * 4 : kLaneSlots * 64 * (vw == 4 ? 2 + 4 : 4));
+constexpr int lanes_wave_bytes(int vw, bool v2 = false, int ns = 64) {
+    return v2 ? ns * 64 * 4 + ns * 4 : (vw <= 1 ? ns * 64 * 2 + ns * 4 : ns * 64 * (vw == 4 ? 2 + 4 : 4));
 }
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
@@ -696,17 +695,17 @@ __device__ __forceinline__ uint32_t map_byte(uint8_t *map, uint32_t idx, uint32_
     return b == kMapClaimed ? free : b;
 }
 
-// slot of key k: 0 .. 62, kLaneTrash when the form is full, kMapFree: not placed yet, ask again
+// slot of key k: 0 .. trash - 1, `trash` when the form is full, kMapFree: not placed yet, ask again
 template <int KS>
-__device__ __forceinline__ uint32_t lanes_slot(LanesShared &S, uint32_t k, uint32_t *overflow) {
+__device__ __forceinline__ uint32_t lanes_slot(LanesShared &S, uint32_t k, uint32_t trash, uint32_t *overflow) {
     uint32_t pg = 1; // one-byte keys: page 1, no first level
     bool placed;
     if constexpr (KS != 0) {
         pg = map_byte(S.l1, k & 0xFFu, 0u, &S.npages, (uint32_t)kLanePages, kMapFull, overflow, placed); // (npages starts at 1)
         if (pg == 0u) return kMapFree;
-        if (pg == kMapFull) return kLaneTrash;
+        if (pg == kMapFull) return trash;
     }
-    const uint32_t id = map_byte(S.l2, (pg << 8) | (KS == 0 ? (k & 0xFFu) : (k >> 8)), kMapFree, &S.nslots, (uint32_t)kLaneTrash, (uint32_t)kLaneTrash, overflow, placed);
+    const uint32_t id = map_byte(S.l2, (pg << 8) | (KS == 0 ? (k & 0xFFu) : (k >> 8)), kMapFree, &S.nslots, trash, trash, overflow, placed);
     if (placed) S.slotkey[id] = k; // (read after the work-group barrier that precedes the flush)
     return id;
 }
@@ -723,16 +722,20 @@ __device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
 
 // KS: key shape -- 0: one 1-byte column, 1: one 2-byte column, 2: two 1-byte columns.  VW: bytes of the aggregated column (0: counts only).
 // V2: a second min / max aggregate, both over 1-byte columns (e.g. max(age), min(age)).
-template <int KS, int VW, bool V2>
+// NS: rows of a lane's table (64 or 128, the last one the trash slot): 63 or 127 distinct keys per work-group.
+template <int KS, int VW, bool V2, int NS>
 __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const int vq, const int vq2) {
     static_assert(!V2 || VW == 1, "two value aggregates: 1-byte columns only");
+    static_assert(NS == 64 || NS == 128, "the map's markers (253 .. 255) must have a bit set that no slot number has");
+    constexpr uint32_t kTrash = NS - 1;
+    constexpr int kWords = NS / 64; // 64-bit words of a slot set
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[]; // the waves' private tables
     __shared__ LanesShared S; // (static: its addresses fold into the LDS instructions' offset fields)
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int n_waves = (int)(blockDim.x >> 6);
-    constexpr int kWaveBytes = lanes_wave_bytes(VW, V2);
+    constexpr int kWaveBytes = lanes_wave_bytes(VW, V2, NS);
     constexpr int NV = VW == 4 ? 4 : (VW == 2 ? 2 : 1);
     // entry of one (slot, lane):  VW 0: u16 count.  VW 1: u16 = value << 8 | count, the 8-bit counts folded into a per-wave
     // u32 table every 15 tiles (a lane adds at most 16 per tile).  VW 2: u32 = value << 16 | count.  VW 4: u16 count + u32 value.
@@ -742,10 +745,10 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
     constexpr bool kPacked = VW == 2;
     uint8_t *wbase = s_dyn + wave * kWaveBytes;
     uint16_t *t16 = (uint16_t *)wbase + (lane & 31) * 2 + (lane >> 5);      // 16-bit: [slot * 64]; lanes l and l + 32 share a dword, so each half-wave hits 32 banks
-    uint32_t *wcnt = (uint32_t *)(wbase + kLaneSlots * 64 * (V2 ? 4 : 2));  // VW 1: [slot] counts folded so far (owned by lane = slot)
+    uint32_t *wcnt = (uint32_t *)(wbase + NS * 64 * (V2 ? 4 : 2));  // VW 1: [slot] counts folded so far (owned by lane = slot)
     uint32_t *tab = (uint32_t *)wbase + lane;                               // packed: [slot * 64]
     uint16_t *cnt = (uint16_t *)wbase + lane;                               // VW == 4: counts [slot * 64] ...
-    uint32_t *val = (uint32_t *)(wbase + kLaneSlots * 64 * 2) + lane;       // ... and values [slot * 64]
+    uint32_t *val = (uint32_t *)(wbase + NS * 64 * 2) + lane;               // ... and values [slot * 64]
     for (int i = t; i < (int)(sizeof(LanesShared) / 4); i += (int)blockDim.x) ((uint32_t *)&S)[i] = i < kLanesOnesBytes / 4 ? 0xFFFFFFFFu : 0u; // l2 + first: ones
     for (int i = t; i < n_waves * kWaveBytes / 4; i += (int)blockDim.x) ((uint32_t *)s_dyn)[i] = 0u;
     __syncthreads();
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
         same2 = a.aggs[vq2].data == a.aggs[vq].data; // e.g. max(age), min(age): one load serves both
     }
     const int sh0 = 8 * a.groups[0].shift, sh1 = KS == 2 ? 8 * a.groups[1].shift : 0;
-    uint64_t seen = 0; // slots this wave has met (wave-uniform)
+    uint64_t seen[kWords] = {}; // slots this wave has met (wave-uniform)
 
     // Software pipeline, kDepth tiles deep: with one read + one wait per tile a wave spent its time in two dependent HBM round
     // trips per tile (bitmap, then columns: 128 of the first version's 173 us).  Every register set is re-loaded right
@@ -790,28 +793,32 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
         }
     };
     int since_fold = 0; // VW 1: tiles since the 8-bit counts were folded (wave-uniform)
-    auto fold_counts = [&]() { // lane = slot: move the 64 lanes' 8-bit counts of its slot into wcnt (rotated: lanes on different banks)
-        uint32_t c = 0;
-        if constexpr (V2) {
-            uint32_t *row = (uint32_t *)wbase + lane * 64;
+    auto fold_counts = [&]() { // lane = slot (NS / 64 passes): move the 64 lanes' 8-bit counts of its slot into wcnt (rotated: lanes on different banks)
+#pragma unroll
+        for (int p = 0; p < kWords; ++p) {
+            const int slot = 64 * p + lane;
+            uint32_t c = 0;
+            if constexpr (V2) {
+                uint32_t *row = (uint32_t *)wbase + slot * 64;
 #pragma unroll 4
-            for (int j = 0; j < 64; ++j) {
-                const int idx = (j + lane) & 63;
-                const uint32_t e = row[idx];
-                c += e & 0xFFu;
-                row[idx] = e & ~0xFFu;
-            }
-        } else {
-            uint16_t *row = (uint16_t *)wbase + lane * 64;
+                for (int j = 0; j < 64; ++j) {
+                    const int idx = (j + lane) & 63;
+                    const uint32_t e = row[idx];
+                    c += e & 0xFFu;
+                    row[idx] = e & ~0xFFu;
+                }
+            } else {
+                uint16_t *row = (uint16_t *)wbase + slot * 64;
 #pragma unroll 4
-            for (int j = 0; j < 64; ++j) {
-                const int idx = (j + lane) & 63;
-                const uint32_t e = row[idx];
-                c += e & 0xFFu;
-                row[idx] = (uint16_t)(e & 0xFF00u);
+                for (int j = 0; j < 64; ++j) {
+                    const int idx = (j + lane) & 63;
+                    const uint32_t e = row[idx];
+                    c += e & 0xFFu;
+                    row[idx] = (uint16_t)(e & 0xFF00u);
+                }
             }
+            wcnt[slot] += c;
         }
-        wcnt[lane] += c;
     };
     auto process = [&](const TileRegs &r, const int64_t tile) {
         const uint32_t bits = r.bits;
@@ -841,13 +848,13 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
 #pragma unroll
             for (int i = 0; i < 16; ++i) sid[i] = S.l2[(min(pg[i], (uint32_t)kLanePages) << 8) | (key[i] >> 8)];
         }
-        uint32_t any = 0; // any row, selected or not, without a slot?  (valid slots < 64; the map's markers 253 .. 255 have bits 6 and 7 set)
+        uint32_t any = 0; // any row, selected or not, without a slot?  (valid slots < NS; the map's markers 253 .. 255 have bit 7 -- and 6 -- set)
 #pragma unroll
         for (int i = 0; i < 16; ++i) any |= sid[i];
-        if (ballot64((any & 0xC0u) != 0u)) { // wave-uniform, warm-up only: every lane places (or looks up again) its own new keys
+        if (ballot64((any & (0x100u - (uint32_t)NS)) != 0u)) { // wave-uniform, warm-up only: every lane places (or looks up again) its own new keys
             uint32_t pend = 0;                        // this lane's selected rows that need a slot
 #pragma unroll
-            for (int i = 0; i < 16; ++i) pend |= (sid[i] >= (uint32_t)kLaneSlots ? 1u : 0u) << i;
+            for (int i = 0; i < 16; ++i) pend |= (sid[i] >= (uint32_t)NS ? 1u : 0u) << i;
             pend &= bits;
             for (int rounds = 0; rounds < 1024 && ballot64(pend != 0u); ++rounds) {
                 if (pend) {
@@ -855,7 +862,7 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
                     uint32_t mine = key[0];
 #pragma unroll
                     for (int i = 1; i < 16; ++i) mine = first == i ? key[i] : mine; // (a run-time index would push key[] into scratch memory)
-                    const uint32_t id = lanes_slot<KS>(S, mine, a.overflow);
+                    const uint32_t id = lanes_slot<KS>(S, mine, kTrash, a.overflow);
                     if (id != kMapFree) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i)
@@ -868,25 +875,40 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
             }
             if (ballot64(pend != 0u)) *a.overflow = 3; // (never seen: a claimed byte is published a few instructions later)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sid[i] = sid[i] < (uint32_t)kLaneSlots ? sid[i] : (uint32_t)kLaneTrash; // keys of rows that are not selected stay unplaced
+            for (int i = 0; i < 16; ++i) sid[i] = sid[i] < (uint32_t)NS ? sid[i] : kTrash; // keys of rows that are not selected stay unplaced
         }
         if (ballot64(bits != 0xFFFFu)) { // wave-uniform: rows that are not selected update the trash slot
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sid[i] = ((bits >> i) & 1u) ? sid[i] : (uint32_t)kLaneTrash;
+            for (int i = 0; i < 16; ++i) sid[i] = ((bits >> i) & 1u) ? sid[i] : kTrash;
         }
         const uint32_t row0 = (uint32_t)(tile * kTileRows + 16 * lane);
         // first-seen rows
         {
-            const uint32_t ns = __hip_atomic_load(&S.nslots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const uint64_t all = ns >= 63u ? 0x7FFFFFFFFFFFFFFFULL : ((1ULL << ns) - 1ULL);
-            if ((seen & all) != all) { // wave-uniform: warm-up, or a key some other wave met and this one has not yet
-                uint64_t here = 0;
+            uint32_t ns = __hip_atomic_load(&S.nslots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ns = ns < kTrash ? ns : kTrash;
+            bool behind = false; // has this wave met every slot handed out so far?
+#pragma unroll
+            for (int p = 0; p < kWords; ++p) {
+                const uint32_t n = ns > 64u * p ? ns - 64u * p : 0u;
+                const uint64_t all = n >= 64u ? ~0ULL : ((1ULL << n) - 1ULL);
+                behind |= (seen[p] & all) != all;
+            }
+            if (behind) { // wave-uniform: warm-up, or a key some other wave met and this one has not yet
+                uint64_t here[kWords] = {};
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    if (((bits >> i) & 1u) && !((seen >> sid[i]) & 1ULL)) atomicMin(&S.first[sid[i]], row0 + i);
-                    here |= ((bits >> i) & 1u) ? (1ULL << sid[i]) : 0ULL;
+                    const bool on = ((bits >> i) & 1u) != 0u;
+                    const uint64_t bit = 1ULL << (sid[i] & 63u);
+                    uint64_t sw = seen[0];
+                    if constexpr (kWords == 2) sw = (sid[i] & 64u) ? seen[1] : seen[0];
+                    if (on && !(sw & bit)) atomicMin(&S.first[sid[i]], row0 + i);
+                    if constexpr (kWords == 2) {
+                        here[0] |= (on && !(sid[i] & 64u)) ? bit : 0ULL;
+                        here[1] |= (on && (sid[i] & 64u)) ? bit : 0ULL;
+                    } else here[0] |= on ? bit : 0ULL;
                 }
-                seen |= wave_or64(here);
+#pragma unroll
+                for (int p = 0; p < kWords; ++p) seen[p] |= wave_or64(here[p]);
             }
         }
         // updates: one row after the other, read -> modify -> write.  LDS executes one wave's operations in order, so a row
@@ -942,41 +964,41 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
     }
     __syncthreads();
 
-    // fold: lane = slot; it sums / maxes its slot over the 64 lanes' private entries (rotated so that lanes hit different banks)
-    {
+    // fold: lane = slot (NS / 64 passes); it sums / maxes its slot over the 64 lanes' private entries (rotated so that lanes hit different banks)
+    if constexpr (VW == 1) fold_counts();
+#pragma unroll
+    for (int p = 0; p < kWords; ++p) {
+        const int slot = 64 * p + lane;
         uint32_t c = 0, m = 0, m2 = 0;
-        if constexpr (VW == 1) {
-            fold_counts();
-            c = wcnt[lane];
-        }
+        if constexpr (VW == 1) c = wcnt[slot];
         for (int l = 0; l < 64; ++l) {
             const int src = (l + lane) & 63;
             if constexpr (V2) {
-                const uint32_t e = ((const uint32_t *)wbase)[lane * 64 + src];
+                const uint32_t e = ((const uint32_t *)wbase)[slot * 64 + src];
                 m = max(m, (e >> 8) & 0xFFu);
                 m2 = max(m2, (e >> 16) & 0xFFu);
             } else if constexpr (kE16) {
-                const uint32_t e = ((const uint16_t *)wbase)[lane * 64 + src];
+                const uint32_t e = ((const uint16_t *)wbase)[slot * 64 + src];
                 if constexpr (VW == 0) c += e;
                 else m = max(m, e >> 8);
             } else if constexpr (kPacked) {
-                const uint32_t e = ((const uint32_t *)wbase)[lane * 64 + src];
+                const uint32_t e = ((const uint32_t *)wbase)[slot * 64 + src];
                 c += e & 0xFFFFu;
                 m = max(m, e >> 16);
             } else {
-                c += ((const uint16_t *)wbase)[lane * 64 + src];
-                m = max(m, ((const uint32_t *)(wbase + kLaneSlots * 64 * 2))[lane * 64 + src]);
+                c += ((const uint16_t *)wbase)[slot * 64 + src];
+                m = max(m, ((const uint32_t *)(wbase + NS * 64 * 2))[slot * 64 + src]);
             }
         }
-        if (lane < kLaneTrash && c) {
-            atomicAdd(&S.count[lane], c);
-            if constexpr (VW != 0) atomicMax(&S.val[lane], m);
-            if constexpr (V2) atomicMax(&S.val2[lane], m2);
+        if ((uint32_t)slot < kTrash && c) {
+            atomicAdd(&S.count[slot], c);
+            if constexpr (VW != 0) atomicMax(&S.val[slot], m);
+            if constexpr (V2) atomicMax(&S.val2[slot], m2);
         }
     }
     __syncthreads();
     // flush: one atomic set per (work-group, group), widened to what the global table holds
-    const uint32_t n_slots = S.nslots < (uint32_t)kLaneTrash ? S.nslots : (uint32_t)kLaneTrash;
+    const uint32_t n_slots = S.nslots < kTrash ? S.nslots : kTrash;
     if ((uint32_t)t < n_slots && S.count[t]) {
         const uint32_t g = global_slot(a, (unsigned long long)S.slotkey[t]);
         if (g != 0xFFFFFFFFu) {
@@ -1057,8 +1079,9 @@ bool group_agg_fast_ok(const AggArgs &a) {
 }
 
 // which form of k_group_agg_lanes takes this aggregation (false: none).  waves: as many as the LDS holds.
-struct LanesPlan { int ks, vw, vq, vq2, v2, waves, lds_bytes; };
-static bool lanes_plan(const AggArgs &a, LanesPlan &p) {
+struct LanesPlan { int ks, vw, vq, vq2, v2, ns, waves, lds_bytes; };
+static bool lanes_plan(const AggArgs &a, int ns, LanesPlan &p) {
+    p.ns = ns;
     if (!group_agg_fast_ok(a)) return false;
     if (a.n_group == 1 && a.groups[0].width == 1) p.ks = 0;
     else if (a.n_group == 1 && a.groups[0].width == 2) p.ks = 1;
@@ -1081,7 +1104,8 @@ static bool lanes_plan(const AggArgs &a, LanesPlan &p) {
         if (p.vw != 1 || a.aggs[p.vq2].width != 1) return false;
         p.v2 = 1;
     }
-    const int per_wave = lanes_wave_bytes(p.vw, p.v2 != 0);
+    if (ns == 128 && p.vw > 1) return false; // 127 keys: only the small-entry instances are built
+    const int per_wave = lanes_wave_bytes(p.vw, p.v2 != 0, ns);
     p.waves = std::min(16, (160 * 1024 - kLanesFixedBytes) / per_wave);
     const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((a.n_tiles + p.waves - 1) / p.waves, 256));
     const int64_t tiles_per_wave = (a.n_tiles + grid * p.waves - 1) / (grid * p.waves);
@@ -1090,15 +1114,15 @@ static bool lanes_plan(const AggArgs &a, LanesPlan &p) {
     return true;
 }
 
-template <int KS, int VW, bool V2>
+template <int KS, int VW, bool V2, int NS>
 static void launch_lanes(const AggArgs &a, const LanesPlan &p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     static bool raised = false; // (the limit is per kernel function, process wide)
     if (!raised) {
-        (void)hipFuncSetAttribute((const void *)k_group_agg_lanes<KS, VW, V2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - kLanesFixedBytes);
+        (void)hipFuncSetAttribute((const void *)k_group_agg_lanes<KS, VW, V2, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - kLanesFixedBytes);
         raised = true;
     }
     const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((a.n_tiles + p.waves - 1) / p.waves, 256)); // one work-group per CU
-    IMM3_LAUNCH_LDS((k_group_agg_lanes<KS, VW, V2>), (unsigned)grid, p.waves * 64, (size_t)p.lds_bytes, s, ev0, ev1, a, p.vq, p.vq2);
+    IMM3_LAUNCH_LDS((k_group_agg_lanes<KS, VW, V2, NS>), (unsigned)grid, p.waves * 64, (size_t)p.lds_bytes, s, ev0, ev1, a, p.vq, p.vq2);
 }
 
 void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
@@ -1108,17 +1132,18 @@ void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_
     int key_bytes = 0;
     for (int g = 0; g < a.n_group; ++g) key_bytes += a.groups[g].width;
     LanesPlan lp;
-    if ((a.debug == 0 || a.debug >= 40) && lanes_plan(a, lp)) { // private per-lane tables, no atomics (debug 7: skip -- also what the host does after an overflow = 3)
-#define IMM3_LANES(KS, VW) if (lp.ks == KS && lp.vw == VW && !lp.v2) { launch_lanes<KS, VW, false>(a, lp, s, ev0, ev1); return; }
-        if (lp.v2) {
-            if (lp.ks == 0) launch_lanes<0, 1, true>(a, lp, s, ev0, ev1);
-            else if (lp.ks == 1) launch_lanes<1, 1, true>(a, lp, s, ev0, ev1);
-            else launch_lanes<2, 1, true>(a, lp, s, ev0, ev1);
-            return;
-        }
-        IMM3_LANES(0, 0) IMM3_LANES(0, 1) IMM3_LANES(0, 2) IMM3_LANES(0, 4)
-        IMM3_LANES(1, 0) IMM3_LANES(1, 1) IMM3_LANES(1, 2) IMM3_LANES(1, 4)
-        IMM3_LANES(2, 0) IMM3_LANES(2, 1) IMM3_LANES(2, 2) IMM3_LANES(2, 4)
+    // private per-lane tables, no atomics: 63 keys per work-group, then 127 (debug 4: what the host asks for after an overflow = 3 of
+    // the 63-key form; debug 7: skip both -- after an overflow = 3 of the 127-key form)
+    if ((a.debug == 0 || a.debug == 4 || a.debug >= 40) && lanes_plan(a, a.debug == 4 ? 128 : 64, lp)) {
+#define IMM3_LANES(KS, VW, V2)                                                                       \
+    if (lp.ks == KS && lp.vw == VW && (lp.v2 != 0) == V2) {                                          \
+        if (lp.ns == 64) launch_lanes<KS, VW, V2, 64>(a, lp, s, ev0, ev1);                           \
+        else if constexpr (VW <= 1) launch_lanes<KS, VW, V2, 128>(a, lp, s, ev0, ev1);               \
+        return;                                                                                      \
+    }
+        IMM3_LANES(0, 0, false) IMM3_LANES(0, 1, false) IMM3_LANES(0, 2, false) IMM3_LANES(0, 4, false) IMM3_LANES(0, 1, true)
+        IMM3_LANES(1, 0, false) IMM3_LANES(1, 1, false) IMM3_LANES(1, 2, false) IMM3_LANES(1, 4, false) IMM3_LANES(1, 1, true)
+        IMM3_LANES(2, 0, false) IMM3_LANES(2, 1, false) IMM3_LANES(2, 2, false) IMM3_LANES(2, 4, false) IMM3_LANES(2, 1, true)
 #undef IMM3_LANES
     }
     if (a.debug != 9 && a.debug != 8 && group_agg_fast_ok(a) && key_bytes <= 2) { // the key indexes a slot map directly (debug 8: skip this form)

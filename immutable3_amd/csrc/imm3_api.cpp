@@ -2064,7 +2064,7 @@ static int settle_groups(imm3_query *q, uint32_t *n_groups) {
     imm3_ctx *ctx = q->ctx;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    for (int attempt = 0; attempt < 4; ++attempt) {
+    for (int attempt = 0; attempt < 5; ++attempt) {
         AggArgs a;
         fill_agg_args(q, a);
         HIPCHK(hipMemsetAsync(q->d_ameta, 0, sizeof(uint32_t), s)); // n_groups only; keep the overflow flag
@@ -2076,7 +2076,7 @@ static int settle_groups(imm3_query *q, uint32_t *n_groups) {
         if (meta[1] == 2 || meta[1] == 3) { // a fast form's per-work-group table filled up: aggregate again with the next form
             AggArgs g;                       // (3: k_group_agg_lanes -> k_group_agg_direct; 2: -> the general kernel)
             fill_agg_args(q, g);
-            g.debug = q->agg_skip = meta[1] == 3 ? 7 : 9;
+            g.debug = q->agg_skip = meta[1] == 3 ? (q->agg_skip == 0 ? 4 : 7) : 9; // lanes 63 -> lanes 127 -> direct -> general
             launch_group_agg(g, s, nullptr, nullptr);
             HIPCHK(hipGetLastError());
             continue;

@@ -259,11 +259,15 @@ def test_lanes_form_overflows_into_the_next_form(ctx):
     many = _codes(rng, n, 64, 8)                                                  # 64 keys: one too many
     pages = _codes(rng, n, 40, 40)                                                # 40 keys, 40 distinct first bytes
     wide = _codes(rng, n, 600, 25)                                                # 600 keys: past the direct form as well
-    for key in (byte_key, many, pages, wide):
+    mid = rng.integers(-50, 50, size=n).astype(np.int8)                            # 100 keys: the 127-key instance of the lanes form
+    for key in (byte_key, mid, many, pages, wide):
         kc = RawColumn(DENSE_TINYINT, 1, key, br) if key.dtype == np.int8 else RawColumn(DENSE_STRING, 2, key, br)
         cols = [RawColumn(DENSE_INT, 4, ids, br), kc]
         check(ctx, cols, [0, 1], [], [1], [("count", 0), ("max", 0)])
         check(ctx, cols, [0, 1], [(0, GT, 0.0)], [1], [("count", 0), ("max", 0)])
+        check(ctx, cols, [0, 1], [], [1], [("count", 0)])
+        if key.dtype == np.int8:
+            check(ctx, cols, [0, 1], [(0, LT, 500.0)], [1], [("max", 1), ("count", 0), ("min", 1)])
     # the same query handle run twice: the second run skips the form that overflowed
     seg = native.DeviceSegment(ctx, [RawColumn(DENSE_INT, 4, ids, br).native(), RawColumn(DENSE_STRING, 2, many, br).native()])
     q = native.DeviceQuery(ctx, seg, [0, 1], [], (), 0, 1024, group_cols=[1], aggs=[(native.AGG_COUNT, 0)])
