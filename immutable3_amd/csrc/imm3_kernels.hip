@@ -233,7 +233,9 @@ __device__ __forceinline__ void stage_full_tile(const TileArgs &a, int lane, con
     A.last = cnt;
     if (lane == 0) tstart[A.slot] = A.arena_n + A.buf_n;
     ++A.slot;
-    vec *l = (vec *)lds + A.buf_n;
+    // 4-dword records: a tile with more than 512 survivors does not fit the (empty) buffer -- it goes straight to the arena
+    const bool direct = L::R * 4 * kTileRows > kArenaBufBytes && cnt > (uint32_t)(kArenaBufBytes / (4 * L::R)); // wave-uniform
+    vec *l = direct ? (vec *)a.stage_rec + wave_id * a.wave_cap + A.arena_n : (vec *)lds + A.buf_n;
     uint32_t base = 0; // wave-uniform: this tile's records so far
 #pragma unroll
     for (int j = 0; j < kTileWords; ++j) {
@@ -246,7 +248,8 @@ __device__ __forceinline__ void stage_full_tile(const TileArgs &a, int lane, con
         if (__builtin_amdgcn_inverse_ballot_w64(m)) (l + base)[rank] = L::pack(rec); // exec = the word itself; `base` stays scalar
         base += (uint32_t)__popcll(m);
     }
-    A.buf_n += base;
+    if (direct) A.arena_n += base;
+    else A.buf_n += base;
 }
 
 // `earlier`: the tile's words from an earlier pass when the caller has loaded them already (pipelined loop), else null and
