@@ -14,7 +14,7 @@ constexpr int kTileRows = 1024;
 constexpr int kTileWords = 16;
 constexpr int kWavesPerBlock = 4;   // 256-thread workgroups
 constexpr int kBlockThreads = 256;
-constexpr int kChunkTiles = 1024;   // tiles per offsets-scan chunk (one scan workgroup)
+constexpr int kChunkTiles = 256;    // tiles per offsets-scan chunk (one scan workgroup; 382 of them per 100 M rows: every CU has one)
 constexpr int kSpanTiles = 16;      // tiles per gather workgroup (kChunkTiles % kSpanTiles == 0)
 constexpr int kSpanWords = kSpanTiles * kTileWords;
 

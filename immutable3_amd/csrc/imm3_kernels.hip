@@ -611,24 +611,36 @@ void launch_sum_counts(const SumCountsArgs &a, hipStream_t s) { hipLaunchKernelG
 
 // ---------------------------------------------------------------------------------------------
 // k_scan: per-tile survivor counts straight from the bitmap (thread t popcounts the 16 words = one 128-B line
-// of tile t), exclusive prefix within chunks of 1024 tiles, per-chunk sums.  Reading the 12.5 MB bitmap here
+// of tile t), exclusive prefix within chunks of kChunkTiles tiles, per-chunk sums.  Reading the 12.5 MB bitmap here
 // is cheaper than making the hot filter kernel store a 4-byte count per tile.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kChunkTiles) void k_scan(const ScanArgs a) {
     __shared__ uint32_t s_wave[kChunkTiles / 64];
+    __shared__ uint32_t s_cnt[kChunkTiles];
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = t >> 6;
-    const int64_t tile = (int64_t)blockIdx.x * kChunkTiles + t;
-    uint32_t c = 0;
-    if (tile < a.n_tiles) { // the bitmap is allocated in whole tiles; words past n_words are zero
-        const uint4 *p = (const uint4 *)(a.bitmap + tile * kTileWords);
+    const int64_t tile0 = (int64_t)blockIdx.x * kChunkTiles;
+    // counts: the chunk's bitmap read in 16-byte pieces, consecutive threads on consecutive pieces (8 threads = one tile's 128
+    // bytes).  One thread per tile reading its own 128 bytes was 64 partial lines per load instruction: 8.0 us for 12.5 MB.
+    const uint4 *p = (const uint4 *)(a.bitmap + tile0 * kTileWords);
+    const int64_t pieces = (a.n_tiles - tile0 < kChunkTiles ? a.n_tiles - tile0 : (int64_t)kChunkTiles) * (kTileWords / 2); // the bitmap is allocated in whole tiles
 #pragma unroll
-        for (int i = 0; i < kTileWords / 2; ++i) {
-            const uint4 v = p[i];
-            c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    for (int i = 0; i < kTileWords / 2; ++i) {
+        const int64_t q = (int64_t)i * kChunkTiles + t;
+        uint32_t c = 0;
+        if (q < pieces) {
+            const uint4 v = p[q];
+            c = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
         }
+        c += __shfl_xor(c, 1);
+        c += __shfl_xor(c, 2);
+        c += __shfl_xor(c, 4);
+        if ((t & 7) == 0) s_cnt[q >> 3] = c; // tile q / 8 of the chunk
     }
+    __syncthreads();
+    const int64_t tile = tile0 + t;
+    const uint32_t c = s_cnt[t];
     uint32_t incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
