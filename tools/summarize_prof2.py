@@ -84,7 +84,7 @@ for name, (fk, ek) in cfgs.items():
                      "hbm_bytes_sum_fetch_x2": traffic, "traffic_ratio": traffic / algo if traffic and algo else None,
                      "bench_line_frac": line["extra"][name]["frac"] if line else None,
                      "bench_line_kernel_ms": line["extra"][name]["kernel_ms"] if line else None}
-agg = kernel("k_group_agg_lanes<1, 1>")   # both aggregation configs of the extra block run this kernel (all rows / sigma = 0.11): same cost per tile
+agg = kernel("k_group_agg_lanes<1, 1, false, 64>")   # both aggregation configs of the extra block run this kernel (all rows / sigma = 0.11): same cost per tile
 summary["agg_group_by_state"] = dict(agg, algorithmic_bytes_all_rows=312.5e6, frac_all_rows=312.5e6 / (agg["avg_us"] * 1e-6) / 8e12,
                                      traffic_ratio_all_rows=agg["hbm_bytes_fetch_x2"] / 312.5e6 if agg["hbm_bytes_fetch_x2"] else None,
                                      bench_line={k: line["extra"][k]["kernel_ms"] for k in ("agg_group_by_state_all_rows", "agg_group_by_state_range_age")} if line else None)
