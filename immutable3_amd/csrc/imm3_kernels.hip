@@ -201,6 +201,7 @@ struct Arena {
     uint32_t last = 0;    // records of the tile staged last (the guess for the next one)
 };
 constexpr int kArenaBufBytes = 8 * 1024; // LDS record buffer per wave: one tile at worst, ~10 tiles at 10 % selectivity
+constexpr int arena_buf_bytes(int R) { return R == 1 ? 4 * 1024 : kArenaBufBytes; } // 1-dword records: a whole tile is 4 KiB, and 4 work-groups fit a CU (C4 filter 50.5 -> 47.3 us)
 constexpr int kArenaSlots = kMaxArenaSlots; // tiles per wave the start table holds
 
 template <int R>
@@ -219,7 +220,7 @@ __device__ __forceinline__ void arena_flush(const TileArgs &a, Arena &A, const u
 
 // would `n` more records overflow the buffer?
 template <int R>
-__device__ __forceinline__ bool arena_full(const Arena &A, uint32_t n) { return A.buf_n + n > (uint32_t)(kArenaBufBytes / (4 * R)); }
+__device__ __forceinline__ bool arena_full(const Arena &A, uint32_t n) { return A.buf_n + n > (uint32_t)(arena_buf_bytes(R) / (4 * R)); }
 
 template <int K0, int K1, int K2>
 __device__ __forceinline__ void stage_full_tile(const TileArgs &a, int lane, const ColRegs<K0> &c0, const ColRegs<K1> &c1, const ColRegs<K2> &c2,
@@ -234,7 +235,7 @@ __device__ __forceinline__ void stage_full_tile(const TileArgs &a, int lane, con
     if (lane == 0) tstart[A.slot] = A.arena_n + A.buf_n;
     ++A.slot;
     // 4-dword records: a tile with more than 512 survivors does not fit the (empty) buffer -- it goes straight to the arena
-    const bool direct = L::R * 4 * kTileRows > kArenaBufBytes && cnt > (uint32_t)(kArenaBufBytes / (4 * L::R)); // wave-uniform
+    const bool direct = L::R * 4 * kTileRows > arena_buf_bytes(L::R) && cnt > (uint32_t)(arena_buf_bytes(L::R) / (4 * L::R)); // wave-uniform
     vec *l = direct ? (vec *)a.stage_rec + wave_id * a.wave_cap + A.arena_n : (vec *)lds + A.buf_n;
     uint32_t base = 0; // wave-uniform: this tile's records so far
 #pragma unroll
@@ -333,7 +334,7 @@ __device__ __forceinline__ uint32_t partial_tile(const TileArgs &a, int64_t tile
 template <int K0, int K1, int K2, int T, bool TABLE, bool DEFER, bool STAGE>
 __global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a) {
     constexpr bool kXpose = K0 == TK_I8 || K0 == TK_S2 || K1 == TK_I8 || K1 == TK_S2 || K2 == TK_I8 || K2 == TK_S2;
-    constexpr int kStage = STAGE ? kArenaBufBytes : 16;
+    constexpr int kStage = STAGE ? arena_buf_bytes(Rec<K0, K1, K2>::R) : 16;
     // narrow-only kernels spend longer on a tile (LDS transpose) than its loads take to issue: the next group's loads go
     // out BEFORE the current group is evaluated.  (With an int32 column the same pipeline measured slower: DESIGN.md finding 8.)
     constexpr bool kPipe = STAGE || (kXpose && K0 != TK_I32 && K1 != TK_I32 && K2 != TK_I32);
