@@ -250,9 +250,16 @@ __global__ __launch_bounds__(kBlockThreads) void k_filter_pfor(const PforArgs a)
         any_bad |= bad;
         // lo <= base + d <= hi  <=>  (d + (base - lo)) <=u (hi - lo)
         const uint32_t k = base - (uint32_t)a.lo;
+        // the borrow of range - (d + k) is the verdict "outside": shifted in through the carry chain (v_sub_co + v_addc_co per
+        // row; a compare would go through a scalar register pair and a v_cndmask), inverted once at the end
         uint32_t bits = 0;
 #pragma unroll
-        for (int i = 15; i >= 0; --i) bits = bits + bits + ((d[i] + k) <= range ? 1u : 0u);
+        for (int i = 15; i >= 0; --i) {
+            uint32_t tmp;
+            // (written out: the compiler turns every C form of this into v_cmp + v_cndmask + shift/or with wait states)
+            asm("v_sub_co_u32_e32 %1, vcc, %2, %3\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(bits), "=&v"(tmp) : "s"(range), "v"(d[i] + k) : "vcc");
+        }
+        bits = ~bits & 0xFFFFu;
         if (bad) bits = 0;
         const int src = (lane & 15) << 2; // word j <- lanes 4j .. 4j+3, 16 bits each
         const uint32_t lo = lane_read(bits, src) | (lane_read(bits, src + 1) << 16);
