@@ -398,12 +398,16 @@ def measure_c2(env: Env, steps: int, warmup: int, with_cpu_baseline: bool):
 C5_ID_LO, C5_ID_HI = 1.0e6, 7.9e8        # the C3 id range stretched over the 8-segment id space [0, 8e8)
 
 
-def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True):
+def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True, solo: bool = False):
+    """solo: EVERY rank runs the whole job (all 8 segments) alone on its own GPU -- the G = 1 point of the strong-scaling curve
+    measured inside an N > 1 run (time = max over ranks); no count collective, the counts are checked locally."""
     torch, native, synth, ctx, args = env.torch, env.native, env.synth, env.ctx, env.args
     from immutable3_amd.distributed import owned_segments
     n = args.rows
-    env.make_comm()
-    mine = owned_segments(C5_SEGMENTS, env.rank, env.world)
+    if not solo:
+        env.make_comm()
+    comm = None if solo else env.comm
+    mine = list(range(C5_SEGMENTS)) if solo else owned_segments(C5_SEGMENTS, env.rank, env.world)
     sels = [(0, native.GT, 18.0), (0, native.LT, 30.0), (1, native.GT, C5_ID_LO), (1, native.LT, C5_ID_HI)]
     segs, queries, expect = [], [], []
     t_stage = time.perf_counter()
@@ -428,7 +432,7 @@ def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True):
         queries.append(q)
         del c, keep, rows, idx, vals
     stage_s = time.perf_counter() - t_stage
-    expect_total = env.sum_over_ranks(sum(expect))     # over gloo: independent of the collective under test
+    expect_total = sum(expect) if solo else env.sum_over_ranks(sum(expect))     # over gloo: independent of the collective under test
 
     log = torch.zeros(max(steps, warmup, 1), dtype=torch.int64, device="cuda")
     env.sync()
@@ -449,18 +453,20 @@ def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True):
         else:
             for q in queries:
                 q.run()                                 # scan+select(+stage) -> offsets scan -> compact+gather, per owned segment
-        if env.comm is not None:
-            env.comm.allreduce_count(queries, device_out=log.data_ptr() + 8 * i, wait=False)
+        if comm is not None:
+            comm.allreduce_count(queries, device_out=log.data_ptr() + 8 * i, wait=False)
+        elif solo:                                      # no collective: the counts are summed once the loop is over
+            pass
         else:                                           # rehearsal on one device: host counts over gloo
             host_counts.append(env.sum_over_ranks(sum(q.count() for q in queries)))
 
     elapsed = env.timed_steps(step, steps, warmup)
-    got = log[:steps].tolist() if env.comm is not None else host_counts[-steps:]
+    got = log[:steps].tolist() if comm is not None else ([sum(q.count() for q in queries)] if solo else host_counts[-steps:])
     assert all(g == expect_total for g in got), (got[:4], expect_total)
     elapsed_plain = None
     if graph is not None:                               # the same passes launched kernel by kernel, for the record
         elapsed_plain = env.timed_steps(lambda i: step(i, graphed=False), steps, min(warmup, 2))
-        got = log[:steps].tolist() if env.comm is not None else host_counts[-steps:]
+        got = log[:steps].tolist() if comm is not None else ([sum(q.count() for q in queries)] if solo else host_counts[-steps:])
         assert all(g == expect_total for g in got), (got[:4], expect_total)
 
     # per-kernel durations of one pass over this rank's segments (second, event-bracketed pass)
@@ -484,7 +490,8 @@ def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True):
                        if graph is not None else "kernel by kernel (--no-graph)"),
             "ms_per_step_kernel_by_kernel": elapsed_plain / steps * 1e3 if elapsed_plain is not None else None,
             "global_selected_rows_per_pass": int(expect_total),
-            "count_allreduce": {"collective": env.count_reduce, "checked": f"all {steps} per-pass global counts == {expect_total} (numpy, summed over ranks via gloo)"},
+            "count_allreduce": ({"collective": "none (solo: every rank runs all 8 segments on its own GPU)", "checked": f"local count == {expect_total} (numpy)"} if solo else
+                                {"collective": env.count_reduce, "checked": f"all {steps} per-pass global counts == {expect_total} (numpy, summed over ranks via gloo)"}),
             "config": {
                 "workload": "C5: 8 x 100M-row segments (age seed 100+s, id = s*1e8 + i), segment s -> rank s mod G, "
                             "RangeFilter(age > 18 AND age < 30) AND RangeFilter(id > 1e6 AND id < 7.9e8) + Project(id, age), "
@@ -635,6 +642,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the extra block (C3, C4, aggregation, C5 at G = 1)")
     ap.add_argument("--no-graph", action="store_true", help="C5: launch every pass kernel by kernel instead of replaying the recorded hipGraph")
+    ap.add_argument("--no-g1", action="store_true", help="N > 1: skip the solo leg (every rank runs the whole C5 job on its own GPU: the G = 1 point)")
     ap.add_argument("--no-c2-weak", action="store_true", help="N > 1: skip the weak-scaling C2 leg")
     ap.add_argument("--no-c5", action="store_true", help="N = 1: leave the C5-at-G=1 leg out of the extra block (profiling runs: its kernels are C3's instances)")
     ap.add_argument("--extra", action="store_true", help="(kept for compatibility: the extra block is on by default)")
@@ -670,14 +678,19 @@ def main():
     else:
         c5 = measure_c5(env, args.steps, args.warmup, use_graph=not args.no_graph)
         c2 = None if args.no_c2_weak else measure_c2(env, max(10, min(args.steps, 50)), 5, with_cpu_baseline=False)
+        g1 = None if args.no_g1 else measure_c5(env, max(3, min(args.steps, 10)), 2, use_graph=not args.no_graph, solo=True)
         if env.rank == 0:
             result = dict(base, scaling="strong", dtype="i32/i8", **c5)
             result["cpu_baseline"] = None               # timed at N = 1 only (contract)
+            if g1 is not None:
+                result["c5_g1_same_run"] = {"value": g1["value"], "ms_per_step": g1["ms_per_step"],
+                                            "note": "the G = 1 point of this strong-scaling curve measured in this run: every rank ran the whole C5 job "
+                                                    "(8 segments) alone on its own GPU, time = max over ranks; no count collective"}
             if c2 is not None:
                 result["c2_weak"] = {k: c2[k] for k in ("value", "ms_per_step", "config", "roofline", "per_rank")}
                 result["c2_weak"]["scaling"] = "weak"
-            result["scaling_note"] = ("value = C5 aggregate rows/s (strong scaling: 8 segments fixed, sharded s mod G); G = 1 point: extra.c5_g1.value of the "
-                                      "--gpus 1 line.  c2_weak.value = the N = 1 headline workload run by every rank (weak scaling)")
+            result["scaling_note"] = ("value = C5 aggregate rows/s (strong scaling: 8 segments fixed, sharded s mod G); G = 1 point: c5_g1_same_run.value "
+                                      "(measured in this run) and extra.c5_g1.value of the --gpus 1 line.  c2_weak.value = the N = 1 headline workload run by every rank (weak scaling)")
     env.close()
     if env.rank == 0:
         print(json.dumps(result))

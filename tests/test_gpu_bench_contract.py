@@ -72,6 +72,8 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert [r["segments"] for r in d["per_rank"]] == [[0, 2, 4, 6], [1, 3, 5, 7]]
     assert d["global_selected_rows_per_pass"] == sum(r["selected_rows"] for r in d["per_rank"])
     assert d["c2_weak"]["per_rank"][1]["rank"] == 1 and d["c2_weak"]["value"] > 0
+    g1 = d["c5_g1_same_run"]                     # the G = 1 point measured in the same run (every rank alone on all 8 segments)
+    assert g1["value"] > 0 and abs(g1["value"] - 8 * 1000000 / (g1["ms_per_step"] * 1e-3)) / g1["value"] < 1e-6
     # a rank count that contradicts the environment is refused, not silently reported as another N
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "100000"], capture_output=True, text=True, cwd=ROOT, timeout=300, env=env2)
