@@ -16,7 +16,9 @@ id = s*10^8 + i), segment s on rank s mod N (Engine.scala:176-180 fans out one p
 RangeFilter(age) AND RangeFilter(id) + Project(id, age).  One STEP = one pass over all 8 segments (each rank runs its
 own) followed by ONE count all-reduce: ncclAllReduce(sum, uint64, 1) over RCCL / xGMI, issued by libimm3
 (imm3_comm_allreduce_count) on the communicator's stream behind the scans that produce the counts.  value = 8e8 rows x K /
-max-over-ranks wall time.  The same line carries `c2_weak`: the N = 1 headline workload run by every rank (weak scaling).
+max-over-ranks wall time.  One pass is launched as one hipGraph (imm3_graph_launch; --no-graph: kernel by kernel).  The same
+line carries `c5_g1_same_run` -- the G = 1 point of this curve measured in the same run: every rank runs all 8 segments alone
+on its own GPU, max over ranks (--no-g1 skips it) -- and `c2_weak`: the N = 1 headline workload run by every rank (weak scaling).
 
 Prints ONE JSON line on rank 0.  Inputs are resident in HBM before any timed region.  roofline.achieved = algorithmic
 bytes per launch / mean kernel duration measured live with HIP events on the launching stream.  cpu_baseline = the
