@@ -121,3 +121,45 @@ def test_fuzz_group_by(ctx, seed):
             col = sels[0][0]
             sels = [(col, cond, val) for (_, cond, val) in sels]
         check_agg(ctx, cols, used, sels, group, aggs)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_compressed_columns(ctx, oracle, seed):
+    """The same differential check with every column's codec drawn at random: dense, PFOR_INT (int32 columns), snappy."""
+    from conftest import PforColumn, SnappyColumn
+    rng = np.random.default_rng(9000 + seed)
+    for _ in range(4):
+        n = int(rng.choice([1, 700, 1024, 1025, 6000, 40_000]))
+        block_rows = blocks_of(n, 1024) if rng.random() < 0.7 else random_layout(rng, n)
+        uniform = len(set(block_rows[:-1])) <= 1 and (not block_rows or block_rows[-1] <= (block_rows[0] if block_rows else 0))
+        block_size = block_rows[0] if (uniform and block_rows and block_rows[0] > 0) else 1024
+        a = np.cumsum(rng.integers(0, int(rng.choice([2, 50, 100000])), size=n)).astype(np.int64)
+        a = (a % (2 ** 31)).astype(np.int32) if rng.random() < 0.7 else rng.integers(-2 ** 31, 2 ** 31, size=n, dtype=np.int64).astype(np.int32)
+        b = rng.integers(-1000, 1000, size=n).astype(np.int32)
+        c = rng.integers(-128, 128, size=n).astype(np.int8)
+        s = np.array([list(CODES[i]) for i in rng.integers(0, int(rng.choice([1, 30])), size=n)], dtype=np.uint8).reshape(n, 2)
+        data = [a, b, c, s]
+
+        def column(i):
+            kind = rng.integers(0, 3)
+            dense = [(DENSE_INT, 4), (DENSE_INT, 4), (DENSE_TINYINT, 1), (DENSE_STRING, 2)][i]
+            if kind == 1 and i < 2:
+                return PforColumn(data[i], block_rows)
+            if kind == 2:
+                return SnappyColumn(dense[0], dense[1], data[i], block_rows)
+            return RawColumn(dense[0], dense[1], data[i], block_rows)
+
+        cols = [column(i) for i in range(4)]
+        n_used = int(rng.integers(1, 5))
+        used = [int(x) for x in rng.permutation(4)[:n_used]]
+        sels = []
+        for j, u in enumerate(used):
+            if rng.random() < 0.3:
+                continue
+            if u == 3:
+                sels.append((j, MATCH, [CODES[i] for i in rng.permutation(30)[: int(rng.choice([1, 3, 8]))]]))
+            else:
+                sels += random_numeric_pred(rng, j, data[u])
+        proj = [int(x) for x in rng.permutation(n_used)[: int(rng.integers(0, n_used + 1))]]
+        limit = int(rng.choice([0, 0, 3, 2000])) if proj else 0
+        check(ctx, oracle, cols, used, sels, proj=proj, limit=limit, block_size=block_size)
