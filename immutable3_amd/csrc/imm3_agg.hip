@@ -1104,7 +1104,6 @@ static bool lanes_plan(const AggArgs &a, int ns, LanesPlan &p) {
         if (p.vw != 1 || a.aggs[p.vq2].width != 1) return false;
         p.v2 = 1;
     }
-    if (ns == 128 && p.vw > 1) return false; // 127 keys: only the small-entry instances are built
     const int per_wave = lanes_wave_bytes(p.vw, p.v2 != 0, ns);
     p.waves = std::min(16, (160 * 1024 - kLanesFixedBytes) / per_wave);
     const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((a.n_tiles + p.waves - 1) / p.waves, 256));
@@ -1138,7 +1137,7 @@ void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_
 #define IMM3_LANES(KS, VW, V2)                                                                       \
     if (lp.ks == KS && lp.vw == VW && (lp.v2 != 0) == V2) {                                          \
         if (lp.ns == 64) launch_lanes<KS, VW, V2, 64>(a, lp, s, ev0, ev1);                           \
-        else if constexpr (VW <= 1) launch_lanes<KS, VW, V2, 128>(a, lp, s, ev0, ev1);               \
+        else launch_lanes<KS, VW, V2, 128>(a, lp, s, ev0, ev1);                                      \
         return;                                                                                      \
     }
         IMM3_LANES(0, 0, false) IMM3_LANES(0, 1, false) IMM3_LANES(0, 2, false) IMM3_LANES(0, 4, false) IMM3_LANES(0, 1, true)
