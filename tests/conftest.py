@@ -72,7 +72,7 @@ class PforColumn:
         self.block_rows = list(block_rows)
         parts, offs, pos = [], [0], 0
         for n in self.block_rows:
-            blk = oracle_c.pfor_encode_block(self.values[pos:pos + n]) if n > 0 else b""
+            blk = oracle_c.pfor_encode_block(self.values[pos:pos + n])   # (an empty block is the 12 bytes the reference's encoder writes for no values)
             parts.append(blk)
             offs.append(offs[-1] + len(blk))
             pos += n
