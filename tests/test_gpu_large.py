@@ -182,3 +182,38 @@ def test_group_by_state_100m(big):
             ext = np.full(65536, -128 if kind == native.AGG_MAX else 127, np.int8)
             red.at(ext, c, a)
             assert vals[:, 1].tolist() == ext[want_keys].astype(np.int64).tolist()
+
+
+@pytest.mark.parametrize("pred_cols", [[2], [0, 2], [0, 1], [0, 1, 2]])
+def test_staged_projection_many_tiles_per_wave(pred_cols):
+    """12.6 M rows = 12 305 tiles: every wave of the staging launch takes 4+ tiles, so its LDS record buffer wraps, flushes and (for
+    4-dword records at high fill) hands whole tiles straight to the arena several times -- at sparse, dense and full tiles."""
+    from immutable3_amd import native, synth
+    ctx = native.Context(0)
+    n = 12_600_000 + 333
+    offs = lambda w: synth.block_offsets(n, w)
+    a = synth.uniform_int30(31, n)
+    b = synth.uniform_int30(32, n)
+    c = synth.uniform_below(33, n, 100, np.int8)
+    data = [a, b, c]
+    seg = native.DeviceSegment(ctx, [(DENSE_INT, 4, a.view(np.uint8), n * 4, offs(4)), (DENSE_INT, 4, b.view(np.uint8), n * 4, offs(4)),
+                                     (DENSE_TINYINT, 1, c.view(np.uint8), n, offs(1))])
+    levels = {"few": {0: 0.97 * 2 ** 30, 1: 0.9 * 2 ** 30, 2: 95.0}, "most": {0: 0.1 * 2 ** 30, 1: 0.05 * 2 ** 30, 2: 5.0}, "all": {0: -1.0, 1: -1.0, 2: -1.0}}
+    pos = {u: i for i, u in enumerate(pred_cols)}
+    for level in ("few", "most", "all"):
+        sels = [(pos[pc], GT, float(levels[level][pc])) for pc in pred_cols]
+        keep = np.ones(n, bool)
+        for pc in pred_cols:
+            keep &= data[pc] > levels[level][pc]
+        q = native.DeviceQuery(ctx, seg, pred_cols, sels, list(range(len(pred_cols))), 0)
+        q.run()
+        q.run()
+        rows = np.flatnonzero(keep)
+        assert q.count() == rows.size
+        idx, vals = q.fetch_rows()
+        assert idx.size == rows.size and (idx == rows).all(), (level, pred_cols)
+        for j, u in enumerate(pred_cols):
+            assert (vals[j].view("<i4" if u < 2 else np.int8).reshape(-1) == data[u][rows]).all(), (level, pred_cols, u)
+        q.close()
+    seg.close()
+    ctx.close()
