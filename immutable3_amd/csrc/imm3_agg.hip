@@ -14,6 +14,7 @@
 // value bytes big-endian-packed into a u64 == lexicographic byte order == String.compareTo for ASCII.
 #include "imm3_internal.h"
 #include "imm3_device.h"
+#include <atomic>
 #include <hip/hip_ext.h>
 
 namespace imm3 {
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(kAggThreads) void k_group_agg(const AggArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) key[k] |= raw[k] << (8 * a.groups[g].shift);
             }
-            if (a.debug == 1) { // ablation: key loads only
+            if (IMM3_ABLATED(a, 1)) { // ablation: key loads only
                 asm volatile("" ::"v"((uint32_t)key[0]), "v"((uint32_t)key[3]));
                 continue;
             }
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_group_agg_tile(const AggArgs 
                     }
                 }
                 slot[j] = s;
-                if (a.debug != 12) { // (ablation)
+                if (!IMM3_ABLATED(a, 12)) {
                     atomicAdd(&s_count[s], 1u);
                     atomicMin(&s_first[s], row);
                 }
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_group_agg_tile(const AggArgs 
         }
         for (int q = 0; q < a.n_agg; ++q) {
             const int kind = a.aggs[q].kind;
-            if (kind == AGG_COUNT || a.debug == 13) continue; // (13: ablation)
+            if (kind == AGG_COUNT || IMM3_ABLATED(a, 13)) continue;
             uint32_t v[kTileWords];
             load_tile_rows(a.aggs[q].data, a.aggs[q].width, tile, lane, xp, v);
             const int w = a.aggs[q].width;
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_group_agg_tile(const AggArgs 
     __syncthreads();
 
     // flush: one atomic set per (work-group, group), widened to what the global table holds
-    if (a.debug == 14) return; // (ablation)
+    if (IMM3_ABLATED(a, 14)) return;
     for (int i = t; i <= kFastSlots; i += kBlockThreads) {
         if (s_count[i] == 0) continue;
         const unsigned long long key = i == kFastSlots ? (unsigned long long)kEmpty32 : (unsigned long long)s_keys[i];
@@ -827,7 +828,7 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
         const auto &kr1 = r.kr1;
         const auto &vr = r.vr;
         const auto &vr2 = r.vr2;
-        if (a.debug == 44) { // (ablation: loads only)
+        if (IMM3_ABLATED(a, 44)) { // ablation: loads only
             asm volatile("" ::"v"(kr0[0]), "v"(kr0[KS == 1 ? 1 : 0]), "v"(vr[0]), "v"(vr[NV - 1]));
             return;
         }
@@ -916,7 +917,7 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
         // 4 or 2 reads with duplicate slots folded in registers measured slower: 109 / 100 us against 97 -- the fold is
         // vector work, which is what this kernel is short of.)
 #pragma unroll
-        for (int i = 0; i < (a.debug == 42 ? 0 : 16); ++i) { // (42: ablation)
+        for (int i = 0; i < (IMM3_ABLATED(a, 42) ? 0 : 16); ++i) {
             const uint32_t s = sid[i];
             uint32_t x = 0;
             if constexpr (VW != 0) {
@@ -1113,15 +1114,25 @@ static bool lanes_plan(const AggArgs &a, int ns, LanesPlan &p) {
     return true;
 }
 
+// false: the device refused the kernel's dynamic LDS size (the caller falls through to the next form)
 template <int KS, int VW, bool V2, int NS>
-static void launch_lanes(const AggArgs &a, const LanesPlan &p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    static bool raised = false; // (the limit is per kernel function, process wide)
-    if (!raised) {
-        (void)hipFuncSetAttribute((const void *)k_group_agg_lanes<KS, VW, V2, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - kLanesFixedBytes);
-        raised = true;
+static bool launch_lanes(const AggArgs &a, const LanesPlan &p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    // The dynamic-LDS limit of a kernel function is raised once per DEVICE (a process may drive all eight GPUs, one
+    // context each, from several threads): 0 = not yet, 1 = raised, 2 = refused.
+    static std::atomic<int> raised[kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return false;
+    int st = raised[dev].load(std::memory_order_acquire);
+    if (st == 0) { // (two threads may both get here: the call is idempotent)
+        const hipError_t e = hipFuncSetAttribute((const void *)k_group_agg_lanes<KS, VW, V2, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - kLanesFixedBytes);
+        if (e != hipSuccess) (void)hipGetLastError();
+        st = e == hipSuccess ? 1 : 2;
+        raised[dev].store(st, std::memory_order_release);
     }
+    if (st != 1) return false;
     const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((a.n_tiles + p.waves - 1) / p.waves, 256)); // one work-group per CU
     IMM3_LAUNCH_LDS((k_group_agg_lanes<KS, VW, V2, NS>), (unsigned)grid, p.waves * 64, (size_t)p.lds_bytes, s, ev0, ev1, a, p.vq, p.vq2);
+    return true;
 }
 
 void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
@@ -1131,28 +1142,29 @@ void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_
     int key_bytes = 0;
     for (int g = 0; g < a.n_group; ++g) key_bytes += a.groups[g].width;
     LanesPlan lp;
-    // private per-lane tables, no atomics: 63 keys per work-group, then 127 (debug 4: what the host asks for after an overflow = 3 of
-    // the 63-key form; debug 7: skip both -- after an overflow = 3 of the 127-key form)
-    if ((a.debug == 0 || a.debug == 4 || a.debug >= 40) && lanes_plan(a, a.debug == 4 ? 128 : 64, lp)) {
+    // The forms, fastest first; a.first_form is where the chain starts (the host raises it when a form's per-work-group
+    // table overflowed on this query's keys: AggForm in imm3_internal.h).
+    // private per-lane tables, no atomics: 63 keys per work-group, then 127
+    if (a.first_form <= AGG_FORM_LANES_WIDE && lanes_plan(a, a.first_form == AGG_FORM_LANES_WIDE ? 128 : 64, lp)) {
 #define IMM3_LANES(KS, VW, V2)                                                                       \
     if (lp.ks == KS && lp.vw == VW && (lp.v2 != 0) == V2) {                                          \
-        if (lp.ns == 64) launch_lanes<KS, VW, V2, 64>(a, lp, s, ev0, ev1);                           \
-        else launch_lanes<KS, VW, V2, 128>(a, lp, s, ev0, ev1);                                      \
-        return;                                                                                      \
+        const bool ok = lp.ns == 64 ? launch_lanes<KS, VW, V2, 64>(a, lp, s, ev0, ev1)               \
+                                    : launch_lanes<KS, VW, V2, 128>(a, lp, s, ev0, ev1);             \
+        if (ok) return;                                                                              \
     }
         IMM3_LANES(0, 0, false) IMM3_LANES(0, 1, false) IMM3_LANES(0, 2, false) IMM3_LANES(0, 4, false) IMM3_LANES(0, 1, true)
         IMM3_LANES(1, 0, false) IMM3_LANES(1, 1, false) IMM3_LANES(1, 2, false) IMM3_LANES(1, 4, false) IMM3_LANES(1, 1, true)
         IMM3_LANES(2, 0, false) IMM3_LANES(2, 1, false) IMM3_LANES(2, 2, false) IMM3_LANES(2, 4, false) IMM3_LANES(2, 1, true)
 #undef IMM3_LANES
     }
-    if (a.debug != 9 && a.debug != 8 && group_agg_fast_ok(a) && key_bytes <= 2) { // the key indexes a slot map directly (debug 8: skip this form)
+    if (a.first_form <= AGG_FORM_DIRECT && group_agg_fast_ok(a) && key_bytes <= 2) { // the key indexes a slot map directly
         const int map_bytes = key_bytes <= 1 ? 256 : 65536;
         const int64_t want = (a.n_tiles + kDirectWaves - 1) / kDirectWaves;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, 256)); // one 1024-thread work-group per CU
         IMM3_LAUNCH_LDS(k_group_agg_direct, grid, kDirectThreads, (size_t)map_bytes, s, ev0, ev1, a, map_bytes);
         return;
     }
-    if (a.debug != 9 && group_agg_fast_ok(a)) { // (debug 9: force the general kernel -- also what the host does after an overflow = 2)
+    if (a.first_form <= AGG_FORM_TILE && group_agg_fast_ok(a)) {
         const int64_t want = (a.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(want, 768)); // ~41 KiB of LDS: 3 per CU
         IMM3_LAUNCH(k_group_agg_tile, grid, kBlockThreads, s, ev0, ev1, a);

@@ -32,79 +32,24 @@ int imm3::fail(int code, const std::string &msg) {
     return code;
 }
 
-#define CTX_LIVE_RUN(c)                                                                               \
-    do {                                                                                              \
-        if (!(c)) return fail(IMM3_ERR_ARG, "ctx is null");                                           \
-        if ((c)->closed) return fail(IMM3_ERR_STATE, "the context of this handle has been destroyed"); \
-    } while (0)
-// every entry point but the run calls: not while a graph capture is open (most of them synchronise or allocate)
-#define CTX_LIVE(c)                                                                                   \
-    do {                                                                                              \
-        CTX_LIVE_RUN(c);                                                                              \
-        if ((c)->capture) return fail(IMM3_ERR_STATE, "a graph capture is open on this context: only imm3_query_run / imm3_query_run_select and imm3_ctx_capture_end are accepted"); \
-    } while (0)
+// Entry into a context (imm3_sync.h): the call passes the context's capture gate -- shared, so calls of any number of
+// threads run side by side; while ANOTHER thread has a graph capture open it waits here until that capture ends.
+// (Declares a scope guard: one use per function scope.)
+#define CTX_LIVE_RUN(c)                                                                           \
+    if (!(c)) return fail(IMM3_ERR_ARG, "ctx is null");                                           \
+    imm3::GateScope imm3_gate_scope_(&(c)->gate);                                                 \
+    if ((c)->closed) return fail(IMM3_ERR_STATE, "the context of this handle has been destroyed")
+// every entry point but the run calls: not while THIS thread's graph capture is open (most of them synchronise or allocate)
+#define CTX_LIVE(c)                                                                               \
+    CTX_LIVE_RUN(c);                                                                              \
+    if ((c)->capture) return fail(IMM3_ERR_STATE, "a graph capture is open on this context: only imm3_query_run / imm3_query_run_select and imm3_ctx_capture_end are accepted")
 
 // ---------------------------------------------------------------------------------------------
-// context-level caching allocator (see imm3_ctx::pool_*)
+// context-level caching allocator (imm3_sync.h: BlockPool, one per context, thread-safe)
 // ---------------------------------------------------------------------------------------------
-static size_t pool_bucket(size_t bytes) {
-    if (bytes < 256) bytes = 256;
-    if (bytes <= (1u << 20)) { size_t b = 256; while (b < bytes) b <<= 1; return b; }
-    return (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
-}
-
-static hipError_t pool_alloc(imm3_ctx *ctx, void **out, size_t bytes) {
-    const size_t b = pool_bucket(bytes);
-    {
-        std::lock_guard<std::mutex> g(ctx->pool_mu);
-        auto it = ctx->pool_free.find(b);
-        if (it != ctx->pool_free.end()) {
-            *out = it->second;
-            ctx->pool_free.erase(it);
-            ctx->pool_cached -= b;
-            return hipSuccess;
-        }
-    }
-    void *p = nullptr;
-    hipError_t e = hipMalloc(&p, b);
-    if (e != hipSuccess) { // give cached blocks back to the driver and retry once
-        std::lock_guard<std::mutex> g(ctx->pool_mu);
-        for (auto &kv : ctx->pool_free) { ctx->pool_size.erase(kv.second); (void)hipFree(kv.second); }
-        ctx->pool_free.clear();
-        ctx->pool_cached = 0;
-        e = hipMalloc(&p, b);
-        if (e != hipSuccess) return e;
-    }
-    {
-        std::lock_guard<std::mutex> g(ctx->pool_mu);
-        ctx->pool_size[p] = b;
-    }
-    *out = p;
-    return hipSuccess;
-}
-
-static void pool_release(imm3_ctx *ctx, void *p) {
-    if (!p) return;
-    std::lock_guard<std::mutex> g(ctx->pool_mu);
-    auto it = ctx->pool_size.find(p);
-    if (it == ctx->pool_size.end()) { (void)hipFree(p); return; }
-    constexpr size_t kMaxCached = (size_t)16 << 30; // keep at most 16 GiB parked
-    if (ctx->pool_cached + it->second > kMaxCached) {
-        ctx->pool_size.erase(it);
-        (void)hipFree(p);
-        return;
-    }
-    ctx->pool_free.emplace(it->second, p);
-    ctx->pool_cached += it->second;
-}
-
-static void pool_drain(imm3_ctx *ctx) {
-    std::lock_guard<std::mutex> g(ctx->pool_mu);
-    for (auto &kv : ctx->pool_free) (void)hipFree(kv.second);
-    ctx->pool_free.clear();
-    ctx->pool_size.clear();
-    ctx->pool_cached = 0;
-}
+static hipError_t pool_alloc(imm3_ctx *ctx, void **out, size_t bytes) { return (hipError_t)ctx->blocks.alloc(out, bytes); }
+static void pool_release(imm3_ctx *ctx, void *p) { ctx->blocks.release(p); }
+static void pool_drain(imm3_ctx *ctx) { ctx->blocks.drain(); }
 
 // ---------------------------------------------------------------------------------------------
 // scalar rules shared with the reference (JVM d2i / i2b): Select.scala:65,73; SURVEY Appendix A.1 rule 5
@@ -167,9 +112,16 @@ extern "C" int imm3_ctx_create(int device, void *stream, imm3_ctx **out) {
     return IMM3_OK;
 }
 
-void imm3::ctx_retain(imm3_ctx *c) { c->refs.fetch_add(1, std::memory_order_relaxed); }
+void imm3::ctx_retain(imm3_ctx *c) { ref_retain(c->refs); }
 void imm3::ctx_release(imm3_ctx *c) {
-    if (c->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete c;
+    if (ref_release(c->refs)) delete c;
+}
+
+// a query's device buffers are about to move (or go): every graph that recorded one of its runs points at the old ones
+static void graphs_mark_stale(imm3_ctx *ctx, const imm3_query *q) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    for (imm3_graph *gr : ctx->graphs)
+        if (std::find(gr->queries.begin(), gr->queries.end(), q) != gr->queries.end()) gr->stale = true;
 }
 
 // Destroying a context with live segments / tables / queries is allowed (see imm3_handles.h, "Lifetimes"): everything the
@@ -178,16 +130,19 @@ extern "C" int imm3_ctx_destroy(imm3_ctx *ctx) {
     if (!ctx) return IMM3_OK;
     if (ctx->closed) return fail(IMM3_ERR_STATE, "context destroyed twice");
     (void)hipSetDevice(ctx->device);
-    if (ctx->capture) { // an abandoned capture: end it and drop what it recorded
-        hipGraph_t g = nullptr;
+    if (ctx->capture) { // an abandoned capture: end it and drop what it recorded.  The imm3_graph was never handed to the
+        hipGraph_t g = nullptr; // caller, so nobody else can free it or the context reference it holds
         (void)hipStreamEndCapture(ctx->stream, &g);
         if (g) (void)hipGraphDestroy(g);
         (void)hipGetLastError();
-        ctx->capture->stale = true;
-        ctx->graphs.push_back(ctx->capture); // (so that it is released below like the others)
+        delete ctx->capture;
         ctx->capture = nullptr;
+        if (ctx->gate.owned_by_me()) ctx->gate.end_exclusive();
+        ctx_release(ctx); // the reference imm3_ctx_capture_begin took
     }
+    // (the caller's contract: no other thread is inside a call on this context or its children while it is destroyed)
     (void)hipStreamSynchronize(ctx->stream);
+    std::lock_guard<std::mutex> lk(ctx->mu);
     for (imm3_graph *g : ctx->graphs) { // the handles stay valid (imm3_graph_destroy frees them); what they recorded is gone
         if (g->exec) (void)hipGraphExecDestroy(g->exec);
         if (g->graph) (void)hipGraphDestroy(g->graph);
@@ -230,14 +185,20 @@ extern "C" int imm3_ctx_sync(imm3_ctx *ctx) {
 // graphs: a recorded sequence of query runs, enqueued with one call (hipGraph)
 // ---------------------------------------------------------------------------------------------
 extern "C" int imm3_ctx_capture_begin(imm3_ctx *ctx) {
-    CTX_LIVE(ctx);
-    HIPCHK(hipSetDevice(ctx->device));
+    if (!ctx) return fail(IMM3_ERR_ARG, "ctx is null");
+    if (ctx->closed) return fail(IMM3_ERR_STATE, "the context of this handle has been destroyed");
+    if (ctx->gate.owned_by_me()) return fail(IMM3_ERR_STATE, "a graph capture is open on this context: only imm3_query_run / imm3_query_run_select and imm3_ctx_capture_end are accepted");
+    // exclusive from here to imm3_ctx_capture_end: calls of other threads on this context wait (whatever they enqueued
+    // on the capturing stream would be recorded into the graph)
+    if (!ctx->gate.begin_exclusive()) return fail(IMM3_ERR_STATE, "imm3_ctx_capture_begin from inside another call on this context");
+    hipError_t e = hipSetDevice(ctx->device);
     imm3_graph *g = new imm3_graph();
     g->ctx = ctx;
-    const hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed);
+    if (e == hipSuccess) e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed);
     if (e != hipSuccess) {
         delete g;
         (void)hipGetLastError();
+        ctx->gate.end_exclusive();
         return fail(IMM3_ERR_DEVICE, std::string("hipStreamBeginCapture: ") + hipGetErrorString(e));
     }
     ctx_retain(ctx);
@@ -247,21 +208,27 @@ extern "C" int imm3_ctx_capture_begin(imm3_ctx *ctx) {
 
 extern "C" int imm3_ctx_capture_end(imm3_ctx *ctx, imm3_graph **out) {
     if (!out) return fail(IMM3_ERR_ARG, "null argument");
-    CTX_LIVE_RUN(ctx);
-    if (!ctx->capture) return fail(IMM3_ERR_STATE, "no capture is open on this context");
+    if (!ctx) return fail(IMM3_ERR_ARG, "ctx is null");
+    if (ctx->closed) return fail(IMM3_ERR_STATE, "the context of this handle has been destroyed");
+    if (!ctx->gate.owned_by_me() || !ctx->capture) return fail(IMM3_ERR_STATE, "no capture is open on this context (begin and end belong to one thread)");
     imm3_graph *g = ctx->capture;
     ctx->capture = nullptr;
-    HIPCHK(hipSetDevice(ctx->device));
-    hipError_t e = hipStreamEndCapture(ctx->stream, &g->graph);
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipStreamEndCapture(ctx->stream, &g->graph);
     if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         if (g->graph) (void)hipGraphDestroy(g->graph);
         delete g;
+        ctx->gate.end_exclusive();
         ctx_release(ctx);
         return fail(IMM3_ERR_DEVICE, std::string("graph capture failed: ") + hipGetErrorString(e));
     }
-    ctx->graphs.push_back(g);
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ctx->graphs.push_back(g);
+    }
+    ctx->gate.end_exclusive();
     *out = g;
     return IMM3_OK;
 }
@@ -269,7 +236,10 @@ extern "C" int imm3_ctx_capture_end(imm3_ctx *ctx, imm3_graph **out) {
 extern "C" int imm3_graph_launch(imm3_graph *g) {
     if (!g) return fail(IMM3_ERR_ARG, "graph is null");
     CTX_LIVE(g->ctx);
-    if (g->stale || !g->exec) return fail(IMM3_ERR_STATE, "a query recorded in this graph has been destroyed");
+    {
+        std::lock_guard<std::mutex> lk(g->ctx->mu);
+        if (g->stale || !g->exec) return fail(IMM3_ERR_STATE, "a query recorded in this graph has been destroyed or has moved its buffers: record the graph again");
+    }
     HIPCHK(hipSetDevice(g->ctx->device));
     HIPCHK(hipGraphLaunch(g->exec, g->ctx->stream));
     return IMM3_OK;
@@ -278,10 +248,12 @@ extern "C" int imm3_graph_launch(imm3_graph *g) {
 extern "C" int imm3_graph_destroy(imm3_graph *g) {
     if (!g) return IMM3_OK;
     imm3_ctx *ctx = g->ctx;
+    imm3::GateScope gate(&ctx->gate);
     if (!ctx->closed) {
         if (ctx->capture) return fail(IMM3_ERR_STATE, "a graph capture is open on this context");
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream); // a launch may still be running
+        std::lock_guard<std::mutex> lk(ctx->mu);
         auto &gs = ctx->graphs;
         gs.erase(std::remove(gs.begin(), gs.end(), g), gs.end());
     }
@@ -310,6 +282,7 @@ extern "C" int imm3_ctx_devclock_enable(imm3_ctx *ctx, int32_t max_launches) {
     CTX_LIVE(ctx);
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::lock_guard<std::mutex> lk(ctx->mu);
     (void)hipFree(ctx->d_stamps); // the stamp buffer only: the snappy CRC table and the buffer pool are not this call's to free
     ctx->d_stamps = nullptr;
     ctx->stamp_slots = 0;
@@ -329,6 +302,7 @@ extern "C" int imm3_ctx_devclock_collect(imm3_ctx *ctx, float *ms_out, int32_t c
     CTX_LIVE(ctx);
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::lock_guard<std::mutex> lk(ctx->mu);
     const int32_t n = ctx->stamp_used;
     std::vector<unsigned long long> h((size_t)kMaxFilterGrid * 2);
     for (int32_t i = 0; i < n && i < cap; ++i) {
@@ -381,6 +355,7 @@ extern "C" int imm3_ctx_measure_read_gbps(imm3_ctx *ctx, uint64_t bytes, int32_t
 extern "C" int imm3_ctx_timing_enable(imm3_ctx *ctx, int32_t max_records) {
     CTX_LIVE(ctx);
     HIPCHK(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> lk(ctx->mu);
     while ((int32_t)ctx->pool.size() < max_records) {
         TimingRecord r{};
         HIPCHK(hipEventCreate(&r.start));
@@ -400,6 +375,7 @@ extern "C" int imm3_ctx_timing_mask(imm3_ctx *ctx, uint32_t kernel_mask) {
 
 extern "C" int imm3_ctx_timing_reset(imm3_ctx *ctx) {
     CTX_LIVE(ctx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->used = 0;
     return IMM3_OK;
 }
@@ -410,6 +386,7 @@ extern "C" int imm3_ctx_timing_collect(imm3_ctx *ctx, int32_t kernel_id, float *
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->aux) HIPCHK(hipStreamSynchronize(ctx->aux));
+    std::lock_guard<std::mutex> lk(ctx->mu);
     int32_t n = 0;
     for (size_t i = 0; i < ctx->used; ++i) {
         if (ctx->pool[i].kernel_id != kernel_id) continue;
@@ -430,7 +407,9 @@ namespace {
 struct LaunchTimer {
     hipEvent_t start = nullptr, stop = nullptr;
     LaunchTimer(imm3_ctx *ctx, int32_t id) {
-        if (ctx->timing && !ctx->capture && ((ctx->timing_mask >> id) & 1u) && ctx->used < ctx->pool.size()) {
+        if (!ctx->timing.load(std::memory_order_relaxed) || ctx->capture || !((ctx->timing_mask.load(std::memory_order_relaxed) >> id) & 1u)) return;
+        std::lock_guard<std::mutex> lk(ctx->mu); // (diagnostics only: the lock is taken when timing is on)
+        if (ctx->used < ctx->pool.size()) {
             TimingRecord &rec = ctx->pool[ctx->used++];
             rec.kernel_id = id;
             start = rec.start;
@@ -449,7 +428,7 @@ static constexpr uint64_t kPad = 16384; // readable slack past every column: a p
 // share one registration, and the range stays pinned until the last of them has finished with it (unpinning it under a
 // copy still in flight is an error the runtime reports much later, on an unrelated call).
 static bool pin_range(imm3_ctx *ctx, void *p, size_t bytes) {
-    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    std::lock_guard<std::mutex> g(ctx->mu);
     auto it = ctx->pinned.find(p);
     if (it != ctx->pinned.end()) { ++it->second; return true; }
     hipError_t re = hipHostRegister(p, bytes, hipHostRegisterDefault);
@@ -459,7 +438,7 @@ static bool pin_range(imm3_ctx *ctx, void *p, size_t bytes) {
     return true;
 }
 static void unpin_range(imm3_ctx *ctx, void *p) {
-    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    std::lock_guard<std::mutex> g(ctx->mu);
     auto it = ctx->pinned.find(p);
     if (it == ctx->pinned.end()) return;
     if (--it->second == 0) {
@@ -606,7 +585,7 @@ static int snappy_index(imm3_ctx *ctx, imm3_segment *seg, SegCol &sc) {
 
 // x^(8 n) mod the CRC-32C polynomial (reflected) for n = 0 .. 32768: moves a slice's CRC past the bytes after it
 static int ensure_xpow8(imm3_ctx *ctx) {
-    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    std::lock_guard<std::mutex> g(ctx->mu);
     if (ctx->d_xpow8) return IMM3_OK;
     std::vector<uint32_t> t(32769);
     uint32_t c = 0x80000000u; // x^0
@@ -710,7 +689,10 @@ static int segment_build(imm3_ctx *ctx, const imm3_column *cols, int32_t ncols, 
     seg->ctx = ctx;
     ctx_retain(ctx);
     seg->cols.resize((size_t)ncols);
-    if (!wrap && !ctx->copy) HIPCHK(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
+    if (!wrap) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (!ctx->copy) HIPCHK(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
+    }
     bool any_compressed = false;
     for (int32_t i = 0; i < ncols; ++i) any_compressed |= is_compressed(cols[i].codec);
     for (int32_t i = 0; i < ncols; ++i) {
@@ -785,6 +767,11 @@ extern "C" int imm3_segment_wait(imm3_segment *seg) {
 extern "C" int imm3_segment_destroy(imm3_segment *seg) {
     if (!seg) return IMM3_OK;
     if (seg->closed) return fail(IMM3_ERR_STATE, "segment destroyed twice");
+    imm3_ctx *ctx = seg->ctx;
+    ctx_retain(ctx); // (the gate lives in the context)
+    struct Unref { imm3_ctx *c; ~Unref() { ctx_release(c); } } unref{ctx};
+    imm3::GateScope gate(&ctx->gate);
+    if (!ctx->closed && ctx->capture) return fail(IMM3_ERR_STATE, "a graph capture is open on this context");
     seg->closed = true;
     if (!seg->ctx->closed) { // (a destroyed context has already drained its streams)
         (void)hipSetDevice(seg->ctx->device);
@@ -843,6 +830,7 @@ static int ensure_row_capacity(imm3_query *q, uint64_t rows) {
     if (rows <= q->cap_rows && q->d_row_index) return IMM3_OK;
     if (rows < 1) rows = 1;
     imm3_ctx *ctx = q->ctx;
+    if (q->d_row_index) graphs_mark_stale(ctx, q); // a recorded run would write through the old pointers (launch: IMM3_ERR_STATE)
     pool_release(ctx, q->d_row_index); // stream-ordered: a gather still in flight finishes before any reuse
     q->d_row_index = nullptr;
     for (auto &p : q->d_proj) {
@@ -1183,7 +1171,7 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
             // 3 per CU (~52 KiB of LDS each); 4 per CU for a lone 2-byte-string column (1-dword records, 4 KiB record buffers: C4's
             // filter 50.5 -> 46.6 us).  Measured per shape: a lone int8 column at 1024 lost 8 us, an int32 column 7 us.
             const bool lone_s2 = q->stage_kinds[0] == TK_S2 && q->stage_kinds[1] == TK_NONE;
-            const int cap = ctx->grid_blocks > 0 ? std::min(ctx->grid_blocks, kMaxFilterGrid) : (R == 1 && lone_s2 ? 1024 : 768);
+            const int cap = ctx->grid_blocks > 0 ? std::min(ctx->grid_blocks.load(), kMaxFilterGrid) : (R == 1 && lone_s2 ? 1024 : 768);
             const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((q->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, cap));
             const int64_t n_waves = grid * kWavesPerBlock;
             const int64_t n_groups = T > 0 ? (q->n_rows / kTileRows) / T : 0;
@@ -1316,6 +1304,11 @@ extern "C" int imm3_table_create(imm3_ctx *ctx, const imm3_segment *const *segs,
 extern "C" int imm3_table_destroy(imm3_table *t) {
     if (!t) return IMM3_OK;
     if (t->closed) return fail(IMM3_ERR_STATE, "table destroyed twice");
+    imm3_ctx *ctx = t->ctx;
+    ctx_retain(ctx);
+    struct Unref { imm3_ctx *c; ~Unref() { ctx_release(c); } } unref{ctx};
+    imm3::GateScope gate(&ctx->gate);
+    if (!ctx->closed && ctx->capture) return fail(IMM3_ERR_STATE, "a graph capture is open on this context");
     t->closed = true;
     if (!t->ctx->closed) {
         (void)hipSetDevice(t->ctx->device);
@@ -1358,13 +1351,21 @@ extern "C" int imm3_query_locate_rows(const imm3_query *q, const uint32_t *row_i
 }
 
 extern "C" int imm3_query_destroy(imm3_query *q) {
-    if (q && q->ctx && !q->ctx->closed) {
-        if (q->ctx->capture) return fail(IMM3_ERR_STATE, "a graph capture is open on this context");
-        for (imm3_graph *g : q->ctx->graphs) // a graph that recorded this query's runs points into its buffers
-            if (std::find(g->queries.begin(), g->queries.end(), q) != g->queries.end()) g->stale = true;
+    if (!q) return IMM3_OK;
+    imm3_ctx *ctx = q->ctx;
+    if (!ctx) { query_free(q); return IMM3_OK; }
+    ctx_retain(ctx); // the gate lives in the context: keep it past query_free
+    int rc = IMM3_OK;
+    {
+        imm3::GateScope gate(&ctx->gate);
+        if (!ctx->closed && ctx->capture) rc = fail(IMM3_ERR_STATE, "a graph capture is open on this context");
+        else {
+            if (!ctx->closed) graphs_mark_stale(ctx, q); // a graph that recorded this query's runs points into its buffers
+            query_free(q);
+        }
     }
-    query_free(q);
-    return IMM3_OK;
+    ctx_release(ctx);
+    return rc;
 }
 
 extern "C" int imm3_query_reserve_rows(imm3_query *q, uint64_t rows) {
@@ -1490,7 +1491,7 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
             a.max_slots = q->stage_max_slots;
             q->stage_written = true;
         }
-        a.debug = (ctx->filter_variant >= 20 && ctx->filter_variant <= 22) ? ctx->filter_variant : 0;
+        a.ablate = (ctx->filter_variant >= 20 && ctx->filter_variant <= 22) ? ctx->filter_variant.load() : 0; // (tools' build only)
         a.and_existing = pass > 0;
         a.n_rows = q->n_rows;
         a.n_words = q->n_words;
@@ -1500,7 +1501,7 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
         a.tile_rows = q->table ? q->table->d_tile_rows : nullptr; // table query: address the columns through the tile table
         bool any_i32 = false;
         for (int k = 0; k < kMaxTileCols; ++k) any_i32 |= (a.kinds[k] == TK_I32);
-        if (ctx->d_stamps && ctx->stamp_used < ctx->stamp_slots) a.stamps = ctx->d_stamps + (size_t)ctx->stamp_used * kMaxFilterGrid * 2;
+        bool stamped = false;
         grid = filter_grid(q->n_tiles, false, any_i32, ctx->grid_blocks); // (no column at all: the store-only kernel also likes 1536 groups, 9.9 vs 17.2 us)
         if (q->stage_written) grid = q->stage_grid; // fixed at creation: the arena layout depends on it
         // A select chain that is ONE tile pass also reduces its count in the kernel (one relaxed atomic per work-group into a
@@ -1514,7 +1515,16 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
         // leave no room for 32 KiB more per group); tuning variant 12 switches it off
         // (64 lines = 32 KiB per work-group at <= 4 groups per CU; 16 lines = 8 KiB for the 1536-group narrow-column kernels)
         a.defer_lines = ctx->filter_variant == 12 ? 0 : (q->stage_written ? 16 : (grid <= 1024 ? kDeferLines : 16));
-        if (a.stamps) { ctx->stamp_grids.push_back(grid); ++ctx->stamp_used; }
+        if (ctx->d_stamps) { // (diagnostics: bench.py's instrumented pass)
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            if (ctx->d_stamps && ctx->stamp_used < ctx->stamp_slots) {
+                a.stamps = ctx->d_stamps + (size_t)ctx->stamp_used * kMaxFilterGrid * 2;
+                ctx->stamp_grids.push_back(grid);
+                ++ctx->stamp_used;
+                stamped = true;
+            }
+        }
+        (void)stamped;
         LaunchTimer t(ctx, 0);
         if (!launch_filter_tile(a, grid, s, t.start, t.stop)) return fail(IMM3_ERR_ARG, "internal: no tile kernel for this column combination");
         HIPCHK(hipGetLastError());
@@ -1540,7 +1550,7 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
         a.status = (uint32_t *)(q->d_total + 2);
         // VALU/LDS-latency bound, 5 waves per SIMD resident: the finest grid balances best (measured 83 us at 2048
         // work-groups, 76 us at 4096, 100 M rows)
-        grid = filter_grid(q->n_tiles, true, false, ctx->grid_blocks > 0 ? ctx->grid_blocks : kMaxFilterGrid);
+        grid = filter_grid(q->n_tiles, true, false, ctx->grid_blocks > 0 ? ctx->grid_blocks.load() : kMaxFilterGrid);
         {
             LaunchTimer t(ctx, 0);
             launch_filter_pfor(a, grid, s, t.start, t.stop);
@@ -1587,7 +1597,10 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
         if (overlap_total) {
             // nothing downstream on the main stream needs the count: reduce it on the aux stream so the next scan
             // starts right behind this one (saves the reduce kernel and two dependent-launch gaps per step)
-            if (!ctx->aux) HIPCHK(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+            {
+                std::lock_guard<std::mutex> lk(ctx->mu);
+                if (!ctx->aux) HIPCHK(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+            }
             if (!q->ev_filter_done) {
                 HIPCHK(hipEventCreateWithFlags(&q->ev_filter_done, hipEventDisableTiming));
                 HIPCHK(hipEventCreateWithFlags(&q->ev_total_done, hipEventDisableTiming));
@@ -1622,7 +1635,7 @@ static int launch_emit_records(imm3_query *q) {
     e.main_tiles = q->stage_main_tiles;
     e.max_slots = q->stage_max_slots;
     e.T = q->stage_T;
-    e.debug = (ctx->filter_variant >= 34 && ctx->filter_variant <= 35) ? ctx->filter_variant : 0;
+    e.ablate = (ctx->filter_variant >= 34 && ctx->filter_variant <= 35) ? ctx->filter_variant.load() : 0; // (tools' build only)
     e.tile_offsets = q->d_tile_offsets;
     e.chunk_sums = q->d_chunk_sums;
     e.n_tiles = q->n_tiles;
@@ -1889,6 +1902,7 @@ extern "C" int imm3_query_row_count(imm3_query *q, uint64_t *rows) {
 
 extern "C" int imm3_query_fetch_rows(imm3_query *q, uint32_t *row_index_out, void *const *col_out, uint64_t max_rows) {
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    CTX_LIVE(q->ctx);
     uint64_t rows = 0;
     const int rc = settle_rows(q, &rows);
     if (rc) return rc;
@@ -2052,7 +2066,10 @@ static int run_agg(imm3_query *q) {
     imm3_ctx *ctx = q->ctx;
     AggArgs a;
     fill_agg_args(q, a);
-    a.debug = ctx->filter_variant >= 100 ? ctx->filter_variant - 100 : q->agg_skip; // (agg_skip: forms this query's keys overflowed before)
+    // tuning variants 100 + AggForm start the chain at that form (tools/aggexp.py); 140 + x: ablation x of the tools' build
+    const int fv = ctx->filter_variant;
+    a.first_form = (fv >= 100 && fv <= 100 + AGG_FORM_GENERAL) ? fv - 100 : q->agg_first_form; // (agg_first_form: past the forms this query's keys overflowed)
+    a.ablate = fv >= 140 ? fv - 100 : 0;
     LaunchTimer t(ctx, 4);
     launch_group_agg(a, ctx->stream, t.start, t.stop);
     HIPCHK(hipGetLastError());
@@ -2079,13 +2096,16 @@ static int settle_groups(imm3_query *q, uint32_t *n_groups) {
         if (meta[1] == 2 || meta[1] == 3) { // a fast form's per-work-group table filled up: aggregate again with the next form
             AggArgs g;                       // (3: k_group_agg_lanes -> k_group_agg_direct; 2: -> the general kernel)
             fill_agg_args(q, g);
-            g.debug = q->agg_skip = meta[1] == 3 ? (q->agg_skip == 0 ? 4 : 7) : 9; // lanes 63 -> lanes 127 -> direct -> general
+            // lanes (63 keys) -> lanes (127 keys) -> direct -> general
+            q->agg_first_form = meta[1] == 3 ? (q->agg_first_form == AGG_FORM_LANES ? AGG_FORM_LANES_WIDE : AGG_FORM_DIRECT) : AGG_FORM_GENERAL;
+            g.first_form = q->agg_first_form;
             launch_group_agg(g, s, nullptr, nullptr);
             HIPCHK(hipGetLastError());
             continue;
         }
         if (meta[1]) return fail(IMM3_ERR_LAYOUT, "more distinct groups than the aggregation table holds (2^27)");
         if (meta[0] <= q->out_cap) { *n_groups = meta[0]; return IMM3_OK; }
+        if (q->d_okeys) graphs_mark_stale(ctx, q);
         pool_release(ctx, q->d_okeys); pool_release(ctx, q->d_ofirst); pool_release(ctx, q->d_ocounts); pool_release(ctx, q->d_ovals);
         q->d_okeys = nullptr; q->d_ofirst = nullptr; q->d_ocounts = nullptr; q->d_ovals = nullptr;
         void *p = nullptr;
@@ -2106,6 +2126,7 @@ extern "C" int imm3_query_group_count(imm3_query *q, uint32_t *n_groups) {
 
 extern "C" int imm3_query_fetch_groups(imm3_query *q, uint64_t *keys, uint32_t *first_row, uint64_t *counts, int64_t *vals, uint32_t max_groups) {
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    CTX_LIVE(q->ctx);
     uint32_t n = 0;
     const int rc = settle_groups(q, &n);
     if (rc) return rc;

@@ -176,9 +176,14 @@ extern "C" int imm3_comm_create_all(imm3_ctx *const *ctxs, int32_t n, imm3_comm 
     NCCLCHK(g_rccl.CommInitAll(ncs.data(), n, devs.data()));
     for (int32_t i = 0; i < n; ++i) {
         const int frc = comm_finish(ctxs[i], ncs[(size_t)i], n, i, &out[i]);
-        if (frc) {
+        if (frc) { // all or nothing: the communicators made so far go too (the caller only sees nulls)
+            const std::string why = imm3_last_error();
             for (int32_t j = i + 1; j < n; ++j) (void)g_rccl.CommDestroy(ncs[(size_t)j]);
-            return frc;
+            for (int32_t j = 0; j < i; ++j) {
+                (void)imm3_comm_destroy(out[j]);
+                out[j] = nullptr;
+            }
+            return fail(frc, why);
         }
     }
     return IMM3_OK;
@@ -187,7 +192,10 @@ extern "C" int imm3_comm_create_all(imm3_ctx *const *ctxs, int32_t n, imm3_comm 
 extern "C" int imm3_comm_destroy(imm3_comm *c) {
     if (!c) return IMM3_OK;
     (void)hipSetDevice(c->ctx->device);
-    if (!c->ctx->closed) (void)hipStreamSynchronize(c->ctx->stream);
+    {
+        imm3::GateScope gate(&c->ctx->gate);
+        if (!c->ctx->closed) (void)hipStreamSynchronize(c->ctx->stream);
+    }
     (void)hipStreamSynchronize(c->stream);
     if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
     (void)hipStreamDestroy(c->stream);
@@ -208,6 +216,7 @@ extern "C" int imm3_comm_info(const imm3_comm *c, int32_t *world, int32_t *rank)
 
 extern "C" int imm3_comm_allreduce_u64(imm3_comm *c, uint64_t *device_buf, uint64_t n) {
     if (!c || !device_buf || n == 0) return fail(IMM3_ERR_ARG, "bad argument");
+    imm3::GateScope gate(&c->ctx->gate);
     if (c->ctx->closed) return fail(IMM3_ERR_STATE, "the context of this communicator has been destroyed");
     HIPCHK(hipSetDevice(c->ctx->device));
     int rc = fence_in(c);
@@ -226,6 +235,7 @@ extern "C" int imm3_comm_sync(imm3_comm *c) {
 
 extern "C" int imm3_comm_join(imm3_comm *c) {
     if (!c) return fail(IMM3_ERR_ARG, "comm is null");
+    imm3::GateScope gate(&c->ctx->gate);
     if (c->ctx->closed) return fail(IMM3_ERR_STATE, "the context of this communicator has been destroyed");
     HIPCHK(hipSetDevice(c->ctx->device));
     if (c->in_flight) HIPCHK(hipStreamWaitEvent(c->ctx->stream, c->ev_done, 0));
@@ -267,6 +277,7 @@ static int local_sum(imm3_comm *c, imm3_query *const *queries, int32_t n_queries
 extern "C" int imm3_comm_allreduce_count(imm3_comm *c, imm3_query *const *queries, int32_t n_queries, uint64_t *device_out,
                                          uint64_t *host_out) {
     if (!c || n_queries < 0 || (n_queries > 0 && !queries)) return fail(IMM3_ERR_ARG, "bad argument");
+    imm3::GateScope gate(&c->ctx->gate);
     if (c->ctx->closed) return fail(IMM3_ERR_STATE, "the context of this communicator has been destroyed");
     HIPCHK(hipSetDevice(c->ctx->device));
     unsigned long long *dst = device_out ? (unsigned long long *)device_out : c->d_slot;
@@ -292,8 +303,11 @@ extern "C" int imm3_comm_allreduce_count(imm3_comm *c, imm3_query *const *querie
 extern "C" int imm3_comm_allreduce_count_all(imm3_comm *const *comms, int32_t n_comms, imm3_query *const *const *queries,
                                              const int32_t *n_queries, uint64_t *host_out) {
     if (!comms || n_comms < 1 || !n_queries || !queries) return fail(IMM3_ERR_ARG, "bad argument");
-    for (int32_t i = 0; i < n_comms; ++i) {
+    for (int32_t i = 0; i < n_comms; ++i)
         if (!comms[i] || n_queries[i] < 0 || (n_queries[i] > 0 && !queries[i])) return fail(IMM3_ERR_ARG, "bad argument");
+    std::vector<std::unique_ptr<imm3::GateScope>> gates; // one context per device, each with its own capture gate
+    for (int32_t i = 0; i < n_comms; ++i) gates.emplace_back(new imm3::GateScope(&comms[i]->ctx->gate));
+    for (int32_t i = 0; i < n_comms; ++i) {
         if (comms[i]->ctx->closed) return fail(IMM3_ERR_STATE, "the context of a communicator has been destroyed");
         HIPCHK(hipSetDevice(comms[i]->ctx->device));
         int rc = local_sum(comms[i], queries[i], n_queries[i], comms[i]->d_slot);

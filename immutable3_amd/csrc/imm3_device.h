@@ -95,6 +95,7 @@ __device__ __forceinline__ void finish_add(unsigned long long *finish, unsigned 
         finish[0] = total;
         finish[1] = (limit > 0 && total > (unsigned long long)limit) ? (unsigned long long)limit : total;
         count_log_append(finish, total);
+        finish[kFinishEpoch] += 1; // a new run of the query starts behind this launch (k_filter_project's descriptors)
         __hip_atomic_store(finish + 4, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
     }
 }

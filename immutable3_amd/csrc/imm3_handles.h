@@ -4,6 +4,7 @@
 
 #include "../../include/imm3.h"
 #include "imm3_internal.h"
+#include "imm3_sync.h"
 
 #include <atomic>
 #include <map>
@@ -42,35 +43,37 @@ struct TimingRecord {
 // by the garbage collector gives no order).  Work submitted through a handle whose context has been destroyed fails
 // with IMM3_ERR_STATE; destroying the same handle twice while dependants keep it alive does too.
 struct imm3_graph;
+struct HipBlockBackend {
+    static int alloc(void **p, size_t bytes) { return (int)hipMalloc(p, bytes); }
+    static void free(void *p) { (void)hipFree(p); }
+};
+// Threading: see imm3_sync.h.  A context may be used by any number of threads at once; `gate` serialises a graph capture
+// against the other threads' calls, `mu` guards the small mutable state below, the buffer pool has its own lock.
 struct imm3_ctx {
     std::atomic<int> refs{1};
-    bool closed = false;            // imm3_ctx_destroy has run: streams, events and the buffer pool are gone
+    std::atomic<bool> closed{false}; // imm3_ctx_destroy has run: streams, events and the buffer pool are gone
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    imm3::CaptureGate gate;
+    std::mutex mu;                  // guards aux / copy creation, pinned, the timing and stamp records, graphs, d_xpow8
     hipStream_t aux = nullptr;      // count reduce of select-only runs: overlaps the next scan on `stream`
     hipStream_t copy = nullptr;     // host -> HBM staging of segments: never on the query stream, so staging overlaps queries
-    std::map<void *, int> pinned;   // host ranges pinned in place for asynchronous staging, by start address, with a use count (pool_mu)
-    int filter_variant = 0;
-    int grid_blocks = 0;
-    bool timing = false;
-    uint32_t timing_mask = 0xFFFFFFFFu;
-    std::vector<TimingRecord> pool; // pre-created event pairs
-    size_t used = 0;
-    // Caching allocator for per-query buffers.  Every user of such a buffer runs on `stream`, so a block freed by one
-    // query and handed to the next is reused in stream order: no synchronisation, no hipMalloc/hipFree (each ~50-100 us)
-    // on the query path once the pool is warm.
-    std::mutex pool_mu;
-    std::multimap<size_t, void *> pool_free;
-    std::unordered_map<void *, size_t> pool_size;
-    size_t pool_cached = 0;
-    // device-clock stamps (diagnostics): slot i = kMaxFilterGrid {start, end} pairs for the i-th tile launch
+    std::map<void *, int> pinned;   // host ranges pinned in place for asynchronous staging, by start address, with a use count
+    std::atomic<int> filter_variant{0};
+    std::atomic<int> grid_blocks{0};
+    std::atomic<bool> timing{false};
+    std::atomic<uint32_t> timing_mask{0xFFFFFFFFu};
+    std::vector<TimingRecord> pool; // pre-created event pairs (mu)
+    size_t used = 0;                // (mu)
+    imm3::BlockPool<HipBlockBackend> blocks; // per-query device buffers, reused in stream order
+    // device-clock stamps (diagnostics): slot i = kMaxFilterGrid {start, end} pairs for the i-th tile launch (mu)
     unsigned long long *d_stamps = nullptr;
     int32_t stamp_slots = 0, stamp_used = 0;
     std::vector<int32_t> stamp_grids;
-    uint32_t *d_xpow8 = nullptr;    // snappy CRC-32C check: x^(8 n) mod P for n = 0 .. 32768
-    imm3_graph *capture = nullptr;  // open stream capture (imm3_ctx_capture_begin .. _end), else null
-    std::vector<imm3_graph *> graphs; // graphs recorded on this context that have not been destroyed yet
+    uint32_t *d_xpow8 = nullptr;    // snappy CRC-32C check: x^(8 n) mod P for n = 0 .. 32768 (mu)
+    imm3_graph *capture = nullptr;  // open stream capture (imm3_ctx_capture_begin .. _end), else null; owned by the capturing thread (gate)
+    std::vector<imm3_graph *> graphs; // graphs recorded on this context that have not been destroyed yet (mu)
 };
 
 // A recorded sequence of query runs (hipGraph): launching it enqueues every kernel of those runs with one call.
@@ -111,7 +114,7 @@ struct SegCol {
 
 struct imm3_segment {
     std::atomic<int> refs{1};
-    bool closed = false;
+    std::atomic<bool> closed{false};
     imm3_ctx *ctx = nullptr;
     std::vector<SegCol> cols;
     uint64_t device_bytes = 0;
@@ -126,7 +129,7 @@ static inline const uint8_t *col_flat(const SegCol &sc) { return is_compressed(s
 
 struct imm3_table { // all segments of one table as one scan unit: the tile table
     std::atomic<int> refs{1};
-    bool closed = false;
+    std::atomic<bool> closed{false};
     imm3_ctx *ctx = nullptr;
     std::vector<const imm3_segment *> segs;
     std::vector<int64_t> seg_rows;     // rows per segment
@@ -189,7 +192,7 @@ struct imm3_query {
     long long *d_avals = nullptr, *d_ovals = nullptr;
     uint32_t out_cap = 0;
     bool ran_agg = false;
-    int agg_skip = 0;              // 0, or the launch_group_agg debug value that skips the forms this query overflowed (7, 9)
+    int32_t agg_first_form = imm3::AGG_FORM_LANES; // first kernel form to try: raised past the forms this query's keys overflowed
     // select-only runs: the count reduce goes to ctx->aux, fenced by these events
     hipEvent_t ev_filter_done = nullptr, ev_total_done = nullptr;
     bool total_on_aux = false;

@@ -6,6 +6,15 @@
 #include <stdint.h>
 #include <algorithm>
 
+// Ablation switches ("what does the kernel cost without its stores?") exist only in the tools' build of the library
+// (make -C csrc ablate: -DIMM3_ABLATE -> lib/libimm3_ablate.so, loaded through IMM3_LIB_PATH).  In the shipped build
+// IMM3_ABLATED is the constant false and the kernels carry none of it.
+#ifdef IMM3_ABLATE
+#define IMM3_ABLATED(args, value) ((args).ablate == (value))
+#else
+#define IMM3_ABLATED(args, value) false
+#endif
+
 namespace imm3 {
 
 // A wave owns one TILE = 1024 rows = 16 bitmap words = exactly one 128-byte line of the bitmap,
@@ -59,7 +68,7 @@ struct TileArgs {
     int32_t kinds[kMaxTileCols];    // sorted ascending, TK_NONE last (selects the template instance)
     int32_t and_existing;
     int32_t defer_lines;            // > 0: park the bitmap lines in (dynamic) LDS and store them in bursts (single segment only)
-    int32_t debug;                  // ablation switch for experiments (0 in production)
+    int32_t ablate;                 // read only by the tools' build (IMM3_ABLATED below); 0 otherwise
     int64_t n_rows, n_words, n_tiles;
     uint64_t *bitmap;
     uint32_t *block_partials;
@@ -130,7 +139,7 @@ struct EmitArgs {
     const uint32_t *tile_start;     // [wave * max_slots + i]
     int64_t wave_cap, n_waves, main_tiles; // arena size in records; waves of the filter launch; tiles its main loop covered (the rest: leftovers)
     int32_t max_slots, T;           // T: tiles per wave iteration of that launch
-    int32_t debug, pad;             // ablation switch for experiments (0 in production)
+    int32_t ablate, pad;            // read only by the tools' build (IMM3_ABLATED); 0 otherwise
     const uint32_t *tile_offsets;
     const uint32_t *chunk_sums;
     int64_t n_tiles;
@@ -141,6 +150,41 @@ struct EmitArgs {
     int32_t R;
 };
 void launch_emit(const EmitArgs &a, int n_gather, int grid_blocks, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+
+// ---- k_filter_project (imm3_project.hip): ScanOp -> SelectOp* -> ProjectOp of one uniform segment in ONE pass ----
+// A work-group owns SPANS of 4 * P consecutive tiles (its four waves P consecutive tiles each); spans go to the
+// work-groups round-robin.  The survivors' records of a wave's range wait in LDS; where they go in the output -- the
+// number of survivors in all earlier tiles -- comes from a chained scan over per-span DESCRIPTORS (decoupled look-back):
+//   desc[s] = epoch << 56 | flag << 54 | value     flag 1: value = survivors of span s (published when the span is done)
+//                                                  flag 2: value = survivors of spans 0..s (published after the look-back)
+//                                                  flag 3: the run is being abandoned (look-back timed out)
+// `epoch` (finish[kFinishEpoch], bumped by the launch's last work-group) tells this run's descriptors from the previous
+// run's, so nothing is cleared between runs.
+constexpr int kProjectMaxP = 64;        // tiles per wave per span (the tile's index in its range takes 6 bits of the record)
+constexpr int kFinishStatus = 2;        // finish[2]: bit 0 malformed PFOR block, bit 1 single-pass projection abandoned
+constexpr int kFinishEpoch = 8;         // finish[8]: run counter of the query (descriptor epochs)
+constexpr unsigned long long kDescValueMask = (1ULL << 54) - 1;
+struct ProjectArgs {
+    TileCol cols[kMaxTileCols];
+    int32_t kinds[kMaxTileCols];    // sorted ascending, TK_NONE last
+    int32_t P;                      // tiles per wave per span
+    int64_t n_rows, n_tiles, n_spans;
+    uint64_t *bitmap;
+    unsigned long long *finish;     // the query's {total, n_emit, status, limit, tally, log ..., epoch} block
+    unsigned long long *desc;       // n_spans descriptors
+    void *arena;                    // spill space: wave_cap records per wave (a range whose records outgrow the LDS buffer)
+    int64_t wave_cap;
+    uint64_t cap_rows;              // capacity of the output arrays
+    uint32_t *row_index;
+    EmitCol out[kMaxProj];          // gathered columns first
+    int32_t n_out, n_gather;
+    int32_t ablate, pad;
+    unsigned long long *stamps;     // diagnostics only
+};
+// false: no instance for these kinds.  grid <= project_max_grid(): every work-group must be resident (they wait on each other)
+bool launch_filter_project(const ProjectArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+int project_max_grid(const int32_t *kinds, int P);   // resident work-groups of the instance on the current device (0: none)
+int project_rec_dwords(const int32_t *kinds);
 
 struct FilterArgs {
     ColPred cols[kMaxPredCols];
@@ -205,6 +249,11 @@ struct GatherArgs {
 constexpr int kMaxGroupCols = 4;
 constexpr int kMaxAggs = 4;
 enum AggKind : int32_t { AGG_COUNT = 0, AGG_MIN = 1, AGG_MAX = 2 };
+// The kernel forms of the aggregation, fastest first (imm3_agg.hip).  A query starts at AGG_FORM_LANES; a form whose
+// per-work-group table cannot hold the query's keys raises the overflow word (3: a lanes form, 2: direct / tile) and the
+// host aggregates again from the next form, remembering it in the query handle.
+enum AggForm : int32_t { AGG_FORM_LANES = 0, AGG_FORM_LANES_WIDE = 1, AGG_FORM_DIRECT = 2, AGG_FORM_TILE = 3, AGG_FORM_GENERAL = 4 };
+constexpr int kMaxDevices = 64; // per-device launch state (dynamic-LDS limits raised)
 
 struct GroupCol {
     const void *data;
@@ -229,7 +278,8 @@ struct AggArgs {
     GroupCol groups[kMaxGroupCols];
     AggCol aggs[kMaxAggs];
     int32_t n_group, n_agg;
-    int32_t debug, pad;          // ablation switch for experiments (0 in production)
+    int32_t first_form;          // AggForm: where the chain of kernel forms starts for this query
+    int32_t ablate;              // read only by the tools' build (IMM3_ABLATED); 0 otherwise
     // global open-addressing table: mask + 1 slots, plus one for the all-ones key
     unsigned long long *keys;
     uint32_t *first;             // first (lowest) selected row of the group
@@ -250,7 +300,7 @@ void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_
 void launch_group_collect(const AggArgs &a, hipStream_t s);
 
 constexpr int kSubTallies = 32;                       // in-kernel count reduce: sub-tallies (finish_add, imm3_device.h)
-constexpr int kFinishWords = 16 + kSubTallies * 16;   // u64 words of a query's `finish` block: header (8, padded to a 128-byte line) + one line per sub-tally
+constexpr int kFinishWords = 16 + kSubTallies * 16;   // u64 words of a query's `finish` block: header (9 used, padded to a 128-byte line) + one line per sub-tally
 constexpr int kMaxFilterGrid = 4096; // capacity of block_partials
 int filter_grid(int64_t units, bool generic, bool any_i32, int grid_blocks);
 // ev0/ev1: optional events stamped with the kernel's own start/end (hipExtLaunchKernelGGL), else null

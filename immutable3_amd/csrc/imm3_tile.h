@@ -1,0 +1,188 @@
+// imm3_tile.h -- device-side pieces shared by the tile kernels (imm3_kernels.hip: k_filter_tile, k_emit, k_gather;
+// imm3_project.hip: k_filter_project): a tile's columns in registers (ColRegs), the survivor-record layout (Rec), and
+// the narrow-value load / store helpers.  gfx950, wave64.
+#pragma once
+
+#include "imm3_internal.h"
+#include "imm3_device.h"
+
+namespace imm3 {
+
+constexpr int kXposeBytes = 2048; // per wave: one tile of the widest transposed kind (2-byte strings)
+
+// LDS hand-off between the lanes of ONE wave needs no wait at all: a wave's LDS instructions execute in order, so a
+// ds_read issued after a ds_write sees it.  Only the compiler must not reorder them.
+__device__ __forceinline__ void lds_wave_order() { asm volatile("" ::: "memory"); }
+
+template <int KIND>
+struct ColRegs { // TK_NONE: no column
+    __device__ __forceinline__ void load(const void *, int64_t, int) {}
+    __device__ __forceinline__ void touch() {}
+    __device__ __forceinline__ void eval(const TileCol &, uint64_t (&)[kTileWords], int, uint8_t *) {}
+    __device__ __forceinline__ bool row(const void *, const TileCol &, int64_t) { return true; }
+    __device__ __forceinline__ uint32_t value(int) const { return 0u; }
+    __device__ __forceinline__ uint32_t rowval(const void *, int64_t) const { return 0u; }
+};
+
+template <>
+struct ColRegs<TK_I32> {
+    int32_t v[kTileWords];
+    __device__ __forceinline__ void load(const void *data, int64_t row0, int lane) {
+        const int32_t *p = (const int32_t *)data + row0 + lane;
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) v[j] = __builtin_nontemporal_load(p + 64 * j);
+    }
+    // "the loaded registers are needed HERE": pins the compiler's s_waitcnt for these loads to this point (see k_filter_tile)
+    __device__ __forceinline__ void touch() {
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) asm volatile("" : "+v"(v[j]));
+    }
+    __device__ __forceinline__ void eval(const TileCol &c, uint64_t (&acc)[kTileWords], int, uint8_t *) {
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) acc[j] &= ballot64(in_closed(v[j], c.lo, c.hi));
+    }
+    __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return in_closed(((const int32_t *)data)[r], c.lo, c.hi); }
+    __device__ __forceinline__ uint32_t value(int j) const { return (uint32_t)v[j]; }
+    __device__ __forceinline__ uint32_t rowval(const void *data, int64_t r) const { return ((const uint32_t *)data)[r]; }
+};
+
+template <>
+struct ColRegs<TK_I8> {
+    v4i raw;
+    uint32_t v[kTileWords]; // after eval(): the byte of row 64j + lane, zero-extended (what a survivor record carries)
+    __device__ __forceinline__ void load(const void *data, int64_t row0, int lane) {
+        raw = __builtin_nontemporal_load((const v4i *)((const int8_t *)data + row0) + lane);
+    }
+    __device__ __forceinline__ void touch() { asm volatile("" : "+v"(raw)); }
+    __device__ __forceinline__ void eval(const TileCol &c, uint64_t (&acc)[kTileWords], int lane, uint8_t *xp) {
+        *(v4i *)(xp + 16 * lane) = raw; // the tile's 1024 bytes in row order
+        lds_wave_order();
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) v[j] = ((const uint8_t *)xp)[64 * j + lane];
+        lds_wave_order();
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) acc[j] &= ballot64(in_closed((int32_t)(int8_t)v[j], c.lo, c.hi)); // (sign extension folds into the subtract: SDWA)
+    }
+    __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return in_closed((int32_t)((const int8_t *)data)[r], c.lo, c.hi); }
+    __device__ __forceinline__ uint32_t value(int j) const { return v[j]; }
+    __device__ __forceinline__ uint32_t rowval(const void *data, int64_t r) const { return ((const uint8_t *)data)[r]; }
+};
+
+template <>
+struct ColRegs<TK_S2> {
+    v4i raw[2];
+    uint32_t v[kTileWords]; // after eval(): the two bytes of row 64j + lane, little-endian
+    __device__ __forceinline__ void load(const void *data, int64_t row0, int lane) {
+        const v4i *p = (const v4i *)((const uint16_t *)data + row0) + lane;
+        raw[0] = __builtin_nontemporal_load(p);
+        raw[1] = __builtin_nontemporal_load(p + 64);
+    }
+    __device__ __forceinline__ void touch() {
+        asm volatile("" : "+v"(raw[0]));
+        asm volatile("" : "+v"(raw[1]));
+    }
+    __device__ __forceinline__ bool hit(const TileCol &c, uint32_t x) {
+        bool f = false;
+        for (int m = 0; m < c.n_match; ++m) f |= (x == c.match[m]);
+        return f;
+    }
+    __device__ __forceinline__ void eval(const TileCol &c, uint64_t (&acc)[kTileWords], int lane, uint8_t *xp) {
+        *(v4i *)(xp + 16 * lane) = raw[0]; // the tile's 2048 bytes in row order
+        *(v4i *)(xp + 1024 + 16 * lane) = raw[1];
+        lds_wave_order();
+#pragma unroll
+        for (int j = 0; j < kTileWords; ++j) v[j] = ((const uint16_t *)xp)[64 * j + lane];
+        lds_wave_order();
+        if (c.n_match == 1) { // SelectIteratorMatch with the one-value list the SQL front end produces (SQLParser.scala:80-84)
+            const uint32_t m0 = c.match[0];
+#pragma unroll
+            for (int j = 0; j < kTileWords; ++j) acc[j] &= ballot64(v[j] == m0);
+        } else { // IN-list outermost (the value sits in one SGPR), eight words at a time: 16 more SGPR pairs would spill
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                uint64_t h[kTileWords / 2];
+#pragma unroll
+                for (int j = 0; j < kTileWords / 2; ++j) h[j] = 0ULL;
+                for (int m = 0; m < c.n_match; ++m) {
+                    const uint32_t mm = c.match[m];
+#pragma unroll
+                    for (int j = 0; j < kTileWords / 2; ++j) h[j] |= ballot64(v[half * (kTileWords / 2) + j] == mm);
+                }
+#pragma unroll
+                for (int j = 0; j < kTileWords / 2; ++j) acc[half * (kTileWords / 2) + j] &= h[j];
+            }
+        }
+    }
+    __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return hit(c, ((const uint16_t *)data)[r]); }
+    __device__ __forceinline__ uint32_t value(int j) const { return v[j]; }
+    __device__ __forceinline__ uint32_t rowval(const void *data, int64_t r) const { return ((const uint16_t *)data)[r]; }
+};
+
+// ---- survivor records ---------------------------------------------------------------------------------------
+// A projecting query whose select chain is ONE tile launch compacts, per tile, one RECORD per survivor -- its position
+// in the tile and the value of every predicate column, all of which are in registers here -- through a per-wave LDS
+// buffer (rank = set bits below the row: s_bcnt1 of the earlier words + v_mbcnt on the row's own word).  The buffer
+// holds SEVERAL tiles; when the next tile might not fit it is written out in one piece to the wave's own ARENA -- a
+// contiguous region of the staging area -- so the record stores are few, large and sequential per wave (~8-16 KiB at
+// a time) instead of one ~800-byte piece per tile at an 8 KiB stride: scattered small writes in between the streaming
+// loads ran at ~3.5 GB/ms (C3: 22 us for 78 MB; with the records aimed at an L2-resident region the cost vanished, so
+// it is the HBM write pattern, not instruction issue).  Where each tile's records start in the arena goes into a small
+// per-wave table (LDS, written once at the end).  k_emit then produces ProjectOp's rows from the records alone: no
+// second look at the bitmap, and no second read of a predicate column (at 10 % selectivity a gather would touch nearly
+// every 64-byte sector of the column again).  Layout: rec_layout() in imm3_internal.h.
+template <int R> struct RecVec;
+template <> struct RecVec<1> { typedef uint32_t type; };
+template <> struct RecVec<2> { typedef uint2 type; };
+template <> struct RecVec<4> { typedef uint4 type; };
+
+template <int K0, int K1, int K2>
+struct Rec {
+    static constexpr int kinds[3] = {K0, K1, K2};
+    static constexpr int R = rec_layout(kinds, -1).dwords;
+    typedef typename RecVec<R>::type vec;
+    template <int K>
+    static __device__ __forceinline__ void put(uint32_t (&rec)[4], uint32_t value) {
+        constexpr RecField f = rec_layout(kinds, K);
+        if (kinds[K] == TK_NONE) return;
+        rec[f.dword] |= value << f.shift;
+    }
+    static __device__ __forceinline__ vec pack(const uint32_t (&rec)[4]) {
+        if constexpr (R == 1) return rec[0];
+        else if constexpr (R == 2) return make_uint2(rec[0], rec[1]);
+        else return make_uint4(rec[0], rec[1], rec[2], rec[3]);
+    }
+};
+
+// 1-, 2- and 4-byte values are fetched as the aligned dword that contains them: sub-dword global loads are several
+// times slower per instruction on this chip (see imm3_agg.hip), and neighbouring survivors share the dword anyway.
+// The store truncates.
+template <int W>
+__device__ __forceinline__ uint32_t load_value(const void *src, int64_t idx) {
+    if constexpr (W == 4) return ((const uint32_t *)src)[idx];
+    else if constexpr (W == 2) return ((const uint32_t *)src)[idx >> 1] >> (16 * ((uint32_t)idx & 1u));
+    else return ((const uint32_t *)src)[idx >> 2] >> (8 * ((uint32_t)idx & 3u));
+}
+template <int W>
+__device__ __forceinline__ void store_value(void *dst, uint64_t out, uint32_t v) {
+    if constexpr (W == 4) ((uint32_t *)dst)[out] = v;
+    else if constexpr (W == 2) ((uint16_t *)dst)[out] = (uint16_t)v;
+    else ((uint8_t *)dst)[out] = (uint8_t)v;
+}
+__device__ __forceinline__ uint32_t load_value_rt(const void *src, int width, int64_t idx) {
+    return width == 4 ? load_value<4>(src, idx) : (width == 2 ? load_value<2>(src, idx) : load_value<1>(src, idx));
+}
+__device__ __forceinline__ void store_value_rt(void *dst, int width, uint64_t out, uint32_t v) {
+    if (width == 4) store_value<4>(dst, out, v);
+    else if (width == 2) store_value<2>(dst, out, v);
+    else store_value<1>(dst, out, v);
+}
+
+// four consecutive output rows of one column, out0 % 4 == 0: one 16-, 8- or 4-byte store
+__device__ __forceinline__ void store_quad(void *dst, int width, unsigned long long out0, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+    if (width == 4) *(uint4 *)((uint32_t *)dst + out0) = make_uint4(v0, v1, v2, v3);
+    else if (width == 2) *(uint2 *)((uint16_t *)dst + out0) = make_uint2((v0 & 0xFFFFu) | (v1 << 16), (v2 & 0xFFFFu) | (v3 << 16));
+    else *(uint32_t *)((uint8_t *)dst + out0) = (v0 & 0xFFu) | ((v1 & 0xFFu) << 8) | ((v2 & 0xFFu) << 16) | (v3 << 24);
+}
+
+
+} // namespace imm3

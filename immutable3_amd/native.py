@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 import weakref
 from typing import List, Optional, Sequence
 
@@ -250,9 +251,11 @@ class Context:
         self.device = device
         # handles created on this context; closed before the context itself (they hold raw pointers into it)
         self._children = weakref.WeakSet()
+        self._children_mu = threading.Lock()   # a context may be shared by threads (include/imm3.h, "Threading")
 
     def _adopt(self, child):
-        self._children.add(child)
+        with self._children_mu:
+            self._children.add(child)
 
     def sync(self):
         _check(load().imm3_ctx_sync(self._h))
@@ -304,7 +307,8 @@ class Context:
         if self._h:
             # The C ABI allows any destruction order (handles are reference counted); closing dependants first simply
             # returns their device memory now instead of when the garbage collector gets to them.
-            kids = list(self._children)
+            with self._children_mu:
+                kids = list(self._children)
             for kind in (Graph, Comm, DeviceQuery, DeviceTable, DeviceSegment):   # graphs, comms, queries -> tables -> segments
                 for k in kids:
                     if isinstance(k, kind):

@@ -10,9 +10,22 @@
  * The entry points below are what a JNI shim for GpuScanOp / GpuSelectOp / GpuProjectOp binds
  * (INTEGRATION.md shows the Scala + JNI side).  Plain pointers and sizes only; no torch types.
  *
- * Threading: one PipelineThread per segment calls the path (Engine.scala:176-180, 247-262), so
- * every handle is independent; calls on DIFFERENT handles are re-entrant.  A context carries its
- * device id and HIP stream; there is no global mutable state except the thread-local error text.
+ * Threading: the reference calls the path from a FixedThreadPool(cpuCount), one PipelineThread per segment
+ * (Engine.scala:176-180, 247-262; SqlCli.scala:64).  The contract here (csrc/imm3_sync.h; tests/test_gpu_threads.py runs
+ * it with 8 threads, tests/test_host_threads.py runs the host pieces under -fsanitize=thread):
+ *   - every entry point may be called from any thread; there is no process-wide mutable state except the thread-local
+ *     error text;
+ *   - a CONTEXT may be used by any number of threads at once (the Scala binding gives every PipelineThread of a device
+ *     the same one): its buffer pool, lazily made streams and diagnostics records are guarded inside; the work of all
+ *     threads lands on the context's one stream in call order;
+ *   - SEGMENTS and TABLES are immutable once created and may be read by any number of queries, threads and contexts of
+ *     the same device (a query's context need not be the context that staged its segment);
+ *   - ONE imm3_query / imm3_graph / imm3_comm is used by one thread at a time (a PipelineThread owns its iterator
+ *     chain), and nothing else may still be inside a call on a handle that is being destroyed;
+ *   - a graph capture is exclusive: imm3_ctx_capture_begin ... _end belong to ONE thread, and calls of other threads on
+ *     that context wait meanwhile.
+ * Worker threads that want their kernels to overlap on the device take one context each (a context = a stream) over the
+ * shared segments.
  *
  * Errors: the reference throws Exception(msg) (Scan.scala:49, Select.scala:22,41,80,118,156).
  * Here every call returns an int status (0 = ok) and imm3_last_error() returns the message for

@@ -30,6 +30,11 @@ import scala.collection.mutable
   *
   * Written against the reference at v0; NOT compiled in this repository (no JDK / sbt in the build image): UNVERIFIED.
   */
+/**
+  * Threading (include/imm3.h, "Threading"): ONE context per device, shared by every PipelineThread of that device
+  * (Engine.scala:176-180: FixedThreadPool(cpuCount), one thread per segment).  The library guards the context's own
+  * state; each thread creates, runs, fetches and destroys its OWN imm3_query, which is all a GpuScanOp does.
+  */
 class GpuSegmentManager(val sm: SegmentManager, val device: Int = 0) {
   val ctx: Long = Native.ctxCreate(device)
   private val segs = mutable.Map[(String, Int), Long]()
