@@ -9,16 +9,18 @@ segments resident in HBM (int32 uniform in [0, 2^30) from splitmix64, rotated so
 serve the reads), predicate GT(2^28) AND LT(3*2^28), ~50 % selectivity.  One STEP = one pass of ScanOp -> SelectOp(GT)
 -> SelectOp(LT) over one segment: the fused scan+select kernel producing the selection bitmap (12.5 MB) and the
 selected-row count (reduced inside the same kernel).  The line also carries an `extra` block, measured in the same
-run: C3 (range on age and id + Project), C4 (Match(state) + Project), group-by aggregation, and C5 at G = 1.
+run: C3 (range on age and id + Project), C4 (Match(state) + Project), group-by aggregation, and C5 at G = 1 (extra.c5).
 
-N > 1 (BASELINE config C5, strong scaling): 8 segments x 100 M rows (segment s: age from splitmix64 seed 100+s,
-id = s*10^8 + i), segment s on rank s mod N (Engine.scala:176-180 fans out one pipeline per segment), query
-RangeFilter(age) AND RangeFilter(id) + Project(id, age).  One STEP = one pass over all 8 segments (each rank runs its
-own) followed by ONE count all-reduce: ncclAllReduce(sum, uint64, 1) over RCCL / xGMI, issued by libimm3
-(imm3_comm_allreduce_count) on the communicator's stream behind the scans that produce the counts.  value = 8e8 rows x K /
-max-over-ranks wall time.  One pass is launched as one hipGraph (imm3_graph_launch; --no-graph: kernel by kernel).  The same
-line carries `c5_g1_same_run` -- the G = 1 point of this curve measured in the same run: every rank runs all 8 segments alone
-on its own GPU, max over ranks (--no-g1 skips it) -- and `c2_weak`: the N = 1 headline workload run by every rank (weak scaling).
+N > 1: `value` stays the SAME workload -- every rank runs the N = 1 step on its own segments (weak scaling: per-GPU work
+fixed), value = N x 1e8 rows x K / max-over-ranks wall time -- so a scaling curve read from `value` compares like with like.
+BASELINE config C5 (strong scaling) rides in `extra.c5` at every N: 8 segments x 100 M rows (segment s: age from splitmix64
+seed 100+s, id = s*10^8 + i), segment s on rank s mod N (Engine.scala:176-180 fans out one pipeline per segment), query
+RangeFilter(age) AND RangeFilter(id) + Project(id, age); one pass = every rank's segments followed by ONE count all-reduce:
+ncclAllReduce(sum, uint64, 1) over RCCL / xGMI, issued by libimm3 (imm3_comm_allreduce_count) on the communicator's stream
+behind the scans that produce the counts; extra.c5.value = 8e8 rows x K / max-over-ranks wall time.  One pass is launched as
+one hipGraph (imm3_graph_launch; --no-graph: kernel by kernel).  At N > 1 extra.c5 also carries `g1_same_run` -- the G = 1
+point of the curve measured in the same run: every rank runs all 8 segments alone on its own GPU, max over ranks (--no-g1
+skips it) -- and `efficiency` = value / (N x g1_same_run.value).
 
 Prints ONE JSON line on rank 0.  Inputs are resident in HBM before any timed region.  roofline.achieved = algorithmic
 bytes per launch / mean kernel duration measured live with HIP events on the launching stream.  cpu_baseline = the
@@ -46,6 +48,22 @@ ROWS_PER_SEGMENT = 100_000_000
 ALGO_BYTES_PER_ROW = 4.125     # 4 B int32 read + 1/8 B bitmap write
 C5_SEGMENTS = 8
 METRIC = "scanned rows/sec + %HBM-roofline, 100M-row RangeFilter, 1/2/4/8 MI355X"
+
+
+HEADLINE_KERNEL = "void imm3::k_filter_tile<0, 3, 3, 1, false, true, false>(imm3::TileArgs)"   # as rocprofv3 names it
+HEADLINE_SOURCES = ("immutable3_amd/csrc/imm3_kernels.hip", "immutable3_amd/csrc/imm3_tile.h", "immutable3_amd/csrc/imm3_device.h",
+                    "immutable3_amd/csrc/imm3_internal.h")
+
+
+def headline_source_sha16() -> str:
+    """Hash of the sources the headline kernel is compiled from: profiles/traffic.json carries the one it was measured on, and a
+    counter figure taken on other sources is not this kernel's."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in HEADLINE_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def c3_bytes_per_row(sel: float) -> float:
@@ -287,6 +305,8 @@ class Env:
             self.dist.destroy_process_group()
 
 
+# kernel id 0 is the scan+select launch; for a projection planned as ONE launch (k_filter_project: the filter kernel writes the rows)
+# it is the whole query, and ids 1 / 2 stay empty
 KERNEL_NAMES = {0: "scan_select", 1: "offsets_scan", 2: "compact_gather", 3: "count_reduce", 4: "group_agg"}
 
 
@@ -352,9 +372,13 @@ def measure_c2(env: Env, steps: int, warmup: int, with_cpu_baseline: bool):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("workload") == "range_filter_i32" and tj.get("rows") == n:
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    tsrc = ("from profiles/traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes of this "
-                            "command, committed; NOT re-measured in this run")
+                    if tj.get("kernel") == HEADLINE_KERNEL and tj.get("source_sha16") == headline_source_sha16():
+                        traffic = tj.get("hbm_bytes_per_launch")
+                        tsrc = ("from profiles/traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes of this "
+                                "command on these kernel sources (kernel name and source hash match), committed; NOT re-measured in this run")
+                    else:
+                        tsrc = ("profiles/traffic.json REFUSED: it was measured on kernel '%s' / sources %s, this build is '%s' / %s -- "
+                                "re-run the --pmc passes (tools/summarize_prof2.py)" % (tj.get("kernel"), tj.get("source_sha16"), HEADLINE_KERNEL, headline_source_sha16()))
             except Exception:
                 traffic = None
         out = {
@@ -440,8 +464,10 @@ def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True, solo: 
     env.sync()
     host_counts = []
 
+    plan = queries[0].plan() if queries else {}
+    kernels_per_query = 1 if plan.get("single_pass") else 3
     # One pass = the runs of every owned segment's query.  They are recorded once (imm3_ctx_capture_begin / _end: a hipGraph of
-    # 3 kernels per segment) and replayed with one call per pass; `--no-graph` issues the runs one by one instead.
+    # the kernels of every segment's query) and replayed with one call per pass; `--no-graph` issues the runs one by one instead.
     graph = None
     if use_graph:
         with ctx.capture() as cap:
@@ -488,7 +514,7 @@ def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True, solo: 
         out = {
             "value": float(n) * C5_SEGMENTS * steps / elapsed,
             "ms_per_step": elapsed / steps * 1e3,
-            "launch": (f"one hipGraph launch per pass ({3 * len(queries)} kernels, imm3_graph_launch) + the count all-reduce"
+            "launch": (f"one hipGraph launch per pass ({kernels_per_query * len(queries)} kernels, imm3_graph_launch) + the count all-reduce"
                        if graph is not None else "kernel by kernel (--no-graph)"),
             "ms_per_step_kernel_by_kernel": elapsed_plain / steps * 1e3 if elapsed_plain is not None else None,
             "global_selected_rows_per_pass": int(expect_total),
@@ -503,7 +529,9 @@ def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True, solo: 
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "per-segment query: scan+select(+stage) -> offsets scan -> compact+gather (rank 0)",
+                "kernel": ("per-segment query: ONE launch, imm3::k_filter_project (scan + select + project; rank 0)" if plan.get("single_pass") else
+                           "per-segment query: scan+select(+stage) -> offsets scan -> compact+gather (rank 0)"),
+                "plan": plan,
                 "kernel_ms_per_query": per_query, "kernel_ms_sum_per_query": kernel_ms_per_query,
                 "algorithmic_bytes_per_query": algo,
                 "algorithmic_bytes_per_row": c3_bytes_per_row(sel),
@@ -564,6 +592,7 @@ def extra_workloads(env: Env, steps: int = 20):
         sel = cnt / n
         algo = bytes_per_row(sel) * n
         out[name] = {
+            "plan": q.plan(),
             "rows_per_s": n / dt, "ms_per_query": dt * 1e3, "selected_rows": int(cnt), "selectivity": sel,
             "algorithmic_bytes_per_row": bytes_per_row(sel), "algorithmic_bytes": algo,
             "kernel_ms": kms, "kernel_ms_sum": ksum,
@@ -645,8 +674,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="N = 1: skip the extra block (C3, C4, aggregation, C5 at G = 1)")
     ap.add_argument("--no-graph", action="store_true", help="C5: launch every pass kernel by kernel instead of replaying the recorded hipGraph")
     ap.add_argument("--no-g1", action="store_true", help="N > 1: skip the solo leg (every rank runs the whole C5 job on its own GPU: the G = 1 point)")
-    ap.add_argument("--no-c2-weak", action="store_true", help="N > 1: skip the weak-scaling C2 leg")
-    ap.add_argument("--no-c5", action="store_true", help="N = 1: leave the C5-at-G=1 leg out of the extra block (profiling runs: its kernels are C3's instances)")
+    ap.add_argument("--no-c5", action="store_true", help="leave the C5 leg out of the extra block (profiling runs: its kernels are C3's instances)")
     ap.add_argument("--extra", action="store_true", help="(kept for compatibility: the extra block is on by default)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--grid", type=int, default=0)
@@ -664,35 +692,37 @@ def main():
     base = {"metric": METRIC, "unit": "rows/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
             "higher_is_better": True, "vs_baseline": None, "data": "synthetic"}
     result = None
+    # `value` is ONE workload at every N: the headline C2 step, every rank on its own segments (weak scaling)
+    c2 = measure_c2(env, args.steps, args.warmup, with_cpu_baseline=(env.world == 1 and not args.no_cpu_baseline))
+    if env.rank == 0:
+        result = dict(base, scaling="weak", dtype="i32", **{k: c2[k] for k in ("value", "ms_per_step", "ms_per_step_with_kernel_events", "config", "roofline", "staging", "per_rank")})
+        result["cpu_baseline"] = c2.get("cpu_baseline") if env.world == 1 else None     # timed at N = 1 only (contract)
+    c5_keys = ("value", "ms_per_step", "launch", "ms_per_step_kernel_by_kernel", "global_selected_rows_per_pass", "count_allreduce", "config", "roofline", "per_rank")
     if env.world == 1:
-        c2 = measure_c2(env, args.steps, args.warmup, with_cpu_baseline=not args.no_cpu_baseline)
-        result = dict(base, scaling="weak", dtype="i32", **{k: c2[k] for k in ("value", "ms_per_step", "ms_per_step_with_kernel_events", "config", "roofline", "staging")})
-        result["cpu_baseline"] = c2.get("cpu_baseline")
         if not args.no_extra:
             extra = extra_workloads(env)
             if not args.no_c5:
                 c5 = measure_c5(env, max(3, min(args.steps, 10)), 2, use_graph=not args.no_graph)
-                extra["c5_g1"] = {k: c5[k] for k in ("value", "ms_per_step", "launch", "ms_per_step_kernel_by_kernel", "global_selected_rows_per_pass", "count_allreduce", "config", "roofline")}
-                extra["c5_g1"]["note"] = "the G = 1 point of the C5 strong-scaling curve whose G > 1 points are the `value` of the --gpus N lines"
+                extra["c5"] = {k: c5[k] for k in c5_keys}
+                extra["c5"]["scaling"] = "strong"
+                extra["c5"]["note"] = "BASELINE config C5 at G = 1: the first point of the strong-scaling curve whose G > 1 points are extra.c5.value of the --gpus N lines"
             result["extra"] = extra
-        result["scaling_note"] = ("N = 1: value = C2 (headline).  N > 1: value = C5 aggregate (strong scaling, 8e8 rows per pass); its G = 1 point is "
-                                  "extra.c5_g1.value; the like-for-like weak-scaling curve of the headline workload is c2_weak.value at N > 1")
-    else:
-        c5 = measure_c5(env, args.steps, args.warmup, use_graph=not args.no_graph)
-        c2 = None if args.no_c2_weak else measure_c2(env, max(10, min(args.steps, 50)), 5, with_cpu_baseline=False)
+    elif not args.no_c5:
+        c5 = measure_c5(env, max(3, min(args.steps, 50)), min(args.warmup, 5), use_graph=not args.no_graph)
         g1 = None if args.no_g1 else measure_c5(env, max(3, min(args.steps, 10)), 2, use_graph=not args.no_graph, solo=True)
         if env.rank == 0:
-            result = dict(base, scaling="strong", dtype="i32/i8", **c5)
-            result["cpu_baseline"] = None               # timed at N = 1 only (contract)
+            x = {k: c5[k] for k in c5_keys}
+            x["scaling"] = "strong"
             if g1 is not None:
-                result["c5_g1_same_run"] = {"value": g1["value"], "ms_per_step": g1["ms_per_step"],
-                                            "note": "the G = 1 point of this strong-scaling curve measured in this run: every rank ran the whole C5 job "
-                                                    "(8 segments) alone on its own GPU, time = max over ranks; no count collective"}
-            if c2 is not None:
-                result["c2_weak"] = {k: c2[k] for k in ("value", "ms_per_step", "config", "roofline", "per_rank")}
-                result["c2_weak"]["scaling"] = "weak"
-            result["scaling_note"] = ("value = C5 aggregate rows/s (strong scaling: 8 segments fixed, sharded s mod G); G = 1 point: c5_g1_same_run.value "
-                                      "(measured in this run) and extra.c5_g1.value of the --gpus 1 line.  c2_weak.value = the N = 1 headline workload run by every rank (weak scaling)")
+                x["g1_same_run"] = {"value": g1["value"], "ms_per_step": g1["ms_per_step"],
+                                    "note": "the G = 1 point of this strong-scaling curve measured in this run: every rank ran the whole C5 job "
+                                            "(8 segments) alone on its own GPU, time = max over ranks; no count collective"}
+                x["efficiency"] = c5["value"] / (env.world * g1["value"])
+            result["extra"] = {"c5": x}
+    if env.rank == 0:
+        result["scaling_note"] = ("value = the headline C2 workload at every N (weak scaling: every rank scans its own 100M-row segments; aggregate rows/s). "
+                                  "BASELINE config C5 (8 segments sharded s mod N, strong scaling, RCCL count all-reduce) is extra.c5: its G = 1 point is "
+                                  "extra.c5.value of the --gpus 1 line and extra.c5.g1_same_run.value of an N > 1 line; extra.c5.efficiency = value / (N x g1_same_run.value)")
     env.close()
     if env.rank == 0:
         print(json.dumps(result))

@@ -291,6 +291,7 @@ extern "C" int imm3_ctx_devclock_enable(imm3_ctx *ctx, int32_t max_launches) {
     if (max_launches > 0) {
         void *p = nullptr;
         HIPCHK(hipMalloc(&p, (size_t)max_launches * kMaxFilterGrid * 2 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(p, 0, (size_t)max_launches * kMaxFilterGrid * 2 * sizeof(unsigned long long)));
         ctx->d_stamps = (unsigned long long *)p;
         ctx->stamp_slots = max_launches;
     }
@@ -313,6 +314,18 @@ extern "C" int imm3_ctx_devclock_collect(imm3_ctx *ctx, float *ms_out, int32_t c
         if (ms_out) ms_out[i] = (float)((double)(hi - lo) / 100000.0); // 100 MHz ticks -> ms
     }
     *n_out = n;
+    return IMM3_OK;
+}
+
+extern "C" int imm3_ctx_devclock_raw(imm3_ctx *ctx, int32_t launch, uint64_t *out, int32_t n) {
+    if (!out || n < 0) return fail(IMM3_ERR_ARG, "null argument");
+    CTX_LIVE(ctx);
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (launch < 0 || launch >= ctx->stamp_used) return fail(IMM3_ERR_ARG, "no such launch");
+    if (n > kMaxFilterGrid * 2) n = kMaxFilterGrid * 2;
+    HIPCHK(hipMemcpy(out, ctx->d_stamps + (size_t)launch * kMaxFilterGrid * 2, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return IMM3_OK;
 }
 
@@ -814,6 +827,8 @@ static void query_free(imm3_query *q) {
     for (auto &p : q->preds) pool_release(ctx, p.d_blob);
     pool_release(ctx, q->d_stage_rec);
     pool_release(ctx, q->d_tile_start);
+    pool_release(ctx, q->d_desc);
+    pool_release(ctx, q->d_sp_arena);
     pool_release(ctx, q->d_akeys); pool_release(ctx, q->d_acounts); pool_release(ctx, q->d_okeys); pool_release(ctx, q->d_ocounts);
     pool_release(ctx, q->d_afirst); pool_release(ctx, q->d_ofirst); pool_release(ctx, q->d_ameta);
     pool_release(ctx, q->d_avals); pool_release(ctx, q->d_ovals);
@@ -1151,12 +1166,15 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
         ok = ok && n_s2 <= 1;
         std::stable_sort(order.begin(), order.end(), [](const FoldedPred *x, const FoldedPred *y) { return tile_kind(*x) < tile_kind(*y); });
         int n_gather = 0;
+        std::vector<int32_t> seen; // predicate columns already mentioned in the SELECT list: a second mention is gathered
         for (int32_t pj : q->proj) {
             const int32_t sci = q->used[(size_t)pj];
             const int32_t w = seg->cols[(size_t)sci].width;
             if (w != 1 && w != 2 && w != 4) ok = false;
             bool is_pred = false;
             for (const FoldedPred *fp : order) is_pred |= fp->seg_col == sci;
+            if (is_pred && std::find(seen.begin(), seen.end(), sci) != seen.end()) is_pred = false;
+            if (is_pred) seen.push_back(sci);
             n_gather += !is_pred;
         }
         if (ok && n_gather <= kMaxEmitGather) {
@@ -1164,7 +1182,55 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
                 q->stage_kinds[k] = tile_kind(*order[k]);
                 q->stage_seg_col[k] = order[k]->seg_col;
             }
-            // Every wave of the staging launch writes its records to its own arena, so the launch geometry is fixed here:
+            // Single pass (k_filter_project): the filter kernel writes the rows itself.  Tuning variant 6 keeps the
+            // three-launch form (records -> k_scan -> k_emit) for A/B runs.
+            // Only when every SELECT-list column is a predicate column (its values ride in the records): gathers issued by the
+            // four writer waves of a CU are latency-bound (C4 154 us against 118 us with the emit kernel's 2048 work-groups).
+            if (ctx->filter_variant != 6 && (n_gather == 0 || ctx->filter_variant == 8)) {
+                const int R = project_rec_dwords(q->stage_kinds);
+                int64_t tile_bytes = 0;
+                for (size_t k = 0; k < order.size(); ++k) tile_bytes += (int64_t)order[k]->width * kTileRows;
+                // Tiles per wave and span (P).  Large enough that a span's prefix (a ~10 us chain through three other work-groups)
+                // and its unpacking fit in the time the streamers need for the next spans; small enough that three ranges of
+                // ~10 % survivors fit a streamer's LDS ring -- the streamers then never wait for a writer -- and that the last
+                // round, whose prefix nothing overlaps, is short.  Within that window P is the value that fills the last round of
+                // spans best (spans are dealt round-robin to one work-group per CU).  Measured on C3 (100 M rows, R = 2): P = 6-8
+                // 127-133 us, P = 12 143 us, P = 4 154 us.
+                int maxg = project_max_grid(q->stage_kinds, 0);
+                if (ctx->grid_blocks > 0) maxg = std::min(maxg, ctx->grid_blocks.load());
+                const int64_t ring_records = 14 * 1024 / (4 * R); // (kProjRingBytes of imm3_project.hip)
+                int64_t p_hi = std::max<int64_t>(4, std::min<int64_t>(16, ring_records / 3 / 85));
+                if (tile_bytes > 0) p_hi = std::max<int64_t>(4, std::min<int64_t>(p_hi, (60 * 1024) / tile_bytes));
+                const int64_t p_lo = std::max<int64_t>(4, p_hi - 1);
+                int64_t P = p_hi;
+                double best = -1.0;
+                for (int64_t p = p_hi; p >= p_lo && maxg > 0; --p) {
+                    const int64_t spans = (q->n_tiles + p * kProjectStreamers - 1) / (p * kProjectStreamers);
+                    const int64_t rounds = (spans + maxg - 1) / maxg;
+                    const double fill = (double)spans / (double)(rounds * maxg);
+                    if (fill > best + 0.02) { best = fill; P = p; }
+                }
+                if (ctx->filter_variant > 200 && ctx->filter_variant <= 200 + kProjectMaxP) P = ctx->filter_variant - 200; // tuning: variant 200 + P
+                const int64_t tiles_per_span = P * kProjectStreamers;
+                const int64_t n_spans = (q->n_tiles + tiles_per_span - 1) / tiles_per_span;
+                const int64_t grid = std::min<int64_t>(maxg, n_spans);
+                if (grid >= 1) {
+                    q->single_pass = true;
+                    q->sp_P = (int32_t)P;
+                    q->sp_grid = (int32_t)grid;
+                    q->sp_spans = n_spans;
+                    q->sp_wave_cap = P * kTileRows;
+                    void *d = nullptr;
+                    const size_t n_rounds = (size_t)((n_spans + grid - 1) / grid);
+                    const size_t desc_bytes = ((size_t)n_spans + n_rounds) * sizeof(unsigned long long) + n_rounds * sizeof(uint32_t);
+                    HIPCHK(pool_alloc(ctx, &d, desc_bytes + 256));
+                    q->d_desc = (unsigned long long *)d;
+                    HIPCHK(hipMemsetAsync(q->d_desc, 0, desc_bytes, ctx->stream)); // (pooled memory: another query's descriptors)
+                    HIPCHK(pool_alloc(ctx, &d, (size_t)grid * kProjectStreamers * (size_t)q->sp_wave_cap * 4 * (size_t)R + 256));
+                    q->d_sp_arena = (uint8_t *)d;
+                }
+            }
+            if (q->single_pass) { /* no survivor records in HBM: the filter kernel writes the rows */ } else {            // Every wave of the staging launch writes its records to its own arena, so the launch geometry is fixed here:
             // 768 work-groups (3 per CU: an 8 KiB record buffer per wave), grid-stride over groups of T tiles.
             const int R = rec_layout(q->stage_kinds, -1).dwords;
             const int T = filter_tile_group(q->stage_kinds);
@@ -1188,6 +1254,7 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
                 q->d_stage_rec = (uint8_t *)d;
                 HIPCHK(pool_alloc(ctx, &d, (size_t)n_waves * (size_t)q->stage_max_slots * sizeof(uint32_t) + 256));
                 q->d_tile_start = (uint32_t *)d;
+            }
             }
         }
     }
@@ -1408,6 +1475,8 @@ static int join_total(imm3_query *q, hipStream_t s) {
 }
 int imm3::join_query_count(imm3_query *q, hipStream_t s) { return join_total(q, s); }
 
+static void fill_tile_col(const imm3_query *q, const FoldedPred &fp, TileCol &c, int kind);
+
 // count_in_scan: a projection follows on the same stream; its offsets scan publishes the count (no k_total launch)
 static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = false) {
     imm3_ctx *ctx = q->ctx;
@@ -1423,6 +1492,7 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
         HIPCHK(hipMemsetAsync(q->d_total, 0, 2 * sizeof(unsigned long long), s)); // (an always-false query logs nothing)
         HIPCHK(hipMemsetAsync(q->d_bitmap, 0, (size_t)std::max<int64_t>(q->n_tiles * kTileWords, 1) * sizeof(uint64_t), s));
         q->ran_select = true;
+        q->ran_single_pass = false;
         return IMM3_OK;
     }
     // Plan the passes.  Uniform layouts: numeric and 2-byte-string predicates go through the tile kernel, up
@@ -1459,6 +1529,7 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
     int grid = 1;
     bool count_done = false; // the filter kernel's last work-group has written total / n_emit
     q->stage_written = false;
+    q->ran_single_pass = false;
     // exactly ONE launch in the whole select chain: only then may that launch publish the count (and append to the count
     // log) itself, and only then are the survivors' values staged
     const bool single_tile_pass = generic_preds.empty() && pfor_preds.empty() && tile_passes.size() == 1;
@@ -1469,17 +1540,9 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
         for (int k = 0; k < kMaxTileCols; ++k) a.kinds[k] = TK_NONE;
         for (int k = 0; k < n; ++k) {
             const FoldedPred &fp = *take[(size_t)k];
-            TileCol &c = a.cols[k];
-            c.data = col_flat(q->seg->cols[(size_t)fp.seg_col]);
             if (q->table) a.tile_ptrs[k] = (const void *const *)q->table->d_tile_ptrs[(size_t)fp.seg_col];
-            c.lo = (int32_t)fp.lo;
-            c.hi = (int32_t)fp.hi;
             a.kinds[k] = tile_kind(fp);
-            if (a.kinds[k] == TK_S2) {
-                c.n_match = (int32_t)fp.match.size();
-                for (size_t m = 0; m < fp.match.size(); ++m)
-                    c.match[m] = (uint32_t)(uint8_t)fp.match[m][0] | ((uint32_t)(uint8_t)fp.match[m][1] << 8);
-            }
+            fill_tile_col(q, fp, a.cols[k], a.kinds[k]);
         }
         if (single_tile_pass && q->d_stage_rec) { // the columns are in the order the records were laid out for (same sort)
             bool same = true;
@@ -1623,25 +1686,8 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
     return IMM3_OK;
 }
 
-// ProjectOp from the survivor records the select launch staged
-static int launch_emit_records(imm3_query *q) {
-    imm3_ctx *ctx = q->ctx;
-    EmitArgs e;
-    std::memset(&e, 0, sizeof(e));
-    e.stage = q->d_stage_rec;
-    e.tile_start = q->d_tile_start;
-    e.wave_cap = q->stage_wave_cap;
-    e.n_waves = (int64_t)q->stage_grid * kWavesPerBlock;
-    e.main_tiles = q->stage_main_tiles;
-    e.max_slots = q->stage_max_slots;
-    e.T = q->stage_T;
-    e.ablate = (ctx->filter_variant >= 34 && ctx->filter_variant <= 35) ? ctx->filter_variant.load() : 0; // (tools' build only)
-    e.tile_offsets = q->d_tile_offsets;
-    e.chunk_sums = q->d_chunk_sums;
-    e.n_tiles = q->n_tiles;
-    e.cap_rows = q->cap_rows;
-    e.row_index = q->d_row_index;
-    e.R = rec_layout(q->stage_kinds, -1).dwords;
+// the SELECT-list columns as the unpacking kernels take them: gathered columns first, then the ones the record carries
+static int fill_emit_cols(const imm3_query *q, EmitCol *out, int &n_out) {
     std::vector<EmitCol> gathered, staged;
     for (size_t j = 0; j < q->proj.size(); ++j) {
         const int32_t sci = q->used[(size_t)q->proj[j]];
@@ -1661,11 +1707,131 @@ static int launch_emit_records(imm3_query *q) {
         else staged.push_back(c);
     }
     int n = 0;
-    for (const auto &c : gathered) e.cols[n++] = c;
-    for (const auto &c : staged) e.cols[n++] = c;
-    e.n_cols = n;
+    for (const auto &c : gathered) out[n++] = c;
+    for (const auto &c : staged) out[n++] = c;
+    n_out = n;
+    return (int)gathered.size();
+}
+
+static void fill_tile_col(const imm3_query *q, const FoldedPred &fp, TileCol &c, int kind) {
+    c.data = col_flat(q->seg->cols[(size_t)fp.seg_col]);
+    c.lo = (int32_t)fp.lo;
+    c.hi = (int32_t)fp.hi;
+    if (kind == TK_S2) {
+        c.n_match = (int32_t)fp.match.size();
+        for (size_t m = 0; m < fp.match.size(); ++m)
+            c.match[m] = (uint32_t)(uint8_t)fp.match[m][0] | ((uint32_t)(uint8_t)fp.match[m][1] << 8);
+    }
+}
+
+// ScanOp -> SelectOp* -> ProjectOp in one launch (k_filter_project): bitmap, count and the projected rows
+static int run_single_pass(imm3_query *q) {
+    imm3_ctx *ctx = q->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    {
+        const int jrc = join_total(q, s);
+        if (jrc) return jrc;
+        q->total_on_aux = false;
+    }
+    // The rows are written by the filter kernel itself, so their arrays exist before the count does: the caller's
+    // reservation, else room for every row of the segment (pooled: allocated once).  A reservation that turns out too
+    // small is answered from the bitmap when the rows are fetched (settle_rows).
+    if (!q->reserved && q->cap_rows < (uint64_t)q->n_rows) {
+        const int rc = ensure_row_capacity(q, (uint64_t)q->n_rows);
+        if (rc) return rc;
+    }
+    ProjectArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int k = 0; k < kMaxTileCols; ++k) {
+        a.kinds[k] = q->stage_kinds[k];
+        if (a.kinds[k] == TK_NONE) continue;
+        const FoldedPred *fp = nullptr;
+        for (const auto &p : q->preds)
+            if (p.seg_col == q->stage_seg_col[k]) fp = &p;
+        if (!fp) return fail(IMM3_ERR_ARG, "internal: single-pass plan lost a predicate column");
+        fill_tile_col(q, *fp, a.cols[k], a.kinds[k]);
+    }
+    a.P = q->sp_P;
+    a.n_rows = q->n_rows;
+    a.n_tiles = q->n_tiles;
+    a.n_spans = q->sp_spans;
+    a.n_rounds = (q->sp_spans + q->sp_grid - 1) / q->sp_grid;
+    a.bitmap = q->d_bitmap;
+    a.finish = q->d_total;
+    a.desc = q->d_desc;
+    a.arena = q->d_sp_arena;
+    a.wave_cap = q->sp_wave_cap;
+    a.cap_rows = q->cap_rows;
+    a.row_index = q->d_row_index;
+    {   // SELECT-list columns: the first mention of a predicate column comes out of the records, everything else is gathered
+        int ng = 0;
+        for (size_t j = 0; j < q->proj.size(); ++j) {
+            const int32_t sci = q->used[(size_t)q->proj[j]];
+            const SegCol &sc = q->seg->cols[(size_t)sci];
+            int k_pred = -1;
+            for (int k = 0; k < kMaxTileCols; ++k)
+                if (q->stage_seg_col[k] == sci && !a.pred_dst[k]) { k_pred = k; break; }
+            if (k_pred >= 0) a.pred_dst[k_pred] = q->d_proj[j];
+            else {
+                if (ng >= kMaxEmitGather) return fail(IMM3_ERR_ARG, "internal: single-pass plan has too many gathered columns");
+                a.gather[ng].dst = q->d_proj[j];
+                a.gather[ng].src = col_flat(sc);
+                a.gather[ng].width = sc.width;
+                ++ng;
+            }
+        }
+        a.n_gather = ng;
+    }
+    const int fv = ctx->filter_variant;
+    a.ablate = (fv >= 50 && fv <= 50 + 127) ? fv - 50 : 0; // (tools' build only: a mask -- 1 no unpack, 2 no chained scan, 4 no records, 16 no output stores, 32 output stores cache resident)
+    if (ctx->d_stamps) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (ctx->d_stamps && ctx->stamp_used < ctx->stamp_slots) {
+            a.stamps = ctx->d_stamps + (size_t)ctx->stamp_used * kMaxFilterGrid * 2;
+            ctx->stamp_grids.push_back(q->sp_grid);
+            ++ctx->stamp_used;
+        }
+    }
+    {
+        LaunchTimer t(ctx, 0);
+        if (!launch_filter_project(a, q->sp_grid, s, t.start, t.stop)) return fail(IMM3_ERR_ARG, "internal: no single-pass kernel for this column combination");
+    }
+    HIPCHK(hipGetLastError());
+    q->stage_written = false;
+    q->count_pending_scan = false;
+    q->has_pfor_pass = false;
+    q->ran_select = true;
+    q->ran_project = true;
+    q->ran_single_pass = true;
+    q->sp_verified = false;
+    return IMM3_OK;
+}
+
+// ProjectOp from the survivor records the select launch staged
+static int launch_emit_records(imm3_query *q) {
+    imm3_ctx *ctx = q->ctx;
+    EmitArgs e;
+    std::memset(&e, 0, sizeof(e));
+    e.stage = q->d_stage_rec;
+    e.tile_start = q->d_tile_start;
+    e.wave_cap = q->stage_wave_cap;
+    e.n_waves = (int64_t)q->stage_grid * kWavesPerBlock;
+    e.main_tiles = q->stage_main_tiles;
+    e.max_slots = q->stage_max_slots;
+    e.T = q->stage_T;
+    e.ablate = (ctx->filter_variant >= 34 && ctx->filter_variant <= 35) ? ctx->filter_variant.load() : 0; // (tools' build only)
+    e.tile_offsets = q->d_tile_offsets;
+    e.chunk_sums = q->d_chunk_sums;
+    e.n_tiles = q->n_tiles;
+    e.cap_rows = q->cap_rows;
+    e.row_index = q->d_row_index;
+    e.R = rec_layout(q->stage_kinds, -1).dwords;
+    int n_cols = 0;
+    const int n_gather = fill_emit_cols(q, e.cols, n_cols);
+    e.n_cols = n_cols;
     LaunchTimer t(ctx, 2);
-    launch_emit(e, (int)gathered.size(), 0, ctx->stream, t.start, t.stop);
+    launch_emit(e, n_gather, 0, ctx->stream, t.start, t.stop);
     HIPCHK(hipGetLastError());
     return IMM3_OK;
 }
@@ -1754,8 +1920,11 @@ static int capture_admit(imm3_query *q) {
     imm3_ctx *ctx = q->ctx;
     if (!ctx->capture) return IMM3_OK;
     if (ctx->filter_variant == 2) return fail(IMM3_ERR_STATE, "tuning variant 2 (count reduce on the aux stream) cannot be captured");
-    if (!q->proj.empty() && !(q->limit > 0) && !q->reserved)
+    const bool sp = q->single_pass && !q->proj.empty() && !q->always_false && q->n_tiles > 0; // (writes its rows without knowing the count)
+    if (!q->proj.empty() && !(q->limit > 0) && !q->reserved && !sp)
         return fail(IMM3_ERR_STATE, "an unlimited projection sizes its output from the count (a synchronisation): call imm3_query_reserve_rows before capturing it");
+    if (sp && !q->reserved && q->cap_rows < (uint64_t)q->n_rows)
+        return fail(IMM3_ERR_STATE, "run the query once (or reserve rows) before capturing it: its output buffers are allocated on first use");
     if (!q->proj.empty() && !q->d_row_index) return fail(IMM3_ERR_STATE, "run the query once (or reserve rows) before capturing it: its output buffers are allocated on first use");
     auto &qs = ctx->capture->queries;
     if (std::find(qs.begin(), qs.end(), q) == qs.end()) qs.push_back(q);
@@ -1787,6 +1956,7 @@ extern "C" int imm3_query_run(imm3_query *q) {
     // Reducing the count on the aux stream (tuning variant 2) measured SLOWER on MI355X / ROCm 7.2 (75.6 vs 67.1 us
     // per step: the cross-queue event packets cost more than the two same-queue launch gaps they remove), so the
     // default keeps the reduce on the main stream.
+    if (q->single_pass && !q->proj.empty() && !q->always_false && q->n_tiles > 0) return run_single_pass(q);
     const bool select_only = q->proj.empty() && !q->is_agg && q->ctx->filter_variant == 2;
     int rc = run_select(q, select_only, !q->proj.empty() && q->n_tiles > 0 && !q->always_false && q->ctx->filter_variant != 7);
     if (rc) return rc;
@@ -1843,6 +2013,24 @@ extern "C" int imm3_query_log_counts(imm3_query *q, uint64_t *device_log, uint64
     return IMM3_OK;
 }
 
+// A single-pass run that was abandoned (a look-back that did not resolve: imm3_project.hip) is answered again through the
+// bitmap path, once, and the query keeps that path from then on.  Called by the getters before they read anything.
+static int settle_single_pass(imm3_query *q) {
+    if (!q->ran_single_pass || q->sp_verified) return IMM3_OK;
+    imm3_ctx *ctx = q->ctx;
+    unsigned long long status = 0;
+    HIPCHK(hipMemcpyAsync(&status, q->d_total + kFinishStatus, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    q->sp_verified = true;
+    if (!(status & 2ULL)) return IMM3_OK;
+    graphs_mark_stale(ctx, q); // a recorded run would take the abandoned path again
+    q->single_pass = false;
+    HIPCHK(hipMemsetAsync(q->d_total + kFinishStatus, 0, sizeof(unsigned long long), ctx->stream));
+    int rc = run_select(q, false, true);
+    if (rc) return rc;
+    return run_project(q);
+}
+
 extern "C" int imm3_query_count(imm3_query *q, uint64_t *selected_rows) {
     if (!q || !selected_rows) return fail(IMM3_ERR_ARG, "null argument");
     CTX_LIVE(q->ctx);
@@ -1850,6 +2038,8 @@ extern "C" int imm3_query_count(imm3_query *q, uint64_t *selected_rows) {
     HIPCHK(hipSetDevice(q->ctx->device));
     unsigned long long total = 0;
     {
+        const int src = settle_single_pass(q);
+        if (src) return src;
         const int jrc = join_total(q, q->ctx->stream);
         if (jrc) return jrc;
     }
@@ -1869,6 +2059,10 @@ extern "C" int imm3_query_bitmap(imm3_query *q, uint64_t *words_out, int64_t n_w
     if (n_words < 0 || n_words > q->n_words) return fail(IMM3_ERR_ARG, "n_words exceeds the bitmap");
     if (n_words && !words_out) return fail(IMM3_ERR_ARG, "words_out is null");
     HIPCHK(hipSetDevice(q->ctx->device));
+    {
+        const int src = settle_single_pass(q);
+        if (src) return src;
+    }
     if (n_words) HIPCHK(hipMemcpyAsync(words_out, q->d_bitmap, (size_t)n_words * sizeof(uint64_t), hipMemcpyDeviceToHost, q->ctx->stream));
     HIPCHK(hipStreamSynchronize(q->ctx->stream));
     return IMM3_OK;
@@ -1878,15 +2072,30 @@ static int settle_rows(imm3_query *q, uint64_t *rows) {
     CTX_LIVE(q->ctx);
     if (!q->ran_project) return fail(IMM3_ERR_STATE, "no projection has been run (n_proj == 0 or imm3_query_run not called)");
     HIPCHK(hipSetDevice(q->ctx->device));
+    {
+        const int src = settle_single_pass(q);
+        if (src) return src;
+    }
     unsigned long long emit = 0;
     if (q->n_tiles > 0) {
         HIPCHK(hipMemcpyAsync(&emit, q->d_n_emit, sizeof(emit), hipMemcpyDeviceToHost, q->ctx->stream));
         HIPCHK(hipStreamSynchronize(q->ctx->stream));
     }
     if (emit > q->cap_rows) {
-        // the reservation was too small: grow and gather again (offsets are still valid)
+        // the reservation was too small: grow and gather again (offsets are still valid; a single-pass run made none:
+        // they come from the bitmap now)
         int rc = ensure_row_capacity(q, emit);
         if (rc) return rc;
+        if (q->ran_single_pass) {
+            ScanArgs sa;
+            std::memset(&sa, 0, sizeof(sa));
+            sa.bitmap = q->d_bitmap;
+            sa.tile_offsets = q->d_tile_offsets;
+            sa.chunk_sums = q->d_chunk_sums;
+            sa.n_tiles = q->n_tiles;
+            launch_scan(sa, q->ctx->stream, nullptr, nullptr);
+            HIPCHK(hipGetLastError());
+        }
         rc = launch_project(q);
         if (rc) return rc;
         HIPCHK(hipStreamSynchronize(q->ctx->stream));
@@ -1934,6 +2143,14 @@ extern "C" int imm3_query_device_ptr(imm3_query *q, int32_t which, void **ptr) {
         }
         return fail(IMM3_ERR_ARG, "unknown device pointer id");
     }
+}
+
+extern "C" int imm3_query_plan(const imm3_query *q, int64_t *out, int32_t n) {
+    if (!q || !out) return fail(IMM3_ERR_ARG, "null argument");
+    const int64_t v[8] = {q->single_pass ? 1 : 0, q->sp_P, q->sp_grid, q->sp_spans, q->d_stage_rec ? 1 : 0,
+                          (q->single_pass || q->d_stage_rec) ? rec_layout(q->stage_kinds, -1).dwords : 0, q->ran_single_pass ? 1 : 0, 0};
+    for (int32_t i = 0; i < n && i < 8; ++i) out[i] = v[i];
+    return IMM3_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -79,12 +79,13 @@ __device__ __forceinline__ void count_log_append(unsigned long long *finish, uns
 // to sub-tally b % kSubTallies (each on a 128-byte line of its own), the last arrival there carries the sub-total to the
 // top tally, the last arrival there publishes.  Serial depth grid / 32 + 32 instead of grid.
 // one thread per work-group: add this work-group's survivors; the last arrival publishes the total
-__device__ __forceinline__ void finish_add(unsigned long long *finish, unsigned long long t) {
+// (true for the launch's last arrival -- the one that published)
+__device__ __forceinline__ bool finish_add(unsigned long long *finish, unsigned long long t) {
     const unsigned int grid = gridDim.x, sub = blockIdx.x % kSubTallies;
     const unsigned int peers = (grid - sub + kSubTallies - 1) / kSubTallies; // work-groups b < grid with b % kSubTallies == sub
     unsigned long long *st = finish + 16 + 16 * sub;
     unsigned long long prev = __hip_atomic_fetch_add(st, t | (1ULL << 40), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((prev >> 40) != (unsigned long long)peers - 1) return;
+    if ((prev >> 40) != (unsigned long long)peers - 1) return false;
     t += prev & ((1ULL << 40) - 1);
     __hip_atomic_store(st, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
     const unsigned int tops = grid < (unsigned int)kSubTallies ? grid : (unsigned int)kSubTallies;
@@ -97,7 +98,9 @@ __device__ __forceinline__ void finish_add(unsigned long long *finish, unsigned 
         count_log_append(finish, total);
         finish[kFinishEpoch] += 1; // a new run of the query starts behind this launch (k_filter_project's descriptors)
         __hip_atomic_store(finish + 4, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
+        return true;
     }
+    return false;
 }
 
 __device__ __forceinline__ void block_partial_finish(unsigned long long *finish, uint32_t wave_total, int lane, int wave) {

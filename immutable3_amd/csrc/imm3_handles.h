@@ -206,6 +206,14 @@ struct imm3_query {
     int32_t stage_grid = 0, stage_T = 1, stage_max_slots = 0;
     int64_t stage_wave_cap = 0, stage_main_tiles = 0;
     bool stage_written = false;   // the last select run filled the records
+    // single-pass projection (k_filter_project, imm3_project.hip): planned at creation for the same queries as the records
+    bool single_pass = false;
+    int32_t sp_P = 0, sp_grid = 0;          // tiles per wave per span; work-groups (all resident: they wait on each other)
+    int64_t sp_spans = 0, sp_wave_cap = 0;  // spans of 4 * P tiles; records per wave of the spill arena
+    unsigned long long *d_desc = nullptr;   // per-span descriptors of the chained scan
+    uint8_t *d_sp_arena = nullptr;
+    bool ran_single_pass = false;           // the last run went through k_filter_project ...
+    bool sp_verified = false;               // ... and its status word has been read since (not abandoned)
     bool count_pending_scan = false; // the last select run left the count to the projection's offsets scan
 };
 

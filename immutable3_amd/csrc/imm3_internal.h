@@ -11,8 +11,10 @@
 // IMM3_ABLATED is the constant false and the kernels carry none of it.
 #ifdef IMM3_ABLATE
 #define IMM3_ABLATED(args, value) ((args).ablate == (value))
+#define IMM3_ABLATE_BIT(args, bit) (((args).ablate & (bit)) != 0) /* k_filter_project: ablate = a mask */
 #else
 #define IMM3_ABLATED(args, value) false
+#define IMM3_ABLATE_BIT(args, bit) false
 #endif
 
 namespace imm3 {
@@ -152,8 +154,8 @@ struct EmitArgs {
 void launch_emit(const EmitArgs &a, int n_gather, int grid_blocks, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 
 // ---- k_filter_project (imm3_project.hip): ScanOp -> SelectOp* -> ProjectOp of one uniform segment in ONE pass ----
-// A work-group owns SPANS of 4 * P consecutive tiles (its four waves P consecutive tiles each); spans go to the
-// work-groups round-robin.  The survivors' records of a wave's range wait in LDS; where they go in the output -- the
+// A work-group owns SPANS of kProjectStreamers * P consecutive tiles (each of its streaming waves P consecutive tiles);
+// spans go to the work-groups round-robin.  The survivors' records of a wave's range wait in LDS; where they go in the output -- the
 // number of survivors in all earlier tiles -- comes from a chained scan over per-span DESCRIPTORS (decoupled look-back):
 //   desc[s] = epoch << 56 | flag << 54 | value     flag 1: value = survivors of span s (published when the span is done)
 //                                                  flag 2: value = survivors of spans 0..s (published after the look-back)
@@ -161,6 +163,7 @@ void launch_emit(const EmitArgs &a, int n_gather, int grid_blocks, hipStream_t s
 // `epoch` (finish[kFinishEpoch], bumped by the launch's last work-group) tells this run's descriptors from the previous
 // run's, so nothing is cleared between runs.
 constexpr int kProjectMaxP = 64;        // tiles per wave per span (the tile's index in its range takes 6 bits of the record)
+constexpr int kProjectStreamers = 8;    // waves of a work-group that stream tiles: a span is kProjectStreamers * P consecutive tiles
 constexpr int kFinishStatus = 2;        // finish[2]: bit 0 malformed PFOR block, bit 1 single-pass projection abandoned
 constexpr int kFinishEpoch = 8;         // finish[8]: run counter of the query (descriptor epochs)
 constexpr unsigned long long kDescValueMask = (1ULL << 54) - 1;
@@ -169,16 +172,18 @@ struct ProjectArgs {
     int32_t kinds[kMaxTileCols];    // sorted ascending, TK_NONE last
     int32_t P;                      // tiles per wave per span
     int64_t n_rows, n_tiles, n_spans;
+    int64_t n_rounds;               // ceil(n_spans / grid)
     uint64_t *bitmap;
     unsigned long long *finish;     // the query's {total, n_emit, status, limit, tally, log ..., epoch} block
-    unsigned long long *desc;       // n_spans descriptors
+    unsigned long long *desc;       // n_spans span descriptors, then n_rounds round totals (u64), then n_rounds arrival counters (u32)
     void *arena;                    // spill space: wave_cap records per wave (a range whose records outgrow the LDS buffer)
     int64_t wave_cap;
     uint64_t cap_rows;              // capacity of the output arrays
     uint32_t *row_index;
-    EmitCol out[kMaxProj];          // gathered columns first
-    int32_t n_out, n_gather;
-    int32_t ablate, pad;
+    void *pred_dst[kMaxTileCols];   // where the values of predicate column k go (packed, its width per row), or null: not in the SELECT list
+    EmitCol gather[kMaxEmitGather]; // the other SELECT-list columns (and second mentions of a predicate column): gathered at the row
+    int32_t n_gather;
+    int32_t ablate;
     unsigned long long *stamps;     // diagnostics only
 };
 // false: no instance for these kinds.  grid <= project_max_grid(): every work-group must be resident (they wait on each other)

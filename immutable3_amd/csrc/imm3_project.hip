@@ -1,0 +1,720 @@
+// imm3_project.hip -- k_filter_project: ScanOp -> SelectOp* -> ProjectOp of one uniform segment in ONE pass over the
+// columns (gfx950, wave64).
+//
+// The reference's ProjectIterator.next (engine/src/main/scala/immutabledb/engine/operator/Project.scala:37-64) is one walk:
+// for every batch, for every set bit in ascending order, emit the SELECT-list values.  Rounds 1-2 needed three launches
+// for it -- the filter kernel staging one record per survivor, an offsets scan, an emit kernel reading the records back
+// (C3: 78 MB written and re-read, 145 us).  Here the filter kernel writes the final rows itself:
+//
+//   * a work-group owns SPANS of 4 * P consecutive tiles, its four waves P consecutive tiles each; spans are dealt to the
+//     work-groups round-robin.  A wave evaluates its tiles exactly as k_filter_tile does (all loads of a tile issued
+//     before the first compare, narrow columns transposed through LDS, v_cmp result == bitmap word) and compacts one
+//     RECORD per survivor -- position, the tile's index in the range, every predicate column -- into its LDS buffer;
+//   * at the end of a range the work-group publishes the span's survivor count in a DESCRIPTOR and one of its waves
+//     looks back over the descriptors of the earlier spans (decoupled look-back: sum the counts down to the nearest span
+//     that already knows its inclusive prefix), which gives the span's first output row; the waves then unpack their
+//     records into the packed output columns -- row index, staged columns out of the record, other SELECT-list columns
+//     gathered at the record's row -- four output rows per lane (16 / 8 / 4-byte stores);
+//   * a range whose records outgrow the LDS buffer (dense survivors: a range predicate on a sorted key) spills to the
+//     wave's arena in HBM and is unpacked from there once the offset is known -- a round trip only for those ranges.
+//
+// Order is deterministic: a row's output slot is the number of survivors before it, whatever the work-groups' timing.
+// Every work-group of the launch must be resident (they wait on each other's descriptors): the host sizes the grid from
+// the occupancy query, and a look-back that does not resolve within a bounded number of polls abandons the run (status
+// bit, every work-group drains) -- the host then answers the query through the bitmap path.
+#include "imm3_internal.h"
+#include "imm3_device.h"
+#include "imm3_tile.h"
+#include <hip/hip_ext.h>
+
+namespace imm3 {
+
+constexpr int kProjParkLines = 16;       // bitmap lines a wave parks in LDS between store bursts
+constexpr uint32_t kLookbackMaxPolls = 1u << 19;
+
+__device__ __forceinline__ unsigned long long desc_pack(uint32_t epoch, uint32_t flag, unsigned long long value) {
+    return ((unsigned long long)(epoch & 0xFFu) << 56) | ((unsigned long long)flag << 54) | (value & kDescValueMask);
+}
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// First output row of span s = survivors of spans 0 .. s-1.  Spans are dealt round-robin to the work-groups, so the spans
+// of one ROUND (s / gridDim.x) finish at about the same time.  Every span publishes its survivor count and arrives at the
+// round's counter; the LAST arrival of a round scans the round's counts -- one wave, coalesced reads of the descriptors,
+// a wave prefix sum -- on top of the previous round's inclusive total, and hands every span of the round its prefix
+// through the span's own descriptor; everybody else polls ONE word.  O(spans) uncached traffic per round: the first
+// version had every work-group sum all earlier descriptors of its round itself, 65 536 bypassing loads on 16 cache lines
+// per round, and the look-back took 30 us per round.  Run by one whole wave.  false: abandoned.
+__device__ __forceinline__ unsigned long long desc_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void desc_store(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool desc_ready(unsigned long long d, uint32_t epoch, uint32_t flag) {
+    return (uint32_t)(d >> 56) == (epoch & 0xFFu) && ((uint32_t)(d >> 54) & 3u) >= flag;
+}
+__device__ __forceinline__ bool desc_dead(unsigned long long d, uint32_t epoch) { return (uint32_t)(d >> 56) == (epoch & 0xFFu) && ((uint32_t)(d >> 54) & 3u) == 3u; }
+
+// wave-uniform poll of one word until `flag` (2 = prefix known); false: abandoned / timed out
+__device__ __forceinline__ bool desc_wait(const ProjectArgs &a, const unsigned long long *p, uint32_t epoch, uint32_t flag, unsigned long long &out) {
+    for (uint32_t polls = 0;; ++polls) {
+        const unsigned long long d = desc_load(p); // (every lane loads the same word: one request)
+        if (desc_dead(d, epoch)) return false;
+        if (desc_ready(d, epoch, flag)) { out = d & kDescValueMask; return true; }
+        if (polls > kLookbackMaxPolls) return false;
+        if ((polls & 63u) == 63u && (desc_load(a.finish + kFinishStatus) & 2ULL)) return false;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+__device__ __forceinline__ bool span_prefix(const ProjectArgs &a, int64_t s, uint32_t epoch, unsigned long long agg, int lane, unsigned long long &prefix) {
+    const int64_t G = gridDim.x;
+    const int64_t r = s / G, first = r * G;
+    const int64_t n_in = a.n_spans - first < G ? a.n_spans - first : G; // spans of this round
+    unsigned long long *round_total = a.desc + a.n_spans;               // [n_rounds] inclusive total through the round
+    uint32_t *round_ctr = (uint32_t *)(round_total + a.n_rounds);       // [n_rounds] arrivals (zero between runs)
+    if (lane == 0) desc_store(a.desc + s, desc_pack(epoch, 1u, agg));
+    uint32_t prev = 0;
+    if (lane == 0) prev = __hip_atomic_fetch_add(round_ctr + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)prev);
+    if ((int64_t)prev == n_in - 1) { // the round's last arrival: scan it
+        unsigned long long base = 0;
+        bool ok = true;
+        if (r > 0) ok = desc_wait(a, round_total + (r - 1), epoch, 2u, base);
+        for (int64_t c0 = 0; ok && c0 < n_in; c0 += 256) { // 256 spans per step: four descriptors per lane, all loads in flight together
+            unsigned long long d[4];
+            for (uint32_t polls = 0;; ++polls) { // (the counts were stored before their arrivals were counted, but nothing orders the two: check)
+                bool all = true, dead = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t i = c0 + 64 * q + lane;
+                    d[q] = i < n_in ? desc_load(a.desc + first + i) : desc_pack(epoch, 1u, 0ULL);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    dead = dead || desc_dead(d[q], epoch);
+                    all = all && desc_ready(d[q], epoch, 1u);
+                }
+                if (ballot64(dead)) { ok = false; break; }
+                if (ballot64(!all) == 0ULL) break;
+                if (polls > kLookbackMaxPolls) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (!ok) break;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t i = c0 + 64 * q + lane;
+                const unsigned long long v = d[q] & kDescValueMask;
+                unsigned long long incl = v;
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) {
+                    const unsigned long long up = __shfl_up(incl, dd);
+                    if (lane >= dd) incl += up;
+                }
+                if (i < n_in) desc_store(a.desc + first + i, desc_pack(epoch, 2u, base + incl - v)); // the span's EXCLUSIVE prefix
+                base += __shfl(incl, 63);
+            }
+        }
+        if (lane == 0) {
+            if (ok) desc_store(round_total + r, desc_pack(epoch, 2u, base));
+            else { // abandoned: nobody of this round (or a later one) may wait for the timeout
+                for (int64_t i = 0; i < n_in; ++i) desc_store(a.desc + first + i, desc_pack(epoch, 3u, 0ULL));
+                desc_store(round_total + r, desc_pack(epoch, 3u, 0ULL));
+            }
+        }
+        if (!ok) return false;
+    }
+    return desc_wait(a, a.desc + s, epoch, 2u, prefix);
+}
+
+// LDS words shared between a streamer and the writers: relaxed work-group-scope atomics stay ds_read / ds_write (a volatile
+// access would become a flat one and drain the wave's global prefetch: DESIGN finding 19)
+__device__ __forceinline__ uint32_t lds_peek(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_poke(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// what a streamer publishes about a finished range (slot = range parity)
+struct RangePub {
+    uint32_t start;    // ring position of the range's first record
+    uint32_t cnt;      // survivors of the range
+    uint32_t in_arena; // 1: the range outgrew the ring, its records are in the wave's arena
+    uint32_t pad;
+};
+
+// Wave specialisation.  A work-group is 10 waves, ONE work-group per CU (grid = number of CUs: every work-group is resident
+// whatever the register footprint -- the occupancy query counted two 5-wave work-groups per CU where the hardware placed
+// one, and work-groups that wait on each other must all be running).  Waves 0-7 are STREAMERS, two per SIMD: they only
+// load, compare and compact -- no global store and no wait on another work-group ever sits in their loop (a wave that
+// stores waits, at its next s_waitcnt for loads, for the stores' write acknowledgements too: vmcnt retires in order; and a
+// look-back issued behind 20 outstanding streaming loads waits for those first).  Waves 8-9 are WRITERS: they collect the
+// streamers' range counts, the first one publishes the span's descriptor and obtains the span's first output row, and
+// each unpacks four streamers' records into the output arrays.  Hand-off through LDS: each streamer compacts into a RING
+// of records; a finished range is published (RangePub + a sequence number), its writer frees it by advancing the ring's
+// head.  A streamer runs at most two ranges ahead of its writer and waits only when its ring is full of undrained ranges.
+constexpr int kProjStreamers = kProjectStreamers;
+constexpr int kProjWriters = 4;
+constexpr int kProjPerWriter = kProjStreamers / kProjWriters;
+constexpr int kProjThreads = 64 * (kProjStreamers + kProjWriters);
+constexpr int kProjRingBytes = 14 * 1024;
+constexpr bool kProjDepth2 = false; // two tiles of loads in flight per streamer instead of one
+constexpr int kProjSlots = 4;   // published ranges a streamer may have waiting for its writer
+
+// ---------------------------------------------------------------------------------------------
+// writer side: the records of one range (in the streamer's LDS ring, or -- slow path -- in its arena in HBM) -> output rows
+// base .. base + n.  The record layout is a compile-time function of the column kinds, so the row index and every
+// predicate column come out of a record with a shift; what is run-time is only WHERE a column goes (a.pred_dst[k], null =
+// not in the SELECT list) and the gathered columns.  A lane owns four consecutive output rows -- a quad aligned in the
+// GLOBAL output index -- and stores 16 / 8 / 4 bytes per column; the quads that straddle the range's first or last row are
+// written row by row.  (The first version walked run-time column descriptors per row: 2.5 wave instructions per record and
+// pass, 60 % of what the streamers execute -- the writers were the bottleneck at ~50 us per span.)
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void store_quad_w(void *dst, uint32_t out0, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
+    if constexpr (W == 4) *(uint4 *)((uint32_t *)dst + out0) = make_uint4(v0, v1, v2, v3);
+    else if constexpr (W == 2) *(uint2 *)((uint16_t *)dst + out0) = make_uint2((v0 & 0xFFFFu) | (v1 << 16), (v2 & 0xFFFFu) | (v3 << 16));
+    else *(uint32_t *)((uint8_t *)dst + out0) = (v0 & 0xFFu) | ((v1 & 0xFFu) << 8) | ((v2 & 0xFFu) << 16) | (v3 << 24);
+}
+constexpr int kind_width(int k) { return k == TK_I32 ? 4 : (k == TK_S2 ? 2 : 1); }
+
+template <int R>
+__device__ __forceinline__ void rec_words(const typename RecVec<R>::type &r, uint32_t (&w)[4]) {
+    if constexpr (R == 1) { w[0] = r; w[1] = w[2] = w[3] = 0u; }
+    else if constexpr (R == 2) { w[0] = r.x; w[1] = r.y; w[2] = w[3] = 0u; }
+    else { w[0] = r.x; w[1] = r.y; w[2] = r.z; w[3] = r.w; }
+}
+
+// predicate column K (compile time) of a quad of records -> dst
+template <int K0, int K1, int K2, int K>
+__device__ __forceinline__ void store_pred_col(void *dst, const uint32_t (&rw)[4][4], const bool (&ok)[4], bool whole, uint32_t out0) {
+    constexpr int kinds[3] = {K0, K1, K2};
+    if constexpr (kinds[K] != TK_NONE) {
+        if (!dst) return; // wave-uniform: the column is not in the SELECT list
+        constexpr RecField f = rec_layout(kinds, K);
+        constexpr int W = kind_width(kinds[K]);
+        uint32_t v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rw[e][f.dword] >> f.shift;
+        if (whole) store_quad_w<W>(dst, out0, v[0], v[1], v[2], v[3]);
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (ok[e]) store_value<W>(dst, out0 + e, v[e]);
+        }
+    }
+}
+
+// src: the ring (start, cap = its position and capacity) or the arena (start 0, cap ~0)
+template <int K0, int K1, int K2>
+__device__ __forceinline__ void unpack_range(const ProjectArgs &a, const typename Rec<K0, K1, K2>::vec *src, uint32_t start, uint32_t cap, uint32_t n,
+                                             uint32_t base, uint32_t tile0, int lane) {
+    typedef Rec<K0, K1, K2> L;
+    constexpr int R = L::R;
+    const uint32_t cap_rows = a.cap_rows > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)a.cap_rows;
+    if (base >= cap_rows) return; // wave-uniform: the output arrays are full (the host gathers again from the bitmap)
+    if (n > cap_rows - base) n = cap_rows - base;
+    if (!n) return;
+    const uint32_t q0 = base >> 2;
+    const uint32_t n_quads = ((base + n + 3) >> 2) - q0;
+    uint32_t *row_index = a.row_index;
+    void *d0 = a.pred_dst[0], *d1 = a.pred_dst[1], *d2 = a.pred_dst[2];
+    for (uint32_t qi = lane; qi < n_quads; qi += 64) {
+        const uint32_t out0 = (q0 + qi) << 2;
+        uint32_t rw[4][4];
+        bool ok[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { // (a row outside the range re-reads record 0: no branch)
+            const uint32_t o = out0 + e;
+            ok[e] = o >= base && o - base < n;
+            uint32_t idx = start + (ok[e] ? o - base : 0u);
+            if (idx >= cap) idx -= cap;
+            rec_words<R>(src[idx], rw[e]);
+        }
+        if (IMM3_ABLATE_BIT(a, 16)) { // (no stores)
+            asm volatile("" ::"v"(rw[0][0]), "v"(rw[1][0]), "v"(rw[2][0]), "v"(rw[3][0]));
+            continue;
+        }
+        const bool whole = ok[0] && ok[3]; // (the range's rows are contiguous: first and last in => all four in)
+        uint32_t rowv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rowv[e] = (tile0 + ((rw[e][0] >> 10) & 63u)) * (uint32_t)kTileRows + (rw[e][0] & (uint32_t)(kTileRows - 1));
+        if (whole) *(uint4 *)(row_index + out0) = make_uint4(rowv[0], rowv[1], rowv[2], rowv[3]);
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (ok[e]) row_index[out0 + e] = rowv[e];
+        }
+        store_pred_col<K0, K1, K2, 0>(d0, rw, ok, whole, out0);
+        store_pred_col<K0, K1, K2, 1>(d1, rw, ok, whole, out0);
+        store_pred_col<K0, K1, K2, 2>(d2, rw, ok, whole, out0);
+    }
+    // ---- SELECT-list columns that are not predicate columns: gathered at the records' rows, two quads per lane and step,
+    //      every load of the step -- all columns, all eight rows -- in flight before the first store
+    const int ng = a.n_gather;
+    if (ng == 0) return; // wave-uniform
+    const void *gsrc[kMaxEmitGather];
+    void *gdst[kMaxEmitGather];
+    int gw[kMaxEmitGather];
+#pragma unroll
+    for (int c = 0; c < kMaxEmitGather; ++c) {
+        gsrc[c] = a.gather[c].src;
+        gdst[c] = a.gather[c].dst;
+        gw[c] = a.gather[c].width;
+    }
+    for (uint32_t qi = lane; qi < n_quads; qi += 128) {
+        uint32_t gv[2][4][kMaxEmitGather];
+        bool ok[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t out0 = (q0 + qi + 64 * u) << 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t o = out0 + e;
+                ok[u][e] = qi + 64 * u < n_quads && o >= base && o - base < n;
+                uint32_t idx = start + (ok[u][e] ? o - base : 0u);
+                if (idx >= cap) idx -= cap;
+                uint32_t rw[4];
+                rec_words<R>(src[idx], rw);
+                const uint32_t row = (tile0 + ((rw[0] >> 10) & 63u)) * (uint32_t)kTileRows + (rw[0] & (uint32_t)(kTileRows - 1));
+#pragma unroll
+                for (int c = 0; c < kMaxEmitGather; ++c) {
+                    gv[u][e][c] = 0u;
+                    if (c < ng) { // wave-uniform; the aligned dword that holds the value
+                        const uint32_t byte = row * (uint32_t)gw[c]; // (< 2^32: a segment's .dat is < 2 GiB, Segment.scala:33)
+                        gv[u][e][c] = ((const uint32_t *)gsrc[c])[byte >> 2] >> (8 * (byte & 3u));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t out0 = (q0 + qi + 64 * u) << 2;
+            const bool whole = ok[u][0] && ok[u][3];
+#pragma unroll
+            for (int c = 0; c < kMaxEmitGather; ++c) {
+                if (c < ng) {
+                    if (whole) store_quad(gdst[c], gw[c], out0, gv[u][0][c], gv[u][1][c], gv[u][2][c], gv[u][3][c]);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (ok[u][e]) store_value_rt(gdst[c], gw[c], out0 + e, gv[u][e][c]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// streamer side: one record per survivor of a tile, compacted in ascending row order.  rank = set bits below the row in
+// its word (v_mbcnt) + the survivors of the earlier words (scalar); the store is predicated by the word itself.
+// ---------------------------------------------------------------------------------------------
+template <int K0, int K1, int K2, class Store>
+__device__ __forceinline__ void compact_tile(const uint64_t (&acc)[kTileWords], const ColRegs<K0> &c0, const ColRegs<K1> &c1, const ColRegs<K2> &c2,
+                                             uint32_t lane_j, Store store) {
+    typedef Rec<K0, K1, K2> L;
+    uint32_t done = 0; // wave-uniform
+#pragma unroll
+    for (int w = 0; w < kTileWords; ++w) {
+        const uint64_t m = acc[w];
+        uint32_t rec[4] = {lane_j | (uint32_t)(64 * w), 0u, 0u, 0u};
+        L::template put<0>(rec, c0.value(w));
+        L::template put<1>(rec, c1.value(w));
+        L::template put<2>(rec, c2.value(w));
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, done));
+        if (__builtin_amdgcn_inverse_ballot_w64(m)) store(rank, L::pack(rec)); // exec = the word itself
+        done += (uint32_t)__popcll(m);
+    }
+}
+
+// (Tried and not kept: an unpredicated form in which every lane stores -- survivors at their rank, the others into a trash
+// slot of their own behind the ring, v_cndmask on the word instead of s_and_saveexec / branch / restore -- was 5 us slower
+// on C3: sixteen full-width ds_write_b64 per tile cost more than the five scalar instructions per word they save.)
+template <int K0, int K1, int K2>
+__global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectArgs a) {
+    typedef Rec<K0, K1, K2> L;
+    typedef typename L::vec vec;
+    constexpr int R = L::R;
+    constexpr uint32_t kCap = kProjRingBytes / (4 * R); // records a streamer's ring holds
+    constexpr bool kS2 = K0 == TK_S2 || K1 == TK_S2 || K2 == TK_S2;
+    constexpr bool kXpose = kS2 || K0 == TK_I8 || K1 == TK_I8 || K2 == TK_I8;
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kProjStreamers][kProjRingBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t s_xpose[kProjStreamers][kXpose ? (kS2 ? kXposeBytes : kXposeBytes / 2) : 16];
+    __shared__ __attribute__((aligned(16))) uint64_t s_park[kProjStreamers][kProjParkLines * kTileWords];
+    __shared__ RangePub s_pub[kProjStreamers][kProjSlots];
+    __shared__ uint32_t s_pub_seq[kProjStreamers]; // ranges the streamer has published
+    __shared__ uint32_t s_drained[kProjStreamers]; // ranges the writer has unpacked
+    __shared__ uint32_t s_head[kProjStreamers];    // records the writer has freed in the ring (running total)
+    __shared__ unsigned long long s_prefix[kProjSlots]; // first output row of the span (slot = span mod kProjSlots), from the first writer ...
+    __shared__ uint32_t s_prefix_seq;              // ... and how many spans it has resolved
+    __shared__ uint32_t s_abort;
+    __shared__ uint32_t s_part[kProjStreamers];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x] = wall_clock64();
+    if (threadIdx.x < kProjStreamers) {
+        s_pub_seq[threadIdx.x] = 0u;
+        s_drained[threadIdx.x] = 0u;
+        s_head[threadIdx.x] = 0u;
+    }
+    if (threadIdx.x == 0) {
+        s_abort = 0u;
+        s_prefix_seq = 0u;
+    }
+    __syncthreads();
+    const uint32_t epoch = (uint32_t)a.finish[kFinishEpoch];
+    const int P = a.P;
+    uint32_t lane_total = 0; // streamers, lanes 0..15: survivors in the bitmap words they produced
+
+    if (wave < kProjStreamers) {
+        // ------------------------------------------------------------------ streamer
+        vec *ring = (vec *)s_ring[wave];
+        uint8_t *xp = s_xpose[wave];
+        uint64_t *park = s_park[wave];
+        const int64_t n_full = a.n_rows / kTileRows;
+        vec *arena = (vec *)a.arena + ((int64_t)blockIdx.x * kProjStreamers + wave) * a.wave_cap;
+        // Prefetch: the wave's next full tile is loading while it works on one.  Two register sets take turns (the tile loop
+        // calls its body with the roles swapped every tile: no register copies); the prefetch HEAD walks the wave's tiles in
+        // the order the loop below meets them -- range by range, span by span.
+        ColRegs<K0> A0, B0;
+        ColRegs<K1> A1, B1;
+        ColRegs<K2> A2, B2;
+        int64_t head_t = ((int64_t)blockIdx.x * kProjStreamers + wave) * P, head_last = 0;
+        const int64_t head_jump = ((int64_t)gridDim.x * kProjStreamers - 1) * P; // from the end of a range to the wave's next one
+        int head_j = 0;
+        auto head_load = [&](ColRegs<K0> &r0, ColRegs<K1> &r1, ColRegs<K2> &r2) {
+            int64_t t = head_t;
+            if (IMM3_ABLATE_BIT(a, 8)) { // (timing only: all tiles dealt grid-stride -- every wave of the launch reads one contiguous window, as k_filter_tile)
+                const int64_t span = t / ((int64_t)P * kProjStreamers), round = span / gridDim.x;
+                t = ((round * P + head_j) * gridDim.x + blockIdx.x) * kProjStreamers + wave;
+            }
+            if (t < n_full) head_last = t;
+            else t = head_last; // nothing left: re-read the last tile (a load the compiler sees on every path)
+            r0.load(a.cols[0].data, t * kTileRows, lane);
+            r1.load(a.cols[1].data, t * kTileRows, lane);
+            r2.load(a.cols[2].data, t * kTileRows, lane);
+            ++head_t;
+            if (++head_j == P) {
+                head_j = 0;
+                head_t += head_jump;
+            }
+        };
+        head_load(A0, A1, A2);
+        bool cur_is_A = true;
+        ColRegs<K0> C0; // (kProjDepth2: the tile after the next one)
+        ColRegs<K1> C1;
+        ColRegs<K2> C2;
+        if (kProjDepth2) head_load(C0, C1, C2);
+        int64_t s = blockIdx.x;
+        uint32_t tail_pos = 0, tail_total = 0; // where the next record goes in the ring; records ever put there (minus those taken back by a spill)
+        uint32_t head_seen = 0;                // the ring's head as last read from LDS (it only grows: a stale value is a safe one)
+        uint32_t arena_range = 0;              // 1 + the last range that used the arena
+        bool abandoned = false;
+        for (uint32_t i = 0; s < a.n_spans && !abandoned; s += gridDim.x, ++i) {
+            const int64_t t0 = (s * kProjStreamers + wave) * P;
+            const uint32_t range_start = tail_pos;
+            uint32_t range_cnt = 0; // records of this range (ring or arena)
+            bool in_arena = false;
+            int parked = 0, first_parked = 0;
+            auto flush_park = [&]() { // 4 lines (4 x 16 lanes) per store instruction; the lines of consecutive tiles are contiguous
+                lds_wave_sync();
+                for (int q = lane >> 4; q < parked; q += 4)
+                    __builtin_nontemporal_store(park[q * kTileWords + (lane & 15)], a.bitmap + (t0 + first_parked + q) * kTileWords + (lane & 15));
+                lds_wave_sync();
+                first_parked += parked;
+                parked = 0;
+            };
+            // the range outgrows the ring: what it has there moves to the arena, the rest follows directly
+            auto to_arena = [&]() {
+                while (lds_peek(&s_drained[wave]) < arena_range) { // the arena's previous range must have been unpacked
+                    if (lds_peek(&s_abort)) { abandoned = true; return; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                lds_wave_order();
+                for (uint32_t k = lane; k < range_cnt; k += 64) {
+                    uint32_t idx = range_start + k;
+                    if (idx >= kCap) idx -= kCap;
+                    arena[k] = ring[idx];
+                }
+                lds_wave_order();
+                tail_total -= range_cnt;
+                tail_pos = range_start;
+                in_arena = true;
+                arena_range = i + 1;
+            };
+            // one full tile: its columns are in (c0, c1, c2); the next tile's go to (n0, n1, n2)
+            auto full_tile = [&](ColRegs<K0> &c0, ColRegs<K1> &c1, ColRegs<K2> &c2, ColRegs<K0> &n0, ColRegs<K1> &n1, ColRegs<K2> &n2, int j) {
+                    // software pipeline (k_filter_tile, finding 11): the wait for this tile's loads sits BEFORE the next tile's
+                    // loads are issued
+                    c0.touch();
+                    c1.touch();
+                    c2.touch();
+                    if (kProjDepth2) { // the next tile's loads have been in flight for a tile already; the one after it goes out now
+                        n0 = C0;
+                        n1 = C1;
+                        n2 = C2;
+                        head_load(C0, C1, C2);
+                    } else head_load(n0, n1, n2);
+                    uint64_t acc[kTileWords]; // wave-uniform words (SGPR pairs)
+#pragma unroll
+                    for (int w = 0; w < kTileWords; ++w) acc[w] = ~0ULL;
+                    if (IMM3_ABLATE_BIT(a, 64)) { // (timing only: no compares -- every word keeps 6 fixed rows, ~10 % survivors)
+#pragma unroll
+                        for (int w = 0; w < kTileWords; ++w) acc[w] = 0x0101010100010101ULL << (w & 7);
+                    } else {
+                        c0.eval(a.cols[0], acc, lane, xp);
+                        c1.eval(a.cols[1], acc, lane, xp);
+                        c2.eval(a.cols[2], acc, lane, xp);
+                    }
+                    uint64_t mine = words_to_lanes(acc);
+                    if (lane >= kTileWords) mine = 0;
+                    if (lane < kTileWords) park[parked * kTileWords + lane] = mine;
+                    lane_total += (uint32_t)__popcll(mine);
+                    if (++parked == kProjParkLines) flush_park();
+                    // the survivors' records
+                    uint32_t cnt = 0; // wave-uniform
+#pragma unroll
+                    for (int w = 0; w < kTileWords; ++w) cnt += (uint32_t)__popcll(acc[w]);
+                    if (IMM3_ABLATE_BIT(a, 4)) cnt = 0; // (no records at all)
+                    if (!in_arena && range_cnt + cnt > kCap) to_arena();
+                    if (!in_arena && tail_total + cnt - head_seen > kCap) { // room in the ring?  Only undrained EARLIER ranges can be in the way: the writer frees them
+                        while (tail_total + cnt - (head_seen = lds_peek(&s_head[wave])) > kCap) {
+                            if (lds_peek(&s_abort)) { abandoned = true; break; }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                    }
+                    if (abandoned) return;
+                    const uint32_t lane_j = (uint32_t)lane | ((uint32_t)j << 10);
+                    if (cnt == 0) {
+                    } else if (in_arena) { // (slow path: straight to HBM)
+                        vec *dst = arena + range_cnt;
+                        compact_tile<K0, K1, K2>(acc, c0, c1, c2, lane_j, [&](uint32_t rank, vec v) { dst[rank] = v; });
+                    } else if (tail_pos + cnt <= kCap) { // the common case: the tile's records do not wrap around the ring
+                        vec *dst = ring + tail_pos;
+                        compact_tile<K0, K1, K2>(acc, c0, c1, c2, lane_j, [&](uint32_t rank, vec v) { dst[rank] = v; });
+                    } else {
+                        compact_tile<K0, K1, K2>(acc, c0, c1, c2, lane_j, [&](uint32_t rank, vec v) {
+                            uint32_t idx = tail_pos + rank;
+                            if (idx >= kCap) idx -= kCap;
+                            ring[idx] = v;
+                        });
+                    }
+                    range_cnt += cnt;
+                    if (!in_arena) {
+                        tail_total += cnt;
+                        tail_pos += cnt;
+                        if (tail_pos >= kCap) tail_pos -= kCap;
+                    }
+            };
+            for (int j = 0; j < P && !abandoned; ++j) {
+                const int64_t tile = t0 + j;
+                if (tile >= a.n_tiles) break; // wave-uniform
+                if (tile < n_full) {
+                    if (cur_is_A) full_tile(A0, A1, A2, B0, B1, B2, j);
+                    else full_tile(B0, B1, B2, A0, A1, A2, j);
+                    cur_is_A = !cur_is_A;
+                } else {
+                    // the one partial tile at the end of the segment: rolled, bounds-checked; its range goes through the arena
+                    flush_park();
+                    if (!in_arena) to_arena();
+                    if (abandoned) break;
+                    const int64_t row0 = tile * kTileRows, valid_rows = a.n_rows - row0;
+                    ColRegs<K0> c0;
+                    ColRegs<K1> c1;
+                    ColRegs<K2> c2;
+                    uint64_t mine = ~0ULL;
+                    uint32_t done = 0;
+#pragma unroll 1
+                    for (int w = 0; w < kTileWords; ++w) {
+                        const int64_t r_in = 64 * w + lane;
+                        const bool valid = r_in < valid_rows;
+                        const int64_t r = row0 + (valid ? r_in : 0);
+                        bool keep = valid;
+                        if (valid) keep = c0.row(a.cols[0].data, a.cols[0], r) && c1.row(a.cols[1].data, a.cols[1], r) && c2.row(a.cols[2].data, a.cols[2], r);
+                        const uint64_t m = ballot64(keep);
+                        if (lane == w) mine &= m;
+                        uint32_t rec[4] = {(uint32_t)r_in | ((uint32_t)j << 10), 0u, 0u, 0u};
+                        L::template put<0>(rec, c0.rowval(a.cols[0].data, r));
+                        L::template put<1>(rec, c1.rowval(a.cols[1].data, r));
+                        L::template put<2>(rec, c2.rowval(a.cols[2].data, r));
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, done));
+                        if (keep) arena[range_cnt + rank] = L::pack(rec);
+                        done += (uint32_t)__popcll(m);
+                    }
+                    range_cnt += done;
+                    mine &= low_mask(valid_rows - 64 * (int64_t)lane);
+                    if (lane >= kTileWords) mine = 0;
+                    const int64_t word = tile * kTileWords + lane;
+                    if (lane < kTileWords && word < (a.n_rows + 63) / 64) a.bitmap[word] = mine;
+                    lane_total += (uint32_t)__popcll(mine);
+                }
+            }
+            if (abandoned) break;
+            if (parked) flush_park();
+            // ---- publish the range (the slot's previous range, i - kProjSlots, must have been taken by the writer) ----
+            while (i >= (uint32_t)kProjSlots && lds_peek(&s_drained[wave]) < i - (uint32_t)(kProjSlots - 1)) {
+                if (lds_peek(&s_abort)) { abandoned = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (abandoned) break;
+            if (in_arena) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the writer (another wave of this CU) reads the arena: the stores must have landed
+#ifdef IMM3_ABLATE
+            if (a.stamps && lane == 0 && wave == 0 && i < 6) a.stamps[2 * gridDim.x + blockIdx.x * 18 + i] = wall_clock64(); // (tools: range i done)
+#endif
+            if (lane == 0) {
+                s_pub[wave][i % kProjSlots].start = range_start;
+                s_pub[wave][i % kProjSlots].cnt = range_cnt;
+                s_pub[wave][i % kProjSlots].in_arena = in_arena ? 1u : 0u;
+                lds_wave_order();
+                lds_poke(&s_pub_seq[wave], i + 1); // (a wave's LDS operations execute in order: the slot is written before the sequence number)
+            }
+        }
+    } else {
+        // ------------------------------------------------------------------ writer
+        const int wr = wave - kProjStreamers; // 0: also owns the span's descriptor and its first output row
+        const int w_first = wr * kProjPerWriter;
+        int64_t s = blockIdx.x;
+        for (uint32_t k = 0; s < a.n_spans; s += gridDim.x, ++k) {
+            // the ranges of span s
+            uint32_t cnt[kProjStreamers], start[kProjStreamers], in_arena[kProjStreamers];
+            bool dead = false;
+#pragma unroll
+            for (int w = 0; w < kProjStreamers; ++w) {
+                while (lds_peek(&s_pub_seq[w]) < k + 1) { // (a range takes >= 10 us to stream: poll at ~0.5 us, the streamers need the issue slots)
+                    if (lds_peek(&s_abort)) { dead = true; break; }
+                    __builtin_amdgcn_s_sleep(16);
+                }
+                lds_wave_order();
+                start[w] = s_pub[w][k % kProjSlots].start;
+                cnt[w] = s_pub[w][k % kProjSlots].cnt;
+                in_arena[w] = s_pub[w][k % kProjSlots].in_arena;
+            }
+            if (dead) break;
+            unsigned long long prefix = 0;
+            if (wr == 0) {
+                unsigned long long agg = 0;
+#pragma unroll
+                for (int w = 0; w < kProjStreamers; ++w) agg += cnt[w];
+                bool ok = true;
+                if (IMM3_ABLATE_BIT(a, 2)) prefix = (unsigned long long)s * (unsigned long long)(P * kProjStreamers * 128); // (no chained scan: rows land at wrong, but distinct, offsets)
+                else ok = span_prefix(a, s, epoch, agg, lane, prefix);
+                if (!ok) { // abandoned: tell the host, the other waves and everybody who waits on this work-group's spans
+                    if (lane == 0) {
+                        __hip_atomic_fetch_or(a.finish + kFinishStatus, 2ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int64_t r = s; r < a.n_spans; r += gridDim.x) desc_store(a.desc + r, desc_pack(epoch, 3u, 0ULL));
+                        lds_poke(&s_abort, 1u);
+                    }
+                    break;
+                }
+                if (lane == 0) {
+                    s_prefix[k % kProjSlots] = prefix; // (the slot's previous span, k - 2, was read by the other writer before it drained k - 2 ...
+                    lds_wave_order();
+                    lds_poke(&s_prefix_seq, k + 1); // ... and this wave got here only after the streamers published k, i.e. after k - 2 was drained)
+                }
+            } else {
+                while (lds_peek(&s_prefix_seq) < k + 1) {
+                    if (lds_peek(&s_abort)) { dead = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (dead) break;
+                lds_wave_order();
+                prefix = s_prefix[k % kProjSlots];
+            }
+#ifdef IMM3_ABLATE
+            if (a.stamps && lane == 0 && wr == 0 && k < 6) a.stamps[2 * gridDim.x + blockIdx.x * 18 + 12 + k] = wall_clock64(); // (tools: span k's first row known)
+#endif
+            // this writer's ranges of the span.  While it unpacks the writer outranks the streamers of its SIMD (the issue arbiter
+            // prefers the oldest waves -- the streamers -- and the unpacking is on the critical path of the span's ring space).
+            __builtin_amdgcn_s_setprio(2);
+            unsigned long long base = prefix;
+#pragma unroll
+            for (int w = 0; w < kProjStreamers; ++w) {
+                if (w >= w_first && w < w_first + kProjPerWriter && !IMM3_ABLATE_BIT(a, 1)) { // (wave-uniform)
+                    const uint32_t tile0 = (uint32_t)((s * kProjStreamers + w) * P);
+                    const uint32_t b32 = base > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)base;
+                    if (in_arena[w]) { // (slow path)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        const vec *ar = (const vec *)a.arena + ((int64_t)blockIdx.x * kProjStreamers + w) * a.wave_cap;
+                        unpack_range<K0, K1, K2>(a, ar, 0u, 0xFFFFFFFFu, cnt[w], b32, tile0, lane);
+                    } else {
+                        unpack_range<K0, K1, K2>(a, (const vec *)&s_ring[w][0], start[w], kCap, cnt[w], b32, tile0, lane);
+                    }
+                }
+                base += cnt[w];
+            }
+#ifdef IMM3_ABLATE
+            if (a.stamps && lane == 0 && wr == kProjWriters - 1 && k < 6) a.stamps[2 * gridDim.x + blockIdx.x * 18 + 6 + k] = wall_clock64(); // (tools: span k drained)
+#endif
+            __builtin_amdgcn_s_setprio(0);
+            lds_wave_order();
+            if (lane == 0) { // (behind the ring reads above: a wave's LDS operations execute in order)
+#pragma unroll
+                for (int w = 0; w < kProjStreamers; ++w) {
+                    if (w >= w_first && w < w_first + kProjPerWriter) {
+                        if (!in_arena[w]) lds_poke(&s_head[w], lds_peek(&s_head[w]) + cnt[w]);
+                        lds_poke(&s_drained[w], k + 1);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) lane_total += __shfl_xor(lane_total, d); // lanes 0..15 -> lane 0
+    if (lane == 0 && wave < kProjStreamers) s_part[wave] = lane_total;
+    __syncthreads();
+    if (threadIdx.x == 0) { // the launch's last work-group publishes the count (and bumps the epoch)
+        unsigned long long t = 0;
+#pragma unroll
+        for (int w = 0; w < kProjStreamers; ++w) t += s_part[w];
+        if (finish_add(a.finish, t)) { // the launch's last work-group: every round is over, the arrival counters start the next run at zero
+            uint32_t *round_ctr = (uint32_t *)(a.desc + a.n_spans + a.n_rounds);
+            for (int64_t r = 0; r < a.n_rounds; ++r) round_ctr[r] = 0u;
+        }
+    }
+    if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x + 1] = wall_clock64();
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+#define IMM3_PROJECT_KINDS(X)                                                                       \
+    X(TK_NONE, TK_NONE, TK_NONE)                                                                    \
+    X(TK_I32, TK_NONE, TK_NONE) X(TK_I8, TK_NONE, TK_NONE) X(TK_S2, TK_NONE, TK_NONE)               \
+    X(TK_I32, TK_I32, TK_NONE) X(TK_I32, TK_I8, TK_NONE) X(TK_I8, TK_I8, TK_NONE)                   \
+    X(TK_I32, TK_S2, TK_NONE) X(TK_I8, TK_S2, TK_NONE)                                              \
+    X(TK_I32, TK_I32, TK_I32) X(TK_I32, TK_I32, TK_I8) X(TK_I32, TK_I8, TK_I8)                      \
+    X(TK_I8, TK_I8, TK_I8) X(TK_I32, TK_I32, TK_S2) X(TK_I32, TK_I8, TK_S2) X(TK_I8, TK_I8, TK_S2)
+
+bool launch_filter_project(const ProjectArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+#define IMM3_PROJECT_CASE(k0, k1, k2)                                                               \
+    if (a.kinds[0] == k0 && a.kinds[1] == k1 && a.kinds[2] == k2) {                                 \
+        IMM3_LAUNCH((k_filter_project<k0, k1, k2>), grid, kProjThreads, s, ev0, ev1, a);           \
+        return true;                                                                                \
+    }
+    IMM3_PROJECT_KINDS(IMM3_PROJECT_CASE)
+#undef IMM3_PROJECT_CASE
+    return false;
+}
+
+int project_rec_dwords(const int32_t *kinds) {
+    const int k[kMaxTileCols] = {kinds[0], kinds[1], kinds[2]};
+    return rec_layout(k, -1).dwords;
+}
+
+// Work-groups of the launch: ONE per CU (8 waves, > 80 KB of LDS: a CU never takes a second one, and takes the first whatever
+// the instance's register footprint), so every work-group of the launch is resident -- the look-back needs that.
+int project_max_grid(const int32_t *kinds, int P) {
+    (void)P;
+    bool have = false;
+#define IMM3_PROJECT_HAVE(k0, k1, k2) have = have || (kinds[0] == k0 && kinds[1] == k1 && kinds[2] == k2);
+    IMM3_PROJECT_KINDS(IMM3_PROJECT_HAVE)
+#undef IMM3_PROJECT_HAVE
+    if (!have) return 0;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return cus;
+}
+
+} // namespace imm3

@@ -47,7 +47,7 @@ EXPORTS = [
 # include/imm3_diag.h: measurement / tuning hooks, not part of the drop-in boundary
 DIAG_EXPORTS = [
     "imm3_ctx_timing_enable", "imm3_ctx_timing_reset", "imm3_ctx_timing_mask", "imm3_ctx_timing_collect", "imm3_ctx_set_tuning",
-    "imm3_ctx_measure_read_gbps", "imm3_ctx_devclock_enable", "imm3_ctx_devclock_collect",
+    "imm3_ctx_measure_read_gbps", "imm3_ctx_devclock_enable", "imm3_ctx_devclock_collect", "imm3_ctx_devclock_raw", "imm3_query_plan",
 ]
 COMM_ID_BYTES = 128
 
@@ -165,6 +165,8 @@ def load() -> C.CDLL:
     L.imm3_ctx_measure_read_gbps.argtypes = [vp, u64, i32, P(C.c_double)]
     L.imm3_ctx_devclock_enable.argtypes = [vp, i32]
     L.imm3_ctx_devclock_collect.argtypes = [vp, vp, i32, P(i32)]
+    L.imm3_query_plan.argtypes = [vp, vp, i32]
+    L.imm3_ctx_devclock_raw.argtypes = [vp, i32, vp, i32]
     L.imm3_comm_unique_id.argtypes = [vp]
     L.imm3_comm_create.argtypes = [vp, i32, i32, vp, P(vp)]
     L.imm3_comm_create_all.argtypes = [P(vp), i32, P(vp)]
@@ -287,6 +289,11 @@ class Context:
         n = C.c_int32(0)
         _check(load().imm3_ctx_devclock_collect(self._h, out.ctypes.data, cap, C.byref(n)))
         return out[: min(n.value, cap)]
+
+    def devclock_raw(self, launch: int, n: int = 8192) -> np.ndarray:
+        out = np.zeros(n, dtype=np.uint64)
+        _check(load().imm3_ctx_devclock_raw(self._h, launch, out.ctypes.data, n))
+        return out
 
     def timing_enable(self, max_records: int):
         _check(load().imm3_ctx_timing_enable(self._h, max_records))
@@ -583,6 +590,13 @@ class DeviceQuery:
         vals = np.zeros((max(g, 1), na), np.int64)
         _check(load().imm3_query_fetch_groups(self._h, keys.ctypes.data, first.ctypes.data, counts.ctypes.data, vals.ctypes.data, g))
         return keys[:g], first[:g], counts[:g], vals[:g, : len(self.aggs or [])]
+
+    def plan(self) -> dict:
+        """How the library planned this query (include/imm3_diag.h: imm3_query_plan)."""
+        v = np.zeros(8, np.int64)
+        _check(load().imm3_query_plan(self._h, v.ctypes.data, 8))
+        return {"single_pass": bool(v[0]), "P": int(v[1]), "grid": int(v[2]), "spans": int(v[3]), "records": bool(v[4]),
+                "rec_dwords": int(v[5]), "ran_single_pass": bool(v[6])}
 
     def device_ptr(self, which: int) -> int:
         p = C.c_void_p()

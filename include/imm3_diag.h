@@ -29,6 +29,9 @@ int imm3_ctx_timing_collect(imm3_ctx *ctx, int32_t kernel_id, float *ms_out, int
  * ms, oldest first.  Diagnostics only (bench.py's instrumented pass); costs two stores per work-group. */
 int imm3_ctx_devclock_enable(imm3_ctx *ctx, int32_t max_launches);
 int imm3_ctx_devclock_collect(imm3_ctx *ctx, float *ms_out, int32_t cap, int32_t *n_out);
+/* The raw stamps of one recorded launch (100 MHz ticks): [2 b] / [2 b + 1] = entry / exit of work-group b; the tools' build of
+ * the single-pass kernel adds per-range stamps behind them. */
+int imm3_ctx_devclock_raw(imm3_ctx *ctx, int32_t launch, uint64_t *out, int32_t n);
 
 /* Empirical read-only streaming ceiling of this GPU: times a kernel that only reads `bytes` (non-temporal dword loads,
  * same tiling and grid as the scan+select kernel, three rotated buffers) and returns the median GB/s over `iters`. */
@@ -39,6 +42,13 @@ int imm3_ctx_measure_read_gbps(imm3_ctx *ctx, uint64_t bytes, int32_t iters, dou
  * 4 = stage int32 columns only, 5 = PFOR_INT predicates read the decoded column instead of the compressed blocks,
  * 7 = reduce the count with a separate k_total launch instead of inside the filter kernel. */
 int imm3_ctx_set_tuning(imm3_ctx *ctx, int32_t filter_variant, int32_t grid_blocks);
+
+/* How the library planned a query (tests assert the path they mean to exercise; tools print it).
+ * out[0] = 1 when an unlimited projection runs as ONE launch (k_filter_project: the filter kernel writes the rows), else 0;
+ * out[1] = tiles per wave per span (P); out[2] = work-groups of that launch; out[3] = spans;
+ * out[4] = 1 when the projection goes through survivor records in HBM (filter -> k_scan -> k_emit), else 0;
+ * out[5] = dwords per survivor record; out[6] = 1 when the last run used the single-pass launch.  n <= 8 values are written. */
+int imm3_query_plan(const imm3_query *q, int64_t *out, int32_t n);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ def test_bench_line_has_the_contract_fields():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 3 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["unit"] == "rows/s" and d["data"] == "synthetic"
-    assert "workload" in d["config"] and "model" not in d["config"]
+    assert "workload" in d["config"] and "model" not in d["config"] and d["config"]["workload"].startswith("C2")
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
@@ -49,15 +49,20 @@ def test_bench_cpu_baseline_and_extra_block():
         e = x[name]
         for k in ("algorithmic_bytes", "kernel_ms", "frac", "selected_rows", "ms_per_query"):
             assert k in e, (name, k)
-        assert e["kernel_ms"]["scan_select"] > 0 and e["kernel_ms"]["compact_gather"] > 0 and 0 < e["frac"] < 1.2
+        assert e["kernel_ms"]["scan_select"] > 0 and 0 < e["frac"] < 1.2
+        if e["plan"]["single_pass"]:     # ONE launch: the filter kernel writes the rows (imm3_project.hip)
+            assert e["plan"]["ran_single_pass"] and e["kernel_ms"]["compact_gather"] is None and e["kernel_ms"]["offsets_scan"] is None
+        else:
+            assert e["kernel_ms"]["compact_gather"] > 0
+    assert x["c3_range_age_id_project"]["plan"]["single_pass"]      # every SELECT-list column is a predicate column
     assert x["agg_group_by_state_all_rows"]["groups"] == 51
-    c5 = x["c5_g1"]
-    assert c5["config"]["segments"] == 8 and c5["value"] > 0 and "ncclAllReduce" in c5["count_allreduce"]["collective"]
+    c5 = x["c5"]
+    assert c5["config"]["segments"] == 8 and c5["value"] > 0 and "ncclAllReduce" in c5["count_allreduce"]["collective"] and c5["scaling"] == "strong"
 
 
 def test_bench_gpus_2_launches_its_own_ranks():
-    """`python bench.py --gpus 2` with no rank environment starts two ranks itself and prints an n_gpus = 2 line for the C5
-    shape.  One-device rehearsal: both ranks share cuda:0, so the count all-reduce goes over gloo (RCCL refuses that)."""
+    """`python bench.py --gpus 2` with no rank environment starts two ranks itself and prints an n_gpus = 2 line whose `value`
+    is the headline C2 workload (weak scaling) and whose extra.c5 is the sharded C5 job.  One-device rehearsal: both ranks share cuda:0, so the count all-reduce goes over gloo (RCCL refuses that)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["IMM3_BENCH_ONE_DEVICE"] = "1"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "1000000", "--steps", "4", "--warmup", "1",
@@ -66,14 +71,19 @@ def test_bench_gpus_2_launches_its_own_ranks():
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 4 and d["cpu_baseline"] is None
-    assert d["config"]["segments"] == 8 and d["config"]["segments_per_gpu"] == 4 and d["config"]["workload"].startswith("C5")
-    assert abs(d["value"] - 8 * 1000000 * 4 / (d["ms_per_step"] * 1e-3 * 4)) / d["value"] < 1e-6
-    assert [r["segments"] for r in d["per_rank"]] == [[0, 2, 4, 6], [1, 3, 5, 7]]
-    assert d["global_selected_rows_per_pass"] == sum(r["selected_rows"] for r in d["per_rank"])
-    assert d["c2_weak"]["per_rank"][1]["rank"] == 1 and d["c2_weak"]["value"] > 0
-    g1 = d["c5_g1_same_run"]                     # the G = 1 point measured in the same run (every rank alone on all 8 segments)
+    # `value` is the headline workload at every N (weak scaling): like-for-like with the --gpus 1 line
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 4 and d["cpu_baseline"] is None
+    assert d["config"]["workload"].startswith("C2") and d["dtype"] == "i32"
+    assert abs(d["value"] - 2 * 1000000 * 4 / (d["ms_per_step"] * 1e-3 * 4)) / d["value"] < 1e-6
+    assert [r["rank"] for r in d["per_rank"]] == [0, 1]
+    # BASELINE config C5 (strong scaling, count all-reduce) rides in extra.c5, with its G = 1 point and an explicit efficiency
+    c5 = d["extra"]["c5"]
+    assert c5["scaling"] == "strong" and c5["config"]["segments"] == 8 and c5["config"]["segments_per_gpu"] == 4 and c5["config"]["workload"].startswith("C5")
+    assert [r["segments"] for r in c5["per_rank"]] == [[0, 2, 4, 6], [1, 3, 5, 7]]
+    assert c5["global_selected_rows_per_pass"] == sum(r["selected_rows"] for r in c5["per_rank"])
+    g1 = c5["g1_same_run"]                       # the G = 1 point measured in the same run (every rank alone on all 8 segments)
     assert g1["value"] > 0 and abs(g1["value"] - 8 * 1000000 / (g1["ms_per_step"] * 1e-3)) / g1["value"] < 1e-6
+    assert abs(c5["efficiency"] - c5["value"] / (2 * g1["value"])) < 1e-9
     # a rank count that contradicts the environment is refused, not silently reported as another N
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "100000"], capture_output=True, text=True, cwd=ROOT, timeout=300, env=env2)

@@ -24,6 +24,9 @@ cases = {
 names = {0: "filter", 1: "scan", 2: "project", 3: "count"}
 import os
 VARIANTS = [int(v) for v in os.environ.get("IMM3_VARIANTS", "0").split(",")]
+ONLY = [c for c in os.environ.get("IMM3_CASES", "").split(",") if c]
+if ONLY:
+    cases = {k: v for k, v in cases.items() if k in ONLY}
 grids = [int(g) for g in sys.argv[1:]] or [0]
 for name, (used, sels, proj) in cases.items():
   for variant in VARIANTS:

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Development tool: per-work-group timeline of one k_filter_project launch (tools' build: IMM3_LIB_PATH=.../libimm3_ablate.so).
+usage: sp_timeline.py variant [create_variant]"""
+import sys
+import numpy as np
+sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
+from immutable3_amd import native, synth
+
+n = 100_000_000
+ctx = native.Context(0)
+ids = np.arange(n, dtype=np.int32)
+age = synth.uniform_below(2, n, 100, np.int8)
+seg = native.DeviceSegment(ctx, [(native.DENSE_INT, 4, ids.view(np.uint8), n * 4, synth.block_offsets(n, 4)),
+                                 (native.DENSE_TINYINT, 1, age.view(np.uint8), n, synth.block_offsets(n, 1))])
+variant = int(sys.argv[1])
+create = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+ctx.set_tuning(create, 0)
+q = native.DeviceQuery(ctx, seg, [1, 0], [(0, native.GT, 18.0), (0, native.LT, 30.0), (1, native.GT, 1e6), (1, native.LT, 9e7)], [1, 0], 0, 1024)
+ctx.set_tuning(variant, 0)
+for _ in range(3):
+    q.run()
+ctx.sync()
+ctx.devclock_enable(2)
+q.run()
+ctx.sync()
+plan = q.plan()
+g = plan["grid"]
+raw = ctx.devclock_raw(0).astype(np.int64)
+t0 = raw[0:2 * g:2].min()
+start = (raw[0:2 * g:2] - t0) / 100.0
+end = (raw[1:2 * g:2] - t0) / 100.0
+print(f"plan {plan}")
+print(f"wg start us: min {start.min():.1f} p50 {np.median(start):.1f} max {start.max():.1f};  end us: min {end.min():.1f} p50 {np.median(end):.1f} max {end.max():.1f}")
+ext = raw[2 * g: 2 * g + 18 * g].reshape(g, 18)
+for i in range(6):
+    r = ext[:, i]; d = ext[:, 6 + i]; pk = ext[:, 12 + i]
+    if (r > 0).any():
+        rr = (r[r > 0] - t0) / 100.0; dd = (d[d > 0] - t0) / 100.0; pp = (pk[pk > 0] - t0) / 100.0
+        if pp.size:
+            print(f"range {i}: first row known by us min {pp.min():6.1f} p50 {np.median(pp):6.1f} max {pp.max():6.1f}")
+        print(f"range {i}: streamed by us min {rr.min():6.1f} p50 {np.median(rr):6.1f} max {rr.max():6.1f}   drained by us min {dd.min() if dd.size else 0:6.1f} p50 {np.median(dd) if dd.size else 0:6.1f} max {dd.max() if dd.size else 0:6.1f}")
+order = np.argsort(start)
+print("start us by blockIdx (every 32nd):", " ".join(f"{b}:{start[b]:.0f}" for b in range(0, g, 32)))
+print("sorted starts (every 32nd):", " ".join(f"{start[order[k]]:.0f}" for k in range(0, g, 32)))
+print("end   us by blockIdx (every 32nd):", " ".join(f"{b}:{end[b]:.0f}" for b in range(0, g, 32)))
