@@ -1724,6 +1724,35 @@ static void fill_tile_col(const imm3_query *q, const FoldedPred &fp, TileCol &c,
     }
 }
 
+// Per-device state of the single-pass projection kernel, whose work-groups wait on each other and therefore must own the
+// device while they run (imm3_project.hip): launches of all contexts of a device are chained through one event -- each
+// starts behind the previous one, stream side, no host wait -- and a device word holds the running launch's ticket for
+// whatever the host cannot order (graph replays, other processes on the same GPU).  Internal synchronisation state, guarded
+// by its mutex; it lives as long as the process.
+namespace {
+struct SinglePassDevice {
+    std::mutex mu;
+    hipEvent_t last = nullptr;            // recorded behind the last launch
+    unsigned long long *d_lock = nullptr; // the ticket word
+};
+SinglePassDevice g_single_pass[kMaxDevices];
+} // namespace
+
+static int single_pass_device(int device, SinglePassDevice **out) {
+    if (device < 0 || device >= kMaxDevices) return fail(IMM3_ERR_ARG, "device index out of range");
+    SinglePassDevice &d = g_single_pass[device];
+    std::lock_guard<std::mutex> lk(d.mu);
+    if (!d.d_lock) {
+        void *p = nullptr;
+        HIPCHK(hipMalloc(&p, 64));
+        HIPCHK(hipMemset(p, 0, 64));
+        d.d_lock = (unsigned long long *)p;
+        HIPCHK(hipEventCreateWithFlags(&d.last, hipEventDisableTiming));
+    }
+    *out = &d;
+    return IMM3_OK;
+}
+
 // ScanOp -> SelectOp* -> ProjectOp in one launch (k_filter_project): bitmap, count and the projected rows
 static int run_single_pass(imm3_query *q) {
     imm3_ctx *ctx = q->ctx;
@@ -1793,11 +1822,23 @@ static int run_single_pass(imm3_query *q) {
             ++ctx->stamp_used;
         }
     }
+    SinglePassDevice *dev = nullptr;
     {
-        LaunchTimer t(ctx, 0);
-        if (!launch_filter_project(a, q->sp_grid, s, t.start, t.stop)) return fail(IMM3_ERR_ARG, "internal: no single-pass kernel for this column combination");
+        const int drc = single_pass_device(ctx->device, &dev);
+        if (drc) return drc;
     }
-    HIPCHK(hipGetLastError());
+    a.device_lock = dev->d_lock;
+    {
+        std::lock_guard<std::mutex> lk(dev->mu); // (wait - launch - record is one step: the next launcher waits for THIS launch)
+        const bool chained = !ctx->capture;      // (a capture cannot depend on an event recorded outside it: the device lock covers replays)
+        if (chained) HIPCHK(hipStreamWaitEvent(s, dev->last, 0));
+        {
+            LaunchTimer t(ctx, 0);
+            if (!launch_filter_project(a, q->sp_grid, s, t.start, t.stop)) return fail(IMM3_ERR_ARG, "internal: no single-pass kernel for this column combination");
+        }
+        HIPCHK(hipGetLastError());
+        if (chained) HIPCHK(hipEventRecord(dev->last, s));
+    }
     q->stage_written = false;
     q->count_pending_scan = false;
     q->has_pfor_pass = false;
@@ -2022,9 +2063,11 @@ static int settle_single_pass(imm3_query *q) {
     HIPCHK(hipMemcpyAsync(&status, q->d_total + kFinishStatus, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     q->sp_verified = true;
-    if (!(status & 2ULL)) return IMM3_OK;
-    graphs_mark_stale(ctx, q); // a recorded run would take the abandoned path again
-    q->single_pass = false;
+    if (!(status & 6ULL)) return IMM3_OK;
+    if (status & 2ULL) { // a prefix never came (not every work-group resident?): this query keeps the bitmap path from now on
+        graphs_mark_stale(ctx, q); // (a recorded run would take the abandoned path again)
+        q->single_pass = false;
+    } // else bit 2 alone: the device was busy with another launch of the kernel -- this run only
     HIPCHK(hipMemsetAsync(q->d_total + kFinishStatus, 0, sizeof(unsigned long long), ctx->stream));
     int rc = run_select(q, false, true);
     if (rc) return rc;

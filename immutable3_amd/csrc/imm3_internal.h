@@ -164,7 +164,7 @@ void launch_emit(const EmitArgs &a, int n_gather, int grid_blocks, hipStream_t s
 // run's, so nothing is cleared between runs.
 constexpr int kProjectMaxP = 64;        // tiles per wave per span (the tile's index in its range takes 6 bits of the record)
 constexpr int kProjectStreamers = 8;    // waves of a work-group that stream tiles: a span is kProjectStreamers * P consecutive tiles
-constexpr int kFinishStatus = 2;        // finish[2]: bit 0 malformed PFOR block, bit 1 single-pass projection abandoned
+constexpr int kFinishStatus = 2;        // finish[2]: bit 0 malformed PFOR block; single-pass projection: bit 1 abandoned (a prefix never came), bit 2 device busy
 constexpr int kFinishEpoch = 8;         // finish[8]: run counter of the query (descriptor epochs)
 constexpr unsigned long long kDescValueMask = (1ULL << 54) - 1;
 struct ProjectArgs {
@@ -185,6 +185,7 @@ struct ProjectArgs {
     int32_t n_gather;
     int32_t ablate;
     unsigned long long *stamps;     // diagnostics only
+    unsigned long long *device_lock; // one word per device: the ticket of the launch of this kernel that owns the device, or 0
 };
 // false: no instance for these kinds.  grid <= project_max_grid(): every work-group must be resident (they wait on each other)
 bool launch_filter_project(const ProjectArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);

@@ -30,7 +30,7 @@
 namespace imm3 {
 
 constexpr int kProjParkLines = 16;       // bitmap lines a wave parks in LDS between store bursts
-constexpr uint32_t kLookbackMaxPolls = 1u << 19;
+constexpr uint32_t kLookbackMaxPolls = 1u << 17; // ~0.1-0.2 s of polling: then the run is abandoned
 
 __device__ __forceinline__ unsigned long long desc_pack(uint32_t epoch, uint32_t flag, unsigned long long value) {
     return ((unsigned long long)(epoch & 0xFFu) << 56) | ((unsigned long long)flag << 54) | (value & kDescValueMask);
@@ -360,8 +360,22 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
         s_abort = 0u;
         s_prefix_seq = 0u;
     }
-    __syncthreads();
     const uint32_t epoch = (uint32_t)a.finish[kFinishEpoch];
+    // ONE launch of this kernel per device at a time: two of them, each holding part of the CUs and waiting for work-groups
+    // of its own that the other one keeps from starting, would wait for each other until both time out.  The host chains
+    // its launches with events (imm3_api.cpp); this lock is the net under graphs and under anything the host cannot see:
+    // a launch that finds another one's ticket in the lock gives up at once (status bit 2) and the host answers the query
+    // through the bitmap path.
+    const unsigned long long ticket = ((unsigned long long)(uintptr_t)a.desc << 8) | (unsigned long long)((epoch & 0xFFu) | 1u);
+    if (threadIdx.x == 0 && a.device_lock) {
+        unsigned long long seen = 0ULL;
+        __hip_atomic_compare_exchange_strong(a.device_lock, &seen, ticket, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen != 0ULL && seen != ticket) {
+            __hip_atomic_fetch_or(a.finish + kFinishStatus, 4ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_abort = 1u;
+        }
+    }
+    __syncthreads();
     const int P = a.P;
     uint32_t lane_total = 0; // streamers, lanes 0..15: survivors in the bitmap words they produced
 
@@ -409,6 +423,7 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
         uint32_t head_seen = 0;                // the ring's head as last read from LDS (it only grows: a stale value is a safe one)
         uint32_t arena_range = 0;              // 1 + the last range that used the arena
         bool abandoned = false;
+        if (lds_peek(&s_abort)) abandoned = true; // (the device is busy with another launch of this kernel)
         for (uint32_t i = 0; s < a.n_spans && !abandoned; s += gridDim.x, ++i) {
             const int64_t t0 = (s * kProjStreamers + wave) * P;
             const uint32_t range_start = tail_pos;
@@ -573,7 +588,7 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
         const int wr = wave - kProjStreamers; // 0: also owns the span's descriptor and its first output row
         const int w_first = wr * kProjPerWriter;
         int64_t s = blockIdx.x;
-        for (uint32_t k = 0; s < a.n_spans; s += gridDim.x, ++k) {
+        for (uint32_t k = 0; s < a.n_spans && !lds_peek(&s_abort); s += gridDim.x, ++k) {
             // the ranges of span s
             uint32_t cnt[kProjStreamers], start[kProjStreamers], in_arena[kProjStreamers];
             bool dead = false;
@@ -668,6 +683,10 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
         if (finish_add(a.finish, t)) { // the launch's last work-group: every round is over, the arrival counters start the next run at zero
             uint32_t *round_ctr = (uint32_t *)(a.desc + a.n_spans + a.n_rounds);
             for (int64_t r = 0; r < a.n_rounds; ++r) round_ctr[r] = 0u;
+            if (a.device_lock) { // hand the device on (only if the ticket in the lock is this launch's)
+                unsigned long long mine = ticket;
+                __hip_atomic_compare_exchange_strong(a.device_lock, &mine, 0ULL, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x + 1] = wall_clock64();

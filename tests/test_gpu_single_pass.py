@@ -1,0 +1,207 @@
+"""GPU suite: the single-pass projection (csrc/imm3_project.hip, k_filter_project) -- ScanOp -> SelectOp* -> ProjectOp of one
+uniform segment in ONE launch, which is ProjectIterator.next's one walk over the set bits
+(engine/src/main/scala/immutabledb/engine/operator/Project.scala:37-64).  Through the C ABI, bit-exact: bitmap, count,
+ascending row order, values.  Covered: every column-kind instance at every fill level with several rounds of spans and a
+partial last tile (numpy at that size, the oracle at a smaller one), dense survivors (the ranges spill to the arena),
+reservations that are too small (the host gathers again from the bitmap), an abandoned run (the host answers through the
+bitmap path), graph replays (the descriptors' epochs), a second mention of a column in the SELECT list, and two contexts
+launching the kernel at once (the launches are chained: its work-groups wait on each other and need the device)."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import DENSE_INT, DENSE_STRING, DENSE_TINYINT, GT, LT, MATCH, RawColumn, blocks_of
+from immutable3_amd import native, synth
+from test_gpu_parity import check
+
+pytestmark = pytest.mark.gpu
+
+# predicate columns of the instance (indices into [a:i32, b:i32, c:i8, d:i8, s:s2]): the 16 kind combinations of k_filter_project
+SHAPES = [[0], [2], [4], [0, 1], [0, 2], [2, 3], [0, 4], [2, 4], [0, 1, 2], [0, 2, 3], [2, 3, 4], [0, 1, 4], [0, 2, 4]]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = native.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def big(ctx):
+    """13.4 M rows: 13 100 tiles are several rounds of spans for one work-group per CU, and the last tile is partial."""
+    n = 13_100 * 1024 - 333
+    a = synth.uniform_int30(31, n)
+    b = np.arange(n, dtype=np.int32)                      # a sorted key: range predicates on it give CLUSTERED survivors
+    c = synth.uniform_below(33, n, 100, np.int8)
+    d = (synth.uniform_below(34, n, 100, np.int8) - 50).astype(np.int8)
+    s = synth.state_codes(35, n)
+    br = blocks_of(n, 1024)
+    cols = [RawColumn(DENSE_INT, 4, a, br), RawColumn(DENSE_INT, 4, b, br), RawColumn(DENSE_TINYINT, 1, c, br),
+            RawColumn(DENSE_TINYINT, 1, d, br), RawColumn(DENSE_STRING, 2, s, br)]
+    seg = native.DeviceSegment(ctx, [x.native() for x in cols])
+    yield n, [a, b, c, d, s], seg
+    seg.close()
+
+
+def _predicates(data, pred_cols, level, pos):
+    """keep = AND of one predicate per column at a fill level: none / few (~2 %) / some (~10 % each... ) / most / all."""
+    n = data[0].shape[0]
+    t32 = {"none": 2.0 ** 31, "few": 0.98 * 2 ** 30, "some": 0.9 * 2 ** 30, "most": 0.1 * 2 ** 30, "all": -1.0}
+    tb = {"none": float(n), "few": 0.98 * n, "some": 0.9 * n, "most": 0.1 * n, "all": -1.0}           # on the sorted key: clustered
+    t8 = {"none": 127.0, "few": 97.0, "some": 89.0, "most": 5.0, "all": -1.0}
+    t8d = {"none": 127.0, "few": 47.0, "some": 39.0, "most": -45.0, "all": -128.5}
+    codes = {"none": [b"??"], "few": [b"CA"], "some": [b"CA", b"NY", b"TX", b"WA", b"VA"], "most": None, "all": None}
+    sels, keep = [], np.ones(n, bool)
+    for pc in pred_cols:
+        if pc == 4:
+            lst = codes[level]
+            if lst is None:
+                uniq = [bytes(x) for x in np.unique(data[4], axis=0)]
+                lst = uniq[:8]                                  # (IN-lists above 8 values go through the generic kernel)
+            sels.append((pos[pc], MATCH, lst))
+            m = np.zeros(n, bool)
+            for v in lst:
+                m |= (data[4][:, 0] == v[0]) & (data[4][:, 1] == v[1])
+            keep &= m
+        else:
+            t = {0: t32, 1: tb, 2: t8, 3: t8d}[pc][level]
+            sels.append((pos[pc], GT, float(t)))
+            keep &= data[pc] > t
+    return sels, keep
+
+
+@pytest.mark.parametrize("pred_cols", SHAPES)
+def test_every_instance_at_every_fill_level(ctx, big, pred_cols):
+    n, data, seg = big
+    used = pred_cols or [0]
+    pos = {u: i for i, u in enumerate(used)}
+    for level in ("none", "few", "some", "most", "all"):
+        sels, keep = _predicates(data, pred_cols, level, pos)
+        q = native.DeviceQuery(ctx, seg, used, sels, list(range(len(used))), 0)
+        plan = q.plan()
+        folded_empty = level == "none"          # (a threshold no value passes folds to an empty interval: answered by memset, no kernel)
+        assert (plan["single_pass"] and not plan["records"]) or folded_empty, (pred_cols, plan)     # the path this file is about
+        for _ in range(2):                                                        # twice: rings, descriptors and epochs are reused
+            q.run()
+        assert q.plan()["ran_single_pass"] or folded_empty
+        rows = np.flatnonzero(keep)
+        assert q.count() == rows.size, (level, pred_cols)
+        assert q.bitmap().tobytes() == np.packbits(keep, bitorder="little").tobytes()[: q.total_words * 8].ljust(q.total_words * 8, b"\0"), (level, pred_cols)
+        idx, vals = q.fetch_rows()
+        assert q.plan()["ran_single_pass"] or folded_empty, "the run was abandoned and answered through the bitmap path"
+        assert idx.size == rows.size and (idx == rows).all(), (level, pred_cols)
+        for j, u in enumerate(used):
+            got = vals[j]
+            assert got.tobytes() == np.ascontiguousarray(data[u][rows]).tobytes(), (level, pred_cols, u)
+        q.close()
+
+
+def test_against_the_oracle_with_ragged_tail_and_second_mentions(ctx, oracle):
+    rng = np.random.default_rng(5)
+    for n in (1, 1000, 1024, 70_001, 300_000 + 37):
+        ids = rng.integers(0, 1000, size=n).astype(np.int32)
+        age = rng.integers(0, 100, size=n).astype(np.int8)
+        st = np.array([list(x) for x in rng.choice([b"CA", b"NY", b"TX"], size=n)], dtype=np.uint8).reshape(n, 2)
+        br = blocks_of(n, 1024)
+        cols = [RawColumn(DENSE_INT, 4, ids, br), RawColumn(DENSE_TINYINT, 1, age, br), RawColumn(DENSE_STRING, 2, st, br)]
+        sels = [(0, GT, 18.0), (0, LT, 60.0), (1, GT, 100.0), (2, MATCH, [b"CA", b"TX"])]
+        check(ctx, oracle, cols, [1, 0, 2], sels, proj=[1, 0, 2])
+        check(ctx, oracle, cols, [1, 0, 2], sels, proj=[1, 1, 0, 1])        # second mentions are gathered: not the single-pass plan, same rows
+        check(ctx, oracle, cols, [1, 0], sels[:3], proj=[1, 0], reserve=7)   # reservation too small: gathered again from the bitmap at fetch time
+        check(ctx, oracle, cols, [1, 0], sels[:3], proj=[1, 0], reserve=n + 5)
+
+
+def test_plan_only_when_every_select_list_column_is_a_predicate_column(ctx, big):
+    n, data, seg = big
+    q = native.DeviceQuery(ctx, seg, [2, 0], [(0, GT, 18.0), (0, LT, 30.0), (1, GT, 5.0)], [1, 0], 0)
+    assert q.plan()["single_pass"]
+    q.close()
+    q = native.DeviceQuery(ctx, seg, [2, 0], [(0, GT, 18.0), (0, LT, 30.0)], [1, 0], 0)        # id is gathered: records + k_emit
+    assert not q.plan()["single_pass"] and q.plan()["records"]
+    q.close()
+    q = native.DeviceQuery(ctx, seg, [2, 0], [(0, GT, 18.0), (1, GT, 5.0)], [1, 0], 10)        # limit: the bitmap path
+    assert not q.plan()["single_pass"] and not q.plan()["records"]
+    q.close()
+
+
+def test_reservation_too_small_and_abandoned_run_are_answered_from_the_bitmap(ctx, big):
+    n, data, seg = big
+    a, b, c = data[0], data[1], data[2]
+    keep = (c > 89) & (a > 0.5 * 2 ** 30)
+    rows = np.flatnonzero(keep)
+    sels = [(0, GT, 89.0), (1, GT, float(0.5 * 2 ** 30))]
+    q = native.DeviceQuery(ctx, seg, [2, 0], sels, [1, 0], 0)
+    q.reserve_rows(1000)                          # far too small: the kernel stops writing at the capacity, the count stays exact
+    q.run()
+    assert q.count() == rows.size
+    idx, vals = q.fetch_rows()
+    assert (idx == rows).all() and (vals[0].view("<i4").reshape(-1) == a[rows]).all() and (vals[1].view(np.int8).reshape(-1) == c[rows]).all()
+    # an abandoned run: what the kernel leaves behind when a prefix never comes (status bit 1).  Simulated by setting the bit
+    # between the run and the fetch: the host must answer through the bitmap path, and keep that path for this query.
+    q.run()
+    assert q.plan()["ran_single_pass"]
+    hip = C.CDLL("libamdhip64.so")
+    ctx.sync()
+    status = np.array([2], dtype=np.uint64)
+    assert hip.hipMemcpy(C.c_void_p(q.device_ptr(1) + 16), C.c_void_p(status.ctypes.data), C.c_size_t(8), C.c_int(1)) == 0   # d_total + 2 words
+    idx, vals = q.fetch_rows()
+    assert (idx == rows).all() and (vals[0].view("<i4").reshape(-1) == a[rows]).all()
+    assert not q.plan()["single_pass"] and not q.plan()["ran_single_pass"]
+    q.run()
+    assert q.count() == rows.size and (q.fetch_rows()[0] == rows).all()
+    q.close()
+
+
+def test_graph_replays_and_counts_in_the_log(ctx, big):
+    """A recorded single-pass run replayed: every replay is a new epoch of the same descriptors."""
+    n, data, seg = big
+    c, b = data[2], data[1]
+    keep = (c > 18) & (c < 30) & (b > 1000)
+    rows = np.flatnonzero(keep)
+    q = native.DeviceQuery(ctx, seg, [2, 1], [(0, GT, 18.0), (0, LT, 30.0), (1, GT, 1000.0)], [1, 0], 0)
+    q.run()                                        # allocates the row arrays (room for every row: no reservation needed)
+    with ctx.capture() as cap:
+        q.run()
+    for _ in range(5):
+        cap.graph.launch()
+    assert q.count() == rows.size
+    idx, vals = q.fetch_rows()
+    assert q.plan()["ran_single_pass"] and (idx == rows).all() and (vals[0].view("<i4").reshape(-1) == b[rows]).all()
+    cap.graph.close()
+    q.close()
+
+
+def test_two_contexts_launch_the_kernel_at_once(big):
+    """The kernel's work-groups wait on each other, so two launches must not share the device: launches of different
+    contexts (streams) are chained by the library.  Two threads, a context each, the same segment, 20 runs each."""
+    n, data, seg = big
+    c, a = data[2], data[0]
+    errors = []
+
+    def worker(t):
+        try:
+            cx = native.Context(0)
+            lo = 10.0 + 7 * t
+            keep = (c > lo) & (c < lo + 12) & (a > 1000)
+            rows = np.flatnonzero(keep)
+            q = native.DeviceQuery(cx, seg, [2, 0], [(0, GT, lo), (0, LT, lo + 12), (1, GT, 1000.0)], [1, 0], 0)
+            for _ in range(20):
+                q.run()
+            assert q.count() == rows.size
+            idx, vals = q.fetch_rows()
+            assert (idx == rows).all() and (vals[0].view("<i4").reshape(-1) == a[rows]).all()
+            assert q.plan()["single_pass"], "a run was abandoned for good"
+            q.close()
+            cx.close()
+        except BaseException as ex:  # noqa: BLE001
+            errors.append((t, repr(ex)))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in ths) and not errors, errors
