@@ -1175,6 +1175,44 @@ void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_
     IMM3_LAUNCH(k_group_agg, grid, kAggThreads, s, ev0, ev1, a);
 }
 
+// ---- merge of group tables (imm3_comm_merge_groups): direct-indexed tables for keys of <= 2 bytes ----
+__global__ __launch_bounds__(kBlockThreads) void k_merge_init(const MergeArgs a) {
+    for (uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x; i < a.slots; i += gridDim.x * kBlockThreads) {
+        a.t_counts[i] = 0ULL;
+        a.t_first[i] = ~0ULL;
+        for (int j = 0; j < kMaxAggs; ++j) {
+            const int kind = j < a.n_agg ? a.kinds[j] : AGG_COUNT;
+            a.t_vals[(size_t)j * a.slots + i] = kind == AGG_MIN ? INT64_MAX : ((j < a.n_agg && a.is_str[j]) ? 0 : INT64_MIN);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void k_merge_scatter(const MergeArgs a) {
+    for (uint32_t g = blockIdx.x * kBlockThreads + threadIdx.x; g < a.n_groups; g += gridDim.x * kBlockThreads) {
+        const uint32_t slot = (uint32_t)a.keys[g];
+        if (slot >= a.slots) continue; // (cannot happen: the key is narrower than the table)
+        atomicAdd(a.t_counts + slot, a.counts[g]);
+        atomicMin(a.t_first + slot, a.seg_hi | (unsigned long long)a.first[g]);
+        for (int j = 0; j < a.n_agg; ++j) {
+            const long long v = a.vals[(size_t)g * kMaxAggs + j];
+            long long *t = a.t_vals + (size_t)j * a.slots + slot;
+            if (a.kinds[j] == AGG_MAX) {
+                if (a.is_str[j]) atomicMax((unsigned long long *)t, (unsigned long long)v);
+                else atomicMax(t, v);
+            } else if (a.kinds[j] == AGG_MIN) atomicMin(t, v);
+        }
+    }
+}
+
+void launch_merge_init(const MergeArgs &a, hipStream_t s) {
+    const int grid = (int)std::min<uint32_t>((a.slots + kBlockThreads - 1) / kBlockThreads, 256u);
+    hipLaunchKernelGGL(k_merge_init, dim3(grid < 1 ? 1 : grid), dim3(kBlockThreads), 0, s, a);
+}
+void launch_merge_scatter(const MergeArgs &a, hipStream_t s) {
+    const int grid = (int)std::min<uint32_t>((a.n_groups + kBlockThreads - 1) / kBlockThreads, 256u);
+    hipLaunchKernelGGL(k_merge_scatter, dim3(grid < 1 ? 1 : grid), dim3(kBlockThreads), 0, s, a);
+}
+
 void launch_group_collect(const AggArgs &a, hipStream_t s) {
     const int64_t n = (int64_t)a.mask + 2;
     const int grid = (int)std::min<int64_t>((n + kBlockThreads - 1) / kBlockThreads, 2048);

@@ -1935,12 +1935,16 @@ static int run_project(imm3_query *q) {
         }
         HIPCHK(hipGetLastError());
     }
-    if (!(q->limit > 0) && !q->reserved) {
-        // unlimited projection with no reservation: the output size is the count -> one synchronisation
+    if (!(q->limit > 0) && !q->reserved && !q->d_row_index) {
+        // Unlimited projection, no reservation, FIRST run: the output size is the count -> one synchronisation.  The arrays get
+        // an eighth of headroom and every later run of the query writes into them without asking: a steady-state projecting
+        // query never synchronises (a run that outgrows them is detected when its rows are fetched, and emitted again).
         unsigned long long total = 0;
         HIPCHK(hipMemcpyAsync(&total, q->d_total, sizeof(total), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        const int rc = ensure_row_capacity(q, total);
+        ++q->run_syncs;
+        const unsigned long long want = std::min<unsigned long long>((unsigned long long)std::max<int64_t>(q->n_rows, 1), total + total / 8 + 1024);
+        const int rc = ensure_row_capacity(q, want);
         if (rc) return rc;
     } else if (!q->d_row_index) {
         const int rc = ensure_row_capacity(q, 1);
@@ -1962,8 +1966,8 @@ static int capture_admit(imm3_query *q) {
     if (!ctx->capture) return IMM3_OK;
     if (ctx->filter_variant == 2) return fail(IMM3_ERR_STATE, "tuning variant 2 (count reduce on the aux stream) cannot be captured");
     const bool sp = q->single_pass && !q->proj.empty() && !q->always_false && q->n_tiles > 0; // (writes its rows without knowing the count)
-    if (!q->proj.empty() && !(q->limit > 0) && !q->reserved && !sp)
-        return fail(IMM3_ERR_STATE, "an unlimited projection sizes its output from the count (a synchronisation): call imm3_query_reserve_rows before capturing it");
+    if (!q->proj.empty() && !(q->limit > 0) && !q->reserved && !sp && !q->d_row_index)
+        return fail(IMM3_ERR_STATE, "an unlimited projection sizes its output from the count on its first run (a synchronisation): run it once, or call imm3_query_reserve_rows, before capturing it");
     if (sp && !q->reserved && q->cap_rows < (uint64_t)q->n_rows)
         return fail(IMM3_ERR_STATE, "run the query once (or reserve rows) before capturing it: its output buffers are allocated on first use");
     if (!q->proj.empty() && !q->d_row_index) return fail(IMM3_ERR_STATE, "run the query once (or reserve rows) before capturing it: its output buffers are allocated on first use");
@@ -2127,7 +2131,7 @@ static int settle_rows(imm3_query *q, uint64_t *rows) {
     if (emit > q->cap_rows) {
         // the reservation was too small: grow and gather again (offsets are still valid; a single-pass run made none:
         // they come from the bitmap now)
-        int rc = ensure_row_capacity(q, emit);
+        int rc = ensure_row_capacity(q, q->reserved ? emit : std::min<unsigned long long>((unsigned long long)std::max<int64_t>(q->n_rows, 1), emit + emit / 8 + 1024));
         if (rc) return rc;
         if (q->ran_single_pass) {
             ScanArgs sa;
@@ -2191,7 +2195,7 @@ extern "C" int imm3_query_device_ptr(imm3_query *q, int32_t which, void **ptr) {
 extern "C" int imm3_query_plan(const imm3_query *q, int64_t *out, int32_t n) {
     if (!q || !out) return fail(IMM3_ERR_ARG, "null argument");
     const int64_t v[8] = {q->single_pass ? 1 : 0, q->sp_P, q->sp_grid, q->sp_spans, q->d_stage_rec ? 1 : 0,
-                          (q->single_pass || q->d_stage_rec) ? rec_layout(q->stage_kinds, -1).dwords : 0, q->ran_single_pass ? 1 : 0, 0};
+                          (q->single_pass || q->d_stage_rec) ? rec_layout(q->stage_kinds, -1).dwords : 0, q->ran_single_pass ? 1 : 0, (int64_t)q->run_syncs};
     for (int32_t i = 0; i < n && i < 8; ++i) out[i] = v[i];
     return IMM3_OK;
 }
@@ -2378,6 +2382,8 @@ static int settle_groups(imm3_query *q, uint32_t *n_groups) {
     }
     return fail(IMM3_ERR_DEVICE, "group collection did not converge");
 }
+
+int imm3::query_groups(imm3_query *q, uint32_t *n_groups) { return settle_groups(q, n_groups); }
 
 extern "C" int imm3_query_group_count(imm3_query *q, uint32_t *n_groups) {
     if (!q || !n_groups) return fail(IMM3_ERR_ARG, "null argument");

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 
@@ -28,6 +29,7 @@ struct Rccl {
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -58,6 +60,7 @@ void rccl_bind() {
     g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))sym("ncclCommInitAll");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
     g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
     g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
@@ -337,6 +340,288 @@ extern "C" int imm3_comm_allreduce_count_all(imm3_comm *const *comms, int32_t n_
         HIPCHK(hipStreamSynchronize(c->stream));
         c->in_flight = false;
         *host_out = v;
+    }
+    return IMM3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cross-segment / cross-GPU merge of group tables: ProjectAggregateQueueOp
+// (engine/src/main/scala/immutabledb/engine/operator/ProjectAggregateQueue.scala:9-55) merges the per-segment maps by key --
+// counts add, max / min combine, the first arrival keeps its place (here: ascending segment index, then first row).  Every
+// rank brings the group tables of its own segments' aggregation queries; every rank gets the merged table.
+//   keys of <= 2 bytes : the groups are scattered into a direct-indexed device table (k_merge_scatter) and the ranks' tables
+//                        meet in element-wise all-reduces: sum on the counts, min on `segment << 32 | first row`, max / min
+//                        on each aggregate -- no host work but the final compaction of the occupied slots;
+//   wider keys         : the ranks' (locally merged) group lists are exchanged with ncclAllGather -- fixed-size slots,
+//                        sized by an all-reduce(max) of the list lengths -- and merged by key.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct MergedGroup {
+    unsigned long long key, first, count;
+    long long vals[kMaxAggs];
+};
+
+int same_spec(imm3_query *const *queries, int32_t n, const char **why) {
+    for (int32_t i = 0; i < n; ++i) {
+        imm3_query *q = queries[i];
+        if (!q) { *why = "query is null"; return IMM3_ERR_ARG; }
+        if (!q->is_agg) { *why = "not an aggregation query"; return IMM3_ERR_ARG; }
+        if (!q->ran_agg) { *why = "imm3_query_run has not been called"; return IMM3_ERR_STATE; }
+        imm3_query *q0 = queries[0];
+        if (q->aggs.size() != q0->aggs.size() || q->group_cols.size() != q0->group_cols.size()) { *why = "the queries aggregate differently"; return IMM3_ERR_ARG; }
+        for (size_t j = 0; j < q->aggs.size(); ++j)
+            if (q->aggs[j].kind != q0->aggs[j].kind) { *why = "the queries aggregate differently"; return IMM3_ERR_ARG; }
+    }
+    return IMM3_OK;
+}
+
+void combine(MergedGroup &into, const MergedGroup &g, const int32_t *kinds, const int32_t *is_str, int n_agg) {
+    into.count += g.count;
+    into.first = std::min(into.first, g.first);
+    for (int j = 0; j < n_agg; ++j) {
+        if (kinds[j] == AGG_MAX) {
+            if (is_str[j]) into.vals[j] = (long long)std::max((unsigned long long)into.vals[j], (unsigned long long)g.vals[j]);
+            else into.vals[j] = std::max(into.vals[j], g.vals[j]);
+        } else if (kinds[j] == AGG_MIN) into.vals[j] = std::min(into.vals[j], g.vals[j]);
+    }
+}
+
+} // namespace
+
+extern "C" int imm3_comm_merge_groups(imm3_comm *c, imm3_query *const *queries, const int32_t *segment_index, int32_t n_queries,
+                                      uint64_t *keys, uint64_t *first, uint64_t *counts, int64_t *vals, uint32_t max_groups, uint32_t *n_groups) {
+    if (!c || !n_groups || n_queries < 0 || (n_queries > 0 && (!queries || !segment_index))) return fail(IMM3_ERR_ARG, "bad argument");
+    imm3_ctx *ctx = c->ctx;
+    imm3::GateScope gate(&ctx->gate);
+    if (ctx->closed) return fail(IMM3_ERR_STATE, "the context of this communicator has been destroyed");
+    if (ctx->capture) return fail(IMM3_ERR_STATE, "a graph capture is open on this context");
+    HIPCHK(hipSetDevice(ctx->device));
+    const char *why = "";
+    const int src = same_spec(queries, n_queries, &why);
+    if (src) return fail(src, why);
+    if (n_queries == 0) return fail(IMM3_ERR_ARG, "a rank joins the merge with at least one aggregation query (the aggregates' kinds come from it)");
+    int key_bytes = 0, n_agg = 0;
+    int32_t kinds[kMaxAggs] = {0, 0, 0, 0}, is_str[kMaxAggs] = {0, 0, 0, 0};
+    if (n_queries > 0) {
+        imm3_query *q0 = queries[0];
+        for (int32_t g : q0->group_cols) key_bytes += q0->seg->cols[(size_t)q0->used[(size_t)g]].width;
+        n_agg = (int)q0->aggs.size();
+        for (int j = 0; j < n_agg; ++j) {
+            kinds[j] = q0->aggs[j].kind;
+            is_str[j] = q0->seg->cols[(size_t)q0->used[(size_t)q0->aggs[j].column]].vcodec == IMM3_DENSE_STRING;
+        }
+    }
+    // every rank must take the same road: agree on the widest key (and the number of aggregates) first
+    unsigned long long shape[2] = {(unsigned long long)key_bytes, (unsigned long long)n_agg};
+    hipStream_t s = ctx->stream;
+    if (c->world > 1) {
+        const int rrc = rccl_ready();
+        if (rrc) return rrc;
+        HIPCHK(hipMemcpyAsync(c->d_slot, shape, sizeof(shape), hipMemcpyHostToDevice, s));
+        NCCLCHK(g_rccl.AllReduce(c->d_slot, c->d_slot, 2, ncclUint64, ncclMax, c->nccl, s));
+        HIPCHK(hipMemcpyAsync(shape, c->d_slot, sizeof(shape), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (n_queries > 0 && (shape[0] != (unsigned long long)key_bytes || shape[1] != (unsigned long long)n_agg))
+            return fail(IMM3_ERR_ARG, "the ranks' aggregation queries differ in key width or number of aggregates");
+        key_bytes = (int)shape[0];
+        n_agg = (int)shape[1];
+    }
+    std::vector<MergedGroup> merged;
+    if (key_bytes <= 2) {
+        // ---- direct table + element-wise all-reduces ----
+        const uint32_t K = key_bytes == 0 ? 1u : (key_bytes == 1 ? 256u : 65536u);
+        void *p = nullptr;
+        const size_t words = (size_t)K * (2 + kMaxAggs);
+        HIPCHK(hipMalloc(&p, words * sizeof(unsigned long long)));
+        std::unique_ptr<void, void (*)(void *)> guard(p, [](void *q) { (void)hipFree(q); });
+        MergeArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.slots = K;
+        a.t_counts = (unsigned long long *)p;
+        a.t_first = a.t_counts + K;
+        a.t_vals = (long long *)(a.t_first + K);
+        a.n_agg = n_agg;
+        for (int j = 0; j < kMaxAggs; ++j) { a.kinds[j] = kinds[j]; a.is_str[j] = is_str[j]; }
+        launch_merge_init(a, s);
+        HIPCHK(hipGetLastError());
+        for (int32_t i = 0; i < n_queries; ++i) {
+            imm3_query *q = queries[i];
+            if (q->ctx != ctx) return fail(IMM3_ERR_ARG, "the query runs on another context than the communicator");
+            uint32_t ng = 0;
+            const int grc = query_groups(q, &ng);
+            if (grc) return grc;
+            a.keys = q->d_okeys;
+            a.first = q->d_ofirst;
+            a.counts = q->d_ocounts;
+            a.vals = q->d_ovals;
+            a.n_groups = ng;
+            a.seg_hi = (unsigned long long)(uint32_t)segment_index[i] << 32;
+            if (ng) launch_merge_scatter(a, s);
+            HIPCHK(hipGetLastError());
+        }
+        if (c->world > 1) {
+            NCCLCHK(g_rccl.AllReduce(a.t_counts, a.t_counts, K, ncclUint64, ncclSum, c->nccl, s));
+            NCCLCHK(g_rccl.AllReduce(a.t_first, a.t_first, K, ncclUint64, ncclMin, c->nccl, s));
+            for (int j = 0; j < n_agg; ++j) {
+                long long *t = a.t_vals + (size_t)j * K;
+                if (kinds[j] == AGG_MAX) NCCLCHK(g_rccl.AllReduce(t, t, K, is_str[j] ? ncclUint64 : ncclInt64, ncclMax, c->nccl, s));
+                else if (kinds[j] == AGG_MIN) NCCLCHK(g_rccl.AllReduce(t, t, K, ncclInt64, ncclMin, c->nccl, s));
+            }
+        }
+        std::vector<unsigned long long> h(words);
+        HIPCHK(hipMemcpyAsync(h.data(), p, words * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (uint32_t k = 0; k < K; ++k) {
+            if (!h[k]) continue;
+            MergedGroup g;
+            g.key = k;
+            g.count = h[k];
+            g.first = h[(size_t)K + k];
+            for (int j = 0; j < kMaxAggs; ++j) g.vals[j] = (long long)h[(size_t)K * (2 + j) + k];
+            merged.push_back(g);
+        }
+    } else {
+        // ---- wide keys: local merge, all-gather of fixed-size lists, merge by key ----
+        std::map<unsigned long long, MergedGroup> local;
+        for (int32_t i = 0; i < n_queries; ++i) {
+            imm3_query *q = queries[i];
+            if (q->ctx != ctx) return fail(IMM3_ERR_ARG, "the query runs on another context than the communicator");
+            uint32_t ng = 0;
+            const int grc = query_groups(q, &ng);
+            if (grc) return grc;
+            std::vector<unsigned long long> hk(ng), hc(ng);
+            std::vector<uint32_t> hf(ng);
+            std::vector<long long> hv((size_t)ng * kMaxAggs);
+            if (ng) {
+                HIPCHK(hipMemcpyAsync(hk.data(), q->d_okeys, ng * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipMemcpyAsync(hf.data(), q->d_ofirst, ng * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipMemcpyAsync(hc.data(), q->d_ocounts, ng * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipMemcpyAsync(hv.data(), q->d_ovals, (size_t)ng * kMaxAggs * sizeof(long long), hipMemcpyDeviceToHost, s));
+            }
+            HIPCHK(hipStreamSynchronize(s));
+            for (uint32_t g = 0; g < ng; ++g) {
+                MergedGroup m;
+                m.key = hk[g];
+                m.count = hc[g];
+                m.first = ((unsigned long long)(uint32_t)segment_index[i] << 32) | hf[g];
+                for (int j = 0; j < kMaxAggs; ++j) m.vals[j] = hv[(size_t)g * kMaxAggs + j];
+                auto it = local.find(m.key);
+                if (it == local.end()) local.emplace(m.key, m);
+                else combine(it->second, m, kinds, is_str, n_agg);
+            }
+        }
+        if (c->world == 1) {
+            for (auto &kv : local) merged.push_back(kv.second);
+        } else {
+            // list lengths -> the common slot count
+            unsigned long long mine = local.size(), most = 0;
+            HIPCHK(hipMemcpyAsync(c->d_slot, &mine, sizeof(mine), hipMemcpyHostToDevice, s));
+            NCCLCHK(g_rccl.AllReduce(c->d_slot, c->d_slot, 1, ncclUint64, ncclMax, c->nccl, s));
+            HIPCHK(hipMemcpyAsync(&most, c->d_slot, sizeof(most), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            constexpr size_t W = 3 + kMaxAggs; // u64 words per entry: key, first, count (0 = padding), values
+            const size_t per_rank = (size_t)most * W;
+            std::vector<unsigned long long> send(std::max<size_t>(per_rank, 1), 0ULL), recv(std::max<size_t>(per_rank * (size_t)c->world, 1), 0ULL);
+            size_t e = 0;
+            for (auto &kv : local) {
+                unsigned long long *w = send.data() + e * W;
+                w[0] = kv.second.key;
+                w[1] = kv.second.first;
+                w[2] = kv.second.count;
+                for (int j = 0; j < kMaxAggs; ++j) w[3 + j] = (unsigned long long)kv.second.vals[j];
+                ++e;
+            }
+            if (per_rank) {
+                void *p = nullptr;
+                HIPCHK(hipMalloc(&p, (per_rank + per_rank * (size_t)c->world) * sizeof(unsigned long long)));
+                std::unique_ptr<void, void (*)(void *)> guard(p, [](void *q) { (void)hipFree(q); });
+                unsigned long long *d_send = (unsigned long long *)p, *d_recv = d_send + per_rank;
+                HIPCHK(hipMemcpyAsync(d_send, send.data(), per_rank * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+                NCCLCHK(g_rccl.AllGather(d_send, d_recv, per_rank, ncclUint64, c->nccl, s));
+                HIPCHK(hipMemcpyAsync(recv.data(), d_recv, per_rank * (size_t)c->world * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+            }
+            std::map<unsigned long long, MergedGroup> all;
+            for (size_t i = 0; i < (size_t)most * (size_t)c->world; ++i) {
+                const unsigned long long *w = recv.data() + i * W;
+                if (!w[2]) continue; // padding
+                MergedGroup m;
+                m.key = w[0];
+                m.first = w[1];
+                m.count = w[2];
+                for (int j = 0; j < kMaxAggs; ++j) m.vals[j] = (long long)w[3 + j];
+                auto it = all.find(m.key);
+                if (it == all.end()) all.emplace(m.key, m);
+                else combine(it->second, m, kinds, is_str, n_agg);
+            }
+            for (auto &kv : all) merged.push_back(kv.second);
+        }
+    }
+    std::sort(merged.begin(), merged.end(), [](const MergedGroup &x, const MergedGroup &y) { return x.first < y.first; }); // first arrival first
+    *n_groups = (uint32_t)merged.size();
+    for (size_t o = 0; o < merged.size() && o < max_groups; ++o) {
+        if (keys) keys[o] = merged[o].key;
+        if (first) first[o] = merged[o].first;
+        if (counts) counts[o] = merged[o].count;
+        if (vals)
+            for (int j = 0; j < n_agg; ++j) vals[o * (size_t)n_agg + (size_t)j] = kinds[j] == AGG_COUNT ? (int64_t)merged[o].count : (int64_t)merged[o].vals[j];
+    }
+    return IMM3_OK;
+}
+
+// Single-process flavour (one JVM, every GPU: comms from imm3_comm_create_all): the group tables of all devices are in this
+// process, so they are merged here -- per device the same scatter / list as above (no collective), then one merge by key on
+// the host; the tables are a few KB.  comms[i] brings queries[i][0 .. n_queries[i]) with segment_index[i][...].
+extern "C" int imm3_comm_merge_groups_all(imm3_comm *const *comms, int32_t n_comms, imm3_query *const *const *queries,
+                                          const int32_t *const *segment_index, const int32_t *n_queries,
+                                          uint64_t *keys, uint64_t *first, uint64_t *counts, int64_t *vals, uint32_t max_groups, uint32_t *n_groups) {
+    if (!comms || n_comms < 1 || !queries || !segment_index || !n_queries || !n_groups) return fail(IMM3_ERR_ARG, "bad argument");
+    int n_agg = -1;
+    int32_t kinds[kMaxAggs] = {0, 0, 0, 0}, is_str[kMaxAggs] = {0, 0, 0, 0};
+    std::map<unsigned long long, MergedGroup> all;
+    for (int32_t i = 0; i < n_comms; ++i) {
+        if (!comms[i] || n_queries[i] < 0 || (n_queries[i] > 0 && (!queries[i] || !segment_index[i]))) return fail(IMM3_ERR_ARG, "bad argument");
+        if (n_queries[i] == 0) continue;
+        imm3_comm one = *comms[i]; // the same communicator seen as a world of one: its device's queries merged without a collective
+        one.world = 1;
+        uint32_t n = 0;
+        int rc = imm3_comm_merge_groups(&one, queries[i], segment_index[i], n_queries[i], nullptr, nullptr, nullptr, nullptr, 0, &n);
+        if (rc) return rc;
+        imm3_query *q0 = queries[i][0];
+        const int na = (int)q0->aggs.size();
+        if (n_agg < 0) {
+            n_agg = na;
+            for (int j = 0; j < na; ++j) {
+                kinds[j] = q0->aggs[j].kind;
+                is_str[j] = q0->seg->cols[(size_t)q0->used[(size_t)q0->aggs[j].column]].vcodec == IMM3_DENSE_STRING;
+            }
+        } else if (na != n_agg) return fail(IMM3_ERR_ARG, "the devices' aggregation queries differ");
+        std::vector<uint64_t> k(n), f(n), c(n);
+        std::vector<int64_t> v((size_t)n * (size_t)std::max(na, 1));
+        rc = imm3_comm_merge_groups(&one, queries[i], segment_index[i], n_queries[i], k.data(), f.data(), c.data(), v.data(), n, &n);
+        if (rc) return rc;
+        for (uint32_t g = 0; g < n; ++g) {
+            MergedGroup m;
+            m.key = k[g];
+            m.first = f[g];
+            m.count = c[g];
+            for (int j = 0; j < kMaxAggs; ++j) m.vals[j] = j < na ? v[(size_t)g * na + j] : 0;
+            auto it = all.find(m.key);
+            if (it == all.end()) all.emplace(m.key, m);
+            else combine(it->second, m, kinds, is_str, n_agg);
+        }
+    }
+    std::vector<MergedGroup> merged;
+    for (auto &kv : all) merged.push_back(kv.second);
+    std::sort(merged.begin(), merged.end(), [](const MergedGroup &x, const MergedGroup &y) { return x.first < y.first; });
+    *n_groups = (uint32_t)merged.size();
+    for (size_t o = 0; o < merged.size() && o < max_groups; ++o) {
+        if (keys) keys[o] = merged[o].key;
+        if (first) first[o] = merged[o].first;
+        if (counts) counts[o] = merged[o].count;
+        if (vals)
+            for (int j = 0; j < n_agg; ++j) vals[o * (size_t)n_agg + (size_t)j] = kinds[j] == AGG_COUNT ? (int64_t)merged[o].count : (int64_t)merged[o].vals[j];
     }
     return IMM3_OK;
 }

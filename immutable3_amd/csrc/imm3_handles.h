@@ -182,6 +182,7 @@ struct imm3_query {
     uint64_t cap_rows = 0;
     bool reserved = false;
     bool ran_select = false, ran_project = false;
+    uint32_t run_syncs = 0;        // times imm3_query_run had to wait for the device (diagnostics: imm3_query_plan)
     // group-by aggregation
     bool is_agg = false;
     std::vector<int32_t> group_cols;           // index into `used`
@@ -223,4 +224,5 @@ namespace imm3 {
 void ctx_retain(imm3_ctx *c);
 void ctx_release(imm3_ctx *c);
 int join_query_count(imm3_query *q, hipStream_t s); // make `s` wait for the query's count if it was reduced on the aux stream
+int query_groups(imm3_query *q, uint32_t *n_groups);  // the aggregation's dense group list is complete in q->d_o* (synchronises)
 }

@@ -303,6 +303,28 @@ struct AggArgs {
 };
 
 void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+
+// ---- cross-segment / cross-GPU merge of group tables (ProjectAggregateQueueOp, ProjectAggregateQueue.scala:9-55) ----
+// Keys of <= 2 bytes index a DIRECT table (256 or 65 536 slots; one slot for no group column): every query's dense group
+// list is scattered into it with 64-bit atomics (counts add, first = min of segment << 32 | row, values max / min), and the
+// tables of the ranks then meet in element-wise all-reduces (imm3_comm.cpp).
+struct MergeArgs {
+    const unsigned long long *keys;   // one query's dense groups (k_group_collect's output)
+    const uint32_t *first;
+    const unsigned long long *counts;
+    const long long *vals;            // kMaxAggs per group
+    uint32_t n_groups;
+    uint32_t slots;                   // K
+    unsigned long long seg_hi;        // the query's segment index << 32
+    unsigned long long *t_counts;     // [K]
+    unsigned long long *t_first;      // [K], ~0 = empty
+    long long *t_vals;                // [kMaxAggs][K]
+    int32_t n_agg;
+    int32_t kinds[kMaxAggs];          // AggKind
+    int32_t is_str[kMaxAggs];         // MAX over strings: unsigned compare of the big-endian-packed bytes
+};
+void launch_merge_init(const MergeArgs &a, hipStream_t s);
+void launch_merge_scatter(const MergeArgs &a, hipStream_t s);
 void launch_group_collect(const AggArgs &a, hipStream_t s);
 
 constexpr int kSubTallies = 32;                       // in-kernel count reduce: sub-tallies (finish_add, imm3_device.h)

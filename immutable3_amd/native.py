@@ -40,7 +40,7 @@ EXPORTS = [
     "imm3_query_layout", "imm3_query_batches", "imm3_query_count", "imm3_query_bitmap",
     "imm3_query_row_count", "imm3_query_fetch_rows", "imm3_query_device_ptr",
     "imm3_comm_unique_id", "imm3_comm_create", "imm3_comm_create_all", "imm3_comm_destroy", "imm3_comm_info",
-    "imm3_comm_sync", "imm3_comm_join", "imm3_comm_allreduce_u64", "imm3_comm_allreduce_count", "imm3_comm_allreduce_count_all",
+    "imm3_comm_sync", "imm3_comm_join", "imm3_comm_allreduce_u64", "imm3_comm_allreduce_count", "imm3_comm_allreduce_count_all", "imm3_comm_merge_groups", "imm3_comm_merge_groups_all",
     "imm3_pfor_encode_bound", "imm3_pfor_encode_block", "imm3_pfor_encode_column",
     "imm3_snappy_encode_bound", "imm3_snappy_encode_block",
 ]
@@ -177,6 +177,8 @@ def load() -> C.CDLL:
     L.imm3_comm_allreduce_u64.argtypes = [vp, vp, u64]
     L.imm3_comm_allreduce_count.argtypes = [vp, P(vp), i32, vp, P(u64)]
     L.imm3_comm_allreduce_count_all.argtypes = [P(vp), i32, P(P(vp)), P(i32), P(u64)]
+    L.imm3_comm_merge_groups.argtypes = [vp, P(vp), vp, i32, vp, vp, vp, vp, C.c_uint32, P(C.c_uint32)]
+    L.imm3_comm_merge_groups_all.argtypes = [P(vp), i32, P(P(vp)), P(vp), P(i32), vp, vp, vp, vp, C.c_uint32, P(C.c_uint32)]
     for name in EXPORTS + DIAG_EXPORTS:
         fn = getattr(L, name)
         if name not in ("imm3_last_error", "imm3_pfor_encode_bound", "imm3_snappy_encode_bound"):
@@ -596,7 +598,7 @@ class DeviceQuery:
         v = np.zeros(8, np.int64)
         _check(load().imm3_query_plan(self._h, v.ctypes.data, 8))
         return {"single_pass": bool(v[0]), "P": int(v[1]), "grid": int(v[2]), "spans": int(v[3]), "records": bool(v[4]),
-                "rec_dwords": int(v[5]), "ran_single_pass": bool(v[6])}
+                "rec_dwords": int(v[5]), "ran_single_pass": bool(v[6]), "run_syncs": int(v[7])}
 
     def device_ptr(self, which: int) -> int:
         p = C.c_void_p()
@@ -665,6 +667,40 @@ class Comm:
         _check(load().imm3_comm_allreduce_count(self._h, qs, len(queries), C.c_void_p(device_out) if device_out else None,
                                                 C.byref(host) if wait else None))
         return host.value if wait else None
+
+    def merge_groups(self, queries: Sequence["DeviceQuery"], segment_index: Sequence[int]):
+        """ProjectAggregateQueueOp across segments and ranks: (keys uint64[g], first uint64[g] = segment << 32 | row, counts uint64[g],
+        vals int64[g, n_aggs]) in first-seen order; every rank gets the whole table."""
+        qs = (C.c_void_p * max(1, len(queries)))(*[q._h for q in queries])
+        seg = np.ascontiguousarray(segment_index, dtype=np.int32)
+        na = max(1, len(queries[0].aggs or [])) if queries else 1
+        n = C.c_uint32(0)
+        _check(load().imm3_comm_merge_groups(self._h, qs, seg.ctypes.data, len(queries), None, None, None, None, 0, C.byref(n)))
+        g = n.value
+        keys, first, counts = np.zeros(max(g, 1), np.uint64), np.zeros(max(g, 1), np.uint64), np.zeros(max(g, 1), np.uint64)
+        vals = np.zeros((max(g, 1), na), np.int64)
+        _check(load().imm3_comm_merge_groups(self._h, qs, seg.ctypes.data, len(queries), keys.ctypes.data, first.ctypes.data, counts.ctypes.data,
+                                             vals.ctypes.data, g, C.byref(n)))
+        return keys[:g], first[:g], counts[:g], vals[:g]
+
+    @staticmethod
+    def merge_groups_all(comms: Sequence["Comm"], queries_per_comm: Sequence[Sequence["DeviceQuery"]], segments_per_comm: Sequence[Sequence[int]]):
+        """Single-process flavour of merge_groups: one Comm per device (create_all), each with its queries and their segment indices."""
+        n = len(comms)
+        carr = (C.c_void_p * n)(*[c._h for c in comms])
+        qarrs = [(C.c_void_p * max(1, len(qs)))(*[q._h for q in qs]) for qs in queries_per_comm]
+        qq = (C.POINTER(C.c_void_p) * n)(*[C.cast(a, C.POINTER(C.c_void_p)) for a in qarrs])
+        segs = [np.ascontiguousarray(s, dtype=np.int32) for s in segments_per_comm]
+        ss = (C.c_void_p * n)(*[s.ctypes.data if s.size else None for s in segs])
+        nq = (C.c_int32 * n)(*[len(qs) for qs in queries_per_comm])
+        na = max(1, len(next(q for qs in queries_per_comm for q in qs).aggs or []))
+        g = C.c_uint32(0)
+        _check(load().imm3_comm_merge_groups_all(carr, n, qq, ss, nq, None, None, None, None, 0, C.byref(g)))
+        m = g.value
+        keys, first, counts = np.zeros(max(m, 1), np.uint64), np.zeros(max(m, 1), np.uint64), np.zeros(max(m, 1), np.uint64)
+        vals = np.zeros((max(m, 1), na), np.int64)
+        _check(load().imm3_comm_merge_groups_all(carr, n, qq, ss, nq, keys.ctypes.data, first.ctypes.data, counts.ctypes.data, vals.ctypes.data, m, C.byref(g)))
+        return keys[:m], first[:m], counts[:m], vals[:m]
 
     @staticmethod
     def allreduce_count_all(comms: Sequence["Comm"], queries_per_comm: Sequence[Sequence["DeviceQuery"]]) -> int:

@@ -231,13 +231,18 @@ int imm3_query_group_count(imm3_query *q, uint32_t *n_groups);
 int imm3_query_fetch_groups(imm3_query *q, uint64_t *keys, uint32_t *first_row, uint64_t *counts, int64_t *vals,
                             uint32_t max_groups);
 
-/* Pre-size the projected-row buffers so that imm3_query_run() never has to wait for the count
- * (fully asynchronous run).  Without it an unlimited projection synchronises once to size them. */
+/* Pre-size the projected-row buffers so that not even the FIRST imm3_query_run() has to wait for the count.  Without it an
+ * unlimited projection sizes them once: a query whose SELECT list is predicate columns only (it runs as ONE launch that
+ * writes the rows itself) gets room for every row of the segment; any other one synchronises on its first run to read the
+ * count and keeps the arrays (with an eighth of headroom) for every later run -- a steady-state projecting query never
+ * synchronises.  A run that outgrows the arrays, reserved or not, is detected when its rows are fetched and emitted again. */
 int imm3_query_reserve_rows(imm3_query *q, uint64_t rows);
 
-/* Enqueue the whole pipeline on the context's stream: scan+select kernel (selection bitmap, per-tile
- * counts, total count), then -- if n_proj > 0 -- offsets scan and compact+gather.  Asynchronous
- * unless rows must be sized (see above).  May be called repeatedly on the same query. */
+/* Enqueue the whole pipeline on the context's stream.  n_proj == 0: the scan+select kernel (selection bitmap + count).
+ * Unlimited projection whose SELECT list is predicate columns only, one uniform segment: ONE launch -- scan + select +
+ * project (csrc/imm3_project.hip: the filter kernel writes the rows in ascending order itself).  Otherwise: scan+select,
+ * then an offsets scan and compact+gather.  Asynchronous except for the first run of an unreserved unlimited projection
+ * (see above).  May be called repeatedly on the same query. */
 int imm3_query_run(imm3_query *q);
 /* Only the ScanOp -> SelectOp* part (selection bitmap + count). */
 int imm3_query_run_select(imm3_query *q);
@@ -304,6 +309,24 @@ int imm3_comm_allreduce_count(imm3_comm *c, imm3_query *const *queries, int32_t 
  * collectives inside a group.  host_out (may be NULL) receives the global count. */
 int imm3_comm_allreduce_count_all(imm3_comm *const *comms, int32_t n_comms, imm3_query *const *const *queries,
                                   const int32_t *n_queries, uint64_t *host_out);
+
+/* ---- multi-GPU: the group-by merge.  ProjectAggregateQueueOp (engine/.../operator/ProjectAggregateQueue.scala:9-55) merges
+ * the per-segment group maps by key: counts add, max / min combine, the first arrival keeps its place.  Here every rank
+ * brings the aggregation queries of ITS segments (each already run; same group columns and aggregates everywhere, at least
+ * one per rank), segment_index[i] = the global index of the segment queries[i] ran on, and every rank receives the merged
+ * table in first-seen order -- ascending (segment, first selected row): the reference's arrival order is a race, this is
+ * the order Engine.execute would produce with one thread.  Keys of <= 2 bytes travel as element-wise all-reduces of a
+ * direct-indexed table (sum on counts, min on segment << 32 | row, max / min on each aggregate); wider keys as an
+ * ncclAllGather of the ranks' group lists.  One rank: the same merge over that rank's queries, no collective.
+ *   keys / counts / vals as imm3_query_fetch_groups; first[g] = segment << 32 | first selected row of the group there.
+ * Synchronous (the merged table is returned to the host). */
+int imm3_comm_merge_groups(imm3_comm *c, imm3_query *const *queries, const int32_t *segment_index, int32_t n_queries,
+                           uint64_t *keys, uint64_t *first, uint64_t *counts, int64_t *vals, uint32_t max_groups, uint32_t *n_groups);
+/* Single-process flavour (comms from imm3_comm_create_all): comms[i] brings queries[i][0 .. n_queries[i]) with
+ * segment_index[i][...]; the devices' tables are merged inside this process. */
+int imm3_comm_merge_groups_all(imm3_comm *const *comms, int32_t n_comms, imm3_query *const *const *queries,
+                               const int32_t *const *segment_index, const int32_t *n_queries,
+                               uint64_t *keys, uint64_t *first, uint64_t *counts, int64_t *vals, uint32_t max_groups, uint32_t *n_groups);
 
 /* ---- write side of the PFOR_INT codec (host code, no device involved) ----
  * PFORCodecInt.encode (core/codec/PFORCodec.scala:19-31), which SegmentWriter.flush applies to each block of a PFOR_INT

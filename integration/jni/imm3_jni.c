@@ -277,4 +277,58 @@ done:
     free(qs); free(cs); free(nq);
     return (jlong)total;
 }
+
+/* ProjectAggregateQueueOp across the devices of one JVM (ProjectAggregateQueue.scala:9-55): queries(i) / segments(i) = the
+ * aggregation queries device i ran and the global segment index of each.  Returns the merged table flattened:
+ * [n, keys[n], first[n], counts[n], vals[n * nAggs]] as longs (first = segment << 32 | first selected row; first-seen order). */
+JNIEXPORT jlongArray JNICALL Java_immutabledb_gpu_Native_00024_commMergeGroupsAll(JNIEnv *env, jobject self, jlongArray comms, jobjectArray queries,
+                                                                                  jobjectArray segments, jint nAggs) {
+    jsize n = (*env)->GetArrayLength(env, comms);
+    jlong *ch = (*env)->GetLongArrayElements(env, comms, NULL);
+    imm3_comm **cs = (imm3_comm **)calloc((size_t)n, sizeof(imm3_comm *));
+    imm3_query ***qs = (imm3_query ***)calloc((size_t)n, sizeof(imm3_query **));
+    int32_t **ss = (int32_t **)calloc((size_t)n, sizeof(int32_t *));
+    int32_t *nq = (int32_t *)calloc((size_t)n, sizeof(int32_t));
+    uint64_t *keys = NULL, *first = NULL, *counts = NULL;
+    int64_t *vals = NULL;
+    jlongArray out = NULL;
+    uint32_t g = 0;
+    for (jsize i = 0; i < n; i++) {
+        jlongArray qa = (jlongArray)(*env)->GetObjectArrayElement(env, queries, i);
+        jintArray sa = (jintArray)(*env)->GetObjectArrayElement(env, segments, i);
+        jsize m = (*env)->GetArrayLength(env, qa);
+        jlong *qh = (*env)->GetLongArrayElements(env, qa, NULL);
+        jint *sh = (*env)->GetIntArrayElements(env, sa, NULL);
+        cs[i] = (imm3_comm *)(intptr_t)ch[i];
+        nq[i] = (int32_t)m;
+        qs[i] = (imm3_query **)calloc((size_t)(m > 0 ? m : 1), sizeof(imm3_query *));
+        ss[i] = (int32_t *)calloc((size_t)(m > 0 ? m : 1), sizeof(int32_t));
+        for (jsize k = 0; k < m; k++) { qs[i][k] = (imm3_query *)(intptr_t)qh[k]; ss[i][k] = (int32_t)sh[k]; }
+        (*env)->ReleaseLongArrayElements(env, qa, qh, JNI_ABORT);
+        (*env)->ReleaseIntArrayElements(env, sa, sh, JNI_ABORT);
+        (*env)->DeleteLocalRef(env, qa);
+        (*env)->DeleteLocalRef(env, sa);
+    }
+    CHECKED(imm3_comm_merge_groups_all(cs, (int32_t)n, (imm3_query *const *const *)qs, (const int32_t *const *)ss, nq, NULL, NULL, NULL, NULL, 0, &g));
+    keys = (uint64_t *)calloc(g ? g : 1, sizeof(uint64_t));
+    first = (uint64_t *)calloc(g ? g : 1, sizeof(uint64_t));
+    counts = (uint64_t *)calloc(g ? g : 1, sizeof(uint64_t));
+    vals = (int64_t *)calloc((size_t)(g ? g : 1) * (size_t)(nAggs > 0 ? nAggs : 1), sizeof(int64_t));
+    CHECKED(imm3_comm_merge_groups_all(cs, (int32_t)n, (imm3_query *const *const *)qs, (const int32_t *const *)ss, nq, keys, first, counts, vals, g, &g));
+    {
+        const jsize total = (jsize)(1 + 3 * (size_t)g + (size_t)g * (size_t)nAggs);
+        jlong head = (jlong)g;
+        out = (*env)->NewLongArray(env, total);
+        (*env)->SetLongArrayRegion(env, out, 0, 1, &head);
+        (*env)->SetLongArrayRegion(env, out, 1, (jsize)g, (const jlong *)keys);
+        (*env)->SetLongArrayRegion(env, out, 1 + (jsize)g, (jsize)g, (const jlong *)first);
+        (*env)->SetLongArrayRegion(env, out, 1 + 2 * (jsize)g, (jsize)g, (const jlong *)counts);
+        (*env)->SetLongArrayRegion(env, out, 1 + 3 * (jsize)g, (jsize)((size_t)g * (size_t)nAggs), (const jlong *)vals);
+    }
+done:
+    for (jsize i = 0; i < n; i++) { free(qs[i]); free(ss[i]); }
+    (*env)->ReleaseLongArrayElements(env, comms, ch, JNI_ABORT);
+    free(qs); free(ss); free(cs); free(nq); free(keys); free(first); free(counts); free(vals);
+    return out;
+}
 #endif /* IMM3_HAVE_JNI */

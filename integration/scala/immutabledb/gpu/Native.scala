@@ -52,4 +52,6 @@ object Native {
   /** queries(i): the queries device i ran in this pass.  Selected-row count over all devices: ONE 8-byte
     * ncclAllReduce(sum) per device over RCCL / xGMI -- the only collective of the path (imm3_comm_allreduce_count_all). */
   @native def commAllreduceCountAll(comms: Array[Long], queries: Array[Array[Long]]): Long
+  /** ProjectAggregateQueueOp over the devices: [n, keys(n), first(n) = segment << 32 | row, counts(n), vals(n * nAggs)] */
+  @native def commMergeGroupsAll(comms: Array[Long], queries: Array[Array[Long]], segments: Array[Array[Int]], nAggs: Int): Array[Long]
 }

@@ -66,6 +66,10 @@ class GpuDevices(val sm: SegmentManager, val nDevices: Int) {
   def countAll(queriesPerDevice: Array[Array[Long]]): Long =
     if (nDevices == 1) queriesPerDevice(0).map(Native.queryCount).sum
     else Native.commAllreduceCountAll(comms, queriesPerDevice)
+  /** ProjectAggregateQueueOp (ProjectAggregateQueue.scala:9-55) across the devices: queriesPerDevice(d) = the aggregation queries
+    * device d ran, segmentsPerDevice(d) = the segment index of each; the merged table in first-seen (segment, row) order. */
+  def mergeGroups(queriesPerDevice: Array[Array[Long]], segmentsPerDevice: Array[Array[Int]], nAggs: Int): Array[Long] =
+    Native.commMergeGroupsAll(comms, queriesPerDevice, segmentsPerDevice, nAggs)
 }
 
 object GpuScanOp {

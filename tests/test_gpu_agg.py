@@ -278,3 +278,73 @@ def test_lanes_form_overflows_into_the_next_form(ctx):
     assert k1.size == 64 and (k1 == k2).all() and (f1 == f2).all() and (c1 == c2).all() and int(c1.sum()) == n
     q.close()
     seg.close()
+
+
+# ---- cross-segment merge behind the C ABI: imm3_comm_merge_groups (ProjectAggregateQueueOp) ------------------------------------
+def _decode_merged(ucols, group, aggs, keys, counts, vals):
+    got = []
+    for g in range(keys.shape[0]):
+        raw = int(keys[g]).to_bytes(8, "little")
+        parts, off = [], 0
+        for gi in group:
+            c = ucols[gi]
+            chunk = raw[off: off + c.width]
+            parts.append(chunk.decode() if c.codec == DENSE_STRING else str(int.from_bytes(chunk, "little", signed=True)))
+            off += c.width
+        st = []
+        for j, (kind, ci) in enumerate(aggs):
+            c = ucols[ci]
+            if kind == "count":
+                st.append(int(vals[g, j]))
+            elif c.codec == DENSE_STRING:
+                st.append(int(vals[g, j]).to_bytes(8, "big", signed=True)[8 - c.width:].decode())
+            else:
+                st.append(float(int(vals[g, j])))
+        got.append(("_".join(parts), st))
+    return got
+
+
+@pytest.mark.parametrize("group,aggs", [
+    ([2], [("count", 0), ("max", 1), ("min", 0)]),            # 2-byte key: direct table + element-wise all-reduces
+    ([1], [("count", 1), ("max", 2)]),                        # 1-byte key, MAX over a string column (unsigned compare)
+    ([], [("max", 0), ("count", 0)]),                         # no group column: one group
+    ([1, 2], [("count", 0), ("min", 1), ("max", 0)]),         # 3-byte key: group lists exchanged with ncclAllGather, merged by key
+    ([0], [("count", 0), ("max", 1)]),                        # int32 key
+])
+def test_merge_groups_across_segments_one_rank_rccl(ctx, group, aggs):
+    """Three segments of different lengths on one rank, a real one-rank RCCL communicator: the merged table equals
+    ProjectAggregateQueueOp's restatement (oracle_np.combine_agg) over the per-segment tables, in first-seen order."""
+    rng = np.random.default_rng(31 + len(group))
+    used = [0, 1, 2]
+    sels = [(1, GT, -100.0)]
+    segs, queries, per_seg = [], [], []
+    for s, n in enumerate((70_000, 1, 33_333)):
+        cols = make_cols(rng, n, blocks_of(n, 1024), id_range=40 if s != 1 else 3)
+        _, _, masks = oracle_np.scan_select([c.npcol() for c in cols], sels, 1024)
+        per_seg.append(oracle_np.project_agg([c.npcol() for c in cols], group, aggs, masks))
+        seg = native.DeviceSegment(ctx, [c.native() for c in cols])
+        q = native.DeviceQuery(ctx, seg, used, sels, (), 0, 1024, group_cols=group, aggs=[(KIND[k], c) for k, c in aggs])
+        q.run()
+        segs.append(seg)
+        queries.append(q)
+    expect = oracle_np.combine_agg(per_seg, aggs)
+    comm = native.Comm(ctx, 1, 0, native.comm_unique_id())
+    keys, first, counts, vals = comm.merge_groups(queries, [0, 1, 2])
+    ucols = make_cols(np.random.default_rng(0), 1, [1])
+    got = _decode_merged(ucols, group, aggs, keys, counts, vals)
+    assert got == [(k, v) for k, v in expect.items()]
+    assert (np.diff(first.astype(np.int64)) > 0).all() and int(counts.sum()) == sum(sum(v[[k for k, _ in aggs].index("count")] for v in seg.values()) for seg in per_seg)
+    # the segment index decides the first-seen order: the same queries under reversed indices come out in another order
+    keys2, first2, counts2, vals2 = comm.merge_groups(queries, [2, 1, 0])
+    assert sorted(zip(keys.tolist(), counts.tolist())) == sorted(zip(keys2.tolist(), counts2.tolist()))
+    with pytest.raises(native.Imm3Error):
+        comm.merge_groups([], [])
+    comm.close()
+    (c0,) = native.Comm.create_all([ctx])                     # the single-process flavour (one JVM, every GPU): merged inside the process
+    k3, f3, n3, v3 = native.Comm.merge_groups_all([c0], [queries], [[0, 1, 2]])
+    assert k3.tolist() == keys.tolist() and f3.tolist() == first.tolist() and n3.tolist() == counts.tolist() and v3.tolist() == vals.tolist()
+    c0.close()
+    for q in queries:
+        q.close()
+    for s in segs:
+        s.close()

@@ -205,3 +205,21 @@ def test_two_contexts_launch_the_kernel_at_once(big):
     for t in ths:
         t.join(timeout=300)
     assert not any(t.is_alive() for t in ths) and not errors, errors
+
+
+def test_steady_state_projections_never_wait_for_the_device(ctx, big):
+    """without a reservation an unlimited projection sizes its arrays once -- never (one launch: room for
+    every row) or on its first run (the count) -- and every later imm3_query_run only enqueues."""
+    n, data, seg = big
+    c, a = data[2], data[0]
+    shapes = {"one launch": ([2, 0], [(0, GT, 18.0), (0, LT, 30.0), (1, GT, 5.0)], [1, 0], 0),
+              "records": ([2, 0], [(0, GT, 18.0), (0, LT, 30.0)], [1, 0], 1),
+              "bitmap": ([2, 0, 4], [(0, GT, 18.0), (2, MATCH, [b"CA", b"NY", b"TX", b"WA", b"VA", b"DC", b"CT", b"AL", b"AK"])], [1, 0], 1)}
+    for name, (used, sels, proj, first_run_syncs) in shapes.items():
+        q = native.DeviceQuery(ctx, seg, used, sels, proj, 0)
+        for _ in range(6):
+            q.run()
+        assert q.plan()["run_syncs"] == first_run_syncs, (name, q.plan())
+        rows = q.row_count()
+        assert rows == q.count()
+        q.close()
