@@ -1478,7 +1478,8 @@ int imm3::join_query_count(imm3_query *q, hipStream_t s) { return join_total(q, 
 static void fill_tile_col(const imm3_query *q, const FoldedPred &fp, TileCol &c, int kind);
 
 // count_in_scan: a projection follows on the same stream; its offsets scan publishes the count (no k_total launch)
-static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = false) {
+// count_only: the caller wants selected.size alone -- a chain that is ONE tile launch then stores no bitmap
+static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = false, bool count_only = false) {
     imm3_ctx *ctx = q->ctx;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -1492,6 +1493,7 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
         HIPCHK(hipMemsetAsync(q->d_total, 0, 2 * sizeof(unsigned long long), s)); // (an always-false query logs nothing)
         HIPCHK(hipMemsetAsync(q->d_bitmap, 0, (size_t)std::max<int64_t>(q->n_tiles * kTileWords, 1) * sizeof(uint64_t), s));
         q->ran_select = true;
+        q->bitmap_valid = true;
         q->ran_single_pass = false;
         return IMM3_OK;
     }
@@ -1533,6 +1535,8 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
     // exactly ONE launch in the whole select chain: only then may that launch publish the count (and append to the count
     // log) itself, and only then are the survivors' values staged
     const bool single_tile_pass = generic_preds.empty() && pfor_preds.empty() && tile_passes.size() == 1;
+    const bool skip_bitmap = count_only && single_tile_pass && !q->table && !overlap_total && ctx->filter_variant != 7;
+    q->bitmap_valid = !skip_bitmap;
     for (const auto &take : tile_passes) {
         TileArgs a;
         std::memset(&a, 0, sizeof(a));
@@ -1544,7 +1548,7 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
             a.kinds[k] = tile_kind(fp);
             fill_tile_col(q, fp, a.cols[k], a.kinds[k]);
         }
-        if (single_tile_pass && q->d_stage_rec) { // the columns are in the order the records were laid out for (same sort)
+        if (single_tile_pass && q->d_stage_rec && !skip_bitmap) { // the columns are in the order the records were laid out for (same sort)
             bool same = true;
             for (int k = 0; k < kMaxTileCols; ++k) same = same && a.kinds[k] == q->stage_kinds[k] && (k >= n || take[(size_t)k]->seg_col == q->stage_seg_col[k]);
             if (!same) return fail(IMM3_ERR_ARG, "internal: staged record layout does not match the tile launch");
@@ -1578,6 +1582,10 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
         // leave no room for 32 KiB more per group); tuning variant 12 switches it off
         // (64 lines = 32 KiB per work-group at <= 4 groups per CU; 16 lines = 8 KiB for the 1536-group narrow-column kernels)
         a.defer_lines = ctx->filter_variant == 12 ? 0 : (q->stage_written ? 16 : (grid <= 1024 ? kDeferLines : 16));
+        if (skip_bitmap) { // count-only: the kernel instance that stores nothing (the count is reduced in the kernel)
+            a.bitmap = nullptr;
+            a.defer_lines = 0;
+        }
         if (ctx->d_stamps) { // (diagnostics: bench.py's instrumented pass)
             std::lock_guard<std::mutex> lk(ctx->mu);
             if (ctx->d_stamps && ctx->stamp_used < ctx->stamp_slots) {
@@ -1843,6 +1851,7 @@ static int run_single_pass(imm3_query *q) {
     q->count_pending_scan = false;
     q->has_pfor_pass = false;
     q->ran_select = true;
+    q->bitmap_valid = true;
     q->ran_project = true;
     q->ran_single_pass = true;
     q->sp_verified = false;
@@ -1985,6 +1994,15 @@ extern "C" int imm3_query_run_select(imm3_query *q) {
     return run_select(q, q->ctx->filter_variant == 2);
 }
 
+extern "C" int imm3_query_run_count(imm3_query *q) {
+    if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    CTX_LIVE_RUN(q->ctx);
+    const int ca = capture_admit(q);
+    if (ca) return ca;
+    q->ran_project = false;
+    return run_select(q, false, false, true);
+}
+
 extern "C" int imm3_query_join_count(imm3_query *q) {
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
     CTX_LIVE(q->ctx);
@@ -2103,6 +2121,7 @@ extern "C" int imm3_query_bitmap(imm3_query *q, uint64_t *words_out, int64_t n_w
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
     CTX_LIVE(q->ctx);
     if (!q->ran_select) return fail(IMM3_ERR_STATE, "imm3_query_run has not been called");
+    if (!q->bitmap_valid) return fail(IMM3_ERR_STATE, "the last run was count-only (imm3_query_run_count): it stored no bitmap");
     if (n_words < 0 || n_words > q->n_words) return fail(IMM3_ERR_ARG, "n_words exceeds the bitmap");
     if (n_words && !words_out) return fail(IMM3_ERR_ARG, "words_out is null");
     HIPCHK(hipSetDevice(q->ctx->device));

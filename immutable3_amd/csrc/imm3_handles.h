@@ -182,6 +182,7 @@ struct imm3_query {
     uint64_t cap_rows = 0;
     bool reserved = false;
     bool ran_select = false, ran_project = false;
+    bool bitmap_valid = false;     // the last run stored the selection bitmap (a count-only run does not)
     uint32_t run_syncs = 0;        // times imm3_query_run had to wait for the device (diagnostics: imm3_query_plan)
     // group-by aggregation
     bool is_agg = false;

@@ -72,7 +72,7 @@ struct TileArgs {
     int32_t defer_lines;            // > 0: park the bitmap lines in (dynamic) LDS and store them in bursts (single segment only)
     int32_t ablate;                 // read only by the tools' build (IMM3_ABLATED below); 0 otherwise
     int64_t n_rows, n_words, n_tiles;
-    uint64_t *bitmap;
+    uint64_t *bitmap;               // null: count-only run -- no bitmap line is stored (single-pass chains only: and_existing = 0, defer_lines = 0)
     uint32_t *block_partials;
     unsigned long long *finish;     // {total, n_emit, status, limit, tally, log, log index, log capacity}: the count is reduced in the kernel (block_partial_finish); null = k_total does
     void *stage_rec;                // survivor records (rec_layout(kinds).dwords dwords each): one arena of wave_cap records per wave, or null

@@ -36,7 +36,7 @@ EXPORTS = [
     "imm3_query_segment_starts", "imm3_query_locate_rows",
     "imm3_query_create", "imm3_query_create_agg", "imm3_query_group_count", "imm3_query_fetch_groups",
     "imm3_query_destroy", "imm3_query_reserve_rows",
-    "imm3_query_run", "imm3_query_run_select", "imm3_query_sync", "imm3_query_join_count", "imm3_query_log_counts",
+    "imm3_query_run", "imm3_query_run_select", "imm3_query_run_count", "imm3_query_sync", "imm3_query_join_count", "imm3_query_log_counts",
     "imm3_query_layout", "imm3_query_batches", "imm3_query_count", "imm3_query_bitmap",
     "imm3_query_row_count", "imm3_query_fetch_rows", "imm3_query_device_ptr",
     "imm3_comm_unique_id", "imm3_comm_create", "imm3_comm_create_all", "imm3_comm_destroy", "imm3_comm_info",
@@ -147,6 +147,7 @@ def load() -> C.CDLL:
     L.imm3_query_reserve_rows.argtypes = [vp, u64]
     L.imm3_query_run.argtypes = [vp]
     L.imm3_query_run_select.argtypes = [vp]
+    L.imm3_query_run_count.argtypes = [vp]
     L.imm3_query_sync.argtypes = [vp]
     L.imm3_query_join_count.argtypes = [vp]
     L.imm3_query_log_counts.argtypes = [vp, vp, C.c_uint64]
@@ -544,6 +545,10 @@ class DeviceQuery:
 
     def run_select(self):
         _check(load().imm3_query_run_select(self._h))
+
+    def run_count(self):
+        """ScanOp -> SelectOp* for the count alone: a single-launch chain stores no bitmap."""
+        _check(load().imm3_query_run_count(self._h))
 
     def sync(self):
         _check(load().imm3_query_sync(self._h))

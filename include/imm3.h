@@ -246,6 +246,11 @@ int imm3_query_reserve_rows(imm3_query *q, uint64_t rows);
 int imm3_query_run(imm3_query *q);
 /* Only the ScanOp -> SelectOp* part (selection bitmap + count). */
 int imm3_query_run_select(imm3_query *q);
+/* ScanOp -> SelectOp* for the count alone: `vec.selected.size` summed over the batches (what a count(*)-style consumer of
+ * the pipeline reads, Engine.scala:190-196) without materialising the BitSets.  A select chain that is one fused launch then
+ * stores no bitmap at all -- on a narrow column the 1/8 byte per row of bitmap is a fifth of the kernel -- and
+ * imm3_query_bitmap fails with IMM3_ERR_STATE until the next full run; any other chain runs as imm3_query_run_select. */
+int imm3_query_run_count(imm3_query *q);
 int imm3_query_sync(imm3_query *q);
 /* The selected-row count of a select-only run is reduced on the context's auxiliary stream so that it overlaps the
  * next scan.  Host getters wait for it by themselves; a DEVICE consumer of imm3_query_device_ptr(q, 1) that runs on

@@ -147,6 +147,11 @@ JNIEXPORT void JNICALL Java_immutabledb_gpu_Native_00024_queryRun(JNIEnv *env, j
     if (imm3_query_run((imm3_query *)(intptr_t)q) != IMM3_OK) throw_last(env);
 }
 
+/* the count alone (selected.size summed): a single-launch select chain stores no bitmap */
+JNIEXPORT void JNICALL Java_immutabledb_gpu_Native_00024_queryRunCount(JNIEnv *env, jobject self, jlong q) {
+    if (imm3_query_run_count((imm3_query *)(intptr_t)q) != IMM3_OK) throw_last(env);
+}
+
 /* returns Array(size..., oid..., wordOffLo/Hi ...) packed as long[3 * nBatches] */
 JNIEXPORT jlongArray JNICALL Java_immutabledb_gpu_Native_00024_queryBatches(JNIEnv *env, jobject self, jlong qh) {
     imm3_query *q = (imm3_query *)(intptr_t)qh;

@@ -31,6 +31,7 @@ object Native {
                           proj: Array[Int], limit: Long, blockSize: Int): Long
   @native def queryDestroy(q: Long): Unit
   @native def queryRun(q: Long): Unit
+  @native def queryRunCount(q: Long): Unit   // selected.size summed, no BitSets materialised
 
   /** packed (size(0..n), oid(0..n), wordOff(0..n)) */
   @native def queryBatches(q: Long): Array[Long]

@@ -333,3 +333,45 @@ def test_staged_projection_every_record_size_and_fill(pred_cols, extra):
         q.close()
     seg.close()
     ctx.close()
+
+
+# ---- count-only runs (imm3_query_run_count): the same count, no bitmap ------------------------------------------------------
+def test_count_only_runs_match_the_bitmap_path(ctx, oracle):
+    from immutable3_amd import native
+    rng = np.random.default_rng(99)
+    n = 300_000 + 123
+    br = blocks_of(n, 1024)
+    cols = make_cols(rng, n, br, small_ids=True)
+    seg = native.DeviceSegment(ctx, [c.native() for c in cols])
+    shapes = [([0], [(0, GT, -10.0), (0, LT, 25.0)]), ([1], [(0, GT, 18.0), (0, LT, 30.0)]), ([2], [(0, MATCH, [b"CA", b"TX"])]),
+              ([0, 1], [(0, GT, 0.0), (1, LT, 64.0)]), ([1, 2, 0], [(0, GT, -5.0), (1, MATCH, [b"NY"]), (2, LT, 40.0)]), ([0], []),
+              ([1], [(0, GT, 500.0)]),                                        # always false after narrowing: d2b(500) = -12 ... not empty; see below
+              ([0], [(0, GT, 10.0), (0, LT, 5.0)])]                           # empty interval: answered by memset
+    for used, sels in shapes:
+        q = native.DeviceQuery(ctx, seg, used, sels)
+        q.run_select()
+        want, words = q.count(), q.bitmap()
+        ow, oc = oracle.scan_select([cols[i].ocol() for i in used], sels, 1024, 1)
+        assert want == oc and words.tolist() == ow.tolist()
+        q.run_count()
+        assert q.count() == want
+        single_launch = len(used) <= 3 and want != 0 or not sels
+        try:
+            got = q.bitmap()
+            assert got.tolist() == ow.tolist()                                  # (a chain that is not one launch keeps its bitmap)
+        except native.Imm3Error as e:
+            assert e.code == native.ERR_STATE and "count-only" in e.msg
+        q.run_select()                                                          # a full run brings the bitmap back
+        assert q.bitmap().tolist() == ow.tolist() and q.count() == want
+        q.close()
+    # six predicate columns = two tile passes: run_count falls back to the full select
+    cols6 = [RawColumn(DENSE_INT, 4, rng.integers(-50, 50, size=n).astype(np.int32), br) for _ in range(6)]
+    seg6 = native.DeviceSegment(ctx, [c.native() for c in cols6])
+    sels = [(c, GT, -20.0) for c in range(6)]
+    q = native.DeviceQuery(ctx, seg6, list(range(6)), sels)
+    q.run_count()
+    ow, oc = oracle.scan_select([c.ocol() for c in cols6], sels, 1024, 1)
+    assert q.count() == oc and q.bitmap().tolist() == ow.tolist()
+    q.close()
+    seg6.close()
+    seg.close()

@@ -58,5 +58,16 @@ for name, (used, sels, bpr) in cases.items():
         q.run_select()
     ctx.sync(); step_us = (time.perf_counter() - t0) / 200 * 1e6   # whole select: kernel(s) + count reduce, back to back
     gbs = (bpr + 0.125) * n / (ms * 1e-3) / 1e9
-    print(f"{name:12s} {grid:6d} {ms * 1e3:8.1f} {gbs:22.0f} {gbs / 80:11.1f}%   step {step_us:6.1f} us")
+    # the same chain as a count-only run (imm3_query_run_count: no bitmap stored); algorithmic bytes = the columns alone
+    for _ in range(3):
+        q.run_count()
+    ctx.sync()
+    ctx.timing_enable(64); ctx.timing_mask(1); ctx.timing_reset()
+    for _ in range(20):
+        q.run_count()
+    ctx.sync()
+    cms = float(np.median(ctx.timing_collect(0)))
+    ctx.timing_enable(0)
+    cgbs = bpr * n / (cms * 1e-3) / 1e9 if bpr else 0.0
+    print(f"{name:12s} {grid:6d} {ms * 1e3:8.1f} {gbs:22.0f} {gbs / 80:11.1f}%   step {step_us:6.1f} us   count-only {cms * 1e3:6.1f} us {cgbs:6.0f} GB/s {cgbs / 80:5.1f}%")
     q.close()
