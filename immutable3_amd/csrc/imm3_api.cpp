@@ -1821,7 +1821,7 @@ static int run_single_pass(imm3_query *q) {
         a.n_gather = ng;
     }
     const int fv = ctx->filter_variant;
-    a.ablate = (fv >= 50 && fv <= 50 + 127) ? fv - 50 : 0; // (tools' build only: a mask -- 1 no unpack, 2 no chained scan, 4 no records, 16 no output stores, 32 output stores cache resident)
+    a.ablate = (fv >= 50 && fv <= 50 + 255) ? fv - 50 : 0; // (tools' build only: a mask -- 1 no unpack, 2 no chained scan, 4 no records, 16 no output stores, 32 output stores cache resident)
     if (ctx->d_stamps) {
         std::lock_guard<std::mutex> lk(ctx->mu);
         if (ctx->d_stamps && ctx->stamp_used < ctx->stamp_slots) {

@@ -195,8 +195,13 @@ __device__ __forceinline__ uint32_t partial_tile(const TileArgs &a, int64_t tile
 // TABLE selects the tile-table walk (table queries) at compile time, so the single-segment kernel carries none of it.
 // DEFER (compile time, like TABLE): the bitmap lines of a wave's tiles are parked in LDS and written in bursts.
 // STAGE: the survivors' records are compacted and stored per tile (projecting queries).
+// Waves per SIMD the register allocation must leave room for.  The staging launch over a lone 2-byte-string column runs
+// 1024 work-groups = 4 waves per SIMD (128 VGPRs each); round 3 found that instance at 129 -- one SGPR-spill register too
+// many -- and with it 768 of the 1024 work-groups resident and C4's filter at 62 us instead of 47.
+constexpr int tile_min_waves(int k0, int k1, bool stage) { return stage && k0 == TK_S2 && k1 == TK_NONE ? 4 : 1; }
+
 template <int K0, int K1, int K2, int T, bool TABLE, bool DEFER, bool STAGE>
-__global__ __launch_bounds__(kBlockThreads) void k_filter_tile(const TileArgs a) {
+__global__ __launch_bounds__(kBlockThreads, tile_min_waves(K0, K1, STAGE)) void k_filter_tile(const TileArgs a) {
     constexpr bool kXpose = K0 == TK_I8 || K0 == TK_S2 || K1 == TK_I8 || K1 == TK_S2 || K2 == TK_I8 || K2 == TK_S2;
     constexpr int kStage = STAGE ? arena_buf_bytes(Rec<K0, K1, K2>::R) : 16;
     // narrow-only kernels spend longer on a tile (LDS transpose) than its loads take to issue: the next group's loads go

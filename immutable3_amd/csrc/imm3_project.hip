@@ -155,7 +155,10 @@ constexpr int kProjStreamers = kProjectStreamers;
 constexpr int kProjWriters = 4;
 constexpr int kProjPerWriter = kProjStreamers / kProjWriters;
 constexpr int kProjThreads = 64 * (kProjStreamers + kProjWriters);
-constexpr int kProjRingBytes = 14 * 1024;
+#ifndef IMM3_PROJ_RING_KB
+#define IMM3_PROJ_RING_KB 14
+#endif
+constexpr int kProjRingBytes = IMM3_PROJ_RING_KB * 1024;
 constexpr bool kProjDepth2 = false; // two tiles of loads in flight per streamer instead of one
 constexpr int kProjSlots = 4;   // published ranges a streamer may have waiting for its writer
 
@@ -566,7 +569,7 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
             if (abandoned) break;
             if (parked) flush_park();
             // ---- publish the range (the slot's previous range, i - kProjSlots, must have been taken by the writer) ----
-            while (i >= (uint32_t)kProjSlots && lds_peek(&s_drained[wave]) < i - (uint32_t)(kProjSlots - 1)) {
+            while (!IMM3_ABLATE_BIT(a, 128) && i >= (uint32_t)kProjSlots && lds_peek(&s_drained[wave]) < i - (uint32_t)(kProjSlots - 1)) {
                 if (lds_peek(&s_abort)) { abandoned = true; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
@@ -588,6 +591,7 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
         const int wr = wave - kProjStreamers; // 0: also owns the span's descriptor and its first output row
         const int w_first = wr * kProjPerWriter;
         int64_t s = blockIdx.x;
+        if (IMM3_ABLATE_BIT(a, 128)) s = a.n_spans; // (timing only, with bit 4: the writers leave at once -- what their polling costs the streamers)
         for (uint32_t k = 0; s < a.n_spans && !lds_peek(&s_abort); s += gridDim.x, ++k) {
             // the ranges of span s
             uint32_t cnt[kProjStreamers], start[kProjStreamers], in_arena[kProjStreamers];
