@@ -292,6 +292,7 @@ extern "C" int imm3_ctx_devclock_enable(imm3_ctx *ctx, int32_t max_launches) {
         void *p = nullptr;
         HIPCHK(hipMalloc(&p, (size_t)max_launches * kMaxFilterGrid * 2 * sizeof(unsigned long long)));
         HIPCHK(hipMemset(p, 0, (size_t)max_launches * kMaxFilterGrid * 2 * sizeof(unsigned long long)));
+        HIPCHK(hipStreamSynchronize(nullptr)); // (the memset runs on the null stream and may return early; the context's stream does not wait for that stream)
         ctx->d_stamps = (unsigned long long *)p;
         ctx->stamp_slots = max_launches;
     }

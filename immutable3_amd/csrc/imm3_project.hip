@@ -68,7 +68,7 @@ __device__ __forceinline__ bool desc_wait(const ProjectArgs &a, const unsigned l
     }
 }
 
-__device__ __forceinline__ bool span_prefix(const ProjectArgs &a, int64_t s, uint32_t epoch, unsigned long long agg, int lane, unsigned long long &prefix) {
+__device__ __forceinline__ bool span_arrive(const ProjectArgs &a, int64_t s, uint32_t epoch, unsigned long long agg, int lane) {
     const int64_t G = gridDim.x;
     const int64_t r = s / G, first = r * G;
     const int64_t n_in = a.n_spans - first < G ? a.n_spans - first : G; // spans of this round
@@ -125,7 +125,15 @@ __device__ __forceinline__ bool span_prefix(const ProjectArgs &a, int64_t s, uin
         }
         if (!ok) return false;
     }
-    return desc_wait(a, a.desc + s, epoch, 2u, prefix);
+    return true;
+}
+
+// the run is abandoned (a wait timed out, or another work-group said so): tell the host, the other waves of this work-group and
+// everybody who waits on this work-group's spans.  One lane.
+__device__ __forceinline__ void abandon_run(const ProjectArgs &a, int64_t s, uint32_t epoch, uint32_t *s_abort) {
+    __hip_atomic_fetch_or(a.finish + kFinishStatus, 2ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int64_t r = s; r < a.n_spans; r += gridDim.x) desc_store(a.desc + r, desc_pack(epoch, 3u, 0ULL));
+    __hip_atomic_store(s_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // LDS words shared between a streamer and the writers: relaxed work-group-scope atomics stay ds_read / ds_write (a volatile
@@ -206,6 +214,68 @@ __device__ __forceinline__ void store_pred_col(void *dst, const uint32_t (&rw)[4
     }
 }
 
+// The gathered columns of one range (NG of them, compile time: with a run-time count every load sat behind a branch of its
+// own and was waited for before the next one was issued -- sixteen serialised round trips per step, 25 us per span on C4).
+// Two quads per lane and step; every load of the step -- all columns, all eight rows -- is in flight before the first store.
+template <int K0, int K1, int K2, int NG>
+__device__ __forceinline__ void gather_range(const ProjectArgs &a, const typename Rec<K0, K1, K2>::vec *src, uint32_t start, uint32_t cap, uint32_t n,
+                                             uint32_t base, uint32_t tile0, int lane) {
+    typedef Rec<K0, K1, K2> L;
+    constexpr int R = L::R;
+    const uint32_t q0 = base >> 2;
+    const uint32_t n_quads = ((base + n + 3) >> 2) - q0;
+    const void *gsrc[NG];
+    void *gdst[NG];
+    int gw[NG];
+#pragma unroll
+    for (int c = 0; c < NG; ++c) {
+        gsrc[c] = a.gather[c].src;
+        gdst[c] = a.gather[c].dst;
+        gw[c] = a.gather[c].width;
+    }
+    for (uint32_t qi = lane; qi < n_quads; qi += 128) {
+        uint32_t raw[2][4][NG], sh[2][4][NG];
+        bool ok[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t out0 = (q0 + qi + 64 * u) << 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t o = out0 + e;
+                ok[u][e] = qi + 64 * u < n_quads && o >= base && o - base < n;
+                uint32_t idx = start + (ok[u][e] ? o - base : 0u);
+                if (idx >= cap) idx -= cap;
+                uint32_t rw[4];
+                rec_words<R>(src[idx], rw);
+                const uint32_t row = (tile0 + ((rw[0] >> 10) & 63u)) * (uint32_t)kTileRows + (rw[0] & (uint32_t)(kTileRows - 1));
+#pragma unroll
+                for (int c = 0; c < NG; ++c) { // the aligned dword that holds the value
+                    const uint32_t byte = row * (uint32_t)gw[c]; // (< 2^32: a segment's .dat is < 2 GiB, Segment.scala:33)
+                    raw[u][e][c] = ((const uint32_t *)gsrc[c])[byte >> 2];
+                    sh[u][e][c] = 8 * (byte & 3u);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t out0 = (q0 + qi + 64 * u) << 2;
+            const bool whole = ok[u][0] && ok[u][3];
+#pragma unroll
+            for (int c = 0; c < NG; ++c) {
+                uint32_t v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = raw[u][e][c] >> sh[u][e][c];
+                if (whole) store_quad(gdst[c], gw[c], out0, v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (ok[u][e]) store_value_rt(gdst[c], gw[c], out0 + e, v[e]);
+                }
+            }
+        }
+    }
+}
+
 // src: the ring (start, cap = its position and capacity) or the arena (start 0, cap ~0)
 template <int K0, int K1, int K2>
 __device__ __forceinline__ void unpack_range(const ProjectArgs &a, const typename Rec<K0, K1, K2>::vec *src, uint32_t start, uint32_t cap, uint32_t n,
@@ -250,60 +320,13 @@ __device__ __forceinline__ void unpack_range(const ProjectArgs &a, const typenam
         store_pred_col<K0, K1, K2, 1>(d1, rw, ok, whole, out0);
         store_pred_col<K0, K1, K2, 2>(d2, rw, ok, whole, out0);
     }
-    // ---- SELECT-list columns that are not predicate columns: gathered at the records' rows, two quads per lane and step,
-    //      every load of the step -- all columns, all eight rows -- in flight before the first store
-    const int ng = a.n_gather;
-    if (ng == 0) return; // wave-uniform
-    const void *gsrc[kMaxEmitGather];
-    void *gdst[kMaxEmitGather];
-    int gw[kMaxEmitGather];
-#pragma unroll
-    for (int c = 0; c < kMaxEmitGather; ++c) {
-        gsrc[c] = a.gather[c].src;
-        gdst[c] = a.gather[c].dst;
-        gw[c] = a.gather[c].width;
-    }
-    for (uint32_t qi = lane; qi < n_quads; qi += 128) {
-        uint32_t gv[2][4][kMaxEmitGather];
-        bool ok[2][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t out0 = (q0 + qi + 64 * u) << 2;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t o = out0 + e;
-                ok[u][e] = qi + 64 * u < n_quads && o >= base && o - base < n;
-                uint32_t idx = start + (ok[u][e] ? o - base : 0u);
-                if (idx >= cap) idx -= cap;
-                uint32_t rw[4];
-                rec_words<R>(src[idx], rw);
-                const uint32_t row = (tile0 + ((rw[0] >> 10) & 63u)) * (uint32_t)kTileRows + (rw[0] & (uint32_t)(kTileRows - 1));
-#pragma unroll
-                for (int c = 0; c < kMaxEmitGather; ++c) {
-                    gv[u][e][c] = 0u;
-                    if (c < ng) { // wave-uniform; the aligned dword that holds the value
-                        const uint32_t byte = row * (uint32_t)gw[c]; // (< 2^32: a segment's .dat is < 2 GiB, Segment.scala:33)
-                        gv[u][e][c] = ((const uint32_t *)gsrc[c])[byte >> 2] >> (8 * (byte & 3u));
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t out0 = (q0 + qi + 64 * u) << 2;
-            const bool whole = ok[u][0] && ok[u][3];
-#pragma unroll
-            for (int c = 0; c < kMaxEmitGather; ++c) {
-                if (c < ng) {
-                    if (whole) store_quad(gdst[c], gw[c], out0, gv[u][0][c], gv[u][1][c], gv[u][2][c], gv[u][3][c]);
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (ok[u][e]) store_value_rt(gdst[c], gw[c], out0 + e, gv[u][e][c]);
-                    }
-                }
-            }
-        }
+    // ---- SELECT-list columns that are not predicate columns: gathered at the records' rows
+    switch (a.n_gather) { // wave-uniform
+    case 0: break;
+    case 1: gather_range<K0, K1, K2, 1>(a, src, start, cap, n, base, tile0, lane); break;
+    case 2: gather_range<K0, K1, K2, 2>(a, src, start, cap, n, base, tile0, lane); break;
+    case 3: gather_range<K0, K1, K2, 3>(a, src, start, cap, n, base, tile0, lane); break;
+    default: gather_range<K0, K1, K2, 4>(a, src, start, cap, n, base, tile0, lane); break;
     }
 }
 
@@ -344,24 +367,28 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
     __shared__ __attribute__((aligned(16))) uint8_t s_xpose[kProjStreamers][kXpose ? (kS2 ? kXposeBytes : kXposeBytes / 2) : 16];
     __shared__ __attribute__((aligned(16))) uint64_t s_park[kProjStreamers][kProjParkLines * kTileWords];
     __shared__ RangePub s_pub[kProjStreamers][kProjSlots];
-    __shared__ uint32_t s_pub_seq[kProjStreamers]; // ranges the streamer has published
     __shared__ uint32_t s_drained[kProjStreamers]; // ranges the writer has unpacked
     __shared__ uint32_t s_head[kProjStreamers];    // records the writer has freed in the ring (running total)
     __shared__ unsigned long long s_prefix[kProjSlots]; // first output row of the span (slot = span mod kProjSlots), from the first writer ...
     __shared__ uint32_t s_prefix_seq;              // ... and how many spans it has resolved
     __shared__ uint32_t s_abort;
+    __shared__ uint32_t s_arrive[kProjSlots];      // streamers that have published their range of the span (slot = span mod kProjSlots)
+    __shared__ uint32_t s_span_ready;              // spans of this work-group whose eight ranges are all published ...
+    __shared__ uint32_t s_announced;               // ... and how many of them a writer has announced to the other work-groups
     __shared__ uint32_t s_part[kProjStreamers];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x] = wall_clock64();
     if (threadIdx.x < kProjStreamers) {
-        s_pub_seq[threadIdx.x] = 0u;
         s_drained[threadIdx.x] = 0u;
         s_head[threadIdx.x] = 0u;
     }
+    if (threadIdx.x < kProjSlots) s_arrive[threadIdx.x] = 0u;
     if (threadIdx.x == 0) {
         s_abort = 0u;
         s_prefix_seq = 0u;
+        s_span_ready = 0u;
+        s_announced = 0u;
     }
     const uint32_t epoch = (uint32_t)a.finish[kFinishEpoch];
     // ONE launch of this kernel per device at a time: two of them, each holding part of the CUs and waiting for work-groups
@@ -575,15 +602,24 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
             }
             if (abandoned) break;
             if (in_arena) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the writer (another wave of this CU) reads the arena: the stores must have landed
-#ifdef IMM3_ABLATE
-            if (a.stamps && lane == 0 && wave == 0 && i < 6) a.stamps[2 * gridDim.x + blockIdx.x * 18 + i] = wall_clock64(); // (tools: range i done)
-#endif
             if (lane == 0) {
                 s_pub[wave][i % kProjSlots].start = range_start;
                 s_pub[wave][i % kProjSlots].cnt = range_cnt;
                 s_pub[wave][i % kProjSlots].in_arena = in_arena ? 1u : 0u;
-                lds_wave_order();
-                lds_poke(&s_pub_seq[wave], i + 1); // (a wave's LDS operations execute in order: the slot is written before the sequence number)
+            }
+            // the work-group's last range of the span to finish says so: the span can be announced to the other work-groups
+            {
+                const uint32_t slot = i % kProjSlots;
+                uint32_t arrived = 0;
+                if (lane == 0) arrived = __hip_atomic_fetch_add(&s_arrive[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+                if (arrived == (uint32_t)kProjStreamers - 1u && lane == 0) { // (behind the other seven's fetch_adds, hence behind their s_pub writes: the LDS serves a wave's operations in order)
+                    lds_poke(&s_arrive[slot], 0u); // (the slot's next span, i + kProjSlots, is published only after this one was drained)
+                    lds_poke(&s_span_ready, i + 1); // (spans become ready in order: every streamer finishes range i before range i + 1)
+#ifdef IMM3_ABLATE
+                    if (a.stamps && i < 6) a.stamps[2 * gridDim.x + blockIdx.x * 24 + i] = wall_clock64(); // (tools: span i streamed)
+#endif
+                }
             }
         }
     } else {
@@ -592,88 +628,103 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
         const int w_first = wr * kProjPerWriter;
         int64_t s = blockIdx.x;
         if (IMM3_ABLATE_BIT(a, 128)) s = a.n_spans; // (timing only, with bit 4: the writers leave at once -- what their polling costs the streamers)
-        for (uint32_t k = 0; s < a.n_spans && !lds_peek(&s_abort); s += gridDim.x, ++k) {
-            // the ranges of span s
-            uint32_t cnt[kProjStreamers], start[kProjStreamers], in_arena[kProjStreamers];
-            bool dead = false;
-#pragma unroll
-            for (int w = 0; w < kProjStreamers; ++w) {
-                while (lds_peek(&s_pub_seq[w]) < k + 1) { // (a range takes >= 10 us to stream: poll at ~0.5 us, the streamers need the issue slots)
-                    if (lds_peek(&s_abort)) { dead = true; break; }
-                    __builtin_amdgcn_s_sleep(16);
-                }
-                lds_wave_order();
-                start[w] = s_pub[w][k % kProjSlots].start;
-                cnt[w] = s_pub[w][k % kProjSlots].cnt;
-                in_arena[w] = s_pub[w][k % kProjSlots].in_arena;
+        // Announce the work-group's next finished span to the other work-groups: its count, the arrival at the round's
+        // counter, the round's scan if it is the round's last arrival.  ANY writer does it, as soon as it looks -- before
+        // each range it unpacks and while it waits: a span usually finishes streaming while the previous one is being
+        // unpacked, and its first output row takes ~10 us of dependent device-scope round trips to come back.  (With one
+        // fixed writer announcing span k + 1 after it had unpacked span k the chain was serial: unpack -> announce -> wait
+        // -> unpack, 33 us per span on C4.  With the streamer that finishes the span announcing it, the slowest streamer
+        // of the slowest work-group paid for the round's scan every round: 20 us per round on C3.)  false: abandoned.
+        auto announce = [&]() -> bool {
+            if (IMM3_ABLATE_BIT(a, 2)) return true;
+            const uint32_t ready = lds_peek(&s_span_ready), ann = lds_peek(&s_announced);
+            if (ann >= ready) return true;
+            uint32_t got = 0;
+            if (lane == 0) {
+                uint32_t expect = ann;
+                got = __hip_atomic_compare_exchange_strong(&s_announced, &expect, ann + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
             }
-            if (dead) break;
+            if (!__builtin_amdgcn_readfirstlane((int)got)) return true; // (another writer has it)
+#ifdef IMM3_ABLATE
+            if (a.stamps && lane == 0 && ann < 6) a.stamps[2 * gridDim.x + blockIdx.x * 24 + 18 + ann] = wall_clock64(); // (tools: span about to be announced)
+#endif
+            lds_wave_order();
+            const unsigned long long agg = wave_sum_u64(lane < kProjStreamers ? (unsigned long long)s_pub[lane][ann % kProjSlots].cnt : 0ULL);
+            const int64_t sp = (int64_t)blockIdx.x + (int64_t)ann * gridDim.x;
+            if (span_arrive(a, sp, epoch, agg, lane)) return true;
+            if (lane == 0) abandon_run(a, sp, epoch, &s_abort);
+            return false;
+        };
+        for (uint32_t k = 0; s < a.n_spans && !lds_peek(&s_abort); s += gridDim.x, ++k) {
+            // the ranges of span s: wait until all eight are published
+            const uint32_t slot = k % kProjSlots;
+            bool dead = false;
+            while (lds_peek(&s_span_ready) < k + 1) { // (a range takes >= 10 us to stream: poll at ~0.5 us, the streamers need the issue slots)
+                if (lds_peek(&s_abort)) { dead = true; break; }
+                __builtin_amdgcn_s_sleep(16);
+            }
+            if (dead || !announce()) break;
+            lds_wave_order();
+            unsigned long long before = 0; // survivors of the span before this writer's ranges
+#pragma unroll 1
+            for (int w = 0; w < w_first; ++w) before += s_pub[w][slot].cnt;
             unsigned long long prefix = 0;
             if (wr == 0) {
-                unsigned long long agg = 0;
-#pragma unroll
-                for (int w = 0; w < kProjStreamers; ++w) agg += cnt[w];
                 bool ok = true;
                 if (IMM3_ABLATE_BIT(a, 2)) prefix = (unsigned long long)s * (unsigned long long)(P * kProjStreamers * 128); // (no chained scan: rows land at wrong, but distinct, offsets)
-                else ok = span_prefix(a, s, epoch, agg, lane, prefix);
-                if (!ok) { // abandoned: tell the host, the other waves and everybody who waits on this work-group's spans
-                    if (lane == 0) {
-                        __hip_atomic_fetch_or(a.finish + kFinishStatus, 2ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        for (int64_t r = s; r < a.n_spans; r += gridDim.x) desc_store(a.desc + r, desc_pack(epoch, 3u, 0ULL));
-                        lds_poke(&s_abort, 1u);
-                    }
+                else ok = desc_wait(a, a.desc + s, epoch, 2u, prefix);
+                if (!ok) {
+                    if (lane == 0) abandon_run(a, s, epoch, &s_abort);
                     break;
                 }
                 if (lane == 0) {
-                    s_prefix[k % kProjSlots] = prefix; // (the slot's previous span, k - 2, was read by the other writer before it drained k - 2 ...
+                    s_prefix[slot] = prefix; // (the slot's previous span, k - kProjSlots, was read by the other writers before they drained it ...
                     lds_wave_order();
-                    lds_poke(&s_prefix_seq, k + 1); // ... and this wave got here only after the streamers published k, i.e. after k - 2 was drained)
+                    lds_poke(&s_prefix_seq, k + 1); // ... and this wave got here only after the streamers published k, i.e. after k - kProjSlots was drained)
                 }
             } else {
                 while (lds_peek(&s_prefix_seq) < k + 1) {
-                    if (lds_peek(&s_abort)) { dead = true; break; }
+                    if (lds_peek(&s_abort) || !announce()) { dead = true; break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
                 if (dead) break;
                 lds_wave_order();
-                prefix = s_prefix[k % kProjSlots];
+                prefix = s_prefix[slot];
             }
 #ifdef IMM3_ABLATE
-            if (a.stamps && lane == 0 && wr == 0 && k < 6) a.stamps[2 * gridDim.x + blockIdx.x * 18 + 12 + k] = wall_clock64(); // (tools: span k's first row known)
+            if (a.stamps && lane == 0 && wr == 0 && k < 6) a.stamps[2 * gridDim.x + blockIdx.x * 24 + 12 + k] = wall_clock64(); // (tools: span k's first row known)
 #endif
             // this writer's ranges of the span.  While it unpacks the writer outranks the streamers of its SIMD (the issue arbiter
             // prefers the oldest waves -- the streamers -- and the unpacking is on the critical path of the span's ring space).
             __builtin_amdgcn_s_setprio(2);
-            unsigned long long base = prefix;
-#pragma unroll
-            for (int w = 0; w < kProjStreamers; ++w) {
-                if (w >= w_first && w < w_first + kProjPerWriter && !IMM3_ABLATE_BIT(a, 1)) { // (wave-uniform)
+            unsigned long long base = prefix + before;
+#pragma unroll 1
+            for (int q = 0; q < kProjPerWriter && !dead; ++q) {
+                if (!announce()) { dead = true; break; } // (the next span may have finished streaming meanwhile)
+                const int w = w_first + q;
+                const uint32_t cnt = s_pub[w][slot].cnt, start = s_pub[w][slot].start, in_arena = s_pub[w][slot].in_arena;
+                if (!IMM3_ABLATE_BIT(a, 1)) {
                     const uint32_t tile0 = (uint32_t)((s * kProjStreamers + w) * P);
                     const uint32_t b32 = base > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)base;
-                    if (in_arena[w]) { // (slow path)
+                    if (in_arena) { // (slow path)
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                         const vec *ar = (const vec *)a.arena + ((int64_t)blockIdx.x * kProjStreamers + w) * a.wave_cap;
-                        unpack_range<K0, K1, K2>(a, ar, 0u, 0xFFFFFFFFu, cnt[w], b32, tile0, lane);
+                        unpack_range<K0, K1, K2>(a, ar, 0u, 0xFFFFFFFFu, cnt, b32, tile0, lane);
                     } else {
-                        unpack_range<K0, K1, K2>(a, (const vec *)&s_ring[w][0], start[w], kCap, cnt[w], b32, tile0, lane);
+                        unpack_range<K0, K1, K2>(a, (const vec *)&s_ring[w][0], start, kCap, cnt, b32, tile0, lane);
                     }
                 }
-                base += cnt[w];
+                base += cnt;
+                lds_wave_order();
+                if (lane == 0) { // the range is free again (behind the ring reads above: a wave's LDS operations execute in order)
+                    if (!in_arena) lds_poke(&s_head[w], lds_peek(&s_head[w]) + cnt);
+                    lds_poke(&s_drained[w], k + 1);
+                }
             }
-#ifdef IMM3_ABLATE
-            if (a.stamps && lane == 0 && wr == kProjWriters - 1 && k < 6) a.stamps[2 * gridDim.x + blockIdx.x * 18 + 6 + k] = wall_clock64(); // (tools: span k drained)
-#endif
             __builtin_amdgcn_s_setprio(0);
-            lds_wave_order();
-            if (lane == 0) { // (behind the ring reads above: a wave's LDS operations execute in order)
-#pragma unroll
-                for (int w = 0; w < kProjStreamers; ++w) {
-                    if (w >= w_first && w < w_first + kProjPerWriter) {
-                        if (!in_arena[w]) lds_poke(&s_head[w], lds_peek(&s_head[w]) + cnt[w]);
-                        lds_poke(&s_drained[w], k + 1);
-                    }
-                }
-            }
+#ifdef IMM3_ABLATE
+            if (a.stamps && lane == 0 && wr == kProjWriters - 1 && k < 6) a.stamps[2 * gridDim.x + blockIdx.x * 24 + 6 + k] = wall_clock64(); // (tools: span k drained)
+#endif
         }
     }
 #pragma unroll

@@ -14,8 +14,16 @@ seg = native.DeviceSegment(ctx, [(native.DENSE_INT, 4, ids.view(np.uint8), n * 4
                                  (native.DENSE_TINYINT, 1, age.view(np.uint8), n, synth.block_offsets(n, 1))])
 variant = int(sys.argv[1])
 create = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+case = sys.argv[3] if len(sys.argv) > 3 else "C3"
 ctx.set_tuning(create, 0)
-q = native.DeviceQuery(ctx, seg, [1, 0], [(0, native.GT, 18.0), (0, native.LT, 30.0), (1, native.GT, 1e6), (1, native.LT, 9e7)], [1, 0], 0, 1024)
+if case == "C4":
+    st = synth.state_codes(3, n)
+    seg = native.DeviceSegment(ctx, [(native.DENSE_INT, 4, ids.view(np.uint8), n * 4, synth.block_offsets(n, 4)),
+                                     (native.DENSE_STRING, 2, st.reshape(-1), n * 2, synth.block_offsets(n, 2)),
+                                     (native.DENSE_TINYINT, 1, age.view(np.uint8), n, synth.block_offsets(n, 1))])
+    q = native.DeviceQuery(ctx, seg, [1, 0, 2], [(0, native.MATCH, [b"CA"])], [1, 0, 2], 0, 1024)
+else:
+    q = native.DeviceQuery(ctx, seg, [1, 0], [(0, native.GT, 18.0), (0, native.LT, 30.0), (1, native.GT, 1e6), (1, native.LT, 9e7)], [1, 0], 0, 1024)
 ctx.set_tuning(variant, 0)
 for _ in range(3):
     q.run()
@@ -26,14 +34,17 @@ ctx.sync()
 plan = q.plan()
 g = plan["grid"]
 raw = ctx.devclock_raw(0).astype(np.int64)
-t0 = raw[0:2 * g:2].min()
+t0 = raw[0:2 * g:2][raw[0:2 * g:2] > 0].min()
 start = (raw[0:2 * g:2] - t0) / 100.0
 end = (raw[1:2 * g:2] - t0) / 100.0
 print(f"plan {plan}")
 print(f"wg start us: min {start.min():.1f} p50 {np.median(start):.1f} max {start.max():.1f};  end us: min {end.min():.1f} p50 {np.median(end):.1f} max {end.max():.1f}")
-ext = raw[2 * g: 2 * g + 18 * g].reshape(g, 18)
+ext = raw[2 * g: 2 * g + 24 * g].reshape(g, 24)
 for i in range(6):
-    r = ext[:, i]; d = ext[:, 6 + i]; pk = ext[:, 12 + i]
+    r = ext[:, i]; d = ext[:, 6 + i]; pk = ext[:, 12 + i]; an = ext[:, 18 + i]
+    if (an > 0).any():
+        aa = (an[an > 0] - t0) / 100.0
+        print(f"range {i}: announce begun by us min {aa.min():6.1f} p50 {np.median(aa):6.1f} max {aa.max():6.1f}")
     if (r > 0).any():
         rr = (r[r > 0] - t0) / 100.0; dd = (d[d > 0] - t0) / 100.0; pp = (pk[pk > 0] - t0) / 100.0
         if pp.size:
