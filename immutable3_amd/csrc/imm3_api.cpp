@@ -829,7 +829,6 @@ static void query_free(imm3_query *q) {
     pool_release(ctx, q->d_stage_rec);
     pool_release(ctx, q->d_tile_start);
     pool_release(ctx, q->d_desc);
-    pool_release(ctx, q->d_sp_arena);
     pool_release(ctx, q->d_akeys); pool_release(ctx, q->d_acounts); pool_release(ctx, q->d_okeys); pool_release(ctx, q->d_ocounts);
     pool_release(ctx, q->d_afirst); pool_release(ctx, q->d_ofirst); pool_release(ctx, q->d_ameta);
     pool_release(ctx, q->d_avals); pool_release(ctx, q->d_ovals);
@@ -926,6 +925,46 @@ static int tile_kind(const FoldedPred &fp) {
     if (fp.kind == KIND_I8) return TK_I8;
     if (fp.kind == KIND_STR && fp.width == 2 && !fp.match.empty() && fp.match.size() <= (size_t)kMaxTileMatch) return TK_S2;
     return TK_NONE;
+}
+
+// ---- single-pass projection: tiles per wave and span (P) ----
+static void single_pass_set_P(imm3_query *q, int32_t P) {
+    const int64_t tiles_per_span = (int64_t)P * kProjectStreamers;
+    q->sp_P = P;
+    q->sp_spans = (q->n_tiles + tiles_per_span - 1) / tiles_per_span;
+    q->sp_grid = (int32_t)std::min<int64_t>(q->sp_max_grid, q->sp_spans);
+}
+// The host has learnt how many rows survive (a count it fetched together with the number of ranges that outgrew their LDS
+// ring, dense_ranges; or a reservation, dense_ranges < 0): later runs use a P at which a range's survivors fill about 45 %
+// of a streamer's ring -- the streamers then keep compacting while the writers unpack, and no range outgrows its ring (a
+// range that does is unpacked from the source columns row by row: several times slower per row than from records).
+// Survivors are taken to sit in the dense ranges when there were any (a sorted key: half the table survives, all of it
+// in one half); when not even two tiles of such a range fit a ring the planned P stays -- there the row-by-row path
+// beats short ranges.  Measured at 100 M rows: 50 % survivors of an int8 column, evenly spread: P = 14 (the plan, made
+// for ~10 %) 386 us, P = 3 164 us (three launches: 180-208); 28 % of int8 + int32: P = 6 506 us, P = 2 190 us (242);
+// id > 5e7 on the sorted key: P = 7 232-269 us, P = 2 364 us, P = 1 426 us (338).  A run recorded in a graph keeps the P
+// it was recorded with (the descriptors' layout does not depend on P).
+static void single_pass_adapt(imm3_query *q, uint64_t survivors, int64_t dense_ranges) {
+    if (!q->single_pass || q->sp_P_fixed || q->n_rows <= 0 || survivors == 0) return;
+    if (dense_ranges < 0 && q->sp_have_stats) return; // (a reservation says less than a run did)
+    if (dense_ranges >= 0) q->sp_have_stats = true;
+    const int R = project_rec_dwords(q->stage_kinds);
+    const double ring_records = 14.0 * 1024.0 / (4.0 * R); // (kProjRingBytes of imm3_project.hip)
+    double sigma = (double)survivors / (double)q->n_rows;
+    const double n_ranges = (double)q->sp_spans * kProjectStreamers;
+    if (dense_ranges > 0 && (double)dense_ranges > 0.02 * n_ranges) sigma = std::min(1.0, sigma * n_ranges / (double)dense_ranges);
+    const double per_tile = sigma * kTileRows;
+    const double fill = per_tile * q->sp_P / ring_records;
+    if (dense_ranges <= 0 && fill >= 0.3 && fill <= 0.6) return; // (close enough: P does not flip between a reservation's estimate and the count)
+    int64_t P = (int64_t)(0.45 * ring_records / per_tile);
+    if (P < 2) P = (int64_t)(0.9 * ring_records / per_tile); // (nearly every row survives: whatever still fits)
+    if (P < 2) P = q->sp_P_plan;
+    P = std::min<int64_t>(P, q->sp_P_plan);
+    if ((int32_t)P == q->sp_P) return;
+    single_pass_set_P(q, (int32_t)P);
+    // the descriptors are tagged with the low byte of the run counter: leave no tag behind in places the new P does not rewrite
+    // every run (stream order: after the runs so far, before the next one)
+    (void)hipMemsetAsync(q->d_desc, 0, q->sp_trash_off, q->ctx->stream);
 }
 
 static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_table *table,
@@ -1212,23 +1251,24 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
                     if (fill > best + 0.02) { best = fill; P = p; }
                 }
                 if (ctx->filter_variant > 200 && ctx->filter_variant <= 200 + kProjectMaxP) P = ctx->filter_variant - 200; // tuning: variant 200 + P
-                const int64_t tiles_per_span = P * kProjectStreamers;
-                const int64_t n_spans = (q->n_tiles + tiles_per_span - 1) / tiles_per_span;
-                const int64_t grid = std::min<int64_t>(maxg, n_spans);
-                if (grid >= 1) {
+                if (maxg >= 1 && q->n_tiles >= 1) {
                     q->single_pass = true;
-                    q->sp_P = (int32_t)P;
-                    q->sp_grid = (int32_t)grid;
-                    q->sp_spans = n_spans;
-                    q->sp_wave_cap = P * kTileRows;
+                    q->sp_P_plan = (int32_t)P;
+                    q->sp_P_fixed = ctx->filter_variant > 200 && ctx->filter_variant <= 200 + kProjectMaxP;
+                    q->sp_max_grid = maxg;
+                    single_pass_set_P(q.get(), (int32_t)P);
+                    // One allocation: round totals and round counters first (at the same place whatever P a run uses), then the span
+                    // descriptors of the smallest P a run may use, then one 64-byte trash line per writer wave.
+                    const int64_t spans_max = (q->n_tiles + kProjectMinP * kProjectStreamers - 1) / (kProjectMinP * kProjectStreamers);
+                    const int64_t grid_min = std::min<int64_t>(maxg, spans_max);
+                    q->sp_rounds_max = (size_t)((spans_max + grid_min - 1) / grid_min);
+                    q->sp_desc_off = (q->sp_rounds_max * (sizeof(unsigned long long) + sizeof(uint32_t)) + 255) / 256 * 256;
+                    const size_t desc_bytes = q->sp_desc_off + (size_t)spans_max * sizeof(unsigned long long);
+                    q->sp_trash_off = (desc_bytes + 255) / 256 * 256;
                     void *d = nullptr;
-                    const size_t n_rounds = (size_t)((n_spans + grid - 1) / grid);
-                    const size_t desc_bytes = ((size_t)n_spans + n_rounds) * sizeof(unsigned long long) + n_rounds * sizeof(uint32_t);
-                    HIPCHK(pool_alloc(ctx, &d, desc_bytes + 256));
+                    HIPCHK(pool_alloc(ctx, &d, q->sp_trash_off + (size_t)maxg * kProjectWriters * 64));
                     q->d_desc = (unsigned long long *)d;
                     HIPCHK(hipMemsetAsync(q->d_desc, 0, desc_bytes, ctx->stream)); // (pooled memory: another query's descriptors)
-                    HIPCHK(pool_alloc(ctx, &d, (size_t)grid * kProjectStreamers * (size_t)q->sp_wave_cap * 4 * (size_t)R + 256));
-                    q->d_sp_arena = (uint8_t *)d;
                 }
             }
             if (q->single_pass) { /* no survivor records in HBM: the filter kernel writes the rows */ } else {            // Every wave of the staging launch writes its records to its own arena, so the launch geometry is fixed here:
@@ -1443,6 +1483,7 @@ extern "C" int imm3_query_reserve_rows(imm3_query *q, uint64_t rows) {
     const int rc = ensure_row_capacity(q, rows);
     if (rc) return rc;
     q->reserved = true;
+    if (rows < (uint64_t)q->n_rows) single_pass_adapt(q, rows, -1); // (the reservation bounds the survivors)
     return IMM3_OK;
 }
 
@@ -1797,9 +1838,10 @@ static int run_single_pass(imm3_query *q) {
     a.n_rounds = (q->sp_spans + q->sp_grid - 1) / q->sp_grid;
     a.bitmap = q->d_bitmap;
     a.finish = q->d_total;
-    a.desc = q->d_desc;
-    a.arena = q->d_sp_arena;
-    a.wave_cap = q->sp_wave_cap;
+    a.desc = (unsigned long long *)((uint8_t *)q->d_desc + q->sp_desc_off);
+    a.round_total = q->d_desc;
+    a.round_ctr = (uint32_t *)(q->d_desc + q->sp_rounds_max);
+    a.trash = (uint8_t *)q->d_desc + q->sp_trash_off;
     a.cap_rows = q->cap_rows;
     a.row_index = q->d_row_index;
     {   // SELECT-list columns: the first mention of a predicate column comes out of the records, everything else is gathered
@@ -2082,11 +2124,16 @@ extern "C" int imm3_query_log_counts(imm3_query *q, uint64_t *device_log, uint64
 static int settle_single_pass(imm3_query *q) {
     if (!q->ran_single_pass || q->sp_verified) return IMM3_OK;
     imm3_ctx *ctx = q->ctx;
-    unsigned long long status = 0;
-    HIPCHK(hipMemcpyAsync(&status, q->d_total + kFinishStatus, sizeof(status), hipMemcpyDeviceToHost, ctx->stream));
+    static_assert(kFinishStatus == 2, "the count and the status word are fetched together");
+    unsigned long long head[kFinishDense + 1] = {0}; // {count, rows emitted, status, ..., dense ranges}
+    HIPCHK(hipMemcpyAsync(head, q->d_total, sizeof(head), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     q->sp_verified = true;
-    if (!(status & 6ULL)) return IMM3_OK;
+    const unsigned long long status = head[kFinishStatus];
+    if (!(status & 6ULL)) {
+        single_pass_adapt(q, head[0], (int64_t)head[kFinishDense]); // (later runs: P from the selectivity this run saw)
+        return IMM3_OK;
+    }
     if (status & 2ULL) { // a prefix never came (not every work-group resident?): this query keeps the bitmap path from now on
         graphs_mark_stale(ctx, q); // (a recorded run would take the abandoned path again)
         q->single_pass = false;

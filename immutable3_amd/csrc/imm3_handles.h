@@ -211,9 +211,14 @@ struct imm3_query {
     // single-pass projection (k_filter_project, imm3_project.hip): planned at creation for the same queries as the records
     bool single_pass = false;
     int32_t sp_P = 0, sp_grid = 0;          // tiles per wave per span; work-groups (all resident: they wait on each other)
-    int64_t sp_spans = 0, sp_wave_cap = 0;  // spans of 4 * P tiles; records per wave of the spill arena
+    int64_t sp_spans = 0;                   // spans of 8 * P tiles
+    int32_t sp_P_plan = 0, sp_max_grid = 0; // P as planned without knowing the selectivity (the ceiling of the adapted P); resident work-groups
+    bool sp_P_fixed = false;                // P was set by the tuning hook: never adapted
+    bool sp_have_stats = false;             // a run's count and dense-range tally have been seen (a reservation's estimate no longer moves P)
+    size_t sp_rounds_max = 0;               // rounds at the smallest P: d_desc = {round totals, round counters, span descriptors (smallest P), trash lines}
+    size_t sp_desc_off = 0;                 // byte offset of the span descriptors in d_desc's allocation
     unsigned long long *d_desc = nullptr;   // per-span descriptors of the chained scan
-    uint8_t *d_sp_arena = nullptr;
+    size_t sp_trash_off = 0;                // byte offset of the writers' trash lines in d_desc's allocation
     bool ran_single_pass = false;           // the last run went through k_filter_project ...
     bool sp_verified = false;               // ... and its status word has been read since (not abandoned)
     bool count_pending_scan = false; // the last select run left the count to the projection's offsets scan

@@ -162,10 +162,13 @@ void launch_emit(const EmitArgs &a, int n_gather, int grid_blocks, hipStream_t s
 //                                                  flag 3: the run is being abandoned (look-back timed out)
 // `epoch` (finish[kFinishEpoch], bumped by the launch's last work-group) tells this run's descriptors from the previous
 // run's, so nothing is cleared between runs.
+constexpr int kProjectMinP = 1;
 constexpr int kProjectMaxP = 64;        // tiles per wave per span (the tile's index in its range takes 6 bits of the record)
-constexpr int kProjectStreamers = 8;    // waves of a work-group that stream tiles: a span is kProjectStreamers * P consecutive tiles
+constexpr int kProjectStreamers = 8;  // waves of a work-group that stream tiles: a span is kProjectStreamers * P consecutive tiles
+constexpr int kProjectWriters = 4;    // waves of a work-group that write the rows
 constexpr int kFinishStatus = 2;        // finish[2]: bit 0 malformed PFOR block; single-pass projection: bit 1 abandoned (a prefix never came), bit 2 device busy
 constexpr int kFinishEpoch = 8;         // finish[8]: run counter of the query (descriptor epochs)
+constexpr int kFinishDense = 9;         // finish[9]: single-pass projection: ranges of the last run that outgrew their LDS ring (finish[10]: the running sum)
 constexpr unsigned long long kDescValueMask = (1ULL << 54) - 1;
 struct ProjectArgs {
     TileCol cols[kMaxTileCols];
@@ -175,9 +178,10 @@ struct ProjectArgs {
     int64_t n_rounds;               // ceil(n_spans / grid)
     uint64_t *bitmap;
     unsigned long long *finish;     // the query's {total, n_emit, status, limit, tally, log ..., epoch} block
-    unsigned long long *desc;       // n_spans span descriptors, then n_rounds round totals (u64), then n_rounds arrival counters (u32)
-    void *arena;                    // spill space: wave_cap records per wave (a range whose records outgrow the LDS buffer)
-    int64_t wave_cap;
+    unsigned long long *desc;       // n_spans span descriptors
+    unsigned long long *round_total; // n_rounds inclusive totals through the round ...
+    uint32_t *round_ctr;            // ... and n_rounds arrival counters (zero between runs).  At fixed places whatever P is: the host changes P between runs
+    uint8_t *trash;                 // one 64-byte line per writer wave: where a dense range's unwanted lanes store (keeps its loop free of branches)
     uint64_t cap_rows;              // capacity of the output arrays
     uint32_t *row_index;
     void *pred_dst[kMaxTileCols];   // where the values of predicate column k go (packed, its width per row), or null: not in the SELECT list

@@ -6,26 +6,28 @@
 // for it -- the filter kernel staging one record per survivor, an offsets scan, an emit kernel reading the records back
 // (C3: 78 MB written and re-read, 145 us).  Here the filter kernel writes the final rows itself:
 //
-//   * a work-group owns SPANS of 4 * P consecutive tiles, its four waves P consecutive tiles each; spans are dealt to the
-//     work-groups round-robin.  A wave evaluates its tiles exactly as k_filter_tile does (all loads of a tile issued
-//     before the first compare, narrow columns transposed through LDS, v_cmp result == bitmap word) and compacts one
-//     RECORD per survivor -- position, the tile's index in the range, every predicate column -- into its LDS buffer;
-//   * at the end of a range the work-group publishes the span's survivor count in a DESCRIPTOR and one of its waves
-//     looks back over the descriptors of the earlier spans (decoupled look-back: sum the counts down to the nearest span
-//     that already knows its inclusive prefix), which gives the span's first output row; the waves then unpack their
-//     records into the packed output columns -- row index, staged columns out of the record, other SELECT-list columns
-//     gathered at the record's row -- four output rows per lane (16 / 8 / 4-byte stores);
-//   * a range whose records outgrow the LDS buffer (dense survivors: a range predicate on a sorted key) spills to the
-//     wave's arena in HBM and is unpacked from there once the offset is known -- a round trip only for those ranges.
+//   * a work-group (one per CU, eight STREAMER waves + four WRITER waves) owns SPANS of 8 * P consecutive tiles, each
+//     streamer a RANGE of P consecutive tiles; spans are dealt to the work-groups round-robin.  A streamer evaluates its
+//     tiles exactly as k_filter_tile does (all loads of a tile issued before the first compare, narrow columns transposed
+//     through LDS, v_cmp result == bitmap word) and compacts one RECORD per survivor -- position, the tile's index in the
+//     range, every predicate column -- into its ring in LDS;
+//   * when a span's eight ranges are done a writer ANNOUNCES it: the span's survivor count goes into a DESCRIPTOR, the
+//     last span of a round to arrive scans the round's counts, and every span reads its first output row from its own
+//     descriptor (span_arrive); the writers then unpack the records into the packed output columns -- row index, the
+//     predicate columns out of the record, other SELECT-list columns gathered at the record's row -- four output rows
+//     per lane (16 / 8 / 4-byte stores);
+//   * a range whose records outgrow the ring (dense survivors: a range predicate on a sorted key) keeps no records: the
+//     writer takes its rows from the source columns again, at the set bits of the range's bitmap lines (unpack_dense).
 //
 // Order is deterministic: a row's output slot is the number of survivors before it, whatever the work-groups' timing.
-// Every work-group of the launch must be resident (they wait on each other's descriptors): the host sizes the grid from
-// the occupancy query, and a look-back that does not resolve within a bounded number of polls abandons the run (status
-// bit, every work-group drains) -- the host then answers the query through the bitmap path.
+// Every work-group of the launch must be resident (they wait on each other's descriptors): one work-group per CU, and a
+// wait that does not resolve within a bounded number of polls abandons the run (status bit, every work-group drains) --
+// the host then answers the query through the bitmap path.
 #include "imm3_internal.h"
 #include "imm3_device.h"
 #include "imm3_tile.h"
 #include <hip/hip_ext.h>
+#include <type_traits>
 
 namespace imm3 {
 
@@ -72,8 +74,8 @@ __device__ __forceinline__ bool span_arrive(const ProjectArgs &a, int64_t s, uin
     const int64_t G = gridDim.x;
     const int64_t r = s / G, first = r * G;
     const int64_t n_in = a.n_spans - first < G ? a.n_spans - first : G; // spans of this round
-    unsigned long long *round_total = a.desc + a.n_spans;               // [n_rounds] inclusive total through the round
-    uint32_t *round_ctr = (uint32_t *)(round_total + a.n_rounds);       // [n_rounds] arrivals (zero between runs)
+    unsigned long long *round_total = a.round_total; // [n_rounds] inclusive total through the round
+    uint32_t *round_ctr = a.round_ctr;               // [n_rounds] arrivals (zero between runs)
     if (lane == 0) desc_store(a.desc + s, desc_pack(epoch, 1u, agg));
     uint32_t prev = 0;
     if (lane == 0) prev = __hip_atomic_fetch_add(round_ctr + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -94,7 +96,7 @@ __device__ __forceinline__ bool span_arrive(const ProjectArgs &a, int64_t s, uin
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     dead = dead || desc_dead(d[q], epoch);
-                    all = all && desc_ready(d[q], epoch, 1u);
+                    all = all && desc_ready(d[q], epoch, 1u) && ((uint32_t)(d[q] >> 54) & 3u) == 1u; // (exactly "count known": prefixes are written below, by this wave only)
                 }
                 if (ballot64(dead)) { ok = false; break; }
                 if (ballot64(!all) == 0ULL) break;
@@ -145,7 +147,7 @@ __device__ __forceinline__ void lds_poke(uint32_t *p, uint32_t v) { __hip_atomic
 struct RangePub {
     uint32_t start;    // ring position of the range's first record
     uint32_t cnt;      // survivors of the range
-    uint32_t in_arena; // 1: the range outgrew the ring, its records are in the wave's arena
+    uint32_t dense;    // 1: the range outgrew the ring -- no records; the writer takes the rows from the columns at the bitmap's bits
     uint32_t pad;
 };
 
@@ -160,7 +162,7 @@ struct RangePub {
 // of records; a finished range is published (RangePub + a sequence number), its writer frees it by advancing the ring's
 // head.  A streamer runs at most two ranges ahead of its writer and waits only when its ring is full of undrained ranges.
 constexpr int kProjStreamers = kProjectStreamers;
-constexpr int kProjWriters = 4;
+constexpr int kProjWriters = kProjectWriters;
 constexpr int kProjPerWriter = kProjStreamers / kProjWriters;
 constexpr int kProjThreads = 64 * (kProjStreamers + kProjWriters);
 #ifndef IMM3_PROJ_RING_KB
@@ -171,7 +173,7 @@ constexpr bool kProjDepth2 = false; // two tiles of loads in flight per streamer
 constexpr int kProjSlots = 4;   // published ranges a streamer may have waiting for its writer
 
 // ---------------------------------------------------------------------------------------------
-// writer side: the records of one range (in the streamer's LDS ring, or -- slow path -- in its arena in HBM) -> output rows
+// writer side: the records of one range (in the streamer's LDS ring) -> output rows
 // base .. base + n.  The record layout is a compile-time function of the column kinds, so the row index and every
 // predicate column come out of a record with a shift; what is run-time is only WHERE a column goes (a.pred_dst[k], null =
 // not in the SELECT list) and the gathered columns.  A lane owns four consecutive output rows -- a quad aligned in the
@@ -276,7 +278,7 @@ __device__ __forceinline__ void gather_range(const ProjectArgs &a, const typenam
     }
 }
 
-// src: the ring (start, cap = its position and capacity) or the arena (start 0, cap ~0)
+// src: the streamer's ring (start, cap = the range's position in it and its capacity)
 template <int K0, int K1, int K2>
 __device__ __forceinline__ void unpack_range(const ProjectArgs &a, const typename Rec<K0, K1, K2>::vec *src, uint32_t start, uint32_t cap, uint32_t n,
                                              uint32_t base, uint32_t tile0, int lane) {
@@ -330,6 +332,179 @@ __device__ __forceinline__ void unpack_range(const ProjectArgs &a, const typenam
     }
 }
 
+// A DENSE range: its survivors did not fit the streamer's ring (a run of rows that mostly survive), or it holds the segment's
+// partial last tile.  The streamer kept the count and the bitmap lines only; the writer takes the rows from the source
+// columns again, at the set bits of the range's bitmap lines: rank = set bits below the row, as the streamer's compaction
+// computes it.  Per tile and column: sixteen predicated loads in flight, then sixteen predicated stores; a fully surviving
+// tile is a straight copy.  The columns were read a moment ago by this CU (L2 / the memory-side cache usually still hold
+// them); nothing goes through HBM twice the way spilled records did (the first version moved an outgrown range to an
+// arena in HBM: written, read back, written again -- 50 M contiguous survivors took 319 us).
+constexpr int kDenseWords = kTileWords / 2; // a UNIT of the dense path: half a tile, eight bitmap words
+
+// What a writer keeps of a unit between issuing its loads and storing its rows: the loaded values and where the unit's
+// rows start.  The rest (which rows, which output slots) is a few scalar and mbcnt instructions away from the bitmap
+// line and is computed again at store time rather than held in registers: registers are what bounds the loads in flight.
+struct DenseSet {
+    uint32_t v[3][kDenseWords]; // the predicate columns' values at the lane's rows
+    unsigned long long ubase;   // output slot of the unit's first survivor
+};
+
+// Four units are in flight per writer (two when more than one predicate column is projected: registers): a unit's loads
+// are issued three units before its rows are stored (the register sets take turns, as the streamers' tile buffers do);
+// the bitmap lines come four tiles -- a CHUNK: 64 words, one per lane -- at a time, the next chunk's fetched while this
+// one's are worked on.  The loop body is STRAIGHT-LINE code: every lane loads (a row that does not survive loads the
+// unit's first row) and every lane stores (a row that is not wanted stores to the wave's trash line), because with a
+// branch per predicated access the compiler waits for ALL outstanding loads (s_waitcnt vmcnt(0)) before every store --
+// one unit in flight whatever the source says.  (Tile by tile, with the tile's bitmap line fetched first and its stores
+// behind its loads, a dense tile cost a writer three dependent round trips: 5 us; with two units and vmcnt(0): 3.5 us.)
+template <int K0, int K1, int K2>
+__device__ __forceinline__ void unpack_dense(const ProjectArgs &a, int64_t tile0, int P, unsigned long long base, int lane, void *trash) {
+    const int64_t n_words = (a.n_rows + 63) / 64;
+    int n_t = P;
+    if ((int64_t)n_t > a.n_tiles - tile0) n_t = (int)(a.n_tiles - tile0);
+    const int n_units = 2 * n_t;
+    constexpr int NS = ((K0 != TK_NONE) + (K1 != TK_NONE) + (K2 != TK_NONE)) <= 1 ? 4 : 2; // units in flight
+    const unsigned long long cap_rows = IMM3_ABLATE_BIT(a, 16) ? 0ULL : a.cap_rows; // (ablation: no stores)
+    // a predicate column that is not in the SELECT list is loaded and stored to the trash line all the same (no branch)
+    void *d0 = a.pred_dst[0] ? a.pred_dst[0] : trash, *d1 = a.pred_dst[1] ? a.pred_dst[1] : trash, *d2 = a.pred_dst[2] ? a.pred_dst[2] : trash;
+    const bool t0 = !a.pred_dst[0], t1 = !a.pred_dst[1], t2 = !a.pred_dst[2];
+    auto fetch_lines = [&](int c) __attribute__((always_inline)) -> unsigned long long { // lane l: word l of the four tiles of chunk c (stored by a streamer of this work-group: read past the L1)
+        const int64_t word = (tile0 + 4 * c) * kTileWords + lane;
+        const bool in = 4 * c < n_t && word < n_words && word < (tile0 + n_t) * kTileWords;
+        const unsigned long long line = __hip_atomic_load(a.bitmap + (in ? word : tile0 * kTileWords), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return in ? line : 0ULL;
+    };
+    unsigned long long line_prev = 0ULL, line_cur = fetch_lines(0), line_nxt = fetch_lines(1); // the bitmap lines of the previous, this and the next chunk
+    int cur_chunk = 0;
+    // the bitmap words of unit t
+    auto unit_words = [&](int t, uint64_t (&m)[kDenseWords]) __attribute__((always_inline)) {
+        const int j = t >> 1;
+        const unsigned long long line = (j >> 2) == cur_chunk ? line_cur : line_prev; // wave-uniform choice (a unit is stored up to NS units after it was issued)
+        const uint32_t lo = (uint32_t)line, hi = (uint32_t)(line >> 32);
+        const int f0 = (j & 3) * kTileWords + (t & 1) * kDenseWords;
+        const bool live = t >= 0 && t < n_units; // (the pipeline's first and last rounds run on empty units)
+#pragma unroll
+        for (int w = 0; w < kDenseWords; ++w) {
+            m[w] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, f0 + w) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)lo, f0 + w);
+            if (!live) m[w] = 0ULL;
+        }
+    };
+    // the lane's row of word w is stored: set in the bitmap, and its output slot o below the capacity (rows past it: the host
+    // gathers again from the bitmap)
+    auto stored = [&](uint64_t m, unsigned long long done, uint32_t &o) __attribute__((always_inline)) -> bool {
+        const unsigned long long o64 = done + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        o = (uint32_t)o64;
+        return __builtin_amdgcn_inverse_ballot_w64(m) && o64 < cap_rows;
+    };
+    auto row_of = [&](int t) __attribute__((always_inline)) -> uint32_t { return (uint32_t)((tile0 + (t >> 1)) * kTileRows) + (uint32_t)((t & 1) * kDenseWords * 64) + (uint32_t)lane; };
+    auto issue = [&](DenseSet &S, int t) __attribute__((always_inline)) {
+        uint64_t m[kDenseWords];
+        unit_words(t, m);
+        S.ubase = base;
+        const int tt = t < n_units ? t : 0;             // (an empty unit loads tile 0's rows: valid addresses)
+        const uint32_t row0 = row_of(tt), safe = row_of(tt & ~1) - (uint32_t)lane; // safe: the tile's first row
+        auto load_col = [&](auto kind, const void *src, uint32_t (&v)[kDenseWords]) __attribute__((always_inline)) {
+            constexpr int K = decltype(kind)::value;
+            if constexpr (K != TK_NONE) {
+                unsigned long long done = S.ubase;
+#pragma unroll
+                for (int w = 0; w < kDenseWords; ++w) {
+                    uint32_t o;
+                    const bool p = stored(m[w], done, o);
+                    v[w] = load_value<kind_width(K)>(src, (int64_t)(p ? row0 + 64u * (uint32_t)w : safe));
+                    done += (uint32_t)__popcll(m[w]);
+                }
+            }
+        };
+        load_col(std::integral_constant<int, K0>(), a.cols[0].data, S.v[0]);
+        load_col(std::integral_constant<int, K1>(), a.cols[1].data, S.v[1]);
+        load_col(std::integral_constant<int, K2>(), a.cols[2].data, S.v[2]);
+#pragma unroll
+        for (int w = 0; w < kDenseWords; ++w) base += (uint32_t)__popcll(m[w]);
+    };
+    auto flush = [&](const DenseSet &S, int t) __attribute__((always_inline)) {
+        uint64_t m[kDenseWords];
+        unit_words(t, m);
+        const uint32_t row0 = row_of(t);
+        {
+            unsigned long long done = S.ubase;
+#pragma unroll
+            for (int w = 0; w < kDenseWords; ++w) {
+                uint32_t o;
+                const bool p = stored(m[w], done, o);
+                uint32_t *dst = p ? a.row_index + o : (uint32_t *)trash;
+                *dst = row0 + 64u * (uint32_t)w;
+                done += (uint32_t)__popcll(m[w]);
+            }
+        }
+        auto store_col = [&](auto kind, void *dst, bool to_trash, const uint32_t (&v)[kDenseWords]) __attribute__((always_inline)) {
+            constexpr int K = decltype(kind)::value;
+            if constexpr (K != TK_NONE) {
+                unsigned long long done = S.ubase;
+#pragma unroll
+                for (int w = 0; w < kDenseWords; ++w) {
+                    uint32_t o;
+                    const bool p = stored(m[w], done, o) && !to_trash;
+                    store_value<kind_width(K)>(p ? dst : trash, p ? o : 0u, v[w]);
+                    done += (uint32_t)__popcll(m[w]);
+                }
+            }
+        };
+        store_col(std::integral_constant<int, K0>(), d0, t0, S.v[0]);
+        store_col(std::integral_constant<int, K1>(), d1, t1, S.v[1]);
+        store_col(std::integral_constant<int, K2>(), d2, t2, S.v[2]);
+    };
+    DenseSet S[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) S[i].ubase = 0ULL;
+#pragma unroll 1
+    for (int t = 0; t < n_units + NS; t += NS) { // (the first round only loads, the last one only stores)
+        if ((t & 7) == 0 && t > 0) { // a new chunk (eight units): the units in flight are of the previous one
+            line_prev = line_cur;
+            line_cur = line_nxt;
+            cur_chunk = t >> 3;
+            line_nxt = fetch_lines(cur_chunk + 1);
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            flush(S[i], t - NS + i);
+            issue(S[i], t + i);
+        }
+    }
+    if (a.n_gather == 0) return;
+    // ---- SELECT-list columns that are not predicate columns (only when the tuning forces this kernel on such a query): a
+    // second walk over the range, unit by unit
+    unsigned long long gbase = base;
+#pragma unroll 1
+    for (int t = n_units - 1; t >= 0; --t) { // backwards from the range's end: base is now the slot behind its last row
+        const int64_t word0 = (tile0 + (t >> 1)) * kTileWords + (t & 1) * kDenseWords;
+        unsigned long long line = 0ULL;
+        if (lane < kDenseWords && word0 + lane < n_words) line = __hip_atomic_load(a.bitmap + word0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t m[kDenseWords];
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < kDenseWords; ++w) {
+            m[w] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(line >> 32), w) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)line, w);
+            total += (uint32_t)__popcll(m[w]);
+        }
+        gbase -= total;
+        if (total == 0) continue;
+        const uint32_t row0 = row_of(t);
+        for (int c = 0; c < a.n_gather; ++c) {
+            const void *src = a.gather[c].src;
+            void *dst = a.gather[c].dst;
+            const int width = a.gather[c].width;
+            unsigned long long done = gbase;
+#pragma unroll
+            for (int w = 0; w < kDenseWords; ++w) {
+                uint32_t o;
+                if (stored(m[w], done, o)) store_value_rt(dst, width, o, load_value_rt(src, width, (int64_t)(row0 + 64u * (uint32_t)w)));
+                done += (uint32_t)__popcll(m[w]);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // streamer side: one record per survivor of a tile, compacted in ascending row order.  rank = set bits below the row in
 // its word (v_mbcnt) + the survivors of the earlier words (scalar); the store is predicated by the word itself.
@@ -376,6 +551,7 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
     __shared__ uint32_t s_span_ready;              // spans of this work-group whose eight ranges are all published ...
     __shared__ uint32_t s_announced;               // ... and how many of them a writer has announced to the other work-groups
     __shared__ uint32_t s_part[kProjStreamers];
+    __shared__ uint32_t s_dense_ranges;            // ranges of this work-group that outgrew their ring (the host sizes P by it)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x] = wall_clock64();
@@ -389,6 +565,7 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
         s_prefix_seq = 0u;
         s_span_ready = 0u;
         s_announced = 0u;
+        s_dense_ranges = 0u;
     }
     const uint32_t epoch = (uint32_t)a.finish[kFinishEpoch];
     // ONE launch of this kernel per device at a time: two of them, each holding part of the CUs and waiting for work-groups
@@ -415,7 +592,6 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
         uint8_t *xp = s_xpose[wave];
         uint64_t *park = s_park[wave];
         const int64_t n_full = a.n_rows / kTileRows;
-        vec *arena = (vec *)a.arena + ((int64_t)blockIdx.x * kProjStreamers + wave) * a.wave_cap;
         // Prefetch: the wave's next full tile is loading while it works on one.  Two register sets take turns (the tile loop
         // calls its body with the roles swapped every tile: no register copies); the prefetch HEAD walks the wave's tiles in
         // the order the loop below meets them -- range by range, span by span.
@@ -451,14 +627,13 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
         int64_t s = blockIdx.x;
         uint32_t tail_pos = 0, tail_total = 0; // where the next record goes in the ring; records ever put there (minus those taken back by a spill)
         uint32_t head_seen = 0;                // the ring's head as last read from LDS (it only grows: a stale value is a safe one)
-        uint32_t arena_range = 0;              // 1 + the last range that used the arena
         bool abandoned = false;
         if (lds_peek(&s_abort)) abandoned = true; // (the device is busy with another launch of this kernel)
         for (uint32_t i = 0; s < a.n_spans && !abandoned; s += gridDim.x, ++i) {
             const int64_t t0 = (s * kProjStreamers + wave) * P;
             const uint32_t range_start = tail_pos;
-            uint32_t range_cnt = 0; // records of this range (ring or arena)
-            bool in_arena = false;
+            uint32_t range_cnt = 0; // survivors of this range
+            bool dense = false;     // the range keeps no records (see unpack_dense)
             int parked = 0, first_parked = 0;
             auto flush_park = [&]() { // 4 lines (4 x 16 lanes) per store instruction; the lines of consecutive tiles are contiguous
                 lds_wave_sync();
@@ -468,23 +643,11 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
                 first_parked += parked;
                 parked = 0;
             };
-            // the range outgrows the ring: what it has there moves to the arena, the rest follows directly
-            auto to_arena = [&]() {
-                while (lds_peek(&s_drained[wave]) < arena_range) { // the arena's previous range must have been unpacked
-                    if (lds_peek(&s_abort)) { abandoned = true; return; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                lds_wave_order();
-                for (uint32_t k = lane; k < range_cnt; k += 64) {
-                    uint32_t idx = range_start + k;
-                    if (idx >= kCap) idx -= kCap;
-                    arena[k] = ring[idx];
-                }
-                lds_wave_order();
+            // the range outgrows the ring: it becomes a dense one -- what it has in the ring is given back
+            auto to_dense = [&]() {
                 tail_total -= range_cnt;
                 tail_pos = range_start;
-                in_arena = true;
-                arena_range = i + 1;
+                dense = true;
             };
             // one full tile: its columns are in (c0, c1, c2); the next tile's go to (n0, n1, n2)
             auto full_tile = [&](ColRegs<K0> &c0, ColRegs<K1> &c1, ColRegs<K2> &c2, ColRegs<K0> &n0, ColRegs<K1> &n1, ColRegs<K2> &n2, int j) {
@@ -520,8 +683,12 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
 #pragma unroll
                     for (int w = 0; w < kTileWords; ++w) cnt += (uint32_t)__popcll(acc[w]);
                     if (IMM3_ABLATE_BIT(a, 4)) cnt = 0; // (no records at all)
-                    if (!in_arena && range_cnt + cnt > kCap) to_arena();
-                    if (!in_arena && tail_total + cnt - head_seen > kCap) { // room in the ring?  Only undrained EARLIER ranges can be in the way: the writer frees them
+                    if (!dense && range_cnt + cnt > kCap) to_dense();
+                    if (dense) { // count and bitmap only
+                        range_cnt += cnt;
+                        return;
+                    }
+                    if (tail_total + cnt - head_seen > kCap) { // room in the ring?  Only undrained EARLIER ranges can be in the way: the writer frees them
                         while (tail_total + cnt - (head_seen = lds_peek(&s_head[wave])) > kCap) {
                             if (lds_peek(&s_abort)) { abandoned = true; break; }
                             __builtin_amdgcn_s_sleep(2);
@@ -530,9 +697,6 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
                     if (abandoned) return;
                     const uint32_t lane_j = (uint32_t)lane | ((uint32_t)j << 10);
                     if (cnt == 0) {
-                    } else if (in_arena) { // (slow path: straight to HBM)
-                        vec *dst = arena + range_cnt;
-                        compact_tile<K0, K1, K2>(acc, c0, c1, c2, lane_j, [&](uint32_t rank, vec v) { dst[rank] = v; });
                     } else if (tail_pos + cnt <= kCap) { // the common case: the tile's records do not wrap around the ring
                         vec *dst = ring + tail_pos;
                         compact_tile<K0, K1, K2>(acc, c0, c1, c2, lane_j, [&](uint32_t rank, vec v) { dst[rank] = v; });
@@ -544,11 +708,9 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
                         });
                     }
                     range_cnt += cnt;
-                    if (!in_arena) {
-                        tail_total += cnt;
-                        tail_pos += cnt;
-                        if (tail_pos >= kCap) tail_pos -= kCap;
-                    }
+                    tail_total += cnt;
+                    tail_pos += cnt;
+                    if (tail_pos >= kCap) tail_pos -= kCap;
             };
             for (int j = 0; j < P && !abandoned; ++j) {
                 const int64_t tile = t0 + j;
@@ -558,16 +720,14 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
                     else full_tile(B0, B1, B2, A0, A1, A2, j);
                     cur_is_A = !cur_is_A;
                 } else {
-                    // the one partial tile at the end of the segment: rolled, bounds-checked; its range goes through the arena
+                    // the one partial tile at the end of the segment: rolled, bounds-checked; its range is a dense one
                     flush_park();
-                    if (!in_arena) to_arena();
-                    if (abandoned) break;
+                    if (!dense) to_dense();
                     const int64_t row0 = tile * kTileRows, valid_rows = a.n_rows - row0;
                     ColRegs<K0> c0;
                     ColRegs<K1> c1;
                     ColRegs<K2> c2;
                     uint64_t mine = ~0ULL;
-                    uint32_t done = 0;
 #pragma unroll 1
                     for (int w = 0; w < kTileWords; ++w) {
                         const int64_t r_in = 64 * w + lane;
@@ -577,15 +737,8 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
                         if (valid) keep = c0.row(a.cols[0].data, a.cols[0], r) && c1.row(a.cols[1].data, a.cols[1], r) && c2.row(a.cols[2].data, a.cols[2], r);
                         const uint64_t m = ballot64(keep);
                         if (lane == w) mine &= m;
-                        uint32_t rec[4] = {(uint32_t)r_in | ((uint32_t)j << 10), 0u, 0u, 0u};
-                        L::template put<0>(rec, c0.rowval(a.cols[0].data, r));
-                        L::template put<1>(rec, c1.rowval(a.cols[1].data, r));
-                        L::template put<2>(rec, c2.rowval(a.cols[2].data, r));
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, done));
-                        if (keep) arena[range_cnt + rank] = L::pack(rec);
-                        done += (uint32_t)__popcll(m);
+                        range_cnt += (uint32_t)__popcll(m);
                     }
-                    range_cnt += done;
                     mine &= low_mask(valid_rows - 64 * (int64_t)lane);
                     if (lane >= kTileWords) mine = 0;
                     const int64_t word = tile * kTileWords + lane;
@@ -601,11 +754,12 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
                 __builtin_amdgcn_s_sleep(2);
             }
             if (abandoned) break;
-            if (in_arena) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the writer (another wave of this CU) reads the arena: the stores must have landed
+            if (dense) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the writer (another wave of this CU) reads the range's bitmap lines: the stores must have landed
             if (lane == 0) {
+                if (dense) __hip_atomic_fetch_add(&s_dense_ranges, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 s_pub[wave][i % kProjSlots].start = range_start;
                 s_pub[wave][i % kProjSlots].cnt = range_cnt;
-                s_pub[wave][i % kProjSlots].in_arena = in_arena ? 1u : 0u;
+                s_pub[wave][i % kProjSlots].dense = dense ? 1u : 0u;
             }
             // the work-group's last range of the span to finish says so: the span can be announced to the other work-groups
             {
@@ -702,14 +856,13 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
             for (int q = 0; q < kProjPerWriter && !dead; ++q) {
                 if (!announce()) { dead = true; break; } // (the next span may have finished streaming meanwhile)
                 const int w = w_first + q;
-                const uint32_t cnt = s_pub[w][slot].cnt, start = s_pub[w][slot].start, in_arena = s_pub[w][slot].in_arena;
+                const uint32_t cnt = s_pub[w][slot].cnt, start = s_pub[w][slot].start, dense = s_pub[w][slot].dense;
                 if (!IMM3_ABLATE_BIT(a, 1)) {
                     const uint32_t tile0 = (uint32_t)((s * kProjStreamers + w) * P);
                     const uint32_t b32 = base > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)base;
-                    if (in_arena) { // (slow path)
+                    if (dense) {
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                        const vec *ar = (const vec *)a.arena + ((int64_t)blockIdx.x * kProjStreamers + w) * a.wave_cap;
-                        unpack_range<K0, K1, K2>(a, ar, 0u, 0xFFFFFFFFu, cnt, b32, tile0, lane);
+                        unpack_dense<K0, K1, K2>(a, (int64_t)tile0, P, base, lane, a.trash + ((size_t)blockIdx.x * kProjWriters + wr) * 64);
                     } else {
                         unpack_range<K0, K1, K2>(a, (const vec *)&s_ring[w][0], start, kCap, cnt, b32, tile0, lane);
                     }
@@ -717,7 +870,7 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
                 base += cnt;
                 lds_wave_order();
                 if (lane == 0) { // the range is free again (behind the ring reads above: a wave's LDS operations execute in order)
-                    if (!in_arena) lds_poke(&s_head[w], lds_peek(&s_head[w]) + cnt);
+                    if (!dense) lds_poke(&s_head[w], lds_peek(&s_head[w]) + cnt);
                     lds_poke(&s_drained[w], k + 1);
                 }
             }
@@ -735,9 +888,12 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
         unsigned long long t = 0;
 #pragma unroll
         for (int w = 0; w < kProjStreamers; ++w) t += s_part[w];
-        if (finish_add(a.finish, t)) { // the launch's last work-group: every round is over, the arrival counters start the next run at zero
-            uint32_t *round_ctr = (uint32_t *)(a.desc + a.n_spans + a.n_rounds);
-            for (int64_t r = 0; r < a.n_rounds; ++r) round_ctr[r] = 0u;
+        if (s_dense_ranges) __hip_atomic_fetch_add(a.finish + kFinishDense + 1, (unsigned long long)s_dense_ranges, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // (the sum is read by the launch's last work-group, behind its arrival below)
+        if (finish_add(a.finish, t)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            a.finish[kFinishDense] = __hip_atomic_exchange(a.finish + kFinishDense + 1, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // the launch's last work-group: every round is over, the arrival counters start the next run at zero
+            for (int64_t r = 0; r < a.n_rounds; ++r) a.round_ctr[r] = 0u;
             if (a.device_lock) { // hand the device on (only if the ticket in the lock is this launch's)
                 unsigned long long mine = ticket;
                 __hip_atomic_compare_exchange_strong(a.device_lock, &mine, 0ULL, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

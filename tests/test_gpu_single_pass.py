@@ -2,7 +2,8 @@
 uniform segment in ONE launch, which is ProjectIterator.next's one walk over the set bits
 (engine/src/main/scala/immutabledb/engine/operator/Project.scala:37-64).  Through the C ABI, bit-exact: bitmap, count,
 ascending row order, values.  Covered: every column-kind instance at every fill level with several rounds of spans and a
-partial last tile (numpy at that size, the oracle at a smaller one), dense survivors (the ranges spill to the arena),
+partial last tile (numpy at that size, the oracle at a smaller one), dense survivors (ranges that outgrow their LDS ring are
+unpacked from the source columns; once the host has seen the count, later runs use shorter ranges),
 reservations that are too small (the host gathers again from the bitmap), an abandoned run (the host answers through the
 bitmap path), graph replays (the descriptors' epochs), a second mention of a column in the SELECT list, and two contexts
 launching the kernel at once (the launches are chained: its work-groups wait on each other and need the device)."""
@@ -222,4 +223,53 @@ def test_steady_state_projections_never_wait_for_the_device(ctx, big):
         assert q.plan()["run_syncs"] == first_run_syncs, (name, q.plan())
         rows = q.row_count()
         assert rows == q.count()
+        q.close()
+
+
+def test_tiles_per_range_follow_the_selectivity(ctx, big):
+    """A range whose survivors outgrow the streamer's LDS ring is unpacked from the source columns (unpack_dense); once the host has
+    read a run's count, later runs use a P at which the ranges fit again -- unless the survivors are clustered so densely (a
+    range predicate on the sorted key) that no useful P would.  Same rows either way; a graph recorded with the first P keeps
+    replaying correctly next to direct runs with the new one."""
+    n, data, seg = big
+    a, b, c = data[0], data[1], data[2]
+    cases = {
+        "spread, int8":        ([2], [(0, GT, 49.0)], c > 49, "smaller"),
+        "spread, int8 + int32": ([2, 0], [(0, GT, 29.0), (1, GT, float(0.2 * 2 ** 30))], (c > 29) & (a > 0.2 * 2 ** 30), "smaller"),
+        "nearly all, int8":    ([2], [(0, GT, 0.0)], c > 0, "smaller"),
+        "clustered, int32":    ([1], [(0, GT, float(n // 2))], b > n // 2, "same"),
+        "sparse":              ([2, 0], [(0, GT, 89.0), (1, GT, float(0.5 * 2 ** 30))], (c > 89) & (a > 0.5 * 2 ** 30), "same"),
+    }
+    for name, (used, sels, keep, expect) in cases.items():
+        rows = np.flatnonzero(keep)
+        q = native.DeviceQuery(ctx, seg, used, sels, list(range(len(used))), 0)
+        p0 = q.plan()
+        assert p0["single_pass"], (name, p0)
+        q.run()
+        g = None
+        if name == "spread, int8":                     # recorded with the planned P, before the host has seen a count
+            with ctx.capture() as cap:
+                q.run()
+            g = cap.graph
+        assert q.count() == rows.size, name            # the host learns the count (and how many ranges outgrew their ring)
+        p1 = q.plan()
+        assert p1["ran_single_pass"], (name, p1)
+        if expect == "smaller":
+            assert 2 <= p1["P"] < p0["P"], (name, p0, p1)
+        else:
+            assert p1["P"] == p0["P"], (name, p0, p1)
+        for rnd in range(3):
+            if g is not None and rnd == 1:
+                g.launch()                             # the old P, between two runs with the new one
+            else:
+                q.run()
+            assert q.count() == rows.size, (name, rnd)
+            idx, vals = q.fetch_rows()
+            assert q.plan()["ran_single_pass"], (name, rnd)
+            assert idx.size == rows.size and (idx == rows).all(), (name, rnd)
+            for j, u in enumerate(used):
+                assert vals[j].tobytes() == np.ascontiguousarray(data[u][rows]).tobytes(), (name, rnd, u)
+        assert q.plan()["P"] == p1["P"], (name, "P keeps still once it fits")
+        if g is not None:
+            g.close()
         q.close()

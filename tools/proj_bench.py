@@ -20,6 +20,9 @@ cases = {
     "age->id": ([2, 0], [(0, native.GT, 18.0), (0, native.LT, 30.0)], [1]),          # projected column is NOT a predicate column
     "id2%": ([0], [(0, native.GT, 9.8e7)], [0]),
     "id50%": ([0], [(0, native.GT, 5e7)], [0]),                                       # sigma = 0.5
+    "age50%": ([2], [(0, native.LT, 50.0)], [0]),                                     # sigma = 0.5, uniformly spread
+    "age30%+id": ([2, 0], [(0, native.GT, 18.0), (0, native.LT, 50.0), (1, native.GT, 1e6), (1, native.LT, 9e7)], [1, 0]),
+    "age99%": ([2], [(0, native.LT, 99.0)], [0]),
 }
 names = {0: "filter", 1: "scan", 2: "project", 3: "count"}
 import os
