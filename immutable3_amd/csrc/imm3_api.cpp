@@ -949,7 +949,7 @@ static void single_pass_adapt(imm3_query *q, uint64_t survivors, int64_t dense_r
     if (dense_ranges < 0 && q->sp_have_stats) return; // (a reservation says less than a run did)
     if (dense_ranges >= 0) q->sp_have_stats = true;
     const int R = project_rec_dwords(q->stage_kinds);
-    const double ring_records = 14.0 * 1024.0 / (4.0 * R); // (kProjRingBytes of imm3_project.hip)
+    const double ring_records = (double)kProjectRingBytes / (4.0 * R);
     double sigma = (double)survivors / (double)q->n_rows;
     const double n_ranges = (double)q->sp_spans * kProjectStreamers;
     if (dense_ranges > 0 && (double)dense_ranges > 0.02 * n_ranges) sigma = std::min(1.0, sigma * n_ranges / (double)dense_ranges);
@@ -1238,7 +1238,7 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
                 // 127-133 us, P = 12 143 us, P = 4 154 us.
                 int maxg = project_max_grid(q->stage_kinds, 0);
                 if (ctx->grid_blocks > 0) maxg = std::min(maxg, ctx->grid_blocks.load());
-                const int64_t ring_records = 14 * 1024 / (4 * R); // (kProjRingBytes of imm3_project.hip)
+                const int64_t ring_records = kProjectRingBytes / (4 * R);
                 int64_t p_hi = std::max<int64_t>(4, std::min<int64_t>(16, ring_records / 3 / 85));
                 if (tile_bytes > 0) p_hi = std::max<int64_t>(4, std::min<int64_t>(p_hi, (60 * 1024) / tile_bytes));
                 const int64_t p_lo = std::max<int64_t>(4, p_hi - 1);

@@ -156,16 +156,26 @@ void launch_emit(const EmitArgs &a, int n_gather, int grid_blocks, hipStream_t s
 // ---- k_filter_project (imm3_project.hip): ScanOp -> SelectOp* -> ProjectOp of one uniform segment in ONE pass ----
 // A work-group owns SPANS of kProjectStreamers * P consecutive tiles (each of its streaming waves P consecutive tiles);
 // spans go to the work-groups round-robin.  The survivors' records of a wave's range wait in LDS; where they go in the output -- the
-// number of survivors in all earlier tiles -- comes from a chained scan over per-span DESCRIPTORS (decoupled look-back):
+// number of survivors in all earlier tiles -- comes from a scan over per-span DESCRIPTORS, one ROUND of spans (one span per
+// work-group) at a time: the round's last span to arrive scans the round's counts (imm3_project.hip, span_arrive):
 //   desc[s] = epoch << 56 | flag << 54 | value     flag 1: value = survivors of span s (published when the span is done)
-//                                                  flag 2: value = survivors of spans 0..s (published after the look-back)
-//                                                  flag 3: the run is being abandoned (look-back timed out)
+//                                                  flag 2: value = survivors of spans 0..s-1: the span's first output row
+//                                                  flag 3: the run is being abandoned (a wait timed out)
 // `epoch` (finish[kFinishEpoch], bumped by the launch's last work-group) tells this run's descriptors from the previous
-// run's, so nothing is cleared between runs.
+// run's, so nothing is cleared between runs.  P is a launch argument: the host lowers it once it has seen how many rows
+// survive (imm3_api.cpp, single_pass_adapt); kProjectMinP sizes the descriptor array.
 constexpr int kProjectMinP = 1;
 constexpr int kProjectMaxP = 64;        // tiles per wave per span (the tile's index in its range takes 6 bits of the record)
-constexpr int kProjectStreamers = 8;  // waves of a work-group that stream tiles: a span is kProjectStreamers * P consecutive tiles
+// (tools: -DIMM3_PROJECT_STREAMERS=12 -DIMM3_PROJECT_RING_KB=9 was tried -- 16 waves cap the kernel at 128 VGPRs: C3 137 us against 125)
+#ifndef IMM3_PROJECT_STREAMERS
+#define IMM3_PROJECT_STREAMERS 8
+#endif
+#ifndef IMM3_PROJECT_RING_KB
+#define IMM3_PROJECT_RING_KB 14
+#endif
+constexpr int kProjectStreamers = IMM3_PROJECT_STREAMERS;  // waves of a work-group that stream tiles: a span is kProjectStreamers * P consecutive tiles
 constexpr int kProjectWriters = 4;    // waves of a work-group that write the rows
+constexpr int kProjectRingBytes = IMM3_PROJECT_RING_KB * 1024; // a streamer's LDS ring of survivor records
 constexpr int kFinishStatus = 2;        // finish[2]: bit 0 malformed PFOR block; single-pass projection: bit 1 abandoned (a prefix never came), bit 2 device busy
 constexpr int kFinishEpoch = 8;         // finish[8]: run counter of the query (descriptor epochs)
 constexpr int kFinishDense = 9;         // finish[9]: single-pass projection: ranges of the last run that outgrew their LDS ring (finish[10]: the running sum)

@@ -165,10 +165,7 @@ constexpr int kProjStreamers = kProjectStreamers;
 constexpr int kProjWriters = kProjectWriters;
 constexpr int kProjPerWriter = kProjStreamers / kProjWriters;
 constexpr int kProjThreads = 64 * (kProjStreamers + kProjWriters);
-#ifndef IMM3_PROJ_RING_KB
-#define IMM3_PROJ_RING_KB 14
-#endif
-constexpr int kProjRingBytes = IMM3_PROJ_RING_KB * 1024;
+constexpr int kProjRingBytes = kProjectRingBytes;
 constexpr bool kProjDepth2 = false; // two tiles of loads in flight per streamer instead of one
 constexpr int kProjSlots = 4;   // published ranges a streamer may have waiting for its writer
 
