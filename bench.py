@@ -378,7 +378,7 @@ def measure_c2(env: Env, steps: int, warmup: int, with_cpu_baseline: bool):
                                 "command on these kernel sources (kernel name and source hash match), committed; NOT re-measured in this run")
                     else:
                         tsrc = ("profiles/traffic.json REFUSED: it was measured on kernel '%s' / sources %s, this build is '%s' / %s -- "
-                                "re-run the --pmc passes (tools/summarize_prof2.py)" % (tj.get("kernel"), tj.get("source_sha16"), HEADLINE_KERNEL, headline_source_sha16()))
+                                "re-run the --pmc passes (tools/summarize_prof3.py)" % (tj.get("kernel"), tj.get("source_sha16"), HEADLINE_KERNEL, headline_source_sha16()))
             except Exception:
                 traffic = None
         out = {

@@ -3,7 +3,7 @@
 Copies the rocprofv3 summaries of one profiling session of `bench.py --no-cpu-baseline --no-c5` from gpurun_out/ (scratch)
 into profiles/ (tracked) and derives, per BASELINE config, kernel durations, HBM traffic and the fraction of the 8 TB/s peak.
 
-    tools/summarize_prof2.py <tag>        reads gpurun_out/<tag>_trace/, <tag>_fetch/, <tag>_write/ and <tag>_trace.log
+    tools/summarize_prof3.py <tag>        reads gpurun_out/<tag>_trace/, <tag>_fetch/, <tag>_write/ and <tag>_trace.log
 
 FETCH_SIZE (KB) counts 64 B per 128-B request on gfx950 for wide coalesced streaming reads -> x2 (MI355X_MICROARCH.md, HBM
 section; calibrated in this session on k_read_stream, which reads exactly 400.0 MB).  For kernels whose reads are NOT wide
