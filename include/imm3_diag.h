@@ -45,7 +45,7 @@ int imm3_ctx_set_tuning(imm3_ctx *ctx, int32_t filter_variant, int32_t grid_bloc
 
 /* How the library planned a query (tests assert the path they mean to exercise; tools print it).
  * out[0] = 1 when an unlimited projection runs as ONE launch (k_filter_project: the filter kernel writes the rows), else 0;
- * out[1] = tiles per wave per span (P); out[2] = work-groups of that launch; out[3] = spans;
+ * out[1] = tiles per wave per span (P: lowered by the library once a getter has seen how many rows a run selected); out[2] = work-groups of that launch; out[3] = spans;
  * out[4] = 1 when the projection goes through survivor records in HBM (filter -> k_scan -> k_emit), else 0;
  * out[5] = dwords per survivor record; out[6] = 1 when the last run used the single-pass launch; out[7] = how often
  * imm3_query_run has waited for the device so far (an unreserved unlimited projection: once, on its first run).  n <= 8 values. */
