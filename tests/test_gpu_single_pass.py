@@ -273,3 +273,42 @@ def test_tiles_per_range_follow_the_selectivity(ctx, big):
         if g is not None:
             g.close()
         q.close()
+
+
+def test_gathered_columns_in_the_one_launch_when_the_tuning_hook_forces_it(big):
+    """The planner keeps gathered SELECT-list columns out of the single launch (the three launches are faster for them); the
+    diagnostics hook (imm3_ctx_set_tuning, variant 8) forces them in for A/B runs, so that code is reachable and has to be
+    right: columns gathered by the writers from records (gather_range) and, for ranges that outgrew their ring, from the
+    bitmap lines (unpack_dense's second walk).  Variant 6 -- never the single launch -- gives the same rows."""
+    n, data, seg0 = big
+    a, b, c, d, s2 = data
+    ctx8 = native.Context(0)
+    br = blocks_of(n, 1024)
+    cols = [RawColumn(DENSE_INT, 4, a, br), RawColumn(DENSE_INT, 4, b, br), RawColumn(DENSE_TINYINT, 1, c, br),
+            RawColumn(DENSE_TINYINT, 1, d, br), RawColumn(DENSE_STRING, 2, s2, br)]
+    seg = native.DeviceSegment(ctx8, [x.native() for x in cols])
+    cases = {
+        "sparse, one gathered":  ([2, 0], [(0, GT, 89.0)], [0, 1], c > 89),
+        "dense, two gathered":   ([2, 0, 4], [(0, GT, 9.0)], [1, 0, 2], c > 9),
+        "clustered, gathered narrow + second mention": ([1, 3], [(0, GT, float(n // 2))], [0, 1, 0], b > n // 2),
+    }
+    try:
+        for variant, want_single in ((8, True), (6, False)):
+            ctx8.set_tuning(variant, 0)
+            for name, (used, sels, proj, keep) in cases.items():
+                rows = np.flatnonzero(keep)
+                q = native.DeviceQuery(ctx8, seg, used, sels, proj, 0)
+                assert q.plan()["single_pass"] == want_single, (variant, name, q.plan())
+                for rnd in range(2):                           # (the second run: P adapted to the count the first one showed)
+                    q.run()
+                    assert q.count() == rows.size, (variant, name, rnd)
+                    idx, vals = q.fetch_rows()
+                    assert q.plan()["ran_single_pass"] == want_single, (variant, name, rnd)
+                    assert idx.size == rows.size and (idx == rows).all(), (variant, name, rnd)
+                    for j, pj in enumerate(proj):
+                        assert vals[j].tobytes() == np.ascontiguousarray(data[used[pj]][rows]).tobytes(), (variant, name, rnd, j)
+                q.close()
+    finally:
+        ctx8.set_tuning(0, 0)
+        seg.close()
+        ctx8.close()
