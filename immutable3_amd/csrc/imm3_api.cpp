@@ -967,6 +967,95 @@ static void single_pass_adapt(imm3_query *q, uint64_t survivors, int64_t dense_r
     (void)hipMemsetAsync(q->d_desc, 0, q->sp_trash_off, q->ctx->stream);
 }
 
+// Plans the one-launch projection for the tile columns in q->stage_kinds: P, the grid, the descriptor allocation.
+// q->single_pass stays false when the kernel cannot run here (no instance, no resident work-group).
+static int single_pass_setup(imm3_query *q) {
+    imm3_ctx *ctx = q->ctx;
+    const int R = project_rec_dwords(q->stage_kinds);
+    int64_t tile_bytes = 0;
+    for (int k = 0; k < kMaxTileCols; ++k)
+        tile_bytes += (q->stage_kinds[k] == TK_I32 ? 4 : (q->stage_kinds[k] == TK_S2 ? 2 : (q->stage_kinds[k] == TK_I8 ? 1 : 0))) * (int64_t)kTileRows;
+    // Tiles per wave and span (P).  Large enough that a span's prefix (a ~10 us chain through three other work-groups)
+    // and its unpacking fit in the time the streamers need for the next spans; small enough that three ranges of
+    // ~10 % survivors fit a streamer's LDS ring -- the streamers then never wait for a writer -- and that the last
+    // round, whose prefix nothing overlaps, is short.  Within that window P is the value that fills the last round of
+    // spans best (spans are dealt round-robin to one work-group per CU).  Measured on C3 (100 M rows, R = 2): P = 6-8
+    // 127-133 us, P = 12 143 us, P = 4 154 us.
+    int maxg = project_max_grid(q->stage_kinds, 0);
+    if (ctx->grid_blocks > 0) maxg = std::min(maxg, ctx->grid_blocks.load());
+    const int64_t ring_records = kProjectRingBytes / (4 * R);
+    int64_t p_hi = std::max<int64_t>(4, std::min<int64_t>(16, ring_records / 3 / 85));
+    if (tile_bytes > 0) p_hi = std::max<int64_t>(4, std::min<int64_t>(p_hi, (60 * 1024) / tile_bytes));
+    const int64_t p_lo = std::max<int64_t>(4, p_hi - 1);
+    int64_t P = p_hi;
+    double best = -1.0;
+    for (int64_t p = p_hi; p >= p_lo && maxg > 0; --p) {
+        const int64_t spans = (q->n_tiles + p * kProjectStreamers - 1) / (p * kProjectStreamers);
+        const int64_t rounds = (spans + maxg - 1) / maxg;
+        const double fill = (double)spans / (double)(rounds * maxg);
+        if (fill > best + 0.02) { best = fill; P = p; }
+    }
+    const bool fixed = ctx->filter_variant > 200 && ctx->filter_variant <= 200 + kProjectMaxP;
+    if (fixed) P = ctx->filter_variant - 200; // tuning: variant 200 + P
+    if (maxg < 1 || q->n_tiles < 1) return IMM3_OK;
+    q->single_pass = true;
+    q->sp_P_plan = (int32_t)P;
+    q->sp_P_fixed = fixed;
+    q->sp_max_grid = maxg;
+    single_pass_set_P(q, (int32_t)P);
+    // One allocation: round totals and round counters first (at the same place whatever P a run uses), then the span
+    // descriptors of the smallest P a run may use, then one 64-byte trash line per writer wave.
+    const int64_t spans_max = (q->n_tiles + kProjectMinP * kProjectStreamers - 1) / (kProjectMinP * kProjectStreamers);
+    const int64_t grid_min = std::min<int64_t>(maxg, spans_max);
+    q->sp_rounds_max = (size_t)((spans_max + grid_min - 1) / grid_min);
+    q->sp_desc_off = (q->sp_rounds_max * (sizeof(unsigned long long) + sizeof(uint32_t)) + 255) / 256 * 256;
+    const size_t desc_bytes = q->sp_desc_off + (size_t)spans_max * sizeof(unsigned long long);
+    q->sp_trash_off = (desc_bytes + 255) / 256 * 256;
+    void *d = nullptr;
+    HIPCHK(pool_alloc(ctx, &d, q->sp_trash_off + (size_t)maxg * kProjectWriters * 64));
+    q->d_desc = (unsigned long long *)d;
+    HIPCHK(hipMemsetAsync(q->d_desc, 0, desc_bytes, ctx->stream)); // (pooled memory: another query's descriptors)
+    return IMM3_OK;
+}
+
+// A projection with gathered SELECT-list columns was planned as three launches (records -> k_scan -> k_emit).  Now the host
+// knows how many rows survive: when that is enough for a gather to touch most 128-byte lines of the column anyway, the
+// column is STREAMED instead -- it joins the one-launch kernel as a tile column whose predicate every value passes, and its
+// values ride in the records like a predicate column's.  (`select id, age ... where age > 18 and age < 30`, 11 % of 100 M rows:
+// 123 us against 174; at 3 % the three launches win.)  Called outside a capture, before the query's row arrays exist or
+// from imm3_query_reserve_rows; the records' buffers go back to the pool.
+static int single_pass_stream_columns(imm3_query *q, uint64_t survivors) {
+    imm3_ctx *ctx = q->ctx;
+    if (!q->alt_ok || q->single_pass || ctx->capture || q->n_rows <= 0) return IMM3_OK;
+    const double sigma = (double)survivors / (double)q->n_rows;
+    if (ctx->filter_variant != 9 && sigma < q->alt_min_sigma) return IMM3_OK;
+    int32_t keep_kinds[kMaxTileCols], keep_cols[kMaxTileCols];
+    for (int k = 0; k < kMaxTileCols; ++k) {
+        keep_kinds[k] = q->stage_kinds[k];
+        keep_cols[k] = q->stage_seg_col[k];
+        q->stage_kinds[k] = q->alt_kinds[k];
+        q->stage_seg_col[k] = q->alt_seg_col[k];
+    }
+    const int rc = single_pass_setup(q);
+    if (rc || !q->single_pass) { // (cannot run here: the three launches stay)
+        for (int k = 0; k < kMaxTileCols; ++k) {
+            q->stage_kinds[k] = keep_kinds[k];
+            q->stage_seg_col[k] = keep_cols[k];
+        }
+        q->alt_ok = false;
+        return rc;
+    }
+    graphs_mark_stale(ctx, q); // (a graph that recorded the three launches points at buffers that go now)
+    pool_release(ctx, q->d_stage_rec);
+    pool_release(ctx, q->d_tile_start);
+    q->d_stage_rec = nullptr;
+    q->d_tile_start = nullptr;
+    q->stage_written = false;
+    q->alt_ok = false;
+    single_pass_adapt(q, survivors, -1);
+    return IMM3_OK;
+}
+
 static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_table *table,
                                  const int32_t *used_cols, int32_t n_used,
                                  const imm3_select *sels, int32_t n_sels,
@@ -1227,48 +1316,49 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
             // Only when every SELECT-list column is a predicate column (its values ride in the records): gathers issued by the
             // four writer waves of a CU are latency-bound (C4 154 us against 118 us with the emit kernel's 2048 work-groups).
             if (ctx->filter_variant != 6 && (n_gather == 0 || ctx->filter_variant == 8)) {
-                const int R = project_rec_dwords(q->stage_kinds);
-                int64_t tile_bytes = 0;
-                for (size_t k = 0; k < order.size(); ++k) tile_bytes += (int64_t)order[k]->width * kTileRows;
-                // Tiles per wave and span (P).  Large enough that a span's prefix (a ~10 us chain through three other work-groups)
-                // and its unpacking fit in the time the streamers need for the next spans; small enough that three ranges of
-                // ~10 % survivors fit a streamer's LDS ring -- the streamers then never wait for a writer -- and that the last
-                // round, whose prefix nothing overlaps, is short.  Within that window P is the value that fills the last round of
-                // spans best (spans are dealt round-robin to one work-group per CU).  Measured on C3 (100 M rows, R = 2): P = 6-8
-                // 127-133 us, P = 12 143 us, P = 4 154 us.
-                int maxg = project_max_grid(q->stage_kinds, 0);
-                if (ctx->grid_blocks > 0) maxg = std::min(maxg, ctx->grid_blocks.load());
-                const int64_t ring_records = kProjectRingBytes / (4 * R);
-                int64_t p_hi = std::max<int64_t>(4, std::min<int64_t>(16, ring_records / 3 / 85));
-                if (tile_bytes > 0) p_hi = std::max<int64_t>(4, std::min<int64_t>(p_hi, (60 * 1024) / tile_bytes));
-                const int64_t p_lo = std::max<int64_t>(4, p_hi - 1);
-                int64_t P = p_hi;
-                double best = -1.0;
-                for (int64_t p = p_hi; p >= p_lo && maxg > 0; --p) {
-                    const int64_t spans = (q->n_tiles + p * kProjectStreamers - 1) / (p * kProjectStreamers);
-                    const int64_t rounds = (spans + maxg - 1) / maxg;
-                    const double fill = (double)spans / (double)(rounds * maxg);
-                    if (fill > best + 0.02) { best = fill; P = p; }
+                const int rc = single_pass_setup(q.get());
+                if (rc) return rc;
+            }
+            if (!q->single_pass && n_gather > 0 && ctx->filter_variant != 6) {
+                // The alternative the first count may switch to (single_pass_stream_columns): every gathered column of the SELECT list
+                // (first mentions; dense int32 / int8) as a tile column that lets every value pass.
+                std::vector<FoldedPred> pass;
+                bool alt = true;
+                for (int32_t pj : q->proj) {
+                    const int32_t sci = q->used[(size_t)pj];
+                    bool have = false;
+                    for (const FoldedPred *fp : order) have |= fp->seg_col == sci;
+                    for (const FoldedPred &fp : pass) have |= fp.seg_col == sci;
+                    if (have) continue;
+                    const SegCol &sc = seg->cols[(size_t)sci];
+                    FoldedPred fp;
+                    fp.seg_col = sci;
+                    fp.width = sc.width;
+                    if (sc.codec == IMM3_DENSE_INT && sc.width == 4) { fp.kind = KIND_I32; fp.lo = INT32_MIN; fp.hi = INT32_MAX; }
+                    else if (sc.codec == IMM3_DENSE_TINYINT && sc.width == 1) { fp.kind = KIND_I8; fp.lo = -128; fp.hi = 127; }
+                    else { alt = false; break; }
+                    if (!col_flat(sc)) { alt = false; break; }
+                    pass.push_back(fp);
                 }
-                if (ctx->filter_variant > 200 && ctx->filter_variant <= 200 + kProjectMaxP) P = ctx->filter_variant - 200; // tuning: variant 200 + P
-                if (maxg >= 1 && q->n_tiles >= 1) {
-                    q->single_pass = true;
-                    q->sp_P_plan = (int32_t)P;
-                    q->sp_P_fixed = ctx->filter_variant > 200 && ctx->filter_variant <= 200 + kProjectMaxP;
-                    q->sp_max_grid = maxg;
-                    single_pass_set_P(q.get(), (int32_t)P);
-                    // One allocation: round totals and round counters first (at the same place whatever P a run uses), then the span
-                    // descriptors of the smallest P a run may use, then one 64-byte trash line per writer wave.
-                    const int64_t spans_max = (q->n_tiles + kProjectMinP * kProjectStreamers - 1) / (kProjectMinP * kProjectStreamers);
-                    const int64_t grid_min = std::min<int64_t>(maxg, spans_max);
-                    q->sp_rounds_max = (size_t)((spans_max + grid_min - 1) / grid_min);
-                    q->sp_desc_off = (q->sp_rounds_max * (sizeof(unsigned long long) + sizeof(uint32_t)) + 255) / 256 * 256;
-                    const size_t desc_bytes = q->sp_desc_off + (size_t)spans_max * sizeof(unsigned long long);
-                    q->sp_trash_off = (desc_bytes + 255) / 256 * 256;
-                    void *d = nullptr;
-                    HIPCHK(pool_alloc(ctx, &d, q->sp_trash_off + (size_t)maxg * kProjectWriters * 64));
-                    q->d_desc = (unsigned long long *)d;
-                    HIPCHK(hipMemsetAsync(q->d_desc, 0, desc_bytes, ctx->stream)); // (pooled memory: another query's descriptors)
+                if (alt && !pass.empty() && order.size() + pass.size() <= (size_t)kMaxTileCols) {
+                    q->sp_pass = pass;
+                    std::vector<const FoldedPred *> all(order);
+                    for (const FoldedPred &fp : q->sp_pass) all.push_back(&fp);
+                    std::stable_sort(all.begin(), all.end(), [](const FoldedPred *x, const FoldedPred *y) { return tile_kind(*x) < tile_kind(*y); });
+                    bool any4 = false;
+                    for (int k = 0; k < kMaxTileCols; ++k) {
+                        q->alt_kinds[k] = (size_t)k < all.size() ? tile_kind(*all[(size_t)k]) : (int)TK_NONE;
+                        q->alt_seg_col[k] = (size_t)k < all.size() ? all[(size_t)k]->seg_col : -1;
+                    }
+                    for (const FoldedPred &fp : q->sp_pass) any4 |= fp.width == 4;
+                    bool any_s2 = false;
+                    for (int k = 0; k < kMaxTileCols; ++k) any_s2 |= q->alt_kinds[k] == TK_S2;
+                    // Measured at 100 M rows (tools/proj_bench.py; one launch / three launches): age in (18, 30) -> id, 11 %: 123 / 174 us;
+                    // 5 %: 120 / 145; 3 %: 116 / 107.  Not with a string predicate (the 2-byte match streams at 74 us with the one-launch
+                    // kernel's 8 streaming waves per CU against 47: state in (5 values) -> age, 10 %: 181 / 120), and not for 1-byte
+                    // columns alone (their gather reads every line of the column from ~3 % on and still costs 33 us at 10 %).
+                    q->alt_min_sigma = 0.04;
+                    q->alt_ok = any4 && !any_s2;
                 }
             }
             if (q->single_pass) { /* no survivor records in HBM: the filter kernel writes the rows */ } else {            // Every wave of the staging launch writes its records to its own arena, so the launch geometry is fixed here:
@@ -1483,6 +1573,10 @@ extern "C" int imm3_query_reserve_rows(imm3_query *q, uint64_t rows) {
     const int rc = ensure_row_capacity(q, rows);
     if (rc) return rc;
     q->reserved = true;
+    if (rows < (uint64_t)q->n_rows) { // (a reservation skips the first run's look at the count: it is the estimate)
+        const int src = single_pass_stream_columns(q, rows);
+        if (src) return src;
+    }
     if (rows < (uint64_t)q->n_rows) single_pass_adapt(q, rows, -1); // (the reservation bounds the survivors)
     return IMM3_OK;
 }
@@ -1828,6 +1922,8 @@ static int run_single_pass(imm3_query *q) {
         const FoldedPred *fp = nullptr;
         for (const auto &p : q->preds)
             if (p.seg_col == q->stage_seg_col[k]) fp = &p;
+        for (const auto &p : q->sp_pass) // (a streamed SELECT-list column: every value passes)
+            if (p.seg_col == q->stage_seg_col[k]) fp = &p;
         if (!fp) return fail(IMM3_ERR_ARG, "internal: single-pass plan lost a predicate column");
         fill_tile_col(q, *fp, a.cols[k], a.kinds[k]);
     }
@@ -1995,6 +2091,11 @@ static int run_project(imm3_query *q) {
         HIPCHK(hipMemcpyAsync(&total, q->d_total, sizeof(total), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         ++q->run_syncs;
+        {   // enough survivors for the gathered columns to be streamed instead?  Then this run is done again as one launch
+            const int src = single_pass_stream_columns(q, total);
+            if (src) return src;
+            if (q->single_pass) return run_single_pass(q);
+        }
         const unsigned long long want = std::min<unsigned long long>((unsigned long long)std::max<int64_t>(q->n_rows, 1), total + total / 8 + 1024);
         const int rc = ensure_row_capacity(q, want);
         if (rc) return rc;

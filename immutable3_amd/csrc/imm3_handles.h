@@ -214,6 +214,11 @@ struct imm3_query {
     int64_t sp_spans = 0;                   // spans of 8 * P tiles
     int32_t sp_P_plan = 0, sp_max_grid = 0; // P as planned without knowing the selectivity (the ceiling of the adapted P); resident work-groups
     bool sp_P_fixed = false;                // P was set by the tuning hook: never adapted
+    // the alternative plan of a projection with gathered columns: those columns streamed as always-true tile columns
+    std::vector<FoldedPred> sp_pass;        // (once switched: part of the single-pass plan)
+    bool alt_ok = false;
+    int32_t alt_kinds[3] = {3, 3, 3}, alt_seg_col[3] = {-1, -1, -1};
+    double alt_min_sigma = 1.0;             // survivors / rows from which the alternative is the faster plan
     bool sp_have_stats = false;             // a run's count and dense-range tally have been seen (a reservation's estimate no longer moves P)
     size_t sp_rounds_max = 0;               // rounds at the smallest P: d_desc = {round totals, round counters, span descriptors (smallest P), trash lines}
     size_t sp_desc_off = 0;                 // byte offset of the span descriptors in d_desc's allocation

@@ -312,3 +312,51 @@ def test_gathered_columns_in_the_one_launch_when_the_tuning_hook_forces_it(big):
         ctx8.set_tuning(0, 0)
         seg.close()
         ctx8.close()
+
+
+def test_gathered_int32_columns_are_streamed_once_the_count_says_so(ctx, big):
+    """`select id, age ... where age > 18 and age < 30` (the reference README's example): id is not a predicate column, so the plan
+    made without knowing the selectivity is the three launches (records, offsets scan, emit with a gather of id).  The first run
+    reads the count anyway (it sizes the row arrays): from 4 % survivors on, the gathered int32 column is streamed through the
+    one-launch kernel as a tile column that lets every value pass -- same rows, in one launch, from that run on."""
+    n, data, seg = big
+    a, b, c, d, s2 = data
+    cases = {
+        # name: used, sels, proj, keep, switches
+        "11 %, id gathered":         ([2, 0], [(0, GT, 18.0), (0, LT, 30.0)], [1, 0], (c > 18) & (c < 30), True),
+        "10 %, two int32 gathered":  ([2, 0, 1], [(0, GT, 89.0)], [2, 0, 1], c > 89, True),
+        "second mention stays a gather": ([3, 0], [(0, GT, 30.0)], [1, 0, 1], d > 30, True),
+        "2 %: the three launches":   ([2, 0], [(0, GT, 97.0)], [1, 0], c > 97, False),
+        "string predicate":          ([4, 0], [(0, MATCH, [b"CA", b"NY", b"TX", b"WA", b"VA"])], [1], None, False),
+        "only a 1-byte column gathered": ([0, 2], [(0, GT, float(0.8 * 2 ** 30))], [1], a > 0.8 * 2 ** 30, False),
+    }
+    for name, (used, sels, proj, keep, switches) in cases.items():
+        if keep is None:
+            keep = np.zeros(n, bool)
+            for v in sels[0][2]:
+                keep |= (s2[:, 0] == v[0]) & (s2[:, 1] == v[1])
+        rows = np.flatnonzero(keep)
+        q = native.DeviceQuery(ctx, seg, used, sels, proj, 0)
+        p0 = q.plan()
+        assert not p0["single_pass"] and p0["records"], (name, p0)
+        for rnd in range(3):
+            q.run()
+            p = q.plan()
+            assert p["single_pass"] == switches and p["ran_single_pass"] == switches and p["records"] == (not switches), (name, rnd, p)
+            assert p["run_syncs"] == 1, (name, rnd, p)           # the first run's look at the count, never again
+            assert q.count() == rows.size, (name, rnd)
+            idx, vals = q.fetch_rows()
+            assert idx.size == rows.size and (idx == rows).all(), (name, rnd)
+            for j, pj in enumerate(proj):
+                assert vals[j].tobytes() == np.ascontiguousarray(data[used[pj]][rows]).tobytes(), (name, rnd, j)
+        q.close()
+    # a reservation stands in for the count the first run would have read
+    q = native.DeviceQuery(ctx, seg, [2, 0], [(0, GT, 18.0), (0, LT, 30.0)], [1, 0], 0)
+    rows = np.flatnonzero((c > 18) & (c < 30))
+    q.reserve_rows(rows.size + 100)
+    assert q.plan()["single_pass"] and not q.plan()["records"]
+    q.run()
+    assert q.plan()["run_syncs"] == 0 and q.plan()["ran_single_pass"]
+    idx, vals = q.fetch_rows()
+    assert (idx == rows).all() and (vals[0].view("<i4").reshape(-1) == a[rows]).all() and vals[1].tobytes() == c[rows].tobytes()
+    q.close()
