@@ -360,3 +360,45 @@ def test_gathered_int32_columns_are_streamed_once_the_count_says_so(ctx, big):
     idx, vals = q.fetch_rows()
     assert (idx == rows).all() and (vals[0].view("<i4").reshape(-1) == a[rows]).all() and vals[1].tobytes() == c[rows].tobytes()
     q.close()
+
+
+def test_random_sizes_predicates_and_select_lists(ctx):
+    """Differential run against numpy over random segment sizes (one row to a few hundred tiles, mostly not a multiple of the tile),
+    random predicates from no survivor to every row, clustered (sorted key) and spread, and random SELECT lists with second
+    mentions and columns that are not predicate columns -- three runs each with the count read in between, so the plan the host
+    adapts (tiles per range, streamed columns) is exercised at sizes where spans < work-groups and ranges are mostly empty."""
+    rng = np.random.default_rng(20261004)
+    for case in range(150):
+        n = int(rng.choice([1, 63, 1024, 1025, 5000, 70_001, 262_144, 400_000 + int(rng.integers(0, 1024))]))
+        # (values one above the types' minima, so that "every row" -- a threshold one below the smallest value -- is still a value of
+        # the type: the reference narrows thresholds the JVM way, (byte)(-129.0) = 127, tests/test_gpu_parity.py)
+        a = rng.integers(-2 ** 31 + 1, 2 ** 31 - 1, size=n, dtype=np.int64).astype(np.int32)
+        b = np.arange(n, dtype=np.int32)
+        c = rng.integers(-127, 128, size=n).astype(np.int8)
+        d = rng.integers(0, 100, size=n).astype(np.int8)
+        data = [a, b, c, d]
+        br = blocks_of(n, 1024)
+        cols = [RawColumn(DENSE_INT, 4, a, br), RawColumn(DENSE_INT, 4, b, br), RawColumn(DENSE_TINYINT, 1, c, br), RawColumn(DENSE_TINYINT, 1, d, br)]
+        seg = native.DeviceSegment(ctx, [x.native() for x in cols])
+        used = [int(x) for x in rng.permutation(4)[: int(rng.integers(1, 4))]]
+        n_pred = int(rng.integers(1, len(used) + 1))
+        sels, keep = [], np.ones(n, bool)
+        for i in range(n_pred):
+            col = data[used[i]]
+            frac = float(rng.choice([0.0, 0.02, 0.1, 0.3, 0.6, 1.0]))
+            srt = np.sort(col)
+            t = float(srt[min(n - 1, int((1.0 - frac) * n))]) - (1.0 if frac == 1.0 else 0.0) if frac > 0.0 else float(srt[-1])
+            sels.append((i, GT, t))
+            keep &= col > t
+        proj = [int(x) for x in rng.integers(0, len(used), size=int(rng.integers(1, 5)))]
+        rows = np.flatnonzero(keep)
+        q = native.DeviceQuery(ctx, seg, used, sels, proj, 0)
+        for rnd in range(3):
+            q.run()
+            assert q.count() == rows.size, (case, rnd, n, used, sels, proj, q.plan())
+            idx, vals = q.fetch_rows()
+            assert idx.size == rows.size and (idx == rows).all(), (case, rnd, n, used, sels, proj, q.plan())
+            for j, pj in enumerate(proj):
+                assert vals[j].tobytes() == np.ascontiguousarray(data[used[pj]][rows]).tobytes(), (case, rnd, j, n, used, sels, proj, q.plan())
+        q.close()
+        seg.close()
