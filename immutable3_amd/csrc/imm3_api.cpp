@@ -944,18 +944,14 @@ static void single_pass_set_P(imm3_query *q, int32_t P) {
 // for ~10 %) 386 us, P = 3 164 us (three launches: 180-208); 28 % of int8 + int32: P = 6 506 us, P = 2 190 us (242);
 // id > 5e7 on the sorted key: P = 7 232-269 us, P = 2 364 us, P = 1 426 us (338).  A run recorded in a graph keeps the P
 // it was recorded with (the descriptors' layout does not depend on P).
-static void single_pass_adapt(imm3_query *q, uint64_t survivors, int64_t dense_ranges) {
-    if (!q->single_pass || q->sp_P_fixed || q->n_rows <= 0 || survivors == 0) return;
-    if (dense_ranges < 0 && q->sp_have_stats) return; // (a reservation says less than a run did)
-    if (dense_ranges >= 0) q->sp_have_stats = true;
+// sigma: survivors per row WHERE THERE ARE SURVIVORS (the local density: what a range has to hold); `sure`: measured by a run
+static void single_pass_pick_P(imm3_query *q, double sigma, bool sure) {
+    if (!q->single_pass || q->sp_P_fixed || !(sigma > 0.0)) return;
     const int R = project_rec_dwords(q->stage_kinds);
     const double ring_records = (double)kProjectRingBytes / (4.0 * R);
-    double sigma = (double)survivors / (double)q->n_rows;
-    const double n_ranges = (double)q->sp_spans * kProjectStreamers;
-    if (dense_ranges > 0 && (double)dense_ranges > 0.02 * n_ranges) sigma = std::min(1.0, sigma * n_ranges / (double)dense_ranges);
-    const double per_tile = sigma * kTileRows;
+    const double per_tile = std::min(1.0, sigma) * kTileRows;
     const double fill = per_tile * q->sp_P / ring_records;
-    if (dense_ranges <= 0 && fill >= 0.3 && fill <= 0.6) return; // (close enough: P does not flip between a reservation's estimate and the count)
+    if (!sure && fill >= 0.3 && fill <= 0.6) return; // (close enough: P does not flip between an estimate and the count)
     int64_t P = (int64_t)(0.45 * ring_records / per_tile);
     if (P < 2) P = (int64_t)(0.9 * ring_records / per_tile); // (nearly every row survives: whatever still fits)
     if (P < 2) P = q->sp_P_plan;
@@ -965,6 +961,16 @@ static void single_pass_adapt(imm3_query *q, uint64_t survivors, int64_t dense_r
     // the descriptors are tagged with the low byte of the run counter: leave no tag behind in places the new P does not rewrite
     // every run (stream order: after the runs so far, before the next one)
     (void)hipMemsetAsync(q->d_desc, 0, q->sp_trash_off, q->ctx->stream);
+}
+static void single_pass_adapt(imm3_query *q, uint64_t survivors, int64_t dense_ranges) {
+    if (!q->single_pass || q->sp_P_fixed || q->n_rows <= 0 || survivors == 0) return;
+    if (dense_ranges < 0 && q->sp_have_stats) return; // (a reservation says less than a run did)
+    if (dense_ranges >= 0) q->sp_have_stats = true;
+    double sigma = (double)survivors / (double)q->n_rows;
+    const double n_ranges = (double)q->sp_spans * kProjectStreamers;
+    const bool clustered = dense_ranges > 0 && (double)dense_ranges > 0.02 * n_ranges;
+    if (clustered) sigma = std::min(1.0, sigma * n_ranges / (double)dense_ranges);
+    single_pass_pick_P(q, sigma, dense_ranges > 0);
 }
 
 // Plans the one-launch projection for the tile columns in q->stage_kinds: P, the grid, the descriptor allocation.
@@ -1053,6 +1059,75 @@ static int single_pass_stream_columns(imm3_query *q, uint64_t survivors) {
     q->stage_written = false;
     q->alt_ok = false;
     single_pass_adapt(q, survivors, -1);
+    return IMM3_OK;
+}
+
+// A look at the data before the first run: the select chain's count over eight evenly spaced chunks of 64 tiles (0.5 % of
+// 100 M rows, eight count-only launches of the scan+select kernel and one strided copy, inside query creation, which ends with
+// a stream synchronisation anyway: + 0.05-0.15 ms on a creation of 0.35-0.6 ms; tools/first_run.py).  Most queries run ONCE (the reference's Engine plans, runs and drops a pipeline per statement),
+// so what later runs learn from a count -- P, streamed SELECT-list columns -- the first run gets from the sample.  Survivors
+// per row are also taken per chunk: weighted by the chunks' own survivors they give the density where the survivors ARE,
+// which tells a sorted key's all-or-nothing ranges (keep the planned P: unpack_dense) from the same number of survivors
+// spread evenly (shorter ranges).
+static void fill_tile_col(const imm3_query *q, const FoldedPred &fp, TileCol &c, int kind);
+static int single_pass_sample(imm3_query *q) {
+    imm3_ctx *ctx = q->ctx;
+    constexpr int kChunks = 8;
+    constexpr int64_t kChunkTiles = 64;
+    const int64_t n_full = q->n_rows / kTileRows;
+    if ((!q->single_pass && !q->alt_ok) || q->sp_P_fixed || ctx->filter_variant == 10 || n_full < 4096) return IMM3_OK; // (below ~4 M rows the sample costs what it saves)
+    TileArgs base;
+    std::memset(&base, 0, sizeof(base));
+    int widths[kMaxTileCols] = {0, 0, 0};
+    bool any_i32 = false, any = false;
+    for (int k = 0; k < kMaxTileCols; ++k) {
+        base.kinds[k] = q->stage_kinds[k];
+        if (base.kinds[k] == TK_NONE) continue;
+        const FoldedPred *fp = nullptr;
+        for (const auto &p : q->preds)
+            if (p.seg_col == q->stage_seg_col[k]) fp = &p;
+        if (!fp) return IMM3_OK; // (a streamed column already: nothing left to decide)
+        fill_tile_col(q, *fp, base.cols[k], base.kinds[k]);
+        widths[k] = base.kinds[k] == TK_I32 ? 4 : (base.kinds[k] == TK_S2 ? 2 : 1);
+        any_i32 |= base.kinds[k] == TK_I32;
+        any = true;
+    }
+    if (!any) return IMM3_OK; // (no predicate: every row survives, the plan for that is the dense path at the planned P)
+    void *d = nullptr;
+    const size_t block = (size_t)kFinishWords * sizeof(unsigned long long);
+    HIPCHK(pool_alloc(ctx, &d, block * kChunks));
+    HIPCHK(hipMemsetAsync(d, 0, block * kChunks, ctx->stream));
+    unsigned long long counts[kChunks] = {0};
+    for (int i = 0; i < kChunks; ++i) {
+        int64_t tile0 = (int64_t)((2 * i + 1) * n_full / (2 * kChunks)) - kChunkTiles / 2;
+        tile0 = std::max<int64_t>(0, std::min<int64_t>(tile0, n_full - kChunkTiles));
+        TileArgs a = base;
+        for (int k = 0; k < kMaxTileCols; ++k)
+            if (a.kinds[k] != TK_NONE) a.cols[k].data = (const uint8_t *)a.cols[k].data + tile0 * kTileRows * widths[k];
+        a.n_rows = kChunkTiles * kTileRows;
+        a.n_words = kChunkTiles * kTileWords;
+        a.n_tiles = kChunkTiles;
+        a.bitmap = nullptr; // count-only
+        a.block_partials = q->d_block_partials;
+        a.finish = (unsigned long long *)((uint8_t *)d + block * (size_t)i);
+        const int grid = filter_grid(a.n_tiles, false, any_i32, 0);
+        if (!launch_filter_tile(a, grid, ctx->stream, nullptr, nullptr)) { pool_release(ctx, d); return IMM3_OK; }
+    }
+    // (one strided copy: word 0 of every block)
+    HIPCHK(hipMemcpy2DAsync(counts, sizeof(unsigned long long), d, block, sizeof(unsigned long long), kChunks, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    pool_release(ctx, d);
+    const double chunk_rows = (double)(kChunkTiles * kTileRows);
+    double sum = 0.0, sum_sq = 0.0;
+    for (int i = 0; i < kChunks; ++i) {
+        sum += (double)counts[i];
+        sum_sq += (double)counts[i] * (double)counts[i];
+    }
+    if (sum <= 0.0) return IMM3_OK; // (nothing in the sample: the plan for few survivors stands)
+    const double sigma = sum / (chunk_rows * kChunks), sigma_local = sum_sq / (sum * chunk_rows);
+    const int rc = single_pass_stream_columns(q, (uint64_t)(sigma * (double)q->n_rows));
+    if (rc) return rc;
+    single_pass_pick_P(q, sigma_local, false);
     return IMM3_OK;
 }
 
@@ -1388,6 +1463,10 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
             }
             }
         }
+    }
+    {
+        const int src = single_pass_sample(q.get());
+        if (src) return src;
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *out = q.release();

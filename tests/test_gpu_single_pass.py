@@ -120,7 +120,7 @@ def test_plan_only_when_every_select_list_column_is_a_predicate_column(ctx, big)
     q = native.DeviceQuery(ctx, seg, [2, 0], [(0, GT, 18.0), (0, LT, 30.0), (1, GT, 5.0)], [1, 0], 0)
     assert q.plan()["single_pass"]
     q.close()
-    q = native.DeviceQuery(ctx, seg, [2, 0], [(0, GT, 18.0), (0, LT, 30.0)], [1, 0], 0)        # id is gathered: records + k_emit
+    q = native.DeviceQuery(ctx, seg, [2, 0], [(0, GT, 97.0)], [1, 0], 0)                       # id is gathered, 2 % survive: records + k_emit
     assert not q.plan()["single_pass"] and q.plan()["records"]
     q.close()
     q = native.DeviceQuery(ctx, seg, [2, 0], [(0, GT, 18.0), (1, GT, 5.0)], [1, 0], 10)        # limit: the bitmap path
@@ -214,7 +214,8 @@ def test_steady_state_projections_never_wait_for_the_device(ctx, big):
     n, data, seg = big
     c, a = data[2], data[0]
     shapes = {"one launch": ([2, 0], [(0, GT, 18.0), (0, LT, 30.0), (1, GT, 5.0)], [1, 0], 0),
-              "records": ([2, 0], [(0, GT, 18.0), (0, LT, 30.0)], [1, 0], 1),
+              "records": ([2, 0], [(0, GT, 97.0)], [1, 0], 1),
+              "streamed": ([2, 0], [(0, GT, 18.0), (0, LT, 30.0)], [1, 0], 0),      # (decided by the sample taken at creation)
               "bitmap": ([2, 0, 4], [(0, GT, 18.0), (2, MATCH, [b"CA", b"NY", b"TX", b"WA", b"VA", b"DC", b"CT", b"AL", b"AK"])], [1, 0], 1)}
     for name, (used, sels, proj, first_run_syncs) in shapes.items():
         q = native.DeviceQuery(ctx, seg, used, sels, proj, 0)
@@ -242,7 +243,12 @@ def test_tiles_per_range_follow_the_selectivity(ctx, big):
     }
     for name, (used, sels, keep, expect) in cases.items():
         rows = np.flatnonzero(keep)
-        q = native.DeviceQuery(ctx, seg, used, sels, list(range(len(used))), 0)
+        sampled = native.DeviceQuery(ctx, seg, used, sels, list(range(len(used))), 0)     # the plan from the sample taken at creation ...
+        ctx.set_tuning(10, 0)                                                              # ... and without it: what the first count teaches
+        try:
+            q = native.DeviceQuery(ctx, seg, used, sels, list(range(len(used))), 0)
+        finally:
+            ctx.set_tuning(0, 0)
         p0 = q.plan()
         assert p0["single_pass"], (name, p0)
         q.run()
@@ -270,6 +276,12 @@ def test_tiles_per_range_follow_the_selectivity(ctx, big):
             for j, u in enumerate(used):
                 assert vals[j].tobytes() == np.ascontiguousarray(data[u][rows]).tobytes(), (name, rnd, u)
         assert q.plan()["P"] == p1["P"], (name, "P keeps still once it fits")
+        ps = sampled.plan()
+        assert (ps["P"] < p0["P"]) == (expect == "smaller"), (name, p0, ps)           # the sample leads to the same side of the planned P
+        sampled.run()
+        idx, vals = sampled.fetch_rows()
+        assert sampled.plan()["ran_single_pass"] and idx.size == rows.size and (idx == rows).all(), name
+        sampled.close()
         if g is not None:
             g.close()
         q.close()
@@ -336,7 +348,20 @@ def test_gathered_int32_columns_are_streamed_once_the_count_says_so(ctx, big):
             for v in sels[0][2]:
                 keep |= (s2[:, 0] == v[0]) & (s2[:, 1] == v[1])
         rows = np.flatnonzero(keep)
-        q = native.DeviceQuery(ctx, seg, used, sels, proj, 0)
+        sampled = native.DeviceQuery(ctx, seg, used, sels, proj, 0)    # the sample taken at creation decides before the first run ...
+        ps = sampled.plan()
+        assert ps["single_pass"] == switches and ps["records"] == (not switches), (name, ps)
+        sampled.run()
+        idx, vals = sampled.fetch_rows()
+        assert sampled.plan()["run_syncs"] == (0 if switches else 1) and idx.size == rows.size and (idx == rows).all(), (name, sampled.plan())
+        for j, pj in enumerate(proj):
+            assert vals[j].tobytes() == np.ascontiguousarray(data[used[pj]][rows]).tobytes(), (name, j)
+        sampled.close()
+        ctx.set_tuning(10, 0)                                           # ... without it, the first run's count does
+        try:
+            q = native.DeviceQuery(ctx, seg, used, sels, proj, 0)
+        finally:
+            ctx.set_tuning(0, 0)
         p0 = q.plan()
         assert not p0["single_pass"] and p0["records"], (name, p0)
         for rnd in range(3):
@@ -351,7 +376,12 @@ def test_gathered_int32_columns_are_streamed_once_the_count_says_so(ctx, big):
                 assert vals[j].tobytes() == np.ascontiguousarray(data[used[pj]][rows]).tobytes(), (name, rnd, j)
         q.close()
     # a reservation stands in for the count the first run would have read
-    q = native.DeviceQuery(ctx, seg, [2, 0], [(0, GT, 18.0), (0, LT, 30.0)], [1, 0], 0)
+    ctx.set_tuning(10, 0)
+    try:
+        q = native.DeviceQuery(ctx, seg, [2, 0], [(0, GT, 18.0), (0, LT, 30.0)], [1, 0], 0)
+    finally:
+        ctx.set_tuning(0, 0)
+    assert not q.plan()["single_pass"]
     rows = np.flatnonzero((c > 18) & (c < 30))
     q.reserve_rows(rows.size + 100)
     assert q.plan()["single_pass"] and not q.plan()["records"]
