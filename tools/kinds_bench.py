@@ -26,6 +26,7 @@ cases = {
     "I32+I8": ([0, 2], [(0, GT, 1e6), (1, GT, 18.0), (1, LT, 30.0)], 5),
     "I8+I8": ([2, 3], [(0, GT, 18.0), (1, LT, 30.0)], 2),
     "I32+S2": ([0, 4], [(0, GT, 1e6), (1, MATCH, [b"CA"])], 6),
+    "I8+S2": ([2, 4], [(0, GT, 18.0), (1, MATCH, [b"CA"])], 3),
     "I32+I8+S2": ([0, 2, 4], [(0, GT, 1e6), (1, GT, 18.0), (2, MATCH, [b"CA"])], 7),
     "I32+I32+I8": ([0, 1, 2], [(0, GT, 1e6), (1, LT, 3 * 2.0 ** 28), (2, GT, 18.0)], 9),
     "none": ([0], [], 0),
