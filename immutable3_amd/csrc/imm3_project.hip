@@ -140,7 +140,10 @@ __device__ __forceinline__ void abandon_run(const ProjectArgs &a, int64_t s, uin
 
 // LDS words shared between a streamer and the writers: relaxed work-group-scope atomics stay ds_read / ds_write (a volatile
 // access would become a flat one and drain the wave's global prefetch: DESIGN finding 19)
-__device__ __forceinline__ uint32_t lds_peek(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// (every lane reads the same word; readfirstlane tells the compiler so: what is decided on it stays scalar control flow)
+__device__ __forceinline__ uint32_t lds_peek(const uint32_t *p) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
 __device__ __forceinline__ void lds_poke(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // what a streamer publishes about a finished range (slot = range parity)
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
     __shared__ uint32_t s_part[kProjStreamers];
     __shared__ uint32_t s_dense_ranges;            // ranges of this work-group that outgrew their ring (the host sizes P by it)
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (scalar: what follows from it -- the wave's tiles, its role -- is wave-uniform control flow and SGPR address arithmetic)
     if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x] = wall_clock64();
     if (threadIdx.x < kProjStreamers) {
         s_drained[threadIdx.x] = 0u;
