@@ -154,16 +154,17 @@ struct RangePub {
     uint32_t pad;
 };
 
-// Wave specialisation.  A work-group is 10 waves, ONE work-group per CU (grid = number of CUs: every work-group is resident
+// Wave specialisation.  A work-group is 12 waves, ONE work-group per CU (grid = number of CUs: every work-group is resident
 // whatever the register footprint -- the occupancy query counted two 5-wave work-groups per CU where the hardware placed
 // one, and work-groups that wait on each other must all be running).  Waves 0-7 are STREAMERS, two per SIMD: they only
 // load, compare and compact -- no global store and no wait on another work-group ever sits in their loop (a wave that
 // stores waits, at its next s_waitcnt for loads, for the stores' write acknowledgements too: vmcnt retires in order; and a
-// look-back issued behind 20 outstanding streaming loads waits for those first).  Waves 8-9 are WRITERS: they collect the
-// streamers' range counts, the first one publishes the span's descriptor and obtains the span's first output row, and
-// each unpacks four streamers' records into the output arrays.  Hand-off through LDS: each streamer compacts into a RING
-// of records; a finished range is published (RangePub + a sequence number), its writer frees it by advancing the ring's
-// head.  A streamer runs at most two ranges ahead of its writer and waits only when its ring is full of undrained ranges.
+// descriptor poll issued behind 20 outstanding streaming loads waits for those first).  Waves 8-11 are WRITERS, one per
+// SIMD: whichever is idle announces a finished span (span_arrive), the first one waits for the span's first output row
+// and hands it to the others, and each unpacks two streamers' records into the output arrays.  Hand-off through LDS: each
+// streamer compacts into a RING of records; a finished range is published (RangePub; the span's last range bumps
+// s_span_ready), its writer frees it by advancing the ring's head.  A streamer runs at most kProjSlots ranges ahead of its
+// writer and waits only when its ring is full of undrained ranges.
 constexpr int kProjStreamers = kProjectStreamers;
 constexpr int kProjWriters = kProjectWriters;
 constexpr int kProjPerWriter = kProjStreamers / kProjWriters;
@@ -930,8 +931,8 @@ int project_rec_dwords(const int32_t *kinds) {
     return rec_layout(k, -1).dwords;
 }
 
-// Work-groups of the launch: ONE per CU (8 waves, > 80 KB of LDS: a CU never takes a second one, and takes the first whatever
-// the instance's register footprint), so every work-group of the launch is resident -- the look-back needs that.
+// Work-groups of the launch: ONE per CU (12 waves, > 80 KB of LDS: a CU never takes a second one, and takes the first whatever
+// the instance's register footprint), so every work-group of the launch is resident -- they wait on each other's descriptors.
 int project_max_grid(const int32_t *kinds, int P) {
     (void)P;
     bool have = false;
