@@ -1062,6 +1062,22 @@ static int single_pass_stream_columns(imm3_query *q, uint64_t survivors) {
     return IMM3_OK;
 }
 
+// Survivor records planned, but the projected predicate columns are all one byte wide and few rows survive: gathering those
+// bytes from the bitmap costs less than the staging instance of the filter kernel does (age > 97 -> id, age: 1 % 75 us with
+// records, 65 without; 3 % 106 / 95; at 11 % the columns are streamed anyway).  The records' buffers go back to the pool.
+static void records_drop_if_narrow(imm3_query *q, uint64_t survivors) {
+    imm3_ctx *ctx = q->ctx;
+    if (q->single_pass || !q->d_stage_rec || !q->records_narrow_only || ctx->capture || ctx->filter_variant == 11 || q->n_rows <= 0) return;
+    if ((double)survivors > 0.08 * (double)q->n_rows) return;
+    graphs_mark_stale(ctx, q);
+    pool_release(ctx, q->d_stage_rec);
+    pool_release(ctx, q->d_tile_start);
+    q->d_stage_rec = nullptr;
+    q->d_tile_start = nullptr;
+    q->stage_written = false;
+    q->alt_ok = false; // (settled: three launches from the bitmap)
+}
+
 // A look at the data before the first run: the select chain's count over eight evenly spaced chunks of 64 tiles (0.5 % of
 // 100 M rows, eight count-only launches of the scan+select kernel and one strided copy, inside query creation, which ends with
 // a stream synchronisation anyway: + 0.05-0.15 ms on a creation of 0.35-0.6 ms; tools/first_run.py).  Most queries run ONCE (the reference's Engine plans, runs and drops a pipeline per statement),
@@ -1075,7 +1091,8 @@ static int single_pass_sample(imm3_query *q) {
     constexpr int kChunks = 8;
     constexpr int64_t kChunkTiles = 64;
     const int64_t n_full = q->n_rows / kTileRows;
-    if ((!q->single_pass && !q->alt_ok) || q->sp_P_fixed || ctx->filter_variant == 10 || n_full < 4096) return IMM3_OK; // (below ~4 M rows the sample costs what it saves)
+    const bool undecided = q->single_pass || q->alt_ok || (q->d_stage_rec && q->records_narrow_only);
+    if (!undecided || q->sp_P_fixed || ctx->filter_variant == 10 || n_full < 4096) return IMM3_OK; // (below ~4 M rows the sample costs what it saves)
     TileArgs base;
     std::memset(&base, 0, sizeof(base));
     int widths[kMaxTileCols] = {0, 0, 0};
@@ -1127,6 +1144,7 @@ static int single_pass_sample(imm3_query *q) {
     const double sigma = sum / (chunk_rows * kChunks), sigma_local = sum_sq / (sum * chunk_rows);
     const int rc = single_pass_stream_columns(q, (uint64_t)(sigma * (double)q->n_rows));
     if (rc) return rc;
+    records_drop_if_narrow(q, (uint64_t)(sigma * (double)q->n_rows));
     single_pass_pick_P(q, sigma_local, false);
     return IMM3_OK;
 }
@@ -1370,6 +1388,8 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
         ok = ok && n_s2 <= 1;
         std::stable_sort(order.begin(), order.end(), [](const FoldedPred *x, const FoldedPred *y) { return tile_kind(*x) < tile_kind(*y); });
         int n_gather = 0;
+        int n_pred_proj = 0;       // predicate columns in the SELECT list (first mentions: their values ride in the records) ...
+        bool pred_proj_wide = false; // ... and whether one of them is wider than a byte
         std::vector<int32_t> seen; // predicate columns already mentioned in the SELECT list: a second mention is gathered
         for (int32_t pj : q->proj) {
             const int32_t sci = q->used[(size_t)pj];
@@ -1378,7 +1398,11 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
             bool is_pred = false;
             for (const FoldedPred *fp : order) is_pred |= fp->seg_col == sci;
             if (is_pred && std::find(seen.begin(), seen.end(), sci) != seen.end()) is_pred = false;
-            if (is_pred) seen.push_back(sci);
+            if (is_pred) {
+                seen.push_back(sci);
+                ++n_pred_proj;
+                pred_proj_wide |= w > 1;
+            }
             n_gather += !is_pred;
         }
         if (ok && n_gather <= kMaxEmitGather) {
@@ -1432,11 +1456,18 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
                     // 5 %: 120 / 145; 3 %: 116 / 107.  Not with a string predicate (the 2-byte match streams at 74 us with the one-launch
                     // kernel's 8 streaming waves per CU against 47: state in (5 values) -> age, 10 %: 181 / 120), and not for 1-byte
                     // columns alone (their gather reads every line of the column from ~3 % on and still costs 33 us at 10 %).
-                    q->alt_min_sigma = 0.04;
+                    // Against the bitmap path (below), which a query takes when none of its predicate columns is projected: age -> id
+                    // 11 % 123 / 122, 5 % 119 / 100: from 12 % on.
+                    q->alt_min_sigma = n_pred_proj == 0 ? 0.12 : 0.04;
                     q->alt_ok = any4 && !any_s2;
                 }
             }
-            if (q->single_pass) { /* no survivor records in HBM: the filter kernel writes the rows */ } else {            // Every wave of the staging launch writes its records to its own arena, so the launch geometry is fixed here:
+            // Survivor records pay when the predicate columns' values are wanted: the staging instances of the filter kernel cost
+            // 12 (string) to 33 us (int8) per 100 M rows more than the plain ones, and buy the emit kernel the projected predicate
+            // columns.  When none is projected they buy nothing -- state in (5 values) -> age, 10 %: 120 us with records, 87 without
+            // (filter -> offsets scan -> gather from the bitmap); age in (18, 30) -> id, 11 %: 167 / 122; 3 %: 106 / 79.
+            q->records_narrow_only = n_pred_proj > 0 && !pred_proj_wide;
+            if (q->single_pass || (n_gather > 0 && n_pred_proj == 0 && ctx->filter_variant != 11)) { /* no survivor records in HBM */ } else {            // Every wave of the staging launch writes its records to its own arena, so the launch geometry is fixed here:
             // 768 work-groups (3 per CU: an 8 KiB record buffer per wave), grid-stride over groups of T tiles.
             const int R = rec_layout(q->stage_kinds, -1).dwords;
             const int T = filter_tile_group(q->stage_kinds);
@@ -2174,6 +2205,7 @@ static int run_project(imm3_query *q) {
             const int src = single_pass_stream_columns(q, total);
             if (src) return src;
             if (q->single_pass) return run_single_pass(q);
+            records_drop_if_narrow(q, total); // (this run's rows then come from the bitmap the staging launch wrote as well)
         }
         const unsigned long long want = std::min<unsigned long long>((unsigned long long)std::max<int64_t>(q->n_rows, 1), total + total / 8 + 1024);
         const int rc = ensure_row_capacity(q, want);

@@ -120,8 +120,11 @@ def test_plan_only_when_every_select_list_column_is_a_predicate_column(ctx, big)
     q = native.DeviceQuery(ctx, seg, [2, 0], [(0, GT, 18.0), (0, LT, 30.0), (1, GT, 5.0)], [1, 0], 0)
     assert q.plan()["single_pass"]
     q.close()
-    q = native.DeviceQuery(ctx, seg, [2, 0], [(0, GT, 97.0)], [1, 0], 0)                       # id is gathered, 2 % survive: records + k_emit
+    q = native.DeviceQuery(ctx, seg, [4, 0], [(0, MATCH, [b"CA"])], [1, 0], 0)                 # id is gathered, the string predicate column projected: records + k_emit
     assert not q.plan()["single_pass"] and q.plan()["records"]
+    q.close()
+    q = native.DeviceQuery(ctx, seg, [4, 0], [(0, MATCH, [b"CA"])], [1], 0)                    # no predicate column projected: records would buy nothing
+    assert not q.plan()["single_pass"] and not q.plan()["records"]
     q.close()
     q = native.DeviceQuery(ctx, seg, [2, 0], [(0, GT, 18.0), (1, GT, 5.0)], [1, 0], 10)        # limit: the bitmap path
     assert not q.plan()["single_pass"] and not q.plan()["records"]
@@ -327,33 +330,43 @@ def test_gathered_columns_in_the_one_launch_when_the_tuning_hook_forces_it(big):
 
 
 def test_gathered_int32_columns_are_streamed_once_the_count_says_so(ctx, big):
-    """`select id, age ... where age > 18 and age < 30` (the reference README's example): id is not a predicate column, so the plan
-    made without knowing the selectivity is the three launches (records, offsets scan, emit with a gather of id).  The first run
-    reads the count anyway (it sizes the row arrays): from 4 % survivors on, the gathered int32 column is streamed through the
-    one-launch kernel as a tile column that lets every value pass -- same rows, in one launch, from that run on."""
+    """`select id, age ... where age > 18 and age < 30` (the reference README's example): id is not a predicate column.  Three plans
+    exist for such a projection -- survivor records -> offsets scan -> emit (the predicate columns' values ride in the records),
+    the same from the bitmap alone (no records: the plain filter kernel, the gather reads every SELECT-list column), and the one
+    launch with the gathered int32 columns streamed through it as tile columns that let every value pass.  Which one is the
+    fastest depends on how many rows survive and on which predicate columns are projected; the library decides from a sample
+    counted at query creation and, without one (small segments; here: tuning variant 10), from the first run's count.  Same rows
+    whatever the plan."""
     n, data, seg = big
     a, b, c, d, s2 = data
     cases = {
-        # name: used, sels, proj, keep, switches
-        "11 %, id gathered":         ([2, 0], [(0, GT, 18.0), (0, LT, 30.0)], [1, 0], (c > 18) & (c < 30), True),
-        "10 %, two int32 gathered":  ([2, 0, 1], [(0, GT, 89.0)], [2, 0, 1], c > 89, True),
-        "second mention stays a gather": ([3, 0], [(0, GT, 30.0)], [1, 0, 1], d > 30, True),
-        "2 %: the three launches":   ([2, 0], [(0, GT, 97.0)], [1, 0], c > 97, False),
-        "string predicate":          ([4, 0], [(0, MATCH, [b"CA", b"NY", b"TX", b"WA", b"VA"])], [1], None, False),
-        "only a 1-byte column gathered": ([0, 2], [(0, GT, float(0.8 * 2 ** 30))], [1], a > 0.8 * 2 ** 30, False),
+        # name: used, sels, proj, keep, plan with the sample / plan at creation without it / plan after the first run without it
+        "11 %, id gathered":         ([2, 0], [(0, GT, 18.0), (0, LT, 30.0)], [1, 0], (c > 18) & (c < 30), "one launch", "records", "one launch"),
+        "10 %, two int32 gathered":  ([2, 0, 1], [(0, GT, 89.0)], [2, 0, 1], c > 89, "one launch", "records", "one launch"),
+        "second mention stays a gather": ([3, 0], [(0, GT, 30.0)], [1, 0, 1], d > 30, "one launch", "records", "one launch"),
+        "2 %, int8 predicate projected": ([2, 0], [(0, GT, 97.0)], [1, 0], c > 97, "bitmap", "records", "bitmap"),
+        "2 %, string predicate projected": ([4, 0], [(0, MATCH, [b"CA"])], [1, 0], None, "records", "records", "records"),
+        "string predicate, not projected": ([4, 0], [(0, MATCH, [b"CA", b"NY", b"TX", b"WA", b"VA"])], [1], None, "bitmap", "bitmap", "bitmap"),
+        "only a 1-byte column gathered": ([0, 2], [(0, GT, float(0.8 * 2 ** 30))], [1], a > 0.8 * 2 ** 30, "bitmap", "bitmap", "bitmap"),
+        "20 %, no predicate column projected": ([2, 0], [(0, GT, 79.0)], [1], c > 79, "one launch", "bitmap", "one launch"),
+        "5 %, no predicate column projected": ([2, 0], [(0, GT, 94.0)], [1], c > 94, "bitmap", "bitmap", "bitmap"),
     }
-    for name, (used, sels, proj, keep, switches) in cases.items():
+
+    def kind(p):
+        return "one launch" if p["single_pass"] else ("records" if p["records"] else "bitmap")
+
+    for name, (used, sels, proj, keep, want_sampled, want_created, want_run) in cases.items():
         if keep is None:
             keep = np.zeros(n, bool)
             for v in sels[0][2]:
                 keep |= (s2[:, 0] == v[0]) & (s2[:, 1] == v[1])
         rows = np.flatnonzero(keep)
         sampled = native.DeviceQuery(ctx, seg, used, sels, proj, 0)    # the sample taken at creation decides before the first run ...
-        ps = sampled.plan()
-        assert ps["single_pass"] == switches and ps["records"] == (not switches), (name, ps)
+        assert kind(sampled.plan()) == want_sampled, (name, sampled.plan())
         sampled.run()
         idx, vals = sampled.fetch_rows()
-        assert sampled.plan()["run_syncs"] == (0 if switches else 1) and idx.size == rows.size and (idx == rows).all(), (name, sampled.plan())
+        assert kind(sampled.plan()) == want_sampled and sampled.plan()["run_syncs"] == (0 if want_sampled == "one launch" else 1), (name, sampled.plan())
+        assert idx.size == rows.size and (idx == rows).all(), name
         for j, pj in enumerate(proj):
             assert vals[j].tobytes() == np.ascontiguousarray(data[used[pj]][rows]).tobytes(), (name, j)
         sampled.close()
@@ -362,12 +375,11 @@ def test_gathered_int32_columns_are_streamed_once_the_count_says_so(ctx, big):
             q = native.DeviceQuery(ctx, seg, used, sels, proj, 0)
         finally:
             ctx.set_tuning(0, 0)
-        p0 = q.plan()
-        assert not p0["single_pass"] and p0["records"], (name, p0)
+        assert kind(q.plan()) == want_created, (name, q.plan())
         for rnd in range(3):
             q.run()
             p = q.plan()
-            assert p["single_pass"] == switches and p["ran_single_pass"] == switches and p["records"] == (not switches), (name, rnd, p)
+            assert kind(p) == want_run and p["ran_single_pass"] == (want_run == "one launch"), (name, rnd, p)
             assert p["run_syncs"] == 1, (name, rnd, p)           # the first run's look at the count, never again
             assert q.count() == rows.size, (name, rnd)
             idx, vals = q.fetch_rows()
@@ -381,7 +393,7 @@ def test_gathered_int32_columns_are_streamed_once_the_count_says_so(ctx, big):
         q = native.DeviceQuery(ctx, seg, [2, 0], [(0, GT, 18.0), (0, LT, 30.0)], [1, 0], 0)
     finally:
         ctx.set_tuning(0, 0)
-    assert not q.plan()["single_pass"]
+    assert not q.plan()["single_pass"] and q.plan()["records"]
     rows = np.flatnonzero((c > 18) & (c < 30))
     q.reserve_rows(rows.size + 100)
     assert q.plan()["single_pass"] and not q.plan()["records"]

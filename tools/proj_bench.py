@@ -20,9 +20,14 @@ cases = {
     "age->id": ([2, 0], [(0, native.GT, 18.0), (0, native.LT, 30.0)], [1]),          # projected column is NOT a predicate column
     "age5%->id": ([2, 0], [(0, native.GT, 18.0), (0, native.LT, 24.0)], [1]),
     "age3%->id": ([2, 0], [(0, native.GT, 18.0), (0, native.LT, 22.0)], [1]),
-    "age11%->id,age": ([2, 0], [(0, native.GT, 18.0), (0, native.LT, 30.0)], [1, 0]),     # the reference README's example query
+    "age11%->id+age": ([2, 0], [(0, native.GT, 18.0), (0, native.LT, 30.0)], [1, 0]),     # the reference README's example query
     "st10%->age": ([1, 2], [(0, native.MATCH, [b"CA", b"NY", b"TX", b"WA", b"VA"])], [1]),
     "st2%->age": ([1, 2], [(0, native.MATCH, [b"CA"])], [1]),
+    "age1%->id": ([2, 0], [(0, native.GT, 98.0)], [1]),
+    "age1%->id+age": ([2, 0], [(0, native.GT, 98.0)], [1, 0]),
+    "age3%->id+age": ([2, 0], [(0, native.GT, 18.0), (0, native.LT, 22.0)], [1, 0]),
+    "st2%->id": ([1, 0], [(0, native.MATCH, [b"CA"])], [1]),
+    "st2%->id+st": ([1, 0], [(0, native.MATCH, [b"CA"])], [1, 0]),
     "id2%": ([0], [(0, native.GT, 9.8e7)], [0]),
     "id50%": ([0], [(0, native.GT, 5e7)], [0]),                                       # sigma = 0.5
     "age50%": ([2], [(0, native.LT, 50.0)], [0]),                                     # sigma = 0.5, uniformly spread
