@@ -240,8 +240,8 @@ int imm3_query_reserve_rows(imm3_query *q, uint64_t rows);
 
 /* Enqueue the whole pipeline on the context's stream.  n_proj == 0: the scan+select kernel (selection bitmap + count).
  * Unlimited projection whose SELECT list is predicate columns only, one uniform segment: ONE launch -- scan + select +
- * project (csrc/imm3_project.hip: the filter kernel writes the rows in ascending order itself).  Otherwise: scan+select,
- * then an offsets scan and compact+gather -- unless enough rows survive for the other SELECT-list columns to be streamed
+ * project (csrc/imm3_project.hip: the filter kernel writes the rows in ascending order itself).  Otherwise: scan+select
+ * (staging a record per survivor when a predicate column is projected), then an offsets scan and compact+gather -- unless enough rows survive for the other SELECT-list columns to be streamed
  * through that one launch as well (dense int32 columns, from 4 % survivors on; no string predicate): decided from a sample
  * counted at query creation (segments of 4 M rows and more), a reservation, or the first run's count.  Asynchronous except for the first run of an unreserved unlimited projection
  * (see above).  May be called repeatedly on the same query. */
