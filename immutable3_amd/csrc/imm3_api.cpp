@@ -1078,6 +1078,26 @@ static void records_drop_if_narrow(imm3_query *q, uint64_t survivors) {
     q->alt_ok = false; // (settled: three launches from the bitmap)
 }
 
+// The one-launch kernel costs ~85 us per 100 M rows whatever the columns' widths (it is bound by instructions per row, DESIGN
+// finding 21); the plain filter over 1- and 2-byte columns takes 21-45 us.  A projection of narrow predicate columns alone is
+// therefore better off with filter -> offsets scan -> gather from the bitmap until many rows survive (select age ... where
+// age > 98, 1 %: 89 us in one launch, 53 in three; 3 %: 97 / 58).  Decided on the sample, or on the first count.
+constexpr double kNarrowOneLaunchMinSigma = 0.30;
+static void single_pass_drop_if_narrow(imm3_query *q, uint64_t survivors) {
+    imm3_ctx *ctx = q->ctx;
+    if (!q->single_pass || !q->sp_pass.empty() || q->sp_P_fixed || ctx->capture || ctx->filter_variant == 8 || ctx->filter_variant == 11 || q->n_rows <= 0) return;
+    bool any = false;
+    for (int k = 0; k < kMaxTileCols; ++k) {
+        if (q->stage_kinds[k] == TK_I32) return;
+        any |= q->stage_kinds[k] != TK_NONE;
+    }
+    if (!any || (double)survivors >= kNarrowOneLaunchMinSigma * (double)q->n_rows) return;
+    graphs_mark_stale(ctx, q);
+    q->single_pass = false;
+    pool_release(ctx, q->d_desc);
+    q->d_desc = nullptr;
+}
+
 // A look at the data before the first run: the select chain's count over eight evenly spaced chunks of 64 tiles (0.5 % of
 // 100 M rows, eight count-only launches of the scan+select kernel and one strided copy, inside query creation, which ends with
 // a stream synchronisation anyway: + 0.05-0.15 ms on a creation of 0.35-0.6 ms; tools/first_run.py).  Most queries run ONCE (the reference's Engine plans, runs and drops a pipeline per statement),
@@ -1145,6 +1165,7 @@ static int single_pass_sample(imm3_query *q) {
     const int rc = single_pass_stream_columns(q, (uint64_t)(sigma * (double)q->n_rows));
     if (rc) return rc;
     records_drop_if_narrow(q, (uint64_t)(sigma * (double)q->n_rows));
+    single_pass_drop_if_narrow(q, (uint64_t)(sigma * (double)q->n_rows));
     single_pass_pick_P(q, sigma_local, false);
     return IMM3_OK;
 }
@@ -2344,6 +2365,10 @@ static int settle_single_pass(imm3_query *q) {
     const unsigned long long status = head[kFinishStatus];
     if (!(status & 6ULL)) {
         single_pass_adapt(q, head[0], (int64_t)head[kFinishDense]); // (later runs: P from the selectivity this run saw)
+        if (!q->sp_narrow_checked) { // (once: the data do not change)
+            q->sp_narrow_checked = true;
+            single_pass_drop_if_narrow(q, head[0]);
+        }
         return IMM3_OK;
     }
     if (status & 2ULL) { // a prefix never came (not every work-group resident?): this query keeps the bitmap path from now on

@@ -220,6 +220,7 @@ struct imm3_query {
     int32_t alt_kinds[3] = {3, 3, 3}, alt_seg_col[3] = {-1, -1, -1};
     double alt_min_sigma = 1.0;             // survivors / rows from which the alternative is the faster plan
     bool records_narrow_only = false;       // the projected predicate columns are all 1 byte wide (few survivors: the bitmap path beats the records)
+    bool sp_narrow_checked = false;         // the first count has been looked at for "narrow columns, few survivors: three launches"
     bool sp_have_stats = false;             // a run's count and dense-range tally have been seen (a reservation's estimate no longer moves P)
     size_t sp_rounds_max = 0;               // rounds at the smallest P: d_desc = {round totals, round counters, span descriptors (smallest P), trash lines}
     size_t sp_desc_off = 0;                 // byte offset of the span descriptors in d_desc's allocation

@@ -239,7 +239,8 @@ int imm3_query_fetch_groups(imm3_query *q, uint64_t *keys, uint32_t *first_row, 
 int imm3_query_reserve_rows(imm3_query *q, uint64_t rows);
 
 /* Enqueue the whole pipeline on the context's stream.  n_proj == 0: the scan+select kernel (selection bitmap + count).
- * Unlimited projection whose SELECT list is predicate columns only, one uniform segment: ONE launch -- scan + select +
+ * Unlimited projection whose SELECT list is predicate columns only (one of them an int32 column, or >= 30 % of the rows
+ * surviving), one uniform segment: ONE launch -- scan + select +
  * project (csrc/imm3_project.hip: the filter kernel writes the rows in ascending order itself).  Otherwise: scan+select
  * (staging a record per survivor when a predicate column is projected), then an offsets scan and compact+gather -- unless enough rows survive for the other SELECT-list columns to be streamed
  * through that one launch as well (dense int32 columns, from 4 % survivors on; no string predicate): decided from a sample

@@ -81,7 +81,11 @@ def test_every_instance_at_every_fill_level(ctx, big, pred_cols):
     pos = {u: i for i, u in enumerate(used)}
     for level in ("none", "few", "some", "most", "all"):
         sels, keep = _predicates(data, pred_cols, level, pos)
-        q = native.DeviceQuery(ctx, seg, used, sels, list(range(len(used))), 0)
+        ctx.set_tuning(10, 0)        # (no sample at creation: with few survivors of narrow columns the planner would pick three launches)
+        try:
+            q = native.DeviceQuery(ctx, seg, used, sels, list(range(len(used))), 0)
+        finally:
+            ctx.set_tuning(0, 0)
         plan = q.plan()
         folded_empty = level == "none"          # (a threshold no value passes folds to an empty interval: answered by memset, no kernel)
         assert (plan["single_pass"] and not plan["records"]) or folded_empty, (pred_cols, plan)     # the path this file is about
@@ -444,3 +448,44 @@ def test_random_sizes_predicates_and_select_lists(ctx):
                 assert vals[j].tobytes() == np.ascontiguousarray(data[used[pj]][rows]).tobytes(), (case, rnd, j, n, used, sels, proj, q.plan())
         q.close()
         seg.close()
+
+
+def test_narrow_columns_alone_take_three_launches_until_many_rows_survive(ctx, big):
+    """The one-launch kernel costs about the same per row whatever the columns' widths; the plain filter over 1- and 2-byte columns
+    is four times cheaper than over an int32 column.  `select age ... where age > 98` is therefore planned as filter -> offsets
+    scan -> gather from the bitmap when the sample taken at creation shows few survivors (< 30 %), and as one launch when it
+    shows many; without a sample the first count decides for the runs after it."""
+    n, data, seg = big
+    a, b, c, d, s2 = data
+
+    def kind(p):
+        return "one launch" if p["single_pass"] else ("records" if p["records"] else "bitmap")
+
+    cases = {
+        "int8, 10 %":        ([2], [(0, GT, 89.0)], c > 89, "bitmap"),
+        "int8, 50 %":        ([2], [(0, GT, 49.0)], c > 49, "one launch"),
+        "int8 + int8, 5 %":  ([2, 3], [(0, GT, 89.0), (1, GT, 0.0)], (c > 89) & (d > 0), "bitmap"),
+        "string, 2 %":       ([4], [(0, MATCH, [b"CA"])], (s2[:, 0] == ord("C")) & (s2[:, 1] == ord("A")), "bitmap"),
+        "int8 + int32, 10 %": ([2, 0], [(0, GT, 89.0), (1, GT, -1.0)], (c > 89) & (a > -1), "one launch"),    # an int32 column: the one launch at any selectivity
+    }
+    for name, (used, sels, keep, want) in cases.items():
+        rows = np.flatnonzero(keep)
+        proj = list(range(len(used)))
+        q = native.DeviceQuery(ctx, seg, used, sels, proj, 0)
+        assert kind(q.plan()) == want, (name, q.plan())
+        ctx.set_tuning(10, 0)
+        try:
+            late = native.DeviceQuery(ctx, seg, used, sels, proj, 0)
+        finally:
+            ctx.set_tuning(0, 0)
+        assert kind(late.plan()) == "one launch", (name, late.plan())
+        for qq in (q, late):
+            for rnd in range(3):
+                qq.run()
+                assert qq.count() == rows.size, (name, rnd)
+                idx, vals = qq.fetch_rows()
+                assert idx.size == rows.size and (idx == rows).all(), (name, rnd)
+                for j, u in enumerate(used):
+                    assert vals[j].tobytes() == np.ascontiguousarray(data[u][rows]).tobytes(), (name, rnd, j)
+            assert kind(qq.plan()) == want, (name, qq.plan())        # the first count brought `late` to the same plan
+            qq.close()

@@ -29,6 +29,15 @@ cases = {
     "st2%->id": ([1, 0], [(0, native.MATCH, [b"CA"])], [1]),
     "st2%->id+st": ([1, 0], [(0, native.MATCH, [b"CA"])], [1, 0]),
     "id2%": ([0], [(0, native.GT, 9.8e7)], [0]),
+    "age1%+id": ([2, 0], [(0, native.GT, 98.0), (1, native.GT, 1e6), (1, native.LT, 9e7)], [1, 0]),
+    "age3%+id": ([2, 0], [(0, native.GT, 18.0), (0, native.LT, 22.0), (1, native.GT, 1e6), (1, native.LT, 9e7)], [1, 0]),
+    "age1%": ([2], [(0, native.GT, 98.0)], [0]),
+    "age11%": ([2], [(0, native.GT, 18.0), (0, native.LT, 30.0)], [0]),
+    "age30%": ([2], [(0, native.LT, 30.0)], [0]),
+    "st2%": ([1], [(0, native.MATCH, [b"CA"])], [0]),
+    "st10%": ([1], [(0, native.MATCH, [b"CA", b"NY", b"TX", b"WA", b"VA"])], [0]),
+    "age11%+st10%": ([2, 1], [(0, native.GT, 18.0), (0, native.LT, 30.0), (1, native.MATCH, [b"CA", b"NY", b"TX", b"WA", b"VA"])], [0, 1]),
+    "age3%": ([2], [(0, native.GT, 18.0), (0, native.LT, 22.0)], [0]),
     "id50%": ([0], [(0, native.GT, 5e7)], [0]),                                       # sigma = 0.5
     "age50%": ([2], [(0, native.LT, 50.0)], [0]),                                     # sigma = 0.5, uniformly spread
     "age30%+id": ([2, 0], [(0, native.GT, 18.0), (0, native.LT, 50.0), (1, native.GT, 1e6), (1, native.LT, 9e7)], [1, 0]),
