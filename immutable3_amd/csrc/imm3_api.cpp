@@ -1078,6 +1078,37 @@ static void records_drop_if_narrow(imm3_query *q, uint64_t survivors) {
     q->alt_ok = false; // (settled: three launches from the bitmap)
 }
 
+// Survivor records (k_filter_tile STAGE -> k_emit) for the tile columns in q->stage_kinds.  Every wave of the staging launch
+// writes its records to its own arena, so the launch geometry is fixed here: 768 work-groups (3 per CU: an 8 KiB record
+// buffer per wave), grid-stride over groups of T tiles.
+static int records_setup(imm3_query *q) {
+    imm3_ctx *ctx = q->ctx;
+    const int R = rec_layout(q->stage_kinds, -1).dwords;
+    const int T = filter_tile_group(q->stage_kinds);
+    // 3 per CU (~52 KiB of LDS each); 4 per CU for a lone 2-byte-string column (1-dword records, 4 KiB record buffers: C4's
+    // filter 50.5 -> 46.6 us).  Measured per shape: a lone int8 column at 1024 lost 8 us, an int32 column 7 us.
+    const bool lone_s2 = q->stage_kinds[0] == TK_S2 && q->stage_kinds[1] == TK_NONE;
+    const int cap = ctx->grid_blocks > 0 ? std::min(ctx->grid_blocks.load(), kMaxFilterGrid) : (R == 1 && lone_s2 ? 1024 : 768);
+    const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((q->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, cap));
+    const int64_t n_waves = grid * kWavesPerBlock;
+    const int64_t n_groups = T > 0 ? (q->n_rows / kTileRows) / T : 0;
+    const int64_t main_tiles = n_groups * T;
+    const int64_t max_slots = ((n_groups + n_waves - 1) / n_waves) * T + (q->n_tiles - main_tiles + n_waves - 1) / n_waves;
+    if (T > 0 && max_slots <= kMaxArenaSlots) {
+        q->stage_grid = (int32_t)grid;
+        q->stage_T = T;
+        q->stage_max_slots = (int32_t)std::max<int64_t>(max_slots, 1);
+        q->stage_wave_cap = (int64_t)q->stage_max_slots * kTileRows; // (skewing the arena bases off their 128 KiB-aligned stride changed nothing)
+        q->stage_main_tiles = main_tiles;
+        void *d = nullptr;
+        HIPCHK(pool_alloc(ctx, &d, (size_t)n_waves * (size_t)q->stage_wave_cap * 4 * (size_t)R + 256));
+        q->d_stage_rec = (uint8_t *)d;
+        HIPCHK(pool_alloc(ctx, &d, (size_t)n_waves * (size_t)q->stage_max_slots * sizeof(uint32_t) + 256));
+        q->d_tile_start = (uint32_t *)d;
+    }
+    return IMM3_OK;
+}
+
 // The one-launch kernel costs ~85 us per 100 M rows whatever the columns' widths (it is bound by instructions per row, DESIGN
 // finding 21); the plain filter over 1- and 2-byte columns takes 21-45 us.  A projection of narrow predicate columns alone is
 // therefore better off with filter -> offsets scan -> gather from the bitmap until many rows survive (select age ... where
@@ -1096,6 +1127,9 @@ static void single_pass_drop_if_narrow(imm3_query *q, uint64_t survivors) {
     q->single_pass = false;
     pool_release(ctx, q->d_desc);
     q->d_desc = nullptr;
+    // a projected string column and few survivors: its two bytes are better staged than gathered (state = CA -> state, 2 %: 62 us
+    // with records, 75 from the bitmap; at 10 % 108 / 106)
+    if (!q->records_narrow_only && !q->d_stage_rec && (double)survivors < 0.06 * (double)q->n_rows) (void)records_setup(q);
 }
 
 // A look at the data before the first run: the select chain's count over eight evenly spaced chunks of 64 tiles (0.5 % of
@@ -1488,31 +1522,9 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
             // columns.  When none is projected they buy nothing -- state in (5 values) -> age, 10 %: 120 us with records, 87 without
             // (filter -> offsets scan -> gather from the bitmap); age in (18, 30) -> id, 11 %: 167 / 122; 3 %: 106 / 79.
             q->records_narrow_only = n_pred_proj > 0 && !pred_proj_wide;
-            if (q->single_pass || (n_gather > 0 && n_pred_proj == 0 && ctx->filter_variant != 11)) { /* no survivor records in HBM */ } else {            // Every wave of the staging launch writes its records to its own arena, so the launch geometry is fixed here:
-            // 768 work-groups (3 per CU: an 8 KiB record buffer per wave), grid-stride over groups of T tiles.
-            const int R = rec_layout(q->stage_kinds, -1).dwords;
-            const int T = filter_tile_group(q->stage_kinds);
-            // 3 per CU (~52 KiB of LDS each); 4 per CU for a lone 2-byte-string column (1-dword records, 4 KiB record buffers: C4's
-            // filter 50.5 -> 46.6 us).  Measured per shape: a lone int8 column at 1024 lost 8 us, an int32 column 7 us.
-            const bool lone_s2 = q->stage_kinds[0] == TK_S2 && q->stage_kinds[1] == TK_NONE;
-            const int cap = ctx->grid_blocks > 0 ? std::min(ctx->grid_blocks.load(), kMaxFilterGrid) : (R == 1 && lone_s2 ? 1024 : 768);
-            const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((q->n_tiles + kWavesPerBlock - 1) / kWavesPerBlock, cap));
-            const int64_t n_waves = grid * kWavesPerBlock;
-            const int64_t n_groups = T > 0 ? (q->n_rows / kTileRows) / T : 0;
-            const int64_t main_tiles = n_groups * T;
-            const int64_t max_slots = ((n_groups + n_waves - 1) / n_waves) * T + (q->n_tiles - main_tiles + n_waves - 1) / n_waves;
-            if (T > 0 && max_slots <= kMaxArenaSlots) {
-                q->stage_grid = (int32_t)grid;
-                q->stage_T = T;
-                q->stage_max_slots = (int32_t)std::max<int64_t>(max_slots, 1);
-                q->stage_wave_cap = (int64_t)q->stage_max_slots * kTileRows; // (skewing the arena bases off their 128 KiB-aligned stride changed nothing)
-                q->stage_main_tiles = main_tiles;
-                void *d = nullptr;
-                HIPCHK(pool_alloc(ctx, &d, (size_t)n_waves * (size_t)q->stage_wave_cap * 4 * (size_t)R + 256));
-                q->d_stage_rec = (uint8_t *)d;
-                HIPCHK(pool_alloc(ctx, &d, (size_t)n_waves * (size_t)q->stage_max_slots * sizeof(uint32_t) + 256));
-                q->d_tile_start = (uint32_t *)d;
-            }
+            if (q->single_pass || (n_gather > 0 && n_pred_proj == 0 && ctx->filter_variant != 11)) { /* no survivor records in HBM */ } else {
+                const int rc = records_setup(q.get());
+                if (rc) return rc;
             }
         }
     }

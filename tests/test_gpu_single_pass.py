@@ -465,10 +465,15 @@ def test_narrow_columns_alone_take_three_launches_until_many_rows_survive(ctx, b
         "int8, 10 %":        ([2], [(0, GT, 89.0)], c > 89, "bitmap"),
         "int8, 50 %":        ([2], [(0, GT, 49.0)], c > 49, "one launch"),
         "int8 + int8, 5 %":  ([2, 3], [(0, GT, 89.0), (1, GT, 0.0)], (c > 89) & (d > 0), "bitmap"),
-        "string, 2 %":       ([4], [(0, MATCH, [b"CA"])], (s2[:, 0] == ord("C")) & (s2[:, 1] == ord("A")), "bitmap"),
+        "string, 2 %":       ([4], [(0, MATCH, [b"CA"])], (s2[:, 0] == ord("C")) & (s2[:, 1] == ord("A")), "records"),   # (two bytes per survivor: staged, not gathered)
+        "string, 10 %":      ([4], [(0, MATCH, [b"CA", b"NY", b"TX", b"WA", b"VA"])], None, "bitmap"),
         "int8 + int32, 10 %": ([2, 0], [(0, GT, 89.0), (1, GT, -1.0)], (c > 89) & (a > -1), "one launch"),    # an int32 column: the one launch at any selectivity
     }
     for name, (used, sels, keep, want) in cases.items():
+        if keep is None:
+            keep = np.zeros(n, bool)
+            for v in sels[0][2]:
+                keep |= (s2[:, 0] == v[0]) & (s2[:, 1] == v[1])
         rows = np.flatnonzero(keep)
         proj = list(range(len(used)))
         q = native.DeviceQuery(ctx, seg, used, sels, proj, 0)
