@@ -1129,7 +1129,13 @@ static void single_pass_drop_if_narrow(imm3_query *q, uint64_t survivors) {
     q->d_desc = nullptr;
     // a projected string column and few survivors: its two bytes are better staged than gathered (state = CA -> state, 2 %: 62 us
     // with records, 75 from the bitmap; at 10 % 108 / 106)
-    if (!q->records_narrow_only && !q->d_stage_rec && (double)survivors < 0.06 * (double)q->n_rows) (void)records_setup(q);
+    if (!q->records_narrow_only && !q->d_stage_rec && (double)survivors < 0.06 * (double)q->n_rows) {
+        if (records_setup(q) != IMM3_OK || !q->d_tile_start) { // (no memory for the records: the bitmap path needs none)
+            pool_release(ctx, q->d_stage_rec);
+            q->d_stage_rec = nullptr;
+            (void)hipGetLastError();
+        }
+    }
 }
 
 // A look at the data before the first run: the select chain's count over eight evenly spaced chunks of 64 tiles (0.5 % of
