@@ -1,5 +1,6 @@
-"""Builds lib/libimm3.so (hipcc, gfx950) from csrc/ and the C++ host CLIs (bin/imm3_sql, bin/imm3_loader).
-hipcc cross-compiles without a GPU."""
+"""Builds lib/libimm3.so (hipcc, gfx950) from csrc/, the tools' build lib/libimm3_ablate.so (the same sources with the kernels'
+ablation switches and the single-pass kernel's fault injection compiled in: tools/ and tests/test_gpu_fault_injection.py) and the
+C++ host CLIs (bin/imm3_sql, bin/imm3_loader).  hipcc cross-compiles without a GPU."""
 from __future__ import annotations
 
 import os
@@ -18,9 +19,10 @@ def build_native(force: bool = False) -> str:
     host = os.path.join(_PKG, "host")
     srcs += [os.path.join(host, f) for f in os.listdir(host) if f.endswith(".hpp")]
     srcs += [os.path.join(host, "cli", f) for f in os.listdir(os.path.join(host, "cli"))]
-    outs = [out, os.path.join(_PKG, "bin", "imm3_sql"), os.path.join(_PKG, "bin", "imm3_loader")]
+    outs = [out, os.path.join(_PKG, "lib", "libimm3_ablate.so"), os.path.join(_PKG, "bin", "imm3_sql"), os.path.join(_PKG, "bin", "imm3_loader")]
     if force or not all(os.path.exists(o) for o in outs) or min(os.path.getmtime(o) for o in outs) < max(os.path.getmtime(s) for s in srcs):
-        cmd = ["make", "-C", csrc, "-s"] + (["-B"] if force else [])
+        jobs = max(1, min(8, os.cpu_count() or 1))   # one object per source file: the kernel files compile side by side
+        cmd = ["make", "-C", csrc, "-s", f"-j{jobs}"] + (["-B"] if force else []) + ["all", "ablate"]
         subprocess.check_call(cmd)
     return out
 

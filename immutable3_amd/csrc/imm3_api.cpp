@@ -242,6 +242,23 @@ extern "C" int imm3_graph_launch(imm3_graph *g) {
     }
     HIPCHK(hipSetDevice(g->ctx->device));
     HIPCHK(hipGraphLaunch(g->exec, g->ctx->stream));
+    // A replay is the recorded runs again: every recorded query gets back the state it had after its recorded run (a getter of a
+    // single-pass run then reads THIS replay's status word -- round 3 left `sp_verified` set by an earlier getter, or
+    // `ran_single_pass` cleared by an earlier fallback, and a busy or abandoned replay went unnoticed).
+    for (size_t i = 0; i < g->queries.size() && i < g->states.size(); ++i) {
+        imm3_query *q = g->queries[i];
+        const QueryRunState &st = g->states[i];
+        q->ran_select = st.ran_select;
+        q->ran_project = st.ran_project;
+        q->bitmap_valid = st.bitmap_valid;
+        q->ran_single_pass = st.ran_single_pass;
+        q->stage_written = st.stage_written;
+        q->count_pending_scan = st.count_pending_scan;
+        q->has_pfor_pass = st.has_pfor_pass;
+        q->ran_agg = st.ran_agg;
+        q->offsets_valid = st.offsets_valid;
+        q->sp_verified = false;
+    }
     return IMM3_OK;
 }
 
@@ -275,6 +292,37 @@ extern "C" int imm3_ctx_set_tuning(imm3_ctx *ctx, int32_t filter_variant, int32_
     CTX_LIVE(ctx);
     ctx->filter_variant = filter_variant;
     ctx->grid_blocks = grid_blocks;
+    return IMM3_OK;
+}
+
+// Fault injection into the single-pass projection kernel (imm3_diag.h).  The fields travel in every launch's arguments; only the
+// tools' build of the kernel (-DIMM3_ABLATE) reads them.
+extern "C" int imm3_ctx_inject_fault(imm3_ctx *ctx, int32_t work_group, int32_t span, uint32_t max_polls) {
+    CTX_LIVE(ctx);
+#ifndef IMM3_ABLATE
+    if (work_group >= 0 || max_polls) return fail(IMM3_ERR_STATE, "fault injection exists only in the tools' build of the library (make -C csrc ablate)");
+#endif
+    ctx->fault_wg = work_group;
+    ctx->fault_span = span;
+    ctx->fault_max_polls = max_polls;
+    return IMM3_OK;
+}
+
+static int single_pass_lock_word(int device, unsigned long long **out);
+
+// The device's ticket word of the single-pass kernel (0 = free).  Tests put a foreign ticket there to make every launch find the
+// device busy, deterministically; imm3_project.hip and run_single_pass say what the word is for.
+extern "C" int imm3_ctx_debug_device_lock(imm3_ctx *ctx, uint64_t value, uint64_t *previous) {
+    CTX_LIVE(ctx);
+    HIPCHK(hipSetDevice(ctx->device));
+    unsigned long long *word = nullptr;
+    const int rc = single_pass_lock_word(ctx->device, &word);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    unsigned long long old = 0, v = (unsigned long long)value;
+    HIPCHK(hipMemcpy(&old, word, sizeof(old), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(word, &v, sizeof(v), hipMemcpyHostToDevice));
+    if (previous) *previous = old;
     return IMM3_OK;
 }
 
@@ -957,10 +1005,14 @@ static void single_pass_pick_P(imm3_query *q, double sigma, bool sure) {
     if (P < 2) P = q->sp_P_plan;
     P = std::min<int64_t>(P, q->sp_P_plan);
     if ((int32_t)P == q->sp_P) return;
+    // The descriptors are tagged with the run counter (26 bits): leave no tag behind in places the new P does not rewrite every
+    // run (stream order: after the runs so far, before the next one).  Hygiene, not correctness -- an alias would need 2^26 runs --
+    // so a failed memset only means the old P stays.
+    if (hipMemsetAsync(q->d_desc, 0, q->sp_trash_off, q->ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
     single_pass_set_P(q, (int32_t)P);
-    // the descriptors are tagged with the low byte of the run counter: leave no tag behind in places the new P does not rewrite
-    // every run (stream order: after the runs so far, before the next one)
-    (void)hipMemsetAsync(q->d_desc, 0, q->sp_trash_off, q->ctx->stream);
 }
 static void single_pass_adapt(imm3_query *q, uint64_t survivors, int64_t dense_ranges) {
     if (!q->single_pass || q->sp_P_fixed || q->n_rows <= 0 || survivors == 0) return;
@@ -1004,23 +1056,31 @@ static int single_pass_setup(imm3_query *q) {
     const bool fixed = ctx->filter_variant > 200 && ctx->filter_variant <= 200 + kProjectMaxP;
     if (fixed) P = ctx->filter_variant - 200; // tuning: variant 200 + P
     if (maxg < 1 || q->n_tiles < 1) return IMM3_OK;
+    // One allocation: round totals and round counters first (at the same place whatever P a run uses), then the span
+    // descriptors of the smallest P a run may use, then one 64-byte trash line per writer wave.  The plan is committed only
+    // once the allocation stands (a query whose descriptors could not be allocated keeps the three launches).
+    const int64_t spans_max = (q->n_tiles + kProjectMinP * kProjectStreamers - 1) / (kProjectMinP * kProjectStreamers);
+    const int64_t grid_min = std::min<int64_t>(maxg, spans_max);
+    const size_t rounds_max = (size_t)((spans_max + grid_min - 1) / grid_min);
+    const size_t desc_off = (rounds_max * (sizeof(unsigned long long) + sizeof(uint32_t)) + 255) / 256 * 256;
+    const size_t desc_bytes = desc_off + (size_t)spans_max * sizeof(unsigned long long);
+    const size_t trash_off = (desc_bytes + 255) / 256 * 256;
+    void *d = nullptr;
+    HIPCHK(pool_alloc(ctx, &d, trash_off + (size_t)maxg * kProjectWriters * 64));
+    const hipError_t me = hipMemsetAsync(d, 0, desc_bytes, ctx->stream); // (pooled memory: another query's descriptors)
+    if (me != hipSuccess) {
+        pool_release(ctx, d);
+        HIPCHK(me);
+    }
+    q->d_desc = (unsigned long long *)d;
+    q->sp_rounds_max = rounds_max;
+    q->sp_desc_off = desc_off;
+    q->sp_trash_off = trash_off;
     q->single_pass = true;
     q->sp_P_plan = (int32_t)P;
     q->sp_P_fixed = fixed;
     q->sp_max_grid = maxg;
     single_pass_set_P(q, (int32_t)P);
-    // One allocation: round totals and round counters first (at the same place whatever P a run uses), then the span
-    // descriptors of the smallest P a run may use, then one 64-byte trash line per writer wave.
-    const int64_t spans_max = (q->n_tiles + kProjectMinP * kProjectStreamers - 1) / (kProjectMinP * kProjectStreamers);
-    const int64_t grid_min = std::min<int64_t>(maxg, spans_max);
-    q->sp_rounds_max = (size_t)((spans_max + grid_min - 1) / grid_min);
-    q->sp_desc_off = (q->sp_rounds_max * (sizeof(unsigned long long) + sizeof(uint32_t)) + 255) / 256 * 256;
-    const size_t desc_bytes = q->sp_desc_off + (size_t)spans_max * sizeof(unsigned long long);
-    q->sp_trash_off = (desc_bytes + 255) / 256 * 256;
-    void *d = nullptr;
-    HIPCHK(pool_alloc(ctx, &d, q->sp_trash_off + (size_t)maxg * kProjectWriters * 64));
-    q->d_desc = (unsigned long long *)d;
-    HIPCHK(hipMemsetAsync(q->d_desc, 0, desc_bytes, ctx->stream)); // (pooled memory: another query's descriptors)
     return IMM3_OK;
 }
 
@@ -1173,6 +1233,7 @@ static int single_pass_sample(imm3_query *q) {
     void *d = nullptr;
     const size_t block = (size_t)kFinishWords * sizeof(unsigned long long);
     HIPCHK(pool_alloc(ctx, &d, block * kChunks));
+    struct PoolGuard { imm3_ctx *c; void *p; ~PoolGuard() { pool_release(c, p); } } guard{ctx, d}; // (stream-ordered reuse: released on every path out)
     HIPCHK(hipMemsetAsync(d, 0, block * kChunks, ctx->stream));
     unsigned long long counts[kChunks] = {0};
     for (int i = 0; i < kChunks; ++i) {
@@ -1188,12 +1249,11 @@ static int single_pass_sample(imm3_query *q) {
         a.block_partials = q->d_block_partials;
         a.finish = (unsigned long long *)((uint8_t *)d + block * (size_t)i);
         const int grid = filter_grid(a.n_tiles, false, any_i32, 0);
-        if (!launch_filter_tile(a, grid, ctx->stream, nullptr, nullptr)) { pool_release(ctx, d); return IMM3_OK; }
+        if (!launch_filter_tile(a, grid, ctx->stream, nullptr, nullptr)) return IMM3_OK;
     }
     // (one strided copy: word 0 of every block)
     HIPCHK(hipMemcpy2DAsync(counts, sizeof(unsigned long long), d, block, sizeof(unsigned long long), kChunks, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    pool_release(ctx, d);
     const double chunk_rows = (double)(kChunkTiles * kTileRows);
     double sum = 0.0, sum_sq = 0.0;
     for (int i = 0; i < kChunks; ++i) {
@@ -1773,6 +1833,7 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
         if (jrc) return jrc;
         q->total_on_aux = false;
     }
+    q->offsets_valid = false; // (a new bitmap)
     if (q->always_false || q->n_tiles == 0) {
         // an empty interval / empty IN-list clears every bit; nothing to read
         HIPCHK(hipMemsetAsync(q->d_total, 0, 2 * sizeof(unsigned long long), s)); // (an always-false query logs nothing)
@@ -2046,6 +2107,14 @@ static int single_pass_device(int device, SinglePassDevice **out) {
     return IMM3_OK;
 }
 
+static int single_pass_lock_word(int device, unsigned long long **out) {
+    SinglePassDevice *dev = nullptr;
+    const int rc = single_pass_device(device, &dev);
+    if (rc) return rc;
+    *out = dev->d_lock;
+    return IMM3_OK;
+}
+
 // ScanOp -> SelectOp* -> ProjectOp in one launch (k_filter_project): bitmap, count and the projected rows
 static int run_single_pass(imm3_query *q) {
     imm3_ctx *ctx = q->ctx;
@@ -2110,6 +2179,9 @@ static int run_single_pass(imm3_query *q) {
     }
     const int fv = ctx->filter_variant;
     a.ablate = (fv >= 50 && fv <= 50 + 255) ? fv - 50 : 0; // (tools' build only: a mask -- 1 no unpack, 2 no chained scan, 4 no records, 16 no output stores, 32 output stores cache resident)
+    a.max_polls = ctx->fault_max_polls; // (tools' build only: imm3_ctx_inject_fault)
+    a.fault_wg = ctx->fault_wg;
+    a.fault_span = ctx->fault_span;
     if (ctx->d_stamps) {
         std::lock_guard<std::mutex> lk(ctx->mu);
         if (ctx->d_stamps && ctx->stamp_used < ctx->stamp_slots) {
@@ -2143,6 +2215,7 @@ static int run_single_pass(imm3_query *q) {
     q->ran_project = true;
     q->ran_single_pass = true;
     q->sp_verified = false;
+    q->offsets_valid = false;
     return IMM3_OK;
 }
 
@@ -2231,6 +2304,7 @@ static int run_project(imm3_query *q) {
             launch_scan(sa, s, t.start, t.stop);
         }
         HIPCHK(hipGetLastError());
+        q->offsets_valid = true;
     }
     if (!(q->limit > 0) && !q->reserved && !q->d_row_index) {
         // Unlimited projection, no reservation, FIRST run: the output size is the count -> one synchronisation.  The arrays get
@@ -2275,8 +2349,31 @@ static int capture_admit(imm3_query *q) {
         return fail(IMM3_ERR_STATE, "run the query once (or reserve rows) before capturing it: its output buffers are allocated on first use");
     if (!q->proj.empty() && !q->d_row_index) return fail(IMM3_ERR_STATE, "run the query once (or reserve rows) before capturing it: its output buffers are allocated on first use");
     auto &qs = ctx->capture->queries;
-    if (std::find(qs.begin(), qs.end(), q) == qs.end()) qs.push_back(q);
+    if (std::find(qs.begin(), qs.end(), q) == qs.end()) {
+        qs.push_back(q);
+        ctx->capture->states.emplace_back();
+    }
     return IMM3_OK;
+}
+
+// the run has been recorded: what it leaves in the handle is what every replay of the graph leaves (imm3_graph_launch)
+static int capture_note(imm3_query *q, int rc) {
+    imm3_ctx *ctx = q->ctx;
+    if (rc || !ctx->capture) return rc;
+    auto &qs = ctx->capture->queries;
+    const auto it = std::find(qs.begin(), qs.end(), q);
+    if (it == qs.end()) return rc;
+    QueryRunState &st = ctx->capture->states[(size_t)(it - qs.begin())];
+    st.ran_select = q->ran_select;
+    st.ran_project = q->ran_project;
+    st.bitmap_valid = q->bitmap_valid;
+    st.ran_single_pass = q->ran_single_pass;
+    st.stage_written = q->stage_written;
+    st.count_pending_scan = q->count_pending_scan;
+    st.has_pfor_pass = q->has_pfor_pass;
+    st.ran_agg = q->ran_agg;
+    st.offsets_valid = q->offsets_valid;
+    return rc;
 }
 
 extern "C" int imm3_query_run_select(imm3_query *q) {
@@ -2285,7 +2382,7 @@ extern "C" int imm3_query_run_select(imm3_query *q) {
     const int ca = capture_admit(q);
     if (ca) return ca;
     q->ran_project = false;
-    return run_select(q, q->ctx->filter_variant == 2);
+    return capture_note(q, run_select(q, q->ctx->filter_variant == 2));
 }
 
 extern "C" int imm3_query_run_count(imm3_query *q) {
@@ -2294,7 +2391,7 @@ extern "C" int imm3_query_run_count(imm3_query *q) {
     const int ca = capture_admit(q);
     if (ca) return ca;
     q->ran_project = false;
-    return run_select(q, false, false, true);
+    return capture_note(q, run_select(q, false, false, true));
 }
 
 extern "C" int imm3_query_join_count(imm3_query *q) {
@@ -2313,13 +2410,13 @@ extern "C" int imm3_query_run(imm3_query *q) {
     // Reducing the count on the aux stream (tuning variant 2) measured SLOWER on MI355X / ROCm 7.2 (75.6 vs 67.1 us
     // per step: the cross-queue event packets cost more than the two same-queue launch gaps they remove), so the
     // default keeps the reduce on the main stream.
-    if (q->single_pass && !q->proj.empty() && !q->always_false && q->n_tiles > 0) return run_single_pass(q);
+    if (q->single_pass && !q->proj.empty() && !q->always_false && q->n_tiles > 0) return capture_note(q, run_single_pass(q));
     const bool select_only = q->proj.empty() && !q->is_agg && q->ctx->filter_variant == 2;
     int rc = run_select(q, select_only, !q->proj.empty() && q->n_tiles > 0 && !q->always_false && q->ctx->filter_variant != 7);
     if (rc) return rc;
     if (!q->proj.empty()) rc = run_project(q);
     if (!rc && q->is_agg) rc = run_agg(q);
-    return rc;
+    return capture_note(q, rc);
 }
 
 extern "C" int imm3_query_sync(imm3_query *q) {
@@ -2370,18 +2467,45 @@ extern "C" int imm3_query_log_counts(imm3_query *q, uint64_t *device_log, uint64
     return IMM3_OK;
 }
 
-// A single-pass run that was abandoned (a look-back that did not resolve: imm3_project.hip) is answered again through the
-// bitmap path, once, and the query keeps that path from then on.  Called by the getters before they read anything.
+// the offsets scan over the bitmap of the last run (for a gather from the bitmap): tile offsets and chunk sums
+static int scan_offsets(imm3_query *q) {
+    if (q->offsets_valid || q->n_tiles <= 0) return IMM3_OK;
+    ScanArgs sa;
+    std::memset(&sa, 0, sizeof(sa));
+    sa.bitmap = q->d_bitmap;
+    sa.tile_offsets = q->d_tile_offsets;
+    sa.chunk_sums = q->d_chunk_sums;
+    sa.n_tiles = q->n_tiles;
+    launch_scan(sa, q->ctx->stream, nullptr, nullptr); // (finish = null: the count is already published)
+    HIPCHK(hipGetLastError());
+    q->offsets_valid = true;
+    return IMM3_OK;
+}
+
+// Did the query's last single-pass launch give up on its rows?  `head` = the first kFinishDense + 1 words of the finish block as
+// fetched AFTER that launch: its flags are tagged with its epoch, and the launch bumped the run counter exactly once.
+static unsigned long long single_pass_flags(const unsigned long long *head) {
+    const unsigned long long status = head[kFinishStatus], epoch_run = head[kFinishEpoch] - 1ULL;
+    if (((status >> kStatusEpochShift) & kStatusEpochMask) != (epoch_run & kStatusEpochMask)) return 0ULL; // (an earlier run's flags)
+    return status & (kStatusAbandoned | kStatusBusy);
+}
+
+// Every getter's first step after a single-pass run: read the run's status word (with the count and the dense-range tally, one
+// copy).  The count and the bitmap of a run are exact whatever the flags say (imm3_project.hip: a work-group that gives up on the
+// rows goes on in count + bitmap mode); only the ROWS of a flagged run are incomplete, and they are gathered here from the bitmap
+// (offsets scan + k_gather into the same arrays).  Abandoned (a prefix never came although the device was this launch's: not
+// every work-group resident?): the query keeps the bitmap path from now on.  Busy (another launch of the kernel owned the device --
+// also when that made other work-groups of this launch time out, flags = busy | abandoned): this run only.
 static int settle_single_pass(imm3_query *q) {
     if (!q->ran_single_pass || q->sp_verified) return IMM3_OK;
     imm3_ctx *ctx = q->ctx;
-    static_assert(kFinishStatus == 2, "the count and the status word are fetched together");
-    unsigned long long head[kFinishDense + 1] = {0}; // {count, rows emitted, status, ..., dense ranges}
+    static_assert(kFinishStatus == 2 && kFinishEpoch < kFinishDense, "count, status word, run counter and dense tally are fetched together");
+    unsigned long long head[kFinishDense + 1] = {0}; // {count, rows emitted, status, ..., run counter, dense ranges}
     HIPCHK(hipMemcpyAsync(head, q->d_total, sizeof(head), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     q->sp_verified = true;
-    const unsigned long long status = head[kFinishStatus];
-    if (!(status & 6ULL)) {
+    const unsigned long long flags = single_pass_flags(head);
+    if (!flags) {
         single_pass_adapt(q, head[0], (int64_t)head[kFinishDense]); // (later runs: P from the selectivity this run saw)
         if (!q->sp_narrow_checked) { // (once: the data do not change)
             q->sp_narrow_checked = true;
@@ -2389,14 +2513,17 @@ static int settle_single_pass(imm3_query *q) {
         }
         return IMM3_OK;
     }
-    if (status & 2ULL) { // a prefix never came (not every work-group resident?): this query keeps the bitmap path from now on
+    if (flags & kStatusBusy) ++q->sp_busy_runs;
+    else {
+        ++q->sp_abandoned_runs;
         graphs_mark_stale(ctx, q); // (a recorded run would take the abandoned path again)
         q->single_pass = false;
-    } // else bit 2 alone: the device was busy with another launch of the kernel -- this run only
-    HIPCHK(hipMemsetAsync(q->d_total + kFinishStatus, 0, sizeof(unsigned long long), ctx->stream));
-    int rc = run_select(q, false, true);
+    }
+    q->ran_single_pass = false; // (the rows the getters see come from the bitmap path)
+    q->stage_written = false;
+    int rc = scan_offsets(q);
     if (rc) return rc;
-    return run_project(q);
+    return q->n_tiles > 0 ? launch_project(q) : IMM3_OK;
 }
 
 extern "C" int imm3_query_count(imm3_query *q, uint64_t *selected_rows) {
@@ -2455,17 +2582,9 @@ static int settle_rows(imm3_query *q, uint64_t *rows) {
         // they come from the bitmap now)
         int rc = ensure_row_capacity(q, q->reserved ? emit : std::min<unsigned long long>((unsigned long long)std::max<int64_t>(q->n_rows, 1), emit + emit / 8 + 1024));
         if (rc) return rc;
-        if (q->ran_single_pass) {
-            ScanArgs sa;
-            std::memset(&sa, 0, sizeof(sa));
-            sa.bitmap = q->d_bitmap;
-            sa.tile_offsets = q->d_tile_offsets;
-            sa.chunk_sums = q->d_chunk_sums;
-            sa.n_tiles = q->n_tiles;
-            launch_scan(sa, q->ctx->stream, nullptr, nullptr);
-            HIPCHK(hipGetLastError());
-        }
-        rc = launch_project(q);
+        rc = scan_offsets(q); // (a single-pass run made no offsets: they come from the bitmap now)
+        if (rc) return rc;
+        rc = launch_project(q); // (from the records when the run staged them, from the bitmap otherwise)
         if (rc) return rc;
         HIPCHK(hipStreamSynchronize(q->ctx->stream));
     }
@@ -2505,6 +2624,7 @@ extern "C" int imm3_query_device_ptr(imm3_query *q, int32_t which, void **ptr) {
     case 1: *ptr = q->d_total; return IMM3_OK;
     case 2: *ptr = q->d_row_index; return IMM3_OK;
     case 3: *ptr = q->d_n_emit; return IMM3_OK;
+    case 4: *ptr = q->d_total + kFinishStatus; return IMM3_OK; // the status word (imm3.h: which device-side consumers must look at it)
     default:
         if (which >= 16 && (size_t)(which - 16) < q->d_proj.size()) {
             *ptr = q->d_proj[(size_t)(which - 16)];
@@ -2516,9 +2636,10 @@ extern "C" int imm3_query_device_ptr(imm3_query *q, int32_t which, void **ptr) {
 
 extern "C" int imm3_query_plan(const imm3_query *q, int64_t *out, int32_t n) {
     if (!q || !out) return fail(IMM3_ERR_ARG, "null argument");
-    const int64_t v[8] = {q->single_pass ? 1 : 0, q->sp_P, q->sp_grid, q->sp_spans, q->d_stage_rec ? 1 : 0,
-                          (q->single_pass || q->d_stage_rec) ? rec_layout(q->stage_kinds, -1).dwords : 0, q->ran_single_pass ? 1 : 0, (int64_t)q->run_syncs};
-    for (int32_t i = 0; i < n && i < 8; ++i) out[i] = v[i];
+    const int64_t v[10] = {q->single_pass ? 1 : 0, q->sp_P, q->sp_grid, q->sp_spans, q->d_stage_rec ? 1 : 0,
+                           (q->single_pass || q->d_stage_rec) ? rec_layout(q->stage_kinds, -1).dwords : 0, q->ran_single_pass ? 1 : 0, (int64_t)q->run_syncs,
+                           (int64_t)q->sp_abandoned_runs, (int64_t)q->sp_busy_runs};
+    for (int32_t i = 0; i < n && i < 10; ++i) out[i] = v[i];
     return IMM3_OK;
 }
 
@@ -2706,6 +2827,19 @@ static int settle_groups(imm3_query *q, uint32_t *n_groups) {
 }
 
 int imm3::query_groups(imm3_query *q, uint32_t *n_groups) { return settle_groups(q, n_groups); }
+
+extern "C" int imm3_query_agg_shape(const imm3_query *q, int32_t *n_group_cols, int32_t *n_aggs, int32_t *key_bytes) {
+    if (!q) return fail(IMM3_ERR_ARG, "query is null");
+    if (!q->is_agg) return fail(IMM3_ERR_ARG, "not an aggregation query");
+    if (n_group_cols) *n_group_cols = (int32_t)q->group_cols.size();
+    if (n_aggs) *n_aggs = (int32_t)q->aggs.size();
+    if (key_bytes) {
+        int32_t kb = 0;
+        for (int32_t g : q->group_cols) kb += q->seg->cols[(size_t)q->used[(size_t)g]].width;
+        *key_bytes = kb;
+    }
+    return IMM3_OK;
+}
 
 extern "C" int imm3_query_group_count(imm3_query *q, uint32_t *n_groups) {
     if (!q || !n_groups) return fail(IMM3_ERR_ARG, "null argument");

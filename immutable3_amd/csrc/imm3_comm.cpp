@@ -397,13 +397,26 @@ extern "C" int imm3_comm_merge_groups(imm3_comm *c, imm3_query *const *queries, 
     if (ctx->closed) return fail(IMM3_ERR_STATE, "the context of this communicator has been destroyed");
     if (ctx->capture) return fail(IMM3_ERR_STATE, "a graph capture is open on this context");
     HIPCHK(hipSetDevice(ctx->device));
-    const char *why = "";
-    const int src = same_spec(queries, n_queries, &why);
-    if (src) return fail(src, why);
-    if (n_queries == 0) return fail(IMM3_ERR_ARG, "a rank joins the merge with at least one aggregation query (the aggregates' kinds come from it)");
+    // Every rank must take the same road AND the same exit: a rank that returned early while the others went on to the next
+    // collective would leave them waiting in hipStreamSynchronize for good.  So everything that can fail on this rank alone --
+    // argument checks, the queries' group lists (device work), the table's allocation -- happens BEFORE the first collective,
+    // and what it found travels with the shape exchange: {key width, aggregates, their complements (max of the complement = min),
+    // error flag}, one all-reduce(max) -- every rank sees whether all ranks agree and whether any of them has failed.
+    int local_rc = IMM3_OK;
+    std::string local_why;
+    auto local_fail = [&](int code, const std::string &msg) {
+        if (local_rc == IMM3_OK) { local_rc = code; local_why = msg; }
+    };
+    {
+        const char *why = "";
+        const int src = same_spec(queries, n_queries, &why);
+        if (src) local_fail(src, why);
+        else if (n_queries == 0) local_fail(IMM3_ERR_ARG, "a rank joins the merge with at least one aggregation query (the aggregates' kinds come from it)");
+    }
     int key_bytes = 0, n_agg = 0;
     int32_t kinds[kMaxAggs] = {0, 0, 0, 0}, is_str[kMaxAggs] = {0, 0, 0, 0};
-    if (n_queries > 0) {
+    std::vector<uint32_t> n_local((size_t)std::max(n_queries, 0), 0u); // groups of each query (its dense list is complete in q->d_o*)
+    if (local_rc == IMM3_OK) {
         imm3_query *q0 = queries[0];
         for (int32_t g : q0->group_cols) key_bytes += q0->seg->cols[(size_t)q0->used[(size_t)g]].width;
         n_agg = (int)q0->aggs.size();
@@ -411,30 +424,48 @@ extern "C" int imm3_comm_merge_groups(imm3_comm *c, imm3_query *const *queries, 
             kinds[j] = q0->aggs[j].kind;
             is_str[j] = q0->seg->cols[(size_t)q0->used[(size_t)q0->aggs[j].column]].vcodec == IMM3_DENSE_STRING;
         }
+        for (int32_t i = 0; i < n_queries && local_rc == IMM3_OK; ++i) {
+            if (queries[i]->ctx != ctx) { local_fail(IMM3_ERR_ARG, "the query runs on another context than the communicator"); break; }
+            const int grc = query_groups(queries[i], &n_local[(size_t)i]);
+            if (grc) local_fail(grc, imm3_last_error());
+        }
     }
-    // every rank must take the same road: agree on the widest key (and the number of aggregates) first
-    unsigned long long shape[2] = {(unsigned long long)key_bytes, (unsigned long long)n_agg};
     hipStream_t s = ctx->stream;
+    // the direct table of narrow keys (allocated before the exchange: a failure here is this rank's to report)
+    void *table = nullptr;
+    std::unique_ptr<void, void (*)(void *)> table_guard(nullptr, [](void *q) { (void)hipFree(q); });
+    const uint32_t K = key_bytes == 0 ? 1u : (key_bytes == 1 ? 256u : 65536u);
+    const size_t table_words = (size_t)K * (2 + kMaxAggs);
+    if (local_rc == IMM3_OK && key_bytes <= 2) {
+        const hipError_t e = hipMalloc(&table, table_words * sizeof(unsigned long long));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            local_fail(IMM3_ERR_DEVICE, std::string("hipMalloc of the merge table: ") + hipGetErrorString(e));
+        } else table_guard.reset(table);
+    }
     if (c->world > 1) {
         const int rrc = rccl_ready();
-        if (rrc) return rrc;
+        if (rrc) return rrc; // (no RCCL in this process: no rank of this process can be inside the collective either)
+        // The communicator's word and the communicator itself may still be in use by an imm3_comm_allreduce_count on the
+        // communicator's own stream: the merge's collectives run on the context's stream, behind that one.
+        if (c->in_flight) HIPCHK(hipStreamWaitEvent(s, c->ev_done, 0));
+        unsigned long long shape[5] = {(unsigned long long)key_bytes, (unsigned long long)n_agg, ~(unsigned long long)key_bytes, ~(unsigned long long)n_agg,
+                                       local_rc == IMM3_OK ? 0ULL : 1ULL};
+        if (local_rc != IMM3_OK) { shape[0] = shape[1] = 0ULL; shape[2] = shape[3] = 0ULL; } // (a failed rank does not vote on the shape)
         HIPCHK(hipMemcpyAsync(c->d_slot, shape, sizeof(shape), hipMemcpyHostToDevice, s));
-        NCCLCHK(g_rccl.AllReduce(c->d_slot, c->d_slot, 2, ncclUint64, ncclMax, c->nccl, s));
+        NCCLCHK(g_rccl.AllReduce(c->d_slot, c->d_slot, 5, ncclUint64, ncclMax, c->nccl, s));
         HIPCHK(hipMemcpyAsync(shape, c->d_slot, sizeof(shape), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        if (n_queries > 0 && (shape[0] != (unsigned long long)key_bytes || shape[1] != (unsigned long long)n_agg))
-            return fail(IMM3_ERR_ARG, "the ranks' aggregation queries differ in key width or number of aggregates");
-        key_bytes = (int)shape[0];
-        n_agg = (int)shape[1];
-    }
+        if (local_rc != IMM3_OK) return fail(local_rc, local_why);
+        if (shape[4]) return fail(IMM3_ERR_STATE, "another rank failed before the merge (its call says why); no rank has merged anything");
+        if (shape[0] != ~shape[2] || shape[1] != ~shape[3] || shape[0] != (unsigned long long)key_bytes || shape[1] != (unsigned long long)n_agg)
+            return fail(IMM3_ERR_ARG, "the ranks' aggregation queries differ in key width or number of aggregates"); // (max != min: every rank sees it and leaves here)
+    } else if (local_rc != IMM3_OK) return fail(local_rc, local_why);
     std::vector<MergedGroup> merged;
     if (key_bytes <= 2) {
         // ---- direct table + element-wise all-reduces ----
-        const uint32_t K = key_bytes == 0 ? 1u : (key_bytes == 1 ? 256u : 65536u);
-        void *p = nullptr;
-        const size_t words = (size_t)K * (2 + kMaxAggs);
-        HIPCHK(hipMalloc(&p, words * sizeof(unsigned long long)));
-        std::unique_ptr<void, void (*)(void *)> guard(p, [](void *q) { (void)hipFree(q); });
+        void *p = table;
+        const size_t words = table_words;
         MergeArgs a;
         std::memset(&a, 0, sizeof(a));
         a.slots = K;
@@ -447,10 +478,7 @@ extern "C" int imm3_comm_merge_groups(imm3_comm *c, imm3_query *const *queries, 
         HIPCHK(hipGetLastError());
         for (int32_t i = 0; i < n_queries; ++i) {
             imm3_query *q = queries[i];
-            if (q->ctx != ctx) return fail(IMM3_ERR_ARG, "the query runs on another context than the communicator");
-            uint32_t ng = 0;
-            const int grc = query_groups(q, &ng);
-            if (grc) return grc;
+            const uint32_t ng = n_local[(size_t)i];
             a.keys = q->d_okeys;
             a.first = q->d_ofirst;
             a.counts = q->d_ocounts;
@@ -486,10 +514,7 @@ extern "C" int imm3_comm_merge_groups(imm3_comm *c, imm3_query *const *queries, 
         std::map<unsigned long long, MergedGroup> local;
         for (int32_t i = 0; i < n_queries; ++i) {
             imm3_query *q = queries[i];
-            if (q->ctx != ctx) return fail(IMM3_ERR_ARG, "the query runs on another context than the communicator");
-            uint32_t ng = 0;
-            const int grc = query_groups(q, &ng);
-            if (grc) return grc;
+            const uint32_t ng = n_local[(size_t)i];
             std::vector<unsigned long long> hk(ng), hc(ng);
             std::vector<uint32_t> hf(ng);
             std::vector<long long> hv((size_t)ng * kMaxAggs);

@@ -74,6 +74,17 @@ struct imm3_ctx {
     uint32_t *d_xpow8 = nullptr;    // snappy CRC-32C check: x^(8 n) mod P for n = 0 .. 32768 (mu)
     imm3_graph *capture = nullptr;  // open stream capture (imm3_ctx_capture_begin .. _end), else null; owned by the capturing thread (gate)
     std::vector<imm3_graph *> graphs; // graphs recorded on this context that have not been destroyed yet (mu)
+    // fault injection into k_filter_project (imm3_ctx_inject_fault, imm3_diag.h): read by the tools' build of the kernel only
+    std::atomic<int> fault_wg{-1}, fault_span{-1};
+    std::atomic<uint32_t> fault_max_polls{0};
+};
+
+// What a run leaves in the query handle for the getters: which outputs exist and how they have to be settled.  A graph keeps the
+// state each recorded query had after its (last) recorded run and puts it back at every imm3_graph_launch: a replay IS that run
+// again, whatever direct runs, fallbacks or getters did to the handle in between.
+struct QueryRunState {
+    bool ran_select = false, ran_project = false, bitmap_valid = false, ran_single_pass = false, stage_written = false;
+    bool count_pending_scan = false, has_pfor_pass = false, ran_agg = false, offsets_valid = false;
 };
 
 // A recorded sequence of query runs (hipGraph): launching it enqueues every kernel of those runs with one call.
@@ -82,6 +93,7 @@ struct imm3_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     std::vector<imm3_query *> queries;    // the queries whose runs were recorded (not retained: destroying one makes the graph stale)
+    std::vector<QueryRunState> states;    // per query: its state after the recorded run
     bool stale = false;
 };
 
@@ -227,7 +239,9 @@ struct imm3_query {
     unsigned long long *d_desc = nullptr;   // per-span descriptors of the chained scan
     size_t sp_trash_off = 0;                // byte offset of the writers' trash lines in d_desc's allocation
     bool ran_single_pass = false;           // the last run went through k_filter_project ...
-    bool sp_verified = false;               // ... and its status word has been read since (not abandoned)
+    bool sp_verified = false;               // ... and its status word has been read since (rows complete, or gathered again from the bitmap)
+    bool offsets_valid = false;             // d_tile_offsets / d_chunk_sums describe the last run's bitmap (an offsets scan has run since)
+    uint32_t sp_abandoned_runs = 0, sp_busy_runs = 0; // single-pass runs whose rows were gathered from the bitmap instead: a prefix never came / the device was busy (imm3_query_plan)
     bool count_pending_scan = false; // the last select run left the count to the projection's offsets scan
 };
 

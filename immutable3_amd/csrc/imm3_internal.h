@@ -158,12 +158,15 @@ void launch_emit(const EmitArgs &a, int n_gather, int grid_blocks, hipStream_t s
 // spans go to the work-groups round-robin.  The survivors' records of a wave's range wait in LDS; where they go in the output -- the
 // number of survivors in all earlier tiles -- comes from a scan over per-span DESCRIPTORS, one ROUND of spans (one span per
 // work-group) at a time: the round's last span to arrive scans the round's counts (imm3_project.hip, span_arrive):
-//   desc[s] = epoch << 56 | flag << 54 | value     flag 1: value = survivors of span s (published when the span is done)
+//   desc[s] = epoch << 38 | flag << 36 | value     flag 1: value = survivors of span s (published when the span is done)
 //                                                  flag 2: value = survivors of spans 0..s-1: the span's first output row
 //                                                  flag 3: the run is being abandoned (a wait timed out)
-// `epoch` (finish[kFinishEpoch], bumped by the launch's last work-group) tells this run's descriptors from the previous
-// run's, so nothing is cleared between runs.  P is a launch argument: the host lowers it once it has seen how many rows
-// survive (imm3_api.cpp, single_pass_adapt); kProjectMinP sizes the descriptor array.
+// `epoch` (the low 26 bits of finish[kFinishEpoch], bumped by the launch's last work-group) tells this run's descriptors from
+// earlier runs', so nothing is cleared between runs: a stale tag could only alias after 2^26 runs of the query in which its
+// descriptor was never rewritten (round 3 carried 8 bits: 256 bumps -- every count of the query bumps the counter -- and a graph
+// that keeps a larger P than the direct runs touches descriptors those never rewrite).  A segment has < 2^32 rows, so 36 value
+// bits are plenty.  P is a launch argument: the host lowers it once it has seen how many rows survive (imm3_api.cpp,
+// single_pass_adapt); kProjectMinP sizes the descriptor array.
 constexpr int kProjectMinP = 1;
 constexpr int kProjectMaxP = 64;        // tiles per wave per span (the tile's index in its range takes 6 bits of the record)
 // (tools: -DIMM3_PROJECT_STREAMERS=12 -DIMM3_PROJECT_RING_KB=9 was tried -- 16 waves cap the kernel at 128 VGPRs: C3 137 us against 125)
@@ -176,10 +179,22 @@ constexpr int kProjectMaxP = 64;        // tiles per wave per span (the tile's i
 constexpr int kProjectStreamers = IMM3_PROJECT_STREAMERS;  // waves of a work-group that stream tiles: a span is kProjectStreamers * P consecutive tiles
 constexpr int kProjectWriters = 4;    // waves of a work-group that write the rows
 constexpr int kProjectRingBytes = IMM3_PROJECT_RING_KB * 1024; // a streamer's LDS ring of survivor records
-constexpr int kFinishStatus = 2;        // finish[2]: bit 0 malformed PFOR block; single-pass projection: bit 1 abandoned (a prefix never came), bit 2 device busy
+// finish[2], the query's status word: bit 0 malformed PFOR block (k_filter_pfor); single-pass projection: bit 1 = the run's ROWS
+// are incomplete because a prefix never came (abandoned), bit 2 = ... because another launch of the kernel owned the device (busy).
+// Bits 1-2 are valid for ONE run: bits 8..31 carry the low 24 bits of that run's epoch (status_flag_set / status_raise,
+// imm3_project.hip), so a later launch of the query never mistakes an earlier run's flags for its own and the host never
+// has to clear the word.  Whatever the flags say, a run's COUNT (finish[0], finish[1]) and BITMAP are exact: a work-group that gives up
+// on the rows goes on streaming in count + bitmap mode.
+constexpr int kFinishStatus = 2;
+constexpr unsigned long long kStatusPfor = 1ULL, kStatusAbandoned = 2ULL, kStatusBusy = 4ULL;
+constexpr int kStatusEpochShift = 8;
+constexpr unsigned long long kStatusEpochMask = 0xFFFFFFULL;
 constexpr int kFinishEpoch = 8;         // finish[8]: run counter of the query (descriptor epochs)
 constexpr int kFinishDense = 9;         // finish[9]: single-pass projection: ranges of the last run that outgrew their LDS ring (finish[10]: the running sum)
-constexpr unsigned long long kDescValueMask = (1ULL << 54) - 1;
+constexpr int kDescValueBits = 36, kDescFlagShift = 36, kDescEpochShift = 38;
+constexpr unsigned long long kDescValueMask = (1ULL << kDescValueBits) - 1;
+constexpr unsigned long long kDescEpochMask = (1ULL << (64 - kDescEpochShift)) - 1;
+constexpr uint32_t kProjectMaxPolls = 1u << 17; // polls of a look-back wait (~0.1-0.2 s) before the run's rows are given up
 struct ProjectArgs {
     TileCol cols[kMaxTileCols];
     int32_t kinds[kMaxTileCols];    // sorted ascending, TK_NONE last
@@ -200,6 +215,10 @@ struct ProjectArgs {
     int32_t ablate;
     unsigned long long *stamps;     // diagnostics only
     unsigned long long *device_lock; // one word per device: the ticket of the launch of this kernel that owns the device, or 0
+    // fault injection (imm3_diag.h, imm3_ctx_inject_fault): read only by the tools' build (IMM3_ABLATE); the shipped kernel carries none of it
+    uint32_t max_polls;             // polls before a look-back wait gives up (0: kProjectMaxPolls)
+    int32_t fault_wg, fault_span;   // work-group fault_wg never announces its fault_span-th span (-1: none)
+    int32_t pad2;
 };
 // false: no instance for these kinds.  grid <= project_max_grid(): every work-group must be resident (they wait on each other)
 bool launch_filter_project(const ProjectArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);

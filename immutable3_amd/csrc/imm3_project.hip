@@ -20,9 +20,12 @@
 //     writer takes its rows from the source columns again, at the set bits of the range's bitmap lines (unpack_dense).
 //
 // Order is deterministic: a row's output slot is the number of survivors before it, whatever the work-groups' timing.
-// Every work-group of the launch must be resident (they wait on each other's descriptors): one work-group per CU, and a
-// wait that does not resolve within a bounded number of polls abandons the run (status bit, every work-group drains) --
-// the host then answers the query through the bitmap path.
+// Every work-group of the launch must be resident (they wait on each other's descriptors): one work-group per CU.  A wait
+// that does not resolve within a bounded number of polls, or a device that another launch of this kernel owns, makes the
+// launch give up on the ROWS only: a status flag is raised (tagged with the run's epoch), every writer wave leaves, and every
+// streamer goes on to the end of its tiles in count + bitmap mode -- no records, no ring, no wait of any kind.  The run's
+// COUNT and BITMAP are therefore exact whatever happens (what the RCCL count all-reduce, the count log and every other
+// device-side consumer read); the host gathers the rows of such a run from the bitmap (settle_single_pass, imm3_api.cpp).
 #include "imm3_internal.h"
 #include "imm3_device.h"
 #include "imm3_tile.h"
@@ -32,10 +35,37 @@
 namespace imm3 {
 
 constexpr int kProjParkLines = 16;       // bitmap lines a wave parks in LDS between store bursts
-constexpr uint32_t kLookbackMaxPolls = 1u << 17; // ~0.1-0.2 s of polling: then the run is abandoned
+
+// polls before a look-back wait gives up: ~0.1-0.2 s (the tools' build takes a smaller cap from the fault-injection hook)
+__device__ __forceinline__ uint32_t max_polls(const ProjectArgs &a) {
+#ifdef IMM3_ABLATE
+    if (a.max_polls) return a.max_polls;
+#endif
+    (void)a;
+    return kProjectMaxPolls;
+}
 
 __device__ __forceinline__ unsigned long long desc_pack(uint32_t epoch, uint32_t flag, unsigned long long value) {
-    return ((unsigned long long)(epoch & 0xFFu) << 56) | ((unsigned long long)flag << 54) | (value & kDescValueMask);
+    return (((unsigned long long)epoch & kDescEpochMask) << kDescEpochShift) | ((unsigned long long)flag << kDescFlagShift) | (value & kDescValueMask);
+}
+__device__ __forceinline__ uint32_t desc_epoch(unsigned long long d) { return (uint32_t)(d >> kDescEpochShift); }
+__device__ __forceinline__ uint32_t desc_flag(unsigned long long d) { return (uint32_t)(d >> kDescFlagShift) & 3u; }
+
+// The status word's flags belong to ONE run: bits 8..31 carry the epoch of the run that raised them (imm3_internal.h).
+__device__ __forceinline__ bool status_flag_set(const ProjectArgs &a, uint32_t epoch, unsigned long long flags) {
+    const unsigned long long w = __hip_atomic_load(a.finish + kFinishStatus, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ((w >> kStatusEpochShift) & kStatusEpochMask) == ((unsigned long long)epoch & kStatusEpochMask) && (w & flags) != 0ULL;
+}
+// one lane.  (A compare-and-swap loop: an earlier run's flags are replaced, this run's are added to.)
+__device__ __forceinline__ void status_raise(const ProjectArgs &a, uint32_t epoch, unsigned long long flag) {
+    const unsigned long long tag = ((unsigned long long)epoch & kStatusEpochMask) << kStatusEpochShift;
+    unsigned long long seen = __hip_atomic_load(a.finish + kFinishStatus, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int tries = 0; tries < 1024; ++tries) { // (bounded: at most one writer per work-group and flag ever contends)
+        const bool mine = ((seen >> kStatusEpochShift) & kStatusEpochMask) == ((unsigned long long)epoch & kStatusEpochMask);
+        const unsigned long long want = mine ? (seen | flag) : (tag | flag);
+        if (want == seen) return;
+        if (__hip_atomic_compare_exchange_strong(a.finish + kFinishStatus, &seen, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    }
 }
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
@@ -54,18 +84,19 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 __device__ __forceinline__ unsigned long long desc_load(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void desc_store(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ bool desc_ready(unsigned long long d, uint32_t epoch, uint32_t flag) {
-    return (uint32_t)(d >> 56) == (epoch & 0xFFu) && ((uint32_t)(d >> 54) & 3u) >= flag;
+    return desc_epoch(d) == (uint32_t)(epoch & kDescEpochMask) && desc_flag(d) >= flag;
 }
-__device__ __forceinline__ bool desc_dead(unsigned long long d, uint32_t epoch) { return (uint32_t)(d >> 56) == (epoch & 0xFFu) && ((uint32_t)(d >> 54) & 3u) == 3u; }
+__device__ __forceinline__ bool desc_dead(unsigned long long d, uint32_t epoch) { return desc_epoch(d) == (uint32_t)(epoch & kDescEpochMask) && desc_flag(d) == 3u; }
 
-// wave-uniform poll of one word until `flag` (2 = prefix known); false: abandoned / timed out
+// wave-uniform poll of one word until `flag` (2 = prefix known); false: the rows of this run are given up (abandoned, busy, timed out)
 __device__ __forceinline__ bool desc_wait(const ProjectArgs &a, const unsigned long long *p, uint32_t epoch, uint32_t flag, unsigned long long &out) {
+    const uint32_t cap = max_polls(a);
     for (uint32_t polls = 0;; ++polls) {
         const unsigned long long d = desc_load(p); // (every lane loads the same word: one request)
         if (desc_dead(d, epoch)) return false;
         if (desc_ready(d, epoch, flag)) { out = d & kDescValueMask; return true; }
-        if (polls > kLookbackMaxPolls) return false;
-        if ((polls & 63u) == 63u && (desc_load(a.finish + kFinishStatus) & 2ULL)) return false;
+        if (polls > cap) return false;
+        if ((polls & 63u) == 63u && status_flag_set(a, epoch, kStatusAbandoned | kStatusBusy)) return false; // (somebody of this launch has given up: no need to wait for the time-out)
         __builtin_amdgcn_s_sleep(8);
     }
 }
@@ -84,6 +115,7 @@ __device__ __forceinline__ bool span_arrive(const ProjectArgs &a, int64_t s, uin
         unsigned long long base = 0;
         bool ok = true;
         if (r > 0) ok = desc_wait(a, round_total + (r - 1), epoch, 2u, base);
+        const uint32_t cap = max_polls(a);
         for (int64_t c0 = 0; ok && c0 < n_in; c0 += 256) { // 256 spans per step: four descriptors per lane, all loads in flight together
             unsigned long long d[4];
             for (uint32_t polls = 0;; ++polls) { // (the counts were stored before their arrivals were counted, but nothing orders the two: check)
@@ -96,11 +128,12 @@ __device__ __forceinline__ bool span_arrive(const ProjectArgs &a, int64_t s, uin
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     dead = dead || desc_dead(d[q], epoch);
-                    all = all && desc_ready(d[q], epoch, 1u) && ((uint32_t)(d[q] >> 54) & 3u) == 1u; // (exactly "count known": prefixes are written below, by this wave only)
+                    all = all && desc_ready(d[q], epoch, 1u) && desc_flag(d[q]) == 1u; // (exactly "count known": prefixes are written below, by this wave only)
                 }
                 if (ballot64(dead)) { ok = false; break; }
                 if (ballot64(!all) == 0ULL) break;
-                if (polls > kLookbackMaxPolls) { ok = false; break; }
+                if (polls > cap) { ok = false; break; }
+                if ((polls & 63u) == 63u && status_flag_set(a, epoch, kStatusAbandoned | kStatusBusy)) { ok = false; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
             if (!ok) break;
@@ -130,10 +163,12 @@ __device__ __forceinline__ bool span_arrive(const ProjectArgs &a, int64_t s, uin
     return true;
 }
 
-// the run is abandoned (a wait timed out, or another work-group said so): tell the host, the other waves of this work-group and
-// everybody who waits on this work-group's spans.  One lane.
-__device__ __forceinline__ void abandon_run(const ProjectArgs &a, int64_t s, uint32_t epoch, uint32_t *s_abort) {
-    __hip_atomic_fetch_or(a.finish + kFinishStatus, 2ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// This work-group gives up on the run's ROWS (a wait timed out, another work-group said so, or the device is busy with another
+// launch): tell the host (`flag`, tagged with the run's epoch), the other waves of this work-group (s_abort: the writers leave, the
+// streamers go on in count + bitmap mode) and everybody who waits on this work-group's spans from s on (dead descriptors: a
+// waiter sees them at its next poll instead of at its time-out).  One lane.
+__device__ __forceinline__ void abandon_run(const ProjectArgs &a, int64_t s, uint32_t epoch, uint32_t *s_abort, unsigned long long flag = kStatusAbandoned) {
+    status_raise(a, epoch, flag);
     for (int64_t r = s; r < a.n_spans; r += gridDim.x) desc_store(a.desc + r, desc_pack(epoch, 3u, 0ULL));
     __hip_atomic_store(s_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -145,6 +180,10 @@ __device__ __forceinline__ uint32_t lds_peek(const uint32_t *p) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
 }
 __device__ __forceinline__ void lds_poke(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// the acquiring read that pairs with a release store of another wave of this work-group (after a relaxed poll has matched)
+__device__ __forceinline__ uint32_t lds_peek_acquire(const uint32_t *p) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
 
 // what a streamer publishes about a finished range (slot = range parity)
 struct RangePub {
@@ -574,14 +613,18 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
     // its launches with events (imm3_api.cpp); this lock is the net under graphs and under anything the host cannot see:
     // a launch that finds another one's ticket in the lock gives up at once (status bit 2) and the host answers the query
     // through the bitmap path.
+    // A work-group that finds the device taken, or that finds a flag of THIS run already raised (an earlier work-group of the
+    // launch found it taken: the owner may have finished since, and a late-comer that took the lock now would wait for spans
+    // that will never be announced), raises the busy flag, marks its own spans dead and streams in count + bitmap mode.
     const unsigned long long ticket = ((unsigned long long)(uintptr_t)a.desc << 8) | (unsigned long long)((epoch & 0xFFu) | 1u);
     if (threadIdx.x == 0 && a.device_lock) {
-        unsigned long long seen = 0ULL;
-        __hip_atomic_compare_exchange_strong(a.device_lock, &seen, ticket, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (seen != 0ULL && seen != ticket) {
-            __hip_atomic_fetch_or(a.finish + kFinishStatus, 4ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_abort = 1u;
+        bool busy = status_flag_set(a, epoch, kStatusAbandoned | kStatusBusy);
+        if (!busy) {
+            unsigned long long seen = 0ULL;
+            __hip_atomic_compare_exchange_strong(a.device_lock, &seen, ticket, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            busy = seen != 0ULL && seen != ticket;
         }
+        if (busy) abandon_run(a, blockIdx.x, epoch, &s_abort, kStatusBusy);
     }
     __syncthreads();
     const int P = a.P;
@@ -628,13 +671,16 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
         int64_t s = blockIdx.x;
         uint32_t tail_pos = 0, tail_total = 0; // where the next record goes in the ring; records ever put there (minus those taken back by a spill)
         uint32_t head_seen = 0;                // the ring's head as last read from LDS (it only grows: a stale value is a safe one)
+        // The rows of this run have been given up (s_abort: busy device, a look-back that timed out here or elsewhere): the writers
+        // are gone, and this wave goes on to the end of its tiles in count + bitmap mode -- every range "dense", nothing published,
+        // nothing waited for.  The count this work-group adds at the end and its bitmap lines are exact either way.
         bool abandoned = false;
-        if (lds_peek(&s_abort)) abandoned = true; // (the device is busy with another launch of this kernel)
-        for (uint32_t i = 0; s < a.n_spans && !abandoned; s += gridDim.x, ++i) {
+        for (uint32_t i = 0; s < a.n_spans; s += gridDim.x, ++i) {
+            if (!abandoned && lds_peek(&s_abort)) abandoned = true;
             const int64_t t0 = (s * kProjStreamers + wave) * P;
             const uint32_t range_start = tail_pos;
             uint32_t range_cnt = 0; // survivors of this range
-            bool dense = false;     // the range keeps no records (see unpack_dense)
+            bool dense = abandoned; // the range keeps no records (see unpack_dense)
             int parked = 0, first_parked = 0;
             auto flush_park = [&]() { // 4 lines (4 x 16 lanes) per store instruction; the lines of consecutive tiles are contiguous
                 lds_wave_sync();
@@ -695,7 +741,10 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
                             __builtin_amdgcn_s_sleep(2);
                         }
                     }
-                    if (abandoned) return;
+                    if (abandoned) { // (this tile's line is parked and counted: from here on counts and bitmap lines only)
+                        dense = true;
+                        return;
+                    }
                     const uint32_t lane_j = (uint32_t)lane | ((uint32_t)j << 10);
                     if (cnt == 0) {
                     } else if (tail_pos + cnt <= kCap) { // the common case: the tile's records do not wrap around the ring
@@ -713,7 +762,7 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
                     tail_pos += cnt;
                     if (tail_pos >= kCap) tail_pos -= kCap;
             };
-            for (int j = 0; j < P && !abandoned; ++j) {
+            for (int j = 0; j < P; ++j) {
                 const int64_t tile = t0 + j;
                 if (tile >= a.n_tiles) break; // wave-uniform
                 if (tile < n_full) {
@@ -747,14 +796,14 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
                     lane_total += (uint32_t)__popcll(mine);
                 }
             }
-            if (abandoned) break;
             if (parked) flush_park();
+            if (abandoned) continue; // (nobody takes ranges any more)
             // ---- publish the range (the slot's previous range, i - kProjSlots, must have been taken by the writer) ----
             while (!IMM3_ABLATE_BIT(a, 128) && i >= (uint32_t)kProjSlots && lds_peek(&s_drained[wave]) < i - (uint32_t)(kProjSlots - 1)) {
                 if (lds_peek(&s_abort)) { abandoned = true; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
-            if (abandoned) break;
+            if (abandoned) continue;
             if (dense) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the writer (another wave of this CU) reads the range's bitmap lines: the stores must have landed
             if (lane == 0) {
                 if (dense) __hip_atomic_fetch_add(&s_dense_ranges, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -770,7 +819,10 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
                 arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
                 if (arrived == (uint32_t)kProjStreamers - 1u && lane == 0) { // (behind the other seven's fetch_adds, hence behind their s_pub writes: the LDS serves a wave's operations in order)
                     lds_poke(&s_arrive[slot], 0u); // (the slot's next span, i + kProjSlots, is published only after this one was drained)
-                    lds_poke(&s_span_ready, i + 1); // (spans become ready in order: every streamer finishes range i before range i + 1)
+                    // (spans become ready in order: every streamer finishes range i before range i + 1.)  A RELEASE at work-group scope: the
+                    // other seven streamers' s_pub writes -- and a dense range's fence above -- reach this wave through their relaxed
+                    // fetch_adds on s_arrive, which is not a release sequence by the letter; the store that the writers acquire is.
+                    __hip_atomic_store(&s_span_ready, i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef IMM3_ABLATE
                     if (a.stamps && i < 6) a.stamps[2 * gridDim.x + blockIdx.x * 24 + i] = wall_clock64(); // (tools: span i streamed)
 #endif
@@ -802,6 +854,9 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
             if (!__builtin_amdgcn_readfirstlane((int)got)) return true; // (another writer has it)
 #ifdef IMM3_ABLATE
             if (a.stamps && lane == 0 && ann < 6) a.stamps[2 * gridDim.x + blockIdx.x * 24 + 18 + ann] = wall_clock64(); // (tools: span about to be announced)
+            // fault injection (imm3_ctx_inject_fault): this work-group never announces this span -- its round never completes, every
+            // work-group that waits for a prefix of that round or a later one runs into its poll cap and gives the rows up
+            if ((int)blockIdx.x == a.fault_wg && (int)ann == a.fault_span) return true;
 #endif
             lds_wave_order();
             const unsigned long long agg = wave_sum_u64(lane < kProjStreamers ? (unsigned long long)s_pub[lane][ann % kProjSlots].cnt : 0ULL);
@@ -818,7 +873,9 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
                 if (lds_peek(&s_abort)) { dead = true; break; }
                 __builtin_amdgcn_s_sleep(16);
             }
-            if (dead || !announce()) break;
+            if (dead) break;
+            (void)lds_peek_acquire(&s_span_ready); // (pairs with the release store of the streamer that finished the span: its and the other streamers' s_pub entries are visible)
+            if (!announce()) break;
             lds_wave_order();
             unsigned long long before = 0; // survivors of the span before this writer's ranges
 #pragma unroll 1

@@ -34,7 +34,7 @@ EXPORTS = [
     "imm3_segment_create", "imm3_segment_create_async", "imm3_segment_wait", "imm3_segment_wrap_device", "imm3_segment_destroy", "imm3_segment_bytes",
     "imm3_table_create", "imm3_table_destroy", "imm3_query_create_table", "imm3_query_create_table_agg",
     "imm3_query_segment_starts", "imm3_query_locate_rows",
-    "imm3_query_create", "imm3_query_create_agg", "imm3_query_group_count", "imm3_query_fetch_groups",
+    "imm3_query_create", "imm3_query_create_agg", "imm3_query_group_count", "imm3_query_fetch_groups", "imm3_query_agg_shape",
     "imm3_query_destroy", "imm3_query_reserve_rows",
     "imm3_query_run", "imm3_query_run_select", "imm3_query_run_count", "imm3_query_sync", "imm3_query_join_count", "imm3_query_log_counts",
     "imm3_query_layout", "imm3_query_batches", "imm3_query_count", "imm3_query_bitmap",
@@ -48,6 +48,7 @@ EXPORTS = [
 DIAG_EXPORTS = [
     "imm3_ctx_timing_enable", "imm3_ctx_timing_reset", "imm3_ctx_timing_mask", "imm3_ctx_timing_collect", "imm3_ctx_set_tuning",
     "imm3_ctx_measure_read_gbps", "imm3_ctx_devclock_enable", "imm3_ctx_devclock_collect", "imm3_ctx_devclock_raw", "imm3_query_plan",
+    "imm3_ctx_inject_fault", "imm3_ctx_debug_device_lock",
 ]
 COMM_ID_BYTES = 128
 
@@ -167,6 +168,9 @@ def load() -> C.CDLL:
     L.imm3_ctx_devclock_enable.argtypes = [vp, i32]
     L.imm3_ctx_devclock_collect.argtypes = [vp, vp, i32, P(i32)]
     L.imm3_query_plan.argtypes = [vp, vp, i32]
+    L.imm3_query_agg_shape.argtypes = [vp, P(i32), P(i32), P(i32)]
+    L.imm3_ctx_inject_fault.argtypes = [vp, i32, i32, C.c_uint32]
+    L.imm3_ctx_debug_device_lock.argtypes = [vp, u64, P(u64)]
     L.imm3_ctx_devclock_raw.argtypes = [vp, i32, vp, i32]
     L.imm3_comm_unique_id.argtypes = [vp]
     L.imm3_comm_create.argtypes = [vp, i32, i32, vp, P(vp)]
@@ -278,6 +282,17 @@ class Context:
 
     def set_tuning(self, filter_variant: int = 0, grid_blocks: int = 0):
         _check(load().imm3_ctx_set_tuning(self._h, filter_variant, grid_blocks))
+
+    def inject_fault(self, work_group: int = -1, span: int = -1, max_polls: int = 0):
+        """Tools' build only (imm3_diag.h): work-group `work_group` of every single-pass launch never announces its `span`-th span;
+        look-back waits give up after `max_polls` polls.  (-1, -1, 0) switches it off."""
+        _check(load().imm3_ctx_inject_fault(self._h, work_group, span, max_polls))
+
+    def debug_device_lock(self, value: int) -> int:
+        """Overwrites the device's single-pass ticket word (0 = free); returns what it held (imm3_diag.h)."""
+        prev = C.c_uint64(0)
+        _check(load().imm3_ctx_debug_device_lock(self._h, value, C.byref(prev)))
+        return prev.value
 
     def measure_read_gbps(self, nbytes: int = 400_000_000, iters: int = 30) -> float:
         g = C.c_double(0.0)
@@ -600,10 +615,11 @@ class DeviceQuery:
 
     def plan(self) -> dict:
         """How the library planned this query (include/imm3_diag.h: imm3_query_plan)."""
-        v = np.zeros(8, np.int64)
-        _check(load().imm3_query_plan(self._h, v.ctypes.data, 8))
+        v = np.zeros(10, np.int64)
+        _check(load().imm3_query_plan(self._h, v.ctypes.data, 10))
         return {"single_pass": bool(v[0]), "P": int(v[1]), "grid": int(v[2]), "spans": int(v[3]), "records": bool(v[4]),
-                "rec_dwords": int(v[5]), "ran_single_pass": bool(v[6]), "run_syncs": int(v[7])}
+                "rec_dwords": int(v[5]), "ran_single_pass": bool(v[6]), "run_syncs": int(v[7]),
+                "abandoned_runs": int(v[8]), "busy_runs": int(v[9])}
 
     def device_ptr(self, which: int) -> int:
         p = C.c_void_p()

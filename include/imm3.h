@@ -225,6 +225,10 @@ int imm3_query_create_agg(imm3_ctx *ctx, const imm3_segment *seg,
                           const imm3_aggregate *aggs, int32_t n_aggs,
                           int32_t table_block_size, imm3_query **out);
 int imm3_query_group_count(imm3_query *q, uint32_t *n_groups);
+/* The shape of an aggregation query's result rows: group columns, aggregates (the stride of `vals` in imm3_query_fetch_groups and
+ * imm3_comm_merge_groups[_all]), bytes of the packed group key.  A binding sizes its buffers from THIS, not from what its caller
+ * believes (IMM3_ERR_ARG for a query that is not an aggregation). */
+int imm3_query_agg_shape(const imm3_query *q, int32_t *n_group_cols, int32_t *n_aggs, int32_t *key_bytes);
 /* keys: the group columns' raw bytes packed little-endian in group_cols order; first_row: lowest selected row of
  * the group; counts: selected rows of the group; vals[g * n_aggs + j]: COUNT -> the count, MIN/MAX numeric -> the
  * int32 value sign-extended, MAX string -> the value's bytes packed big-endian.  Sorted by first_row. */
@@ -282,7 +286,18 @@ int imm3_query_fetch_rows(imm3_query *q, uint32_t *row_index_out, void *const *c
 
 /* Device-resident results for callers that stay on the GPU (RCCL count reduce, chained kernels).
  * which: 0 = bitmap (uint64 words), 1 = total count (one uint64), 2 = row indices (uint32),
- *        3 = emitted row count (one uint64), 16+j = projected column j */
+ *        3 = emitted row count (one uint64), 4 = status word (one uint64), 16+j = projected column j.
+ * What a device-side consumer may rely on behind a run, without any host getter in between:
+ *   - bitmap (0), count (1) and emitted row count (3) are exact after EVERY run.  In particular the one-launch projection
+ *     (csrc/imm3_project.hip), whose work-groups wait on each other, degrades to "count + bitmap" when such a wait does not
+ *     resolve or when another launch of that kernel owns the device: the counts that meet in imm3_comm_allreduce_count
+ *     (Engine.scala:190-196) are right whatever happened to the rows;
+ *   - row indices (2) and projected columns (16+j) of a one-launch projection are complete only if the status word (4) shows
+ *     neither bit 1 (a prefix never came) nor bit 2 (device busy) FOR THAT RUN: bits 8..31 of the word are the run's tag,
+ *     (run counter - 1) & 0xFFFFFF with the run counter at count pointer + 8 words.  The host getters (imm3_query_row_count /
+ *     _fetch_rows) check this themselves and gather the rows from the bitmap when needed; a consumer that reads the row arrays
+ *     on the device calls imm3_query_row_count first (it waits for the run) or checks the word.  Pointers 2 and 16+j change
+ *     when the output arrays grow (a reservation that was too small): fetch them again after imm3_query_row_count. */
 int imm3_query_device_ptr(imm3_query *q, int32_t which, void **ptr);
 
 /* ---- multi-GPU: the count reduce.  Segments shard one per GPU -- segment s belongs to GPU s mod G -- and

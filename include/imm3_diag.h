@@ -52,8 +52,24 @@ int imm3_ctx_set_tuning(imm3_ctx *ctx, int32_t filter_variant, int32_t grid_bloc
  * out[1] = tiles per wave per span (P: lowered by the library once a getter has seen how many rows a run selected); out[2] = work-groups of that launch; out[3] = spans;
  * out[4] = 1 when the projection goes through survivor records in HBM (filter -> k_scan -> k_emit), else 0;
  * out[5] = dwords per survivor record; out[6] = 1 when the last run used the single-pass launch; out[7] = how often
- * imm3_query_run has waited for the device so far (an unreserved unlimited projection: once, on its first run).  n <= 8 values. */
+ * imm3_query_run has waited for the device so far (an unreserved unlimited projection: once, on its first run);
+ * out[8] / out[9] = single-pass runs of this query whose rows a getter had to gather from the bitmap because the launch gave up on
+ * them: a look-back wait timed out (the query keeps the bitmap path from then on) / another launch of the kernel owned the device
+ * (that run only).  n <= 10 values. */
 int imm3_query_plan(const imm3_query *q, int64_t *out, int32_t n);
+
+/* ---- fault injection into the single-pass projection kernel (k_filter_project, csrc/imm3_project.hip) ----
+ * The kernel's work-groups wait on each other; what happens when such a wait does not resolve must be exercised on a device.
+ * imm3_ctx_inject_fault: in every later single-pass launch of this context, work-group `work_group` never announces its
+ * `span`-th span (so the round of spans it belongs to never completes), and look-back waits give up after `max_polls` polls
+ * (0 = the shipped cap, ~0.1-0.2 s).  work_group = -1 switches the fault off.  Only the TOOLS' build of the library carries the
+ * code (make -C immutable3_amd/csrc ablate -> lib/libimm3_ablate.so); the shipped library answers IMM3_ERR_STATE to anything
+ * but "off".
+ * imm3_ctx_debug_device_lock: overwrites the per-device ticket word that keeps two launches of the kernel from sharing the
+ * device (0 = free) and returns what it held; with a foreign ticket in place every launch finds the device busy.  Synchronises
+ * the context's stream first.  Works in every build (it only touches the word). */
+int imm3_ctx_inject_fault(imm3_ctx *ctx, int32_t work_group, int32_t span, uint32_t max_polls);
+int imm3_ctx_debug_device_lock(imm3_ctx *ctx, uint64_t value, uint64_t *previous);
 
 #ifdef __cplusplus
 }

@@ -314,6 +314,18 @@ JNIEXPORT jlongArray JNICALL Java_immutabledb_gpu_Native_00024_commMergeGroupsAl
         (*env)->DeleteLocalRef(env, qa);
         (*env)->DeleteLocalRef(env, sa);
     }
+    /* the stride of `vals` is the LIBRARY's number of aggregates (imm3_comm_merge_groups_all writes that many per group: the C ABI
+     * takes no stride): sized from the query handles, and a caller that believes otherwise gets an exception, not a heap overrun */
+    {
+        int32_t libAggs = -1;
+        for (jsize i = 0; i < n && libAggs < 0; i++)
+            if (nq[i] > 0) CHECKED(imm3_query_agg_shape(qs[i][0], NULL, &libAggs, NULL));
+        if (libAggs >= 0 && libAggs != (int32_t)nAggs) {
+            jclass cls = (*env)->FindClass(env, "java/lang/Exception");
+            if (cls) (*env)->ThrowNew(env, cls, "commMergeGroupsAll: nAggs does not match the queries' number of aggregates");
+            goto done;
+        }
+    }
     CHECKED(imm3_comm_merge_groups_all(cs, (int32_t)n, (imm3_query *const *const *)qs, (const int32_t *const *)ss, nq, NULL, NULL, NULL, NULL, 0, &g));
     keys = (uint64_t *)calloc(g ? g : 1, sizeof(uint64_t));
     first = (uint64_t *)calloc(g ? g : 1, sizeof(uint64_t));

@@ -147,17 +147,28 @@ def test_reservation_too_small_and_abandoned_run_are_answered_from_the_bitmap(ct
     assert q.count() == rows.size
     idx, vals = q.fetch_rows()
     assert (idx == rows).all() and (vals[0].view("<i4").reshape(-1) == a[rows]).all() and (vals[1].view(np.int8).reshape(-1) == c[rows]).all()
-    # an abandoned run: what the kernel leaves behind when a prefix never comes (status bit 1).  Simulated by setting the bit
-    # between the run and the fetch: the host must answer through the bitmap path, and keep that path for this query.
+    # an abandoned run: what the kernel leaves behind when a prefix never comes (status bit 1, tagged with the run's epoch: the run
+    # counter at d_total + 8 words, minus the bump of the run itself).  Simulated by setting the word between the run and the fetch:
+    # the host must answer through the bitmap path, and keep that path for this query.  (The kernel's own failure paths run on the
+    # device in tests/test_gpu_fault_injection.py.)  A flag with another run's tag is ignored.
     q.run()
     assert q.plan()["ran_single_pass"]
     hip = C.CDLL("libamdhip64.so")
     ctx.sync()
-    status = np.array([2], dtype=np.uint64)
-    assert hip.hipMemcpy(C.c_void_p(q.device_ptr(1) + 16), C.c_void_p(status.ctypes.data), C.c_size_t(8), C.c_int(1)) == 0   # d_total + 2 words
+    epoch = np.zeros(1, dtype=np.uint64)
+    assert hip.hipMemcpy(C.c_void_p(epoch.ctypes.data), C.c_void_p(q.device_ptr(1) + 64), C.c_size_t(8), C.c_int(2)) == 0
+    stale = np.array([(((int(epoch[0]) - 2) & 0xFFFFFF) << 8) | 2], dtype=np.uint64)
+    assert hip.hipMemcpy(C.c_void_p(q.device_ptr(4)), C.c_void_p(stale.ctypes.data), C.c_size_t(8), C.c_int(1)) == 0
+    idx, vals = q.fetch_rows()
+    assert (idx == rows).all() and q.plan()["single_pass"] and q.plan()["ran_single_pass"] and q.plan()["abandoned_runs"] == 0
+    q.run()
+    ctx.sync()
+    assert hip.hipMemcpy(C.c_void_p(epoch.ctypes.data), C.c_void_p(q.device_ptr(1) + 64), C.c_size_t(8), C.c_int(2)) == 0
+    status = np.array([(((int(epoch[0]) - 1) & 0xFFFFFF) << 8) | 2], dtype=np.uint64)
+    assert hip.hipMemcpy(C.c_void_p(q.device_ptr(4)), C.c_void_p(status.ctypes.data), C.c_size_t(8), C.c_int(1)) == 0   # d_total + 2 words
     idx, vals = q.fetch_rows()
     assert (idx == rows).all() and (vals[0].view("<i4").reshape(-1) == a[rows]).all()
-    assert not q.plan()["single_pass"] and not q.plan()["ran_single_pass"]
+    assert not q.plan()["single_pass"] and not q.plan()["ran_single_pass"] and q.plan()["abandoned_runs"] == 1
     q.run()
     assert q.count() == rows.size and (q.fetch_rows()[0] == rows).all()
     q.close()
