@@ -126,6 +126,43 @@ constexpr RecField rec_layout(const int (&kinds)[kMaxTileCols], int col) {
     return f;
 }
 
+// Ring record of k_filter_project (imm3_project.hip): it never leaves the CU, so its layout is the streamers' to choose.  Dword 0 =
+// the narrow predicate columns from bit 0, as long as they fit 16 bits | the row's position in its RANGE (tile in the range * 1024 +
+// position in the tile) << 16; a narrow field that does not fit starts the next dword at bit 0; every int32 predicate column takes a
+// dword of its own after those.  With the position on top, a record's first dword is ONE v_or3 in the streamer (value as loaded |
+// a per-word constant register | the tile's index) and the row is ONE shift in the writer.  Same sizes as rec_layout: 1, 2 or 4 dwords.
+constexpr RecField ring_layout(const int (&kinds)[kMaxTileCols], int col) {
+    RecField f{0, 0, 0, 0};
+    int d = 0, b = 0, room = 16;
+    for (int i = 0; i < kMaxTileCols; ++i) {
+        const int w = kinds[i] == TK_I8 ? 8 : (kinds[i] == TK_S2 ? 16 : 0);
+        if (!w) continue;
+        if (b + w > room) {
+            ++d;
+            b = 0;
+            room = 32;
+        }
+        if (i == col) {
+            f.dword = d;
+            f.shift = b;
+            f.bits = w;
+        }
+        b += w;
+    }
+    int n = d + 1;
+    for (int i = 0; i < kMaxTileCols; ++i) {
+        if (kinds[i] != TK_I32) continue;
+        if (i == col) {
+            f.dword = n;
+            f.shift = 0;
+            f.bits = 32;
+        }
+        ++n;
+    }
+    f.dwords = n == 3 ? 4 : n;
+    return f;
+}
+
 // k_emit: ProjectOp from the staged records
 constexpr int kEmitTiles = 32;      // tiles per emit work-group (kChunkTiles % kEmitTiles == 0).  32 beat 64 on C3 (34 -> 31 us) and on clustered survivors (2 % contiguous: 77 -> 40 us), lost on 50 % contiguous (167 -> 196 us); 16 lost on C4 (50 -> 60 us)
 constexpr int kMaxEmitGather = 4;   // SELECT-list columns that are not predicate columns: gathered at the record's position

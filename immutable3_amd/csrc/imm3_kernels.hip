@@ -221,6 +221,9 @@ __global__ __launch_bounds__(kBlockThreads, tile_min_waves(K0, K1, STAGE)) void 
     extern __shared__ __attribute__((aligned(16))) uint64_t s_park[]; // [kWavesPerBlock][a.defer_lines][16] when deferring
     uint64_t *park = DEFER ? s_park + (size_t)wave * a.defer_lines * kTileWords : nullptr;
     if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x] = wall_clock64(); // instrumented pass of bench.py only
+#ifdef IMM3_ABLATE
+    const unsigned long long cyc0 = clock64(); // (tools: shader cycles, for the clock the chip holds under this kernel)
+#endif
     uint32_t lane_total = 0; // lanes 0..15: survivors in the words they stored
     Arena A;
     uint32_t *tstart = s_tstart[wave];
@@ -366,6 +369,9 @@ __global__ __launch_bounds__(kBlockThreads, tile_min_waves(K0, K1, STAGE)) void 
     if (a.finish) block_partial_finish(a.finish, lane_total, lane, wave); // the last pass also reduces the count
     else block_partial_store(a.block_partials, lane_total, lane, wave);
     if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x + 1] = wall_clock64(); // after the barrier in the store above
+#ifdef IMM3_ABLATE
+    if (a.stamps && threadIdx.x == 0) a.stamps[2 * gridDim.x + blockIdx.x] = clock64() - cyc0;
+#endif
     }
 }
 

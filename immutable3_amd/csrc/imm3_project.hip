@@ -34,7 +34,29 @@
 
 namespace imm3 {
 
-constexpr int kProjParkLines = 16;       // bitmap lines a wave parks in LDS between store bursts
+#ifndef IMM3_PROJECT_PARK
+#define IMM3_PROJECT_PARK 16
+#endif
+constexpr int kProjParkLines = IMM3_PROJECT_PARK; // bitmap lines a wave parks in LDS between store bursts
+
+// the streamers' ring records (ring_layout, imm3_internal.h)
+template <int K0, int K1, int K2>
+struct RingRec {
+    static constexpr int kinds[3] = {K0, K1, K2};
+    static constexpr int R = ring_layout(kinds, -1).dwords;
+    typedef typename RecVec<R>::type vec;
+    template <int K>
+    static __device__ __forceinline__ void put(uint32_t (&rec)[4], uint32_t value) {
+        constexpr RecField f = ring_layout(kinds, K);
+        if (kinds[K] == TK_NONE) return;
+        rec[f.dword] |= value << f.shift;
+    }
+    static __device__ __forceinline__ vec pack(const uint32_t (&rec)[4]) {
+        if constexpr (R == 1) return rec[0];
+        else if constexpr (R == 2) return make_uint2(rec[0], rec[1]);
+        else return make_uint4(rec[0], rec[1], rec[2], rec[3]);
+    }
+};
 
 // polls before a look-back wait gives up: ~0.1-0.2 s (the tools' build takes a smaller cap from the fault-injection hook)
 __device__ __forceinline__ uint32_t max_polls(const ProjectArgs &a) {
@@ -209,7 +231,22 @@ constexpr int kProjWriters = kProjectWriters;
 constexpr int kProjPerWriter = kProjStreamers / kProjWriters;
 constexpr int kProjThreads = 64 * (kProjStreamers + kProjWriters);
 constexpr int kProjRingBytes = kProjectRingBytes;
-constexpr bool kProjDepth2 = false; // two tiles of loads in flight per streamer instead of one
+// Tiles of loads a streamer keeps in flight AHEAD of the one it works on: ONE.  Round 4 measured the streamers as latency-bound, not
+// issue-bound -- without compares, without records and without writers the kernel streamed C3 in the same 92 us, 1.9 us per tile and
+// wave with one tile's loads in flight per wave -- and built depth 2 properly: three register sets rotating (the tile loop unrolled by
+// three: no copies), the tile loads as inline asm the compiler does not track and hand-counted s_waitcnt immediates (wait_tile),
+// because the compiler's wait-count analysis merges the paths that reach the tile body into vmcnt(0), which drains the tile that
+// should stay in flight.  Result: 115 us of streaming instead of 92 (C3 146 / 123 us): more bytes in flight per wave behave like
+// more waves (DESIGN findings 3, 8) -- the memory system serves FEWER, burstier streams better.  The machinery stays behind the
+// build switch (-DIMM3_PROJECT_DEPTH=2) with what it taught: registers decide where it is possible at all (a set is 16 registers per
+// int32 column, 4 / 8 per narrow one; a wave of this 12-wave work-group has 168), and an instance that counts its own vector-memory
+// operations must not spill (scratch traffic sits in the same counter; tests/test_host.py checks the build's resource remarks) and
+// must keep its register sets alive until every load has landed (ColRegs::keep, imm3_tile.h).
+#ifndef IMM3_PROJECT_DEPTH
+#define IMM3_PROJECT_DEPTH 1
+#endif
+constexpr int tile_set_regs(int k) { return k == TK_I32 ? 16 : (k == TK_S2 ? 8 : (k == TK_I8 ? 4 : 0)); }
+constexpr int project_depth(int k0, int k1, int k2) { return tile_set_regs(k0) + tile_set_regs(k1) + tile_set_regs(k2) <= 20 ? IMM3_PROJECT_DEPTH : 1; }
 constexpr int kProjSlots = 4;   // published ranges a streamer may have waiting for its writer
 
 // ---------------------------------------------------------------------------------------------
@@ -242,7 +279,7 @@ __device__ __forceinline__ void store_pred_col(void *dst, const uint32_t (&rw)[4
     constexpr int kinds[3] = {K0, K1, K2};
     if constexpr (kinds[K] != TK_NONE) {
         if (!dst) return; // wave-uniform: the column is not in the SELECT list
-        constexpr RecField f = rec_layout(kinds, K);
+        constexpr RecField f = ring_layout(kinds, K);
         constexpr int W = kind_width(kinds[K]);
         uint32_t v[4];
 #pragma unroll
@@ -260,9 +297,9 @@ __device__ __forceinline__ void store_pred_col(void *dst, const uint32_t (&rw)[4
 // own and was waited for before the next one was issued -- sixteen serialised round trips per step, 25 us per span on C4).
 // Two quads per lane and step; every load of the step -- all columns, all eight rows -- is in flight before the first store.
 template <int K0, int K1, int K2, int NG>
-__device__ __forceinline__ void gather_range(const ProjectArgs &a, const typename Rec<K0, K1, K2>::vec *src, uint32_t start, uint32_t cap, uint32_t n,
+__device__ __forceinline__ void gather_range(const ProjectArgs &a, const typename RingRec<K0, K1, K2>::vec *src, uint32_t start, uint32_t cap, uint32_t n,
                                              uint32_t base, uint32_t tile0, int lane) {
-    typedef Rec<K0, K1, K2> L;
+    typedef RingRec<K0, K1, K2> L;
     constexpr int R = L::R;
     const uint32_t q0 = base >> 2;
     const uint32_t n_quads = ((base + n + 3) >> 2) - q0;
@@ -289,7 +326,7 @@ __device__ __forceinline__ void gather_range(const ProjectArgs &a, const typenam
                 if (idx >= cap) idx -= cap;
                 uint32_t rw[4];
                 rec_words<R>(src[idx], rw);
-                const uint32_t row = (tile0 + ((rw[0] >> 10) & 63u)) * (uint32_t)kTileRows + (rw[0] & (uint32_t)(kTileRows - 1));
+                const uint32_t row = tile0 * (uint32_t)kTileRows + (rw[0] >> 16); // (the record's position in its range rides on top of dword 0)
 #pragma unroll
                 for (int c = 0; c < NG; ++c) { // the aligned dword that holds the value
                     const uint32_t byte = row * (uint32_t)gw[c]; // (< 2^32: a segment's .dat is < 2 GiB, Segment.scala:33)
@@ -320,9 +357,9 @@ __device__ __forceinline__ void gather_range(const ProjectArgs &a, const typenam
 
 // src: the streamer's ring (start, cap = the range's position in it and its capacity)
 template <int K0, int K1, int K2>
-__device__ __forceinline__ void unpack_range(const ProjectArgs &a, const typename Rec<K0, K1, K2>::vec *src, uint32_t start, uint32_t cap, uint32_t n,
+__device__ __forceinline__ void unpack_range(const ProjectArgs &a, const typename RingRec<K0, K1, K2>::vec *src, uint32_t start, uint32_t cap, uint32_t n,
                                              uint32_t base, uint32_t tile0, int lane) {
-    typedef Rec<K0, K1, K2> L;
+    typedef RingRec<K0, K1, K2> L;
     constexpr int R = L::R;
     const uint32_t cap_rows = a.cap_rows > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)a.cap_rows;
     if (base >= cap_rows) return; // wave-uniform: the output arrays are full (the host gathers again from the bitmap)
@@ -351,7 +388,7 @@ __device__ __forceinline__ void unpack_range(const ProjectArgs &a, const typenam
         const bool whole = ok[0] && ok[3]; // (the range's rows are contiguous: first and last in => all four in)
         uint32_t rowv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) rowv[e] = (tile0 + ((rw[e][0] >> 10) & 63u)) * (uint32_t)kTileRows + (rw[e][0] & (uint32_t)(kTileRows - 1));
+        for (int e = 0; e < 4; ++e) rowv[e] = tile0 * (uint32_t)kTileRows + (rw[e][0] >> 16); // (the record's position in its range rides on top of dword 0)
         if (whole) *(uint4 *)(row_index + out0) = make_uint4(rowv[0], rowv[1], rowv[2], rowv[3]);
         else {
 #pragma unroll
@@ -549,21 +586,135 @@ __device__ __forceinline__ void unpack_dense(const ProjectArgs &a, int64_t tile0
 // streamer side: one record per survivor of a tile, compacted in ascending row order.  rank = set bits below the row in
 // its word (v_mbcnt) + the survivors of the earlier words (scalar); the store is predicated by the word itself.
 // ---------------------------------------------------------------------------------------------
+// the record of the lane's row of word w.  posw = (64 w + lane) << 16, kept in a register per word for the whole kernel; j26 = the
+// tile's index in its range << 26 (scalar).  With a narrow column at bit 0 the first dword is one v_or3 of the value as the
+// transposing LDS read delivered it, posw and j26.
+template <int K0, int K1, int K2>
+__device__ __forceinline__ void build_record(uint32_t (&rec)[4], const ColRegs<K0> &c0, const ColRegs<K1> &c1, const ColRegs<K2> &c2, uint32_t posw, uint32_t j26, int w) {
+    typedef RingRec<K0, K1, K2> L;
+    rec[0] = posw | j26;
+    rec[1] = rec[2] = rec[3] = 0u;
+    L::template put<0>(rec, c0.value(w));
+    L::template put<1>(rec, c1.value(w));
+    L::template put<2>(rec, c2.value(w));
+}
+
 template <int K0, int K1, int K2, class Store>
 __device__ __forceinline__ void compact_tile(const uint64_t (&acc)[kTileWords], const ColRegs<K0> &c0, const ColRegs<K1> &c1, const ColRegs<K2> &c2,
-                                             uint32_t lane_j, Store store) {
-    typedef Rec<K0, K1, K2> L;
+                                             const uint32_t (&posw)[kTileWords], uint32_t j26, Store store) {
+    typedef RingRec<K0, K1, K2> L;
     uint32_t done = 0; // wave-uniform
 #pragma unroll
     for (int w = 0; w < kTileWords; ++w) {
         const uint64_t m = acc[w];
-        uint32_t rec[4] = {lane_j | (uint32_t)(64 * w), 0u, 0u, 0u};
-        L::template put<0>(rec, c0.value(w));
-        L::template put<1>(rec, c1.value(w));
-        L::template put<2>(rec, c2.value(w));
+        uint32_t rec[4];
+        build_record<K0, K1, K2>(rec, c0, c1, c2, posw[w], j26, w);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, done));
         if (__builtin_amdgcn_inverse_ballot_w64(m)) store(rank, L::pack(rec)); // exec = the word itself
         done += (uint32_t)__popcll(m);
+    }
+}
+
+// The same with the bookkeeping moved off the scalar unit (round 4).  The kernel is bound by instruction issue, scalar
+// instructions included (DESIGN finding 21), and the form above spends, per word, s_bcnt1 + s_add on the running count, a v_mov to
+// bring that count into the rank, and -- before it starts -- sixteen more s_bcnt1 + fifteen s_add for the tile's total, which the
+// ring-space check needs first.  Here lanes 0..15 hold the tile's sixteen words (`mine`, made for the bitmap line anyway): their
+// popcounts, a row-wide DPP prefix sum and one v_readlane give the tile's total (five vector instructions instead of thirty-one
+// scalar ones), and the same scan gives every word the LDS ADDRESS of its first record (`word_at`, lane w), fetched per word with
+// one v_readlane: rank = v_mbcnt on the word, address = word_at + rank * record size, store predicated by the word itself.
+// "all but the wave's N youngest vector-memory operations have landed" (loads and stores count together, in issue order: vmcnt
+// has six bits on gfx9, split 4 + 2 in the immediate).  The streamers' tile loads are inline asm the compiler does not track
+// (imm3_tile.h: load_untracked), so this is THE wait for them; operations of the compiler's own that happen to be younger (the
+// burst of parked bitmap lines) only make it wait for a little more than needed.
+template <int N>
+__device__ __forceinline__ void wait_tile() {
+    static_assert(N >= 0 && N < 63, "vmcnt holds 0..63");
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+
+template <int N>
+__device__ __forceinline__ uint32_t dpp_row_shr(uint32_t x) { // lane l of every 16-lane row: x of lane l - N of that row, 0 where there is none
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x110 + N, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t row_inclusive_sum(uint32_t x) {
+    x += dpp_row_shr<1>(x);
+    x += dpp_row_shr<2>(x);
+    x += dpp_row_shr<4>(x);
+    x += dpp_row_shr<8>(x);
+    return x;
+}
+
+// Four words' records stored with the words themselves as exec masks.  Written as one asm block because what costs here is
+// instruction slots: the compiler's form of `if (lane survives) store` is s_and_saveexec + s_cbranch_execz + ... + s_or exec per
+// word, with the rank / address / record arithmetic sunk into the masked region; here that arithmetic runs for all lanes in front
+// of the block (it is needed by the masked lanes only, but a vector instruction costs one slot whatever its exec), and each word is
+// one s_mov to exec and one LDS write; exec goes back to all ones once per four words.  (The streamers run with all 64 lanes
+// active: wave-uniform control flow only.)  ds_write2_b32 takes the record's dwords from any two registers: no register pairs.
+template <int R>
+__device__ __forceinline__ void masked_store4(const uint64_t (&m)[4], const uint32_t (&to)[4], const uint32_t (&d)[4][4]) {
+    if constexpr (R == 1) {
+        asm volatile("s_mov_b64 exec, %0\n\tds_write_b32 %4, %8\n\t"
+                     "s_mov_b64 exec, %1\n\tds_write_b32 %5, %9\n\t"
+                     "s_mov_b64 exec, %2\n\tds_write_b32 %6, %10\n\t"
+                     "s_mov_b64 exec, %3\n\tds_write_b32 %7, %11\n\t"
+                     "s_mov_b64 exec, -1"
+                     :
+                     : "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "v"(to[0]), "v"(to[1]), "v"(to[2]), "v"(to[3]), "v"(d[0][0]), "v"(d[1][0]), "v"(d[2][0]), "v"(d[3][0])
+                     : "memory");
+    } else if constexpr (R == 2) {
+        asm volatile("s_mov_b64 exec, %0\n\tds_write2_b32 %4, %8, %12 offset1:1\n\t"
+                     "s_mov_b64 exec, %1\n\tds_write2_b32 %5, %9, %13 offset1:1\n\t"
+                     "s_mov_b64 exec, %2\n\tds_write2_b32 %6, %10, %14 offset1:1\n\t"
+                     "s_mov_b64 exec, %3\n\tds_write2_b32 %7, %11, %15 offset1:1\n\t"
+                     "s_mov_b64 exec, -1"
+                     :
+                     : "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "v"(to[0]), "v"(to[1]), "v"(to[2]), "v"(to[3]), "v"(d[0][0]), "v"(d[1][0]), "v"(d[2][0]), "v"(d[3][0]),
+                       "v"(d[0][1]), "v"(d[1][1]), "v"(d[2][1]), "v"(d[3][1])
+                     : "memory");
+    }
+}
+// four-dword records (two or three int32 predicate columns): one word at a time -- four words' worth of records would take twenty
+// more registers than these instances have to spare
+__device__ __forceinline__ void masked_store1_r4(uint64_t m, uint32_t to, const uint32_t (&d)[4]) {
+    asm volatile("s_mov_b64 exec, %0\n\tds_write2_b32 %1, %2, %3 offset1:1\n\tds_write2_b32 %1, %4, %5 offset0:2 offset1:3\n\ts_mov_b64 exec, -1"
+                 :
+                 : "s"(m), "v"(to), "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3])
+                 : "memory");
+}
+
+template <int K0, int K1, int K2>
+__device__ __forceinline__ void compact_tile_at(const uint64_t (&acc)[kTileWords], const ColRegs<K0> &c0, const ColRegs<K1> &c1, const ColRegs<K2> &c2,
+                                                const uint32_t (&posw)[kTileWords], uint32_t j26, uint32_t word_at) {
+    typedef RingRec<K0, K1, K2> L;
+    constexpr int R = L::R;
+    if constexpr (R == 4) {
+#pragma unroll
+        for (int w = 0; w < kTileWords; ++w) {
+            uint32_t rec[4];
+            build_record<K0, K1, K2>(rec, c0, c1, c2, posw[w], j26, w);
+            const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)word_at, w);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(acc[w] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)acc[w], 0u));
+            masked_store1_r4(acc[w], at + rank * 16u, rec);
+        }
+        return;
+    }
+#pragma unroll
+    for (int g = 0; g < kTileWords; g += 4) {
+        uint64_t m[4];
+        uint32_t to[4], d[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int w = g + e;
+            m[e] = acc[w];
+            uint32_t rec[4];
+            build_record<K0, K1, K2>(rec, c0, c1, c2, posw[w], j26, w);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[e][k] = rec[k];
+            const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)word_at, w); // wave-uniform: where word w's first record goes
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[e] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[e], 0u));
+            to[e] = at + rank * (uint32_t)(4 * R); // (an LDS address)
+        }
+        masked_store4<R>(m, to, d);
     }
 }
 
@@ -572,12 +723,18 @@ __device__ __forceinline__ void compact_tile(const uint64_t (&acc)[kTileWords], 
 // on C3: sixteen full-width ds_write_b64 per tile cost more than the five scalar instructions per word they save.)
 template <int K0, int K1, int K2>
 __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectArgs a) {
-    typedef Rec<K0, K1, K2> L;
+    typedef RingRec<K0, K1, K2> L;
     typedef typename L::vec vec;
     constexpr int R = L::R;
     constexpr uint32_t kCap = kProjRingBytes / (4 * R); // records a streamer's ring holds
     constexpr bool kS2 = K0 == TK_S2 || K1 == TK_S2 || K2 == TK_S2;
     constexpr bool kXpose = kS2 || K0 == TK_I8 || K1 == TK_I8 || K2 == TK_I8;
+    constexpr int kTileLoads = ColRegs<K0>::kLoads + ColRegs<K1>::kLoads + ColRegs<K2>::kLoads; // vector-memory instructions per tile
+    constexpr int kProjDepth = project_depth(K0, K1, K2);
+    constexpr int kI32 = (K0 == TK_I32) + (K1 == TK_I32) + (K2 == TK_I32);
+    // (the three-column instances with two wide columns have no registers to spare for compact_tile_at's four words at a time:
+    // they keep the compiler's word-by-word form, wrap-around test included)
+    constexpr bool kLeanCompaction = !(kI32 == 2 && K2 != TK_NONE) && !(K0 == TK_I32 && K1 == TK_I8 && K2 == TK_S2);
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[kProjStreamers][kProjRingBytes];
     __shared__ __attribute__((aligned(16))) uint8_t s_xpose[kProjStreamers][kXpose ? (kS2 ? kXposeBytes : kXposeBytes / 2) : 16];
     __shared__ __attribute__((aligned(16))) uint64_t s_park[kProjStreamers][kProjParkLines * kTileWords];
@@ -595,6 +752,9 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (scalar: what follows from it -- the wave's tiles, its role -- is wave-uniform control flow and SGPR address arithmetic)
     if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x] = wall_clock64();
+#ifdef IMM3_ABLATE
+    const unsigned long long cyc0 = clock64(); // (tools: shader cycles, for the clock the chip holds under this kernel)
+#endif
     if (threadIdx.x < kProjStreamers) {
         s_drained[threadIdx.x] = 0u;
         s_head[threadIdx.x] = 0u;
@@ -633,15 +793,24 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
     if (wave < kProjStreamers) {
         // ------------------------------------------------------------------ streamer
         vec *ring = (vec *)s_ring[wave];
+        const uint32_t ring_at = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)s_ring[wave]; // the ring's LDS address (wave-uniform)
         uint8_t *xp = s_xpose[wave];
         uint64_t *park = s_park[wave];
         const int64_t n_full = a.n_rows / kTileRows;
-        // Prefetch: the wave's next full tile is loading while it works on one.  Two register sets take turns (the tile loop
-        // calls its body with the roles swapped every tile: no register copies); the prefetch HEAD walks the wave's tiles in
-        // the order the loop below meets them -- range by range, span by span.
-        ColRegs<K0> A0, B0;
-        ColRegs<K1> A1, B1;
-        ColRegs<K2> A2, B2;
+        // Prefetch: the wave's next kProjDepth full tiles are loading while it works on one.  kProjDepth + 1 register sets take
+        // turns (the tile loop calls its body with the roles rotated every tile: no register copies); the prefetch HEAD walks the
+        // wave's tiles in the order the loop below meets them -- range by range, span by span.
+        ColRegs<K0> A0, B0, C0;
+        ColRegs<K1> A1, B1, C1;
+        ColRegs<K2> A2, B2, C2;
+        // (64 w + lane) << 16 for every word w of a tile: the per-lane, per-word part of a record's first dword, in sixteen registers
+        // for the whole kernel (the empty asm makes the values opaque: the compiler keeps them instead of recomputing one per use)
+        uint32_t posw[kTileWords];
+#pragma unroll
+        for (int w = 0; w < kTileWords; ++w) {
+            posw[w] = (uint32_t)(64 * w + lane) << 16;
+            if constexpr (kI32 <= 1) asm volatile("" : "+v"(posw[w])); // (with more int32 columns the registers are needed for the tiles: one more instruction per word)
+        }
         int64_t head_t = ((int64_t)blockIdx.x * kProjStreamers + wave) * P, head_last = 0;
         const int64_t head_jump = ((int64_t)gridDim.x * kProjStreamers - 1) * P; // from the end of a range to the wave's next one
         int head_j = 0;
@@ -653,9 +822,15 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
             }
             if (t < n_full) head_last = t;
             else t = head_last; // nothing left: re-read the last tile (a load the compiler sees on every path)
-            r0.load(a.cols[0].data, t * kTileRows, lane);
-            r1.load(a.cols[1].data, t * kTileRows, lane);
-            r2.load(a.cols[2].data, t * kTileRows, lane);
+            if constexpr (kProjDepth == 2) { // (asm loads: waited for by wait_tile below, not by the compiler)
+                r0.load_untracked(a.cols[0].data, t * kTileRows, lane);
+                r1.load_untracked(a.cols[1].data, t * kTileRows, lane);
+                r2.load_untracked(a.cols[2].data, t * kTileRows, lane);
+            } else { // (one tile ahead: the compiler's own wait -- everything -- is the right one, and these instances may spill)
+                r0.load(a.cols[0].data, t * kTileRows, lane);
+                r1.load(a.cols[1].data, t * kTileRows, lane);
+                r2.load(a.cols[2].data, t * kTileRows, lane);
+            }
             ++head_t;
             if (++head_j == P) {
                 head_j = 0;
@@ -663,147 +838,57 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
             }
         };
         head_load(A0, A1, A2);
-        bool cur_is_A = true;
-        ColRegs<K0> C0; // (kProjDepth2: the tile after the next one)
-        ColRegs<K1> C1;
-        ColRegs<K2> C2;
-        if (kProjDepth2) head_load(C0, C1, C2);
+        if constexpr (kProjDepth == 2) head_load(B0, B1, B2);
+        // ---- the wave's running state: its current span (s, the work-group's i-th), the ring, whether the rows have been given up
         int64_t s = blockIdx.x;
+        uint32_t i = 0;
         uint32_t tail_pos = 0, tail_total = 0; // where the next record goes in the ring; records ever put there (minus those taken back by a spill)
         uint32_t head_seen = 0;                // the ring's head as last read from LDS (it only grows: a stale value is a safe one)
         // The rows of this run have been given up (s_abort: busy device, a look-back that timed out here or elsewhere): the writers
         // are gone, and this wave goes on to the end of its tiles in count + bitmap mode -- every range "dense", nothing published,
         // nothing waited for.  The count this work-group adds at the end and its bitmap lines are exact either way.
         bool abandoned = false;
-        for (uint32_t i = 0; s < a.n_spans; s += gridDim.x, ++i) {
+        // ---- the current range: tiles t0 .. t0 + P of span s
+        int64_t t0 = 0;
+        int j = 0;                  // the next tile's index in the range
+        uint32_t range_start = 0;   // ring position of the range's first record
+        uint32_t range_cnt = 0;     // survivors of this range
+        bool dense = false;         // the range keeps no records (see unpack_dense)
+        int parked = 0, first_parked = 0;
+        auto flush_park = [&]() { // 4 lines (4 x 16 lanes) per store instruction; the lines of consecutive tiles are contiguous
+            lds_wave_sync();
+            for (int q = lane >> 4; q < parked; q += 4)
+                __builtin_nontemporal_store(park[q * kTileWords + (lane & 15)], a.bitmap + (t0 + first_parked + q) * kTileWords + (lane & 15));
+            lds_wave_sync();
+            first_parked += parked;
+            parked = 0;
+        };
+        // the range outgrows the ring: it becomes a dense one -- what it has in the ring is given back
+        auto to_dense = [&]() {
+            tail_total -= range_cnt;
+            tail_pos = range_start;
+            dense = true;
+        };
+        auto begin_range = [&]() {
             if (!abandoned && lds_peek(&s_abort)) abandoned = true;
-            const int64_t t0 = (s * kProjStreamers + wave) * P;
-            const uint32_t range_start = tail_pos;
-            uint32_t range_cnt = 0; // survivors of this range
-            bool dense = abandoned; // the range keeps no records (see unpack_dense)
-            int parked = 0, first_parked = 0;
-            auto flush_park = [&]() { // 4 lines (4 x 16 lanes) per store instruction; the lines of consecutive tiles are contiguous
-                lds_wave_sync();
-                for (int q = lane >> 4; q < parked; q += 4)
-                    __builtin_nontemporal_store(park[q * kTileWords + (lane & 15)], a.bitmap + (t0 + first_parked + q) * kTileWords + (lane & 15));
-                lds_wave_sync();
-                first_parked += parked;
-                parked = 0;
-            };
-            // the range outgrows the ring: it becomes a dense one -- what it has in the ring is given back
-            auto to_dense = [&]() {
-                tail_total -= range_cnt;
-                tail_pos = range_start;
-                dense = true;
-            };
-            // one full tile: its columns are in (c0, c1, c2); the next tile's go to (n0, n1, n2)
-            auto full_tile = [&](ColRegs<K0> &c0, ColRegs<K1> &c1, ColRegs<K2> &c2, ColRegs<K0> &n0, ColRegs<K1> &n1, ColRegs<K2> &n2, int j) {
-                    // software pipeline (k_filter_tile, finding 11): the wait for this tile's loads sits BEFORE the next tile's
-                    // loads are issued
-                    c0.touch();
-                    c1.touch();
-                    c2.touch();
-                    if (kProjDepth2) { // the next tile's loads have been in flight for a tile already; the one after it goes out now
-                        n0 = C0;
-                        n1 = C1;
-                        n2 = C2;
-                        head_load(C0, C1, C2);
-                    } else head_load(n0, n1, n2);
-                    uint64_t acc[kTileWords]; // wave-uniform words (SGPR pairs)
-#pragma unroll
-                    for (int w = 0; w < kTileWords; ++w) acc[w] = ~0ULL;
-                    if (IMM3_ABLATE_BIT(a, 64)) { // (timing only: no compares -- every word keeps 6 fixed rows, ~10 % survivors)
-#pragma unroll
-                        for (int w = 0; w < kTileWords; ++w) acc[w] = 0x0101010100010101ULL << (w & 7);
-                    } else {
-                        c0.eval(a.cols[0], acc, lane, xp);
-                        c1.eval(a.cols[1], acc, lane, xp);
-                        c2.eval(a.cols[2], acc, lane, xp);
-                    }
-                    uint64_t mine = words_to_lanes(acc);
-                    if (lane >= kTileWords) mine = 0;
-                    if (lane < kTileWords) park[parked * kTileWords + lane] = mine;
-                    lane_total += (uint32_t)__popcll(mine);
-                    if (++parked == kProjParkLines) flush_park();
-                    // the survivors' records
-                    uint32_t cnt = 0; // wave-uniform
-#pragma unroll
-                    for (int w = 0; w < kTileWords; ++w) cnt += (uint32_t)__popcll(acc[w]);
-                    if (IMM3_ABLATE_BIT(a, 4)) cnt = 0; // (no records at all)
-                    if (!dense && range_cnt + cnt > kCap) to_dense();
-                    if (dense) { // count and bitmap only
-                        range_cnt += cnt;
-                        return;
-                    }
-                    if (tail_total + cnt - head_seen > kCap) { // room in the ring?  Only undrained EARLIER ranges can be in the way: the writer frees them
-                        while (tail_total + cnt - (head_seen = lds_peek(&s_head[wave])) > kCap) {
-                            if (lds_peek(&s_abort)) { abandoned = true; break; }
-                            __builtin_amdgcn_s_sleep(2);
-                        }
-                    }
-                    if (abandoned) { // (this tile's line is parked and counted: from here on counts and bitmap lines only)
-                        dense = true;
-                        return;
-                    }
-                    const uint32_t lane_j = (uint32_t)lane | ((uint32_t)j << 10);
-                    if (cnt == 0) {
-                    } else if (tail_pos + cnt <= kCap) { // the common case: the tile's records do not wrap around the ring
-                        vec *dst = ring + tail_pos;
-                        compact_tile<K0, K1, K2>(acc, c0, c1, c2, lane_j, [&](uint32_t rank, vec v) { dst[rank] = v; });
-                    } else {
-                        compact_tile<K0, K1, K2>(acc, c0, c1, c2, lane_j, [&](uint32_t rank, vec v) {
-                            uint32_t idx = tail_pos + rank;
-                            if (idx >= kCap) idx -= kCap;
-                            ring[idx] = v;
-                        });
-                    }
-                    range_cnt += cnt;
-                    tail_total += cnt;
-                    tail_pos += cnt;
-                    if (tail_pos >= kCap) tail_pos -= kCap;
-            };
-            for (int j = 0; j < P; ++j) {
-                const int64_t tile = t0 + j;
-                if (tile >= a.n_tiles) break; // wave-uniform
-                if (tile < n_full) {
-                    if (cur_is_A) full_tile(A0, A1, A2, B0, B1, B2, j);
-                    else full_tile(B0, B1, B2, A0, A1, A2, j);
-                    cur_is_A = !cur_is_A;
-                } else {
-                    // the one partial tile at the end of the segment: rolled, bounds-checked; its range is a dense one
-                    flush_park();
-                    if (!dense) to_dense();
-                    const int64_t row0 = tile * kTileRows, valid_rows = a.n_rows - row0;
-                    ColRegs<K0> c0;
-                    ColRegs<K1> c1;
-                    ColRegs<K2> c2;
-                    uint64_t mine = ~0ULL;
-#pragma unroll 1
-                    for (int w = 0; w < kTileWords; ++w) {
-                        const int64_t r_in = 64 * w + lane;
-                        const bool valid = r_in < valid_rows;
-                        const int64_t r = row0 + (valid ? r_in : 0);
-                        bool keep = valid;
-                        if (valid) keep = c0.row(a.cols[0].data, a.cols[0], r) && c1.row(a.cols[1].data, a.cols[1], r) && c2.row(a.cols[2].data, a.cols[2], r);
-                        const uint64_t m = ballot64(keep);
-                        if (lane == w) mine &= m;
-                        range_cnt += (uint32_t)__popcll(m);
-                    }
-                    mine &= low_mask(valid_rows - 64 * (int64_t)lane);
-                    if (lane >= kTileWords) mine = 0;
-                    const int64_t word = tile * kTileWords + lane;
-                    if (lane < kTileWords && word < (a.n_rows + 63) / 64) a.bitmap[word] = mine;
-                    lane_total += (uint32_t)__popcll(mine);
-                }
-            }
+            t0 = (s * kProjStreamers + wave) * P;
+            j = 0;
+            range_start = tail_pos;
+            range_cnt = 0;
+            dense = abandoned;
+            parked = 0;
+            first_parked = 0;
+        };
+        // the range is streamed: its bitmap lines go out, and it is published for the writers (unless the rows have been given up)
+        auto end_range = [&]() {
             if (parked) flush_park();
-            if (abandoned) continue; // (nobody takes ranges any more)
+            if (abandoned) return; // (nobody takes ranges any more)
             // ---- publish the range (the slot's previous range, i - kProjSlots, must have been taken by the writer) ----
             while (!IMM3_ABLATE_BIT(a, 128) && i >= (uint32_t)kProjSlots && lds_peek(&s_drained[wave]) < i - (uint32_t)(kProjSlots - 1)) {
                 if (lds_peek(&s_abort)) { abandoned = true; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
-            if (abandoned) continue;
+            if (abandoned) return;
             if (dense) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the writer (another wave of this CU) reads the range's bitmap lines: the stores must have landed
             if (lane == 0) {
                 if (dense) __hip_atomic_fetch_add(&s_dense_ranges, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -812,23 +897,166 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
                 s_pub[wave][i % kProjSlots].dense = dense ? 1u : 0u;
             }
             // the work-group's last range of the span to finish says so: the span can be announced to the other work-groups
-            {
-                const uint32_t slot = i % kProjSlots;
-                uint32_t arrived = 0;
-                if (lane == 0) arrived = __hip_atomic_fetch_add(&s_arrive[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
-                if (arrived == (uint32_t)kProjStreamers - 1u && lane == 0) { // (behind the other seven's fetch_adds, hence behind their s_pub writes: the LDS serves a wave's operations in order)
-                    lds_poke(&s_arrive[slot], 0u); // (the slot's next span, i + kProjSlots, is published only after this one was drained)
-                    // (spans become ready in order: every streamer finishes range i before range i + 1.)  A RELEASE at work-group scope: the
-                    // other seven streamers' s_pub writes -- and a dense range's fence above -- reach this wave through their relaxed
-                    // fetch_adds on s_arrive, which is not a release sequence by the letter; the store that the writers acquire is.
-                    __hip_atomic_store(&s_span_ready, i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t slot = i % kProjSlots;
+            uint32_t arrived = 0;
+            if (lane == 0) arrived = __hip_atomic_fetch_add(&s_arrive[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+            if (arrived == (uint32_t)kProjStreamers - 1u && lane == 0) { // (behind the other seven's fetch_adds, hence behind their s_pub writes: the LDS serves a wave's operations in order)
+                lds_poke(&s_arrive[slot], 0u); // (the slot's next span, i + kProjSlots, is published only after this one was drained)
+                // (spans become ready in order: every streamer finishes range i before range i + 1.)  A RELEASE at work-group scope: the
+                // other seven streamers' s_pub writes -- and a dense range's fence above -- reach this wave through their relaxed
+                // fetch_adds on s_arrive, which is not a release sequence by the letter; the store that the writers acquire is.
+                __hip_atomic_store(&s_span_ready, i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef IMM3_ABLATE
-                    if (a.stamps && i < 6) a.stamps[2 * gridDim.x + blockIdx.x * 24 + i] = wall_clock64(); // (tools: span i streamed)
+                if (a.stamps && i < 6) a.stamps[2 * gridDim.x + blockIdx.x * 24 + i] = wall_clock64(); // (tools: span i streamed)
 #endif
+            }
+        };
+        // one full tile: its columns are in (c0, c1, c2); the loads of the tile kProjDepth tiles ahead go to (n0, n1, n2), the set
+        // that was worked on last
+        auto full_tile = [&](ColRegs<K0> &c0, ColRegs<K1> &c1, ColRegs<K2> &c2, ColRegs<K0> &n0, ColRegs<K1> &n1, ColRegs<K2> &n2) {
+            // software pipeline (k_filter_tile, finding 11): the wait for this tile's loads sits BEFORE the next loads are issued (vmcnt
+            // retires in order: what is in flight behind this tile's loads -- the next tile's, at depth 2 -- is not waited for)
+            if constexpr (kProjDepth == 2) wait_tile<kTileLoads>(); // this tile's loads have landed; the next tile's stay in flight
+            c0.touch();
+            c1.touch();
+            c2.touch();
+            head_load(n0, n1, n2);
+            uint64_t acc[kTileWords]; // wave-uniform words (SGPR pairs)
+#pragma unroll
+            for (int w = 0; w < kTileWords; ++w) acc[w] = ~0ULL;
+            if (IMM3_ABLATE_BIT(a, 64)) { // (timing only: no compares -- every word keeps 6 fixed rows, ~10 % survivors)
+#pragma unroll
+                for (int w = 0; w < kTileWords; ++w) acc[w] = 0x0101010100010101ULL << (w & 7);
+            } else {
+                // the narrow columns' LDS transposes are issued first, the int32 columns (kinds are sorted: they come first) are
+                // compared while those are in flight, ONE wait, then the narrow columns' compares
+                c0.stage(lane, xp);
+                c1.stage(lane, xp);
+                c2.stage(lane, xp);
+                if constexpr (K0 == TK_I32) c0.test(a.cols[0], acc);
+                if constexpr (K1 == TK_I32) c1.test(a.cols[1], acc);
+                if constexpr (K2 == TK_I32) c2.test(a.cols[2], acc);
+                if constexpr (kXpose) lds_reads_landed();
+                if constexpr (K0 != TK_I32) c0.test(a.cols[0], acc);
+                if constexpr (K1 != TK_I32) c1.test(a.cols[1], acc);
+                if constexpr (K2 != TK_I32) c2.test(a.cols[2], acc);
+            }
+            uint64_t mine = words_to_lanes(acc);
+            if (lane >= kTileWords) mine = 0;
+            if (lane < kTileWords) park[parked * kTileWords + lane] = mine;
+            const uint32_t pc = (uint32_t)__popcll(mine); // lanes 0..15: survivors of word `lane`
+            lane_total += pc;
+            if (++parked == kProjParkLines) flush_park();
+            // the survivors' records
+            const uint32_t incl = row_inclusive_sum(pc);  // lanes 0..15: survivors of words 0..lane
+            uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)incl, kTileWords - 1); // wave-uniform: the tile's survivors
+            if (IMM3_ABLATE_BIT(a, 4)) cnt = 0; // (no records at all)
+            if (!dense && range_cnt + cnt > kCap) to_dense();
+            if (dense) { // count and bitmap only
+                range_cnt += cnt;
+                return;
+            }
+            if (tail_total + cnt - head_seen > kCap) { // room in the ring?  Only undrained EARLIER ranges can be in the way: the writer frees them
+                while (tail_total + cnt - (head_seen = lds_peek(&s_head[wave])) > kCap) {
+                    if (lds_peek(&s_abort)) { abandoned = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            if (abandoned) { // (this tile's line is parked and counted: from here on counts and bitmap lines only)
+                dense = true;
+                return;
+            }
+            const uint32_t j26 = (uint32_t)j << 26; // the tile's index in its range, where the records carry it
+            if (cnt == 0) {
+            } else if (kLeanCompaction && tail_pos + cnt <= kCap) { // the common case: the tile's records do not wrap around the ring
+                const uint32_t word_at = ring_at + (tail_pos + incl - pc) * (uint32_t)sizeof(vec); // lane w: LDS address of word w's first record
+                compact_tile_at<K0, K1, K2>(acc, c0, c1, c2, posw, j26, word_at);
+            } else {
+                compact_tile<K0, K1, K2>(acc, c0, c1, c2, posw, j26, [&](uint32_t rank, vec v) {
+                    uint32_t idx = tail_pos + rank;
+                    if (idx >= kCap) idx -= kCap;
+                    ring[idx] = v;
+                });
+            }
+            range_cnt += cnt;
+            tail_total += cnt;
+            tail_pos += cnt;
+            if (tail_pos >= kCap) tail_pos -= kCap;
+        };
+        // the one partial tile at the end of the segment: rolled, bounds-checked; its range is a dense one
+        auto partial_tile = [&](int64_t tile) {
+            flush_park();
+            if (!dense) to_dense();
+            const int64_t row0 = tile * kTileRows, valid_rows = a.n_rows - row0;
+            ColRegs<K0> c0;
+            ColRegs<K1> c1;
+            ColRegs<K2> c2;
+            uint64_t mine = ~0ULL;
+#pragma unroll 1
+            for (int w = 0; w < kTileWords; ++w) {
+                const int64_t r_in = 64 * w + lane;
+                const bool valid = r_in < valid_rows;
+                const int64_t r = row0 + (valid ? r_in : 0);
+                bool keep = valid;
+                if (valid) keep = c0.row(a.cols[0].data, a.cols[0], r) && c1.row(a.cols[1].data, a.cols[1], r) && c2.row(a.cols[2].data, a.cols[2], r);
+                const uint64_t m = ballot64(keep);
+                if (lane == w) mine &= m;
+                range_cnt += (uint32_t)__popcll(m);
+            }
+            mine &= low_mask(valid_rows - 64 * (int64_t)lane);
+            if (lane >= kTileWords) mine = 0;
+            const int64_t word = tile * kTileWords + lane;
+            if (lane < kTileWords && word < (a.n_rows + 63) / 64) a.bitmap[word] = mine;
+            lane_total += (uint32_t)__popcll(mine);
+        };
+        // One tile of the wave's sequence -- range by range, span by span; false: the wave has no tile left.  The loop below calls it
+        // with the register sets in rotating roles (an explicit unroll by their number: no register copies).  A partial tile, or a
+        // range that starts behind the segment's end, consumes no register set; both only occur in the wave's last range, so the
+        // strict alternation holds wherever it matters.
+        // every untracked tile load has landed, and up to here the register sets were the columns' (ColRegs::keep says why)
+        auto drain_loads = [&]() {
+            wait_tile<0>();
+            A0.keep(); A1.keep(); A2.keep();
+            B0.keep(); B1.keep(); B2.keep();
+            C0.keep(); C1.keep(); C2.keep();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto step = [&](ColRegs<K0> &c0, ColRegs<K1> &c1, ColRegs<K2> &c2, ColRegs<K0> &n0, ColRegs<K1> &n1, ColRegs<K2> &n2) -> bool {
+            const int64_t tile = t0 + j;
+            if (tile < n_full) full_tile(c0, c1, c2, n0, n1, n2);
+            else {
+                if constexpr (kProjDepth == 2) drain_loads(); // (a step that consumes no register set: what was prefetched is dead from here on)
+                if (tile < a.n_tiles) partial_tile(tile);
+            }
+            ++j;
+            if (j < P && tile + 1 < a.n_tiles) return true; // (wave-uniform)
+            end_range();
+            s += gridDim.x;
+            ++i;
+            if (s >= a.n_spans) return false;
+            begin_range();
+            return true;
+        };
+        if (s < a.n_spans) {
+            begin_range();
+            if constexpr (kProjDepth == 2) {
+                for (;;) {
+                    if (!step(A0, A1, A2, C0, C1, C2)) break;
+                    if (!step(B0, B1, B2, A0, A1, A2)) break;
+                    if (!step(C0, C1, C2, B0, B1, B2)) break;
+                }
+            } else {
+                for (;;) {
+                    if (!step(A0, A1, A2, B0, B1, B2)) break;
+                    if (!step(B0, B1, B2, A0, A1, A2)) break;
                 }
             }
         }
+        if constexpr (kProjDepth == 2) drain_loads(); // the tiles prefetched past the wave's last one are still landing
+#ifdef IMM3_ABLATE
+        if (a.stamps && lane == 0) atomicMax(a.stamps + 26 * gridDim.x + blockIdx.x, (unsigned long long)wall_clock64()); // (tools: this work-group's last streamer is through)
+#endif
     } else {
         // ------------------------------------------------------------------ writer
         const int wr = wave - kProjStreamers; // 0: also owns the span's descriptor and its first output row
@@ -959,6 +1187,9 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
         }
     }
     if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x + 1] = wall_clock64();
+#ifdef IMM3_ABLATE
+    if (a.stamps && threadIdx.x == 0) a.stamps[27 * gridDim.x + blockIdx.x] = clock64() - cyc0;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -985,7 +1216,7 @@ bool launch_filter_project(const ProjectArgs &a, int grid, hipStream_t s, hipEve
 
 int project_rec_dwords(const int32_t *kinds) {
     const int k[kMaxTileCols] = {kinds[0], kinds[1], kinds[2]};
-    return rec_layout(k, -1).dwords;
+    return ring_layout(k, -1).dwords;
 }
 
 // Work-groups of the launch: ONE per CU (12 waves, > 80 KB of LDS: a CU never takes a second one, and takes the first whatever

@@ -14,11 +14,25 @@ constexpr int kXposeBytes = 2048; // per wave: one tile of the widest transposed
 // ds_read issued after a ds_write sees it.  Only the compiler must not reorder them.
 __device__ __forceinline__ void lds_wave_order() { asm volatile("" ::: "memory"); }
 
+// "every LDS read issued so far has landed", as an instruction the compiler's wait-count insertion SEES (s_waitcnt lgkmcnt(0); vmcnt
+// and expcnt left alone): after it the compiler adds no wait of its own in front of the reads' uses.  Without it the sixteen
+// ds_read_u8 of a transposed tile are each waited for separately -- sixteen s_waitcnt, one instruction slot each, in kernels
+// that are bound by instruction issue (k_filter_project: DESIGN finding 21).  The scheduling barrier keeps the reads' uses behind it.
+__device__ __forceinline__ void lds_reads_landed() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int KIND>
 struct ColRegs { // TK_NONE: no column
     __device__ __forceinline__ void load(const void *, int64_t, int) {}
     __device__ __forceinline__ void touch() {}
+    static constexpr int kLoads = 0;
+    __device__ __forceinline__ void load_untracked(const void *, int64_t, int) {}
+    __device__ __forceinline__ void keep() const {}
     __device__ __forceinline__ void eval(const TileCol &, uint64_t (&)[kTileWords], int, uint8_t *) {}
+    __device__ __forceinline__ void stage(int, uint8_t *) {}
+    __device__ __forceinline__ void test(const TileCol &, uint64_t (&)[kTileWords]) {}
     __device__ __forceinline__ bool row(const void *, const TileCol &, int64_t) { return true; }
     __device__ __forceinline__ uint32_t value(int) const { return 0u; }
     __device__ __forceinline__ uint32_t rowval(const void *, int64_t) const { return 0u; }
@@ -32,15 +46,45 @@ struct ColRegs<TK_I32> {
 #pragma unroll
         for (int j = 0; j < kTileWords; ++j) v[j] = __builtin_nontemporal_load(p + 64 * j);
     }
+    // The same loads as inline asm: the compiler does not know they are in flight and inserts NO wait of its own for them --
+    // the caller does the waiting (k_filter_project: wait_tile<N>, "all but the N youngest vector-memory operations have
+    // landed").  With two tiles in flight per wave the compiler's own counts were useless: its wait-count analysis merges the
+    // paths that reach the tile body (range ends, the parked bitmap lines' store burst, the partial tile's loop) into "wait for
+    // everything", vmcnt(0), which drains the tile that should stay in flight.  touch() then ties the registers to the point
+    // behind the caller's wait (an empty asm: nothing is emitted).
+    static constexpr int kLoads = kTileWords;
+    template <int J = 0>
+    __device__ __forceinline__ void load_untracked_from(const int32_t *p) {
+        if constexpr (J < kTileWords) {
+            asm volatile("global_load_dword %0, %1, off offset:%2 nt" : "=v"(v[J]) : "v"(p), "n"(256 * J) : "memory");
+            load_untracked_from<J + 1>(p);
+        }
+    }
+    __device__ __forceinline__ void load_untracked(const void *data, int64_t row0, int lane) { load_untracked_from<0>((const int32_t *)data + row0 + lane); }
+    // "these registers are still this column's HERE" (a use the compiler sees, nothing emitted).  An untracked load writes its
+    // destination when the data arrives; on a path where the loaded value is never used -- the tiles prefetched past the wave's last
+    // one -- the compiler would hand the registers to other values at once, and the landing load would overwrite those (found as
+    // a wrong COUNT next to a right bitmap: the per-lane tally had moved into such a register).  The caller waits for the loads
+    // (vmcnt(0)) and keeps every set alive up to that wait.
+    __device__ __forceinline__ void keep() const {
+        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]),
+                     "v"(v[13]), "v"(v[14]), "v"(v[15]));
+    }
     // "the loaded registers are needed HERE": pins the compiler's s_waitcnt for these loads to this point (see k_filter_tile)
+    // (ONE statement: with one per register the compiler emits one s_waitcnt per register -- vmcnt(15), vmcnt(14), ... -- sixteen
+    // instruction slots where one wait does)
     __device__ __forceinline__ void touch() {
-#pragma unroll
-        for (int j = 0; j < kTileWords; ++j) asm volatile("" : "+v"(v[j]));
+        asm volatile(""
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]),
+                       "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
     }
     __device__ __forceinline__ void eval(const TileCol &c, uint64_t (&acc)[kTileWords], int, uint8_t *) {
 #pragma unroll
         for (int j = 0; j < kTileWords; ++j) acc[j] &= ballot64(in_closed(v[j], c.lo, c.hi));
     }
+    // eval() in two steps (k_filter_project): stage() = the LDS traffic of a narrow column's transpose, test() = the compares
+    __device__ __forceinline__ void stage(int, uint8_t *) {}
+    __device__ __forceinline__ void test(const TileCol &c, uint64_t (&acc)[kTileWords]) { eval(c, acc, 0, nullptr); }
     __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return in_closed(((const int32_t *)data)[r], c.lo, c.hi); }
     __device__ __forceinline__ uint32_t value(int j) const { return (uint32_t)v[j]; }
     __device__ __forceinline__ uint32_t rowval(const void *data, int64_t r) const { return ((const uint32_t *)data)[r]; }
@@ -54,14 +98,26 @@ struct ColRegs<TK_I8> {
         raw = __builtin_nontemporal_load((const v4i *)((const int8_t *)data + row0) + lane);
     }
     __device__ __forceinline__ void touch() { asm volatile("" : "+v"(raw)); }
-    __device__ __forceinline__ void eval(const TileCol &c, uint64_t (&acc)[kTileWords], int lane, uint8_t *xp) {
+    static constexpr int kLoads = 1;
+    __device__ __forceinline__ void load_untracked(const void *data, int64_t row0, int lane) {
+        const v4i *p = (const v4i *)((const int8_t *)data + row0) + lane;
+        asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(raw) : "v"(p) : "memory");
+    }
+    __device__ __forceinline__ void keep() const { asm volatile("" ::"v"(raw)); }
+    __device__ __forceinline__ void stage(int lane, uint8_t *xp) {
         *(v4i *)(xp + 16 * lane) = raw; // the tile's 1024 bytes in row order
         lds_wave_order();
 #pragma unroll
         for (int j = 0; j < kTileWords; ++j) v[j] = ((const uint8_t *)xp)[64 * j + lane];
         lds_wave_order();
+    }
+    __device__ __forceinline__ void test(const TileCol &c, uint64_t (&acc)[kTileWords]) {
 #pragma unroll
         for (int j = 0; j < kTileWords; ++j) acc[j] &= ballot64(in_closed((int32_t)(int8_t)v[j], c.lo, c.hi)); // (sign extension folds into the subtract: SDWA)
+    }
+    __device__ __forceinline__ void eval(const TileCol &c, uint64_t (&acc)[kTileWords], int lane, uint8_t *xp) {
+        stage(lane, xp);
+        test(c, acc);
     }
     __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return in_closed((int32_t)((const int8_t *)data)[r], c.lo, c.hi); }
     __device__ __forceinline__ uint32_t value(int j) const { return v[j]; }
@@ -78,21 +134,33 @@ struct ColRegs<TK_S2> {
         raw[1] = __builtin_nontemporal_load(p + 64);
     }
     __device__ __forceinline__ void touch() {
-        asm volatile("" : "+v"(raw[0]));
-        asm volatile("" : "+v"(raw[1]));
+        asm volatile("" : "+v"(raw[0]), "+v"(raw[1]));
     }
+    static constexpr int kLoads = 2;
+    __device__ __forceinline__ void load_untracked(const void *data, int64_t row0, int lane) {
+        const v4i *p = (const v4i *)((const uint16_t *)data + row0) + lane;
+        asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(raw[0]) : "v"(p) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:1024 nt" : "=v"(raw[1]) : "v"(p) : "memory");
+    }
+    __device__ __forceinline__ void keep() const { asm volatile("" ::"v"(raw[0]), "v"(raw[1])); }
     __device__ __forceinline__ bool hit(const TileCol &c, uint32_t x) {
         bool f = false;
         for (int m = 0; m < c.n_match; ++m) f |= (x == c.match[m]);
         return f;
     }
     __device__ __forceinline__ void eval(const TileCol &c, uint64_t (&acc)[kTileWords], int lane, uint8_t *xp) {
+        stage(lane, xp);
+        test(c, acc);
+    }
+    __device__ __forceinline__ void stage(int lane, uint8_t *xp) {
         *(v4i *)(xp + 16 * lane) = raw[0]; // the tile's 2048 bytes in row order
         *(v4i *)(xp + 1024 + 16 * lane) = raw[1];
         lds_wave_order();
 #pragma unroll
         for (int j = 0; j < kTileWords; ++j) v[j] = ((const uint16_t *)xp)[64 * j + lane];
         lds_wave_order();
+    }
+    __device__ __forceinline__ void test(const TileCol &c, uint64_t (&acc)[kTileWords]) {
         if (c.n_match == 1) { // SelectIteratorMatch with the one-value list the SQL front end produces (SQLParser.scala:80-84)
             const uint32_t m0 = c.match[0];
 #pragma unroll

@@ -261,3 +261,33 @@ def test_get_columns_order_small_sets_and_hash_sets(tmp_path):
     assert p.returncode == 0, p.stdout + p.stderr
     used = [l for l in p.stdout.splitlines() if l.startswith("usedColumns:")][0].split()[1:]
     assert used == order, (used, order)
+
+
+def test_the_single_pass_kernel_instances_that_count_their_own_loads_do_not_spill():
+    """k_filter_project's streamers keep two tiles of loads in flight where registers allow (csrc/imm3_project.hip, project_depth):
+    those instances issue their tile loads as inline asm and wait for them with s_waitcnt immediates of their own, because the
+    compiler's wait-count analysis would drain the tile that should stay in flight.  Scratch traffic (a spill) would sit in the same
+    counter and could store a register whose load has not landed: such an instance must fit its 168 registers.  The build keeps the
+    compiler's resource remarks of that file (csrc/Makefile); instances that stay one tile ahead use the compiler's own waits and may
+    spill a few registers, as they did in round 3."""
+    import re
+    from immutable3_amd.build import build_native
+    build_native()
+    path = os.path.join(ROOT, "immutable3_amd", "lib", "imm3_project.resources.txt")
+    assert os.path.exists(path), "make -C immutable3_amd/csrc writes it next to the library"
+    text = open(path).read()
+    blocks = re.split(r"remark: [^\n]*Function Name: ", text)[1:]
+    assert len(blocks) == 16, len(blocks)                      # the 16 kind combinations of IMM3_PROJECT_KINDS
+    set_regs = {0: 16, 1: 4, 2: 8, 3: 0}                       # TK_I32, TK_I8, TK_S2, TK_NONE (imm3_project.hip: tile_set_regs)
+    seen_deep = 0
+    for b in blocks:
+        m = re.match(r"_ZN4imm316k_filter_projectILi(\d)ELi(\d)ELi(\d)E", b)
+        assert m, b[:80]
+        kinds = [int(x) for x in m.groups()]
+        vgprs = int(re.search(r"VGPRs: (\d+)", b).group(1))
+        scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+        assert vgprs <= 168, (kinds, vgprs)                    # 12 waves of a work-group = 3 per SIMD
+        if sum(set_regs[k] for k in kinds) <= 20:              # two tiles ahead: untracked loads, hand-counted waits
+            seen_deep += 1
+            assert scratch == 0, (kinds, vgprs, scratch)
+    assert seen_deep >= 9

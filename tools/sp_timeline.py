@@ -33,13 +33,17 @@ q.run()
 ctx.sync()
 plan = q.plan()
 g = plan["grid"]
-raw = ctx.devclock_raw(0).astype(np.int64)
+raw = ctx.devclock_raw(0, 27 * 256 + 64).astype(np.int64)
 t0 = raw[0:2 * g:2][raw[0:2 * g:2] > 0].min()
 start = (raw[0:2 * g:2] - t0) / 100.0
 end = (raw[1:2 * g:2] - t0) / 100.0
 print(f"plan {plan}")
 print(f"wg start us: min {start.min():.1f} p50 {np.median(start):.1f} max {start.max():.1f};  end us: min {end.min():.1f} p50 {np.median(end):.1f} max {end.max():.1f}")
 ext = raw[2 * g: 2 * g + 24 * g].reshape(g, 24)
+sd = raw[26 * g: 27 * g]
+if (sd > 0).any():
+    sdu = (sd[sd > 0] - t0) / 100.0
+    print(f"streamers through by us: min {sdu.min():.1f} p50 {np.median(sdu):.1f} max {sdu.max():.1f};  work-group end - streamers through: p50 {np.median(end[sd > 0] - sdu):.1f} max {(end[sd > 0] - sdu).max():.1f}")
 for i in range(6):
     r = ext[:, i]; d = ext[:, 6 + i]; pk = ext[:, 12 + i]; an = ext[:, 18 + i]
     if (an > 0).any():
