@@ -591,8 +591,28 @@ def extra_workloads(env: Env, steps: int = 20):
         ksum = sum(v for v in kms.values() if v)
         sel = cnt / n
         algo = bytes_per_row(sel) * n
+        # The reference plans, runs and drops a pipeline per statement (Engine.scala:158-196): what ONE such statement costs here,
+        # wall clock, handle creation and destruction included -- create (with its sampled selectivity estimate), one run, the
+        # count (the first thing a consumer reads: it waits for the run), destroy.  Median of 7, after one unmeasured round.
+        shots = []
+        for r in range(8):
+            env.sync()
+            t0 = time.perf_counter()
+            q1 = native.DeviceQuery(ctx, seg, used, sels, proj, 0, 1024)
+            t1 = time.perf_counter()
+            q1.run()
+            c1 = q1.count()
+            t2 = time.perf_counter()
+            q1.close()
+            t3 = time.perf_counter()
+            assert c1 == cnt, (name, c1, cnt)
+            if r:
+                shots.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2))
+        shots.sort()
+        shot = shots[len(shots) // 2]
         out[name] = {
             "plan": q.plan(),
+            "one_shot_ms": shot[0] * 1e3, "one_shot_parts_ms": {"create": shot[1] * 1e3, "run_and_count": shot[2] * 1e3, "destroy": shot[3] * 1e3},
             "rows_per_s": n / dt, "ms_per_query": dt * 1e3, "selected_rows": int(cnt), "selectivity": sel,
             "algorithmic_bytes_per_row": bytes_per_row(sel), "algorithmic_bytes": algo,
             "kernel_ms": kms, "kernel_ms_sum": ksum,

@@ -519,6 +519,8 @@ static void segment_free(imm3_segment *seg) {
         if (c.d_row_base) (void)hipFree(c.d_row_base);
         if (c.d_dense) (void)hipFree(c.d_dense);
     }
+    for (auto &kv : seg->d_sample_ptrs) (void)hipFree(kv.second);
+    (void)hipFree(seg->d_sample_rows);
     if (seg->ctx) for (void *p : seg->registered) unpin_range(seg->ctx, p);
     if (seg->ready) (void)hipEventDestroy(seg->ready);
     if (seg->ctx) ctx_release(seg->ctx);
@@ -917,23 +919,15 @@ static int ensure_row_capacity(imm3_query *q, uint64_t rows) {
 // takes each block by a relative get from a rewound buffer (Segment.scala:159-168), i.e. from a running cursor.
 // Every other used column must hold the same rows in the same blocks, otherwise the reference either throws
 // ArrayIndexOutOfBounds (shorter) or silently joins the wrong rows (longer): refused.
-struct SegLayout {
-    std::vector<int32_t> size, oid;
-    std::vector<int64_t> word_off; // within the segment's own bitmap
-    int64_t rows = 0, words = 0;
-    bool ragged = false;
-};
-
 // rows of block k of a column: DENSE_* = bytes / width; PFOR_INT = the count the block declares
 static inline int64_t block_rows_of(const SegCol &sc, int32_t k, int64_t len) {
     return is_compressed(sc.codec) ? (int64_t)sc.block_rows[(size_t)k] : len / sc.width;
 }
 
-static int segment_layout(const imm3_segment *seg, const std::vector<int32_t> &used, int32_t table_block_size, SegLayout &L) {
-    const SegCol &first = seg->cols[(size_t)used[0]];
+static int compute_layout(const imm3_segment *seg, int32_t first_col, SegLayout &L) {
+    const SegCol &first = seg->cols[(size_t)first_col];
     const int32_t nb = first.offsets.empty() ? 0 : (int32_t)first.offsets.size() - 1;
     L.size.resize((size_t)nb);
-    L.oid.resize((size_t)nb);
     L.word_off.resize((size_t)nb);
     uint64_t cursor = 0;
     for (int32_t k = 0; k < nb; ++k) {
@@ -943,7 +937,6 @@ static int segment_layout(const imm3_segment *seg, const std::vector<int32_t> &u
         if (cursor + (uint64_t)len > first.bytes) return fail(IMM3_ERR_LAYOUT, "block " + std::to_string(k) + ": bytes [" + std::to_string(cursor) + ", " + std::to_string(cursor + (uint64_t)len) + ") run past the segment data of " + std::to_string(first.bytes) + " bytes (BufferUnderflowException in the reference)");
         const int64_t n = block_rows_of(first, k, len);
         L.size[(size_t)k] = (int32_t)n;
-        L.oid[(size_t)k] = (int32_t)((uint32_t)k * (uint32_t)table_block_size); // vecCounter * table.blockSize
         L.word_off[(size_t)k] = L.words;
         if (k < nb - 1 && (n % 64)) L.ragged = true;
         L.words += (n + 63) / 64;
@@ -951,19 +944,46 @@ static int segment_layout(const imm3_segment *seg, const std::vector<int32_t> &u
         cursor += (uint64_t)len;
     }
     if (L.rows > 0xFFFFFFFFLL) return fail(IMM3_ERR_LAYOUT, "segment too large");
-    for (size_t i = 1; i < used.size(); ++i) {
-        const SegCol &sc = seg->cols[(size_t)used[i]];
-        const int32_t nbc = sc.offsets.empty() ? 0 : (int32_t)sc.offsets.size() - 1;
-        if (nbc < nb) return fail(IMM3_ERR_LAYOUT, "used column " + std::to_string(i) + " has fewer blocks than the first used column (ArrayIndexOutOfBounds in the reference)");
-        uint64_t cur = 0;
-        for (int32_t k = 0; k < nb; ++k) {
-            const int64_t len = (int64_t)sc.offsets[(size_t)k + 1] - (int64_t)sc.offsets[(size_t)k];
-            if (len < 0 || (!is_compressed(sc.codec) && len % sc.width) || block_rows_of(sc, k, len) != L.size[(size_t)k])
-                return fail(IMM3_ERR_LAYOUT, "used column " + std::to_string(i) + " block " + std::to_string(k) + " does not hold the same rows as the first used column");
-            if (cur + (uint64_t)len > sc.bytes) return fail(IMM3_ERR_LAYOUT, "used column " + std::to_string(i) + " block " + std::to_string(k) + " runs past the segment data");
-            cur += (uint64_t)len;
-        }
+    return IMM3_OK;
+}
+
+// does used column `other` hold the same rows in the same blocks as the layout's first column?
+static int check_same_blocks(const imm3_segment *seg, const SegLayout &L, int32_t other, size_t i) {
+    const SegCol &sc = seg->cols[(size_t)other];
+    const int32_t nb = (int32_t)L.size.size();
+    const int32_t nbc = sc.offsets.empty() ? 0 : (int32_t)sc.offsets.size() - 1;
+    if (nbc < nb) return fail(IMM3_ERR_LAYOUT, "used column " + std::to_string(i) + " has fewer blocks than the first used column (ArrayIndexOutOfBounds in the reference)");
+    uint64_t cur = 0;
+    for (int32_t k = 0; k < nb; ++k) {
+        const int64_t len = (int64_t)sc.offsets[(size_t)k + 1] - (int64_t)sc.offsets[(size_t)k];
+        if (len < 0 || (!is_compressed(sc.codec) && len % sc.width) || block_rows_of(sc, k, len) != L.size[(size_t)k])
+            return fail(IMM3_ERR_LAYOUT, "used column " + std::to_string(i) + " block " + std::to_string(k) + " does not hold the same rows as the first used column");
+        if (cur + (uint64_t)len > sc.bytes) return fail(IMM3_ERR_LAYOUT, "used column " + std::to_string(i) + " block " + std::to_string(k) + " runs past the segment data");
+        cur += (uint64_t)len;
     }
+    return IMM3_OK;
+}
+
+// The layout for these used columns, from the segment's cache (segments are immutable once created; any thread, any context).
+static int segment_layout(const imm3_segment *cseg, const std::vector<int32_t> &used, std::shared_ptr<const SegLayout> &out) {
+    imm3_segment *seg = const_cast<imm3_segment *>(cseg);
+    std::lock_guard<std::mutex> g(seg->layout_mu);
+    auto it = seg->layouts.find(used[0]);
+    if (it == seg->layouts.end()) {
+        auto L = std::make_shared<SegLayout>();
+        const int rc = compute_layout(seg, used[0], *L);
+        if (rc) return rc; // (a malformed column is reported every time it is asked for: nothing cached)
+        it = seg->layouts.emplace(used[0], std::move(L)).first;
+    }
+    for (size_t i = 1; i < used.size(); ++i) {
+        if (used[i] == used[0]) continue;
+        const auto key = std::make_pair(used[0], used[i]);
+        if (seg->same_blocks.count(key)) continue;
+        const int rc = check_same_blocks(seg, *it->second, used[i], i);
+        if (rc) return rc;
+        seg->same_blocks[key] = true;
+    }
+    out = it->second;
     return IMM3_OK;
 }
 
@@ -1206,62 +1226,97 @@ static void single_pass_drop_if_narrow(imm3_query *q, uint64_t survivors) {
 // which tells a sorted key's all-or-nothing ranges (keep the planned P: unpack_dense) from the same number of survivors
 // spread evenly (shorter ranges).
 static void fill_tile_col(const imm3_query *q, const FoldedPred &fp, TileCol &c, int kind);
+constexpr int kSampleChunks = 8;
+constexpr int64_t kSampleChunkTiles = 64;
+constexpr int kSampleTiles = kSampleChunks * (int)kSampleChunkTiles;
+
+// the sample's tile table for one column of the segment (cached on the segment: the sampled tiles are the segment's, not the query's)
+static int sample_tile_ptrs(imm3_ctx *ctx, const imm3_segment *cseg, int32_t col, int64_t n_full, void ***out, uint32_t **rows_out) {
+    imm3_segment *seg = const_cast<imm3_segment *>(cseg);
+    std::lock_guard<std::mutex> g(seg->layout_mu);
+    if (seg->sample_full_tiles >= 0 && seg->sample_full_tiles != n_full) return fail(IMM3_ERR_STATE, "internal: the segment's sample was laid out for another row count");
+    if (!seg->d_sample_rows) {
+        std::vector<uint32_t> rows((size_t)kSampleTiles, (uint32_t)kTileRows);
+        void *p = nullptr;
+        HIPCHK(hipMalloc(&p, rows.size() * sizeof(uint32_t)));
+        const hipError_t e = hipMemcpy(p, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(p); HIPCHK(e); }
+        seg->d_sample_rows = (uint32_t *)p;
+        seg->sample_full_tiles = n_full;
+    }
+    auto it = seg->d_sample_ptrs.find(col);
+    if (it == seg->d_sample_ptrs.end()) {
+        const SegCol &sc = seg->cols[(size_t)col];
+        std::vector<const void *> ptrs((size_t)kSampleTiles);
+        for (int i = 0; i < kSampleChunks; ++i) {
+            int64_t tile0 = (int64_t)((2 * i + 1) * n_full / (2 * kSampleChunks)) - kSampleChunkTiles / 2;
+            tile0 = std::max<int64_t>(0, std::min<int64_t>(tile0, n_full - kSampleChunkTiles));
+            for (int64_t t = 0; t < kSampleChunkTiles; ++t)
+                ptrs[(size_t)(i * kSampleChunkTiles + t)] = col_flat(sc) + (size_t)(tile0 + t) * kTileRows * (size_t)sc.width;
+        }
+        void *p = nullptr;
+        HIPCHK(hipMalloc(&p, ptrs.size() * sizeof(void *)));
+        const hipError_t e = hipMemcpy(p, ptrs.data(), ptrs.size() * sizeof(void *), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(p); HIPCHK(e); }
+        it = seg->d_sample_ptrs.emplace(col, (void **)p).first;
+    }
+    (void)ctx;
+    *out = it->second;
+    *rows_out = seg->d_sample_rows;
+    return IMM3_OK;
+}
+
 static int single_pass_sample(imm3_query *q) {
     imm3_ctx *ctx = q->ctx;
-    constexpr int kChunks = 8;
-    constexpr int64_t kChunkTiles = 64;
     const int64_t n_full = q->n_rows / kTileRows;
     const bool undecided = q->single_pass || q->alt_ok || (q->d_stage_rec && q->records_narrow_only);
     if (!undecided || q->sp_P_fixed || ctx->filter_variant == 10 || n_full < 4096) return IMM3_OK; // (below ~4 M rows the sample costs what it saves)
-    TileArgs base;
-    std::memset(&base, 0, sizeof(base));
-    int widths[kMaxTileCols] = {0, 0, 0};
-    bool any_i32 = false, any = false;
+    // ONE count-only launch of the scan+select kernel's table instance over the sample's tile table (round 3: eight launches, a
+    // memset and a strided copy): 128 work-groups, one tile per wave, so that work-groups 16 i .. 16 i + 15 hold chunk i's count
+    // in their partials.
+    TileArgs a;
+    std::memset(&a, 0, sizeof(a));
+    bool any = false;
     for (int k = 0; k < kMaxTileCols; ++k) {
-        base.kinds[k] = q->stage_kinds[k];
-        if (base.kinds[k] == TK_NONE) continue;
+        a.kinds[k] = q->stage_kinds[k];
+        if (a.kinds[k] == TK_NONE) continue;
         const FoldedPred *fp = nullptr;
         for (const auto &p : q->preds)
             if (p.seg_col == q->stage_seg_col[k]) fp = &p;
         if (!fp) return IMM3_OK; // (a streamed column already: nothing left to decide)
-        fill_tile_col(q, *fp, base.cols[k], base.kinds[k]);
-        widths[k] = base.kinds[k] == TK_I32 ? 4 : (base.kinds[k] == TK_S2 ? 2 : 1);
-        any_i32 |= base.kinds[k] == TK_I32;
+        if (is_compressed(q->seg->cols[(size_t)fp->seg_col].codec) && !q->seg->cols[(size_t)fp->seg_col].d_dense) return IMM3_OK;
+        fill_tile_col(q, *fp, a.cols[k], a.kinds[k]);
+        void **ptrs = nullptr;
+        uint32_t *rows = nullptr;
+        const int rc = sample_tile_ptrs(ctx, q->seg, fp->seg_col, n_full, &ptrs, &rows);
+        if (rc) return rc;
+        a.tile_ptrs[k] = (const void *const *)ptrs;
+        a.tile_rows = rows;
         any = true;
     }
     if (!any) return IMM3_OK; // (no predicate: every row survives, the plan for that is the dense path at the planned P)
-    void *d = nullptr;
-    const size_t block = (size_t)kFinishWords * sizeof(unsigned long long);
-    HIPCHK(pool_alloc(ctx, &d, block * kChunks));
-    struct PoolGuard { imm3_ctx *c; void *p; ~PoolGuard() { pool_release(c, p); } } guard{ctx, d}; // (stream-ordered reuse: released on every path out)
-    HIPCHK(hipMemsetAsync(d, 0, block * kChunks, ctx->stream));
-    unsigned long long counts[kChunks] = {0};
-    for (int i = 0; i < kChunks; ++i) {
-        int64_t tile0 = (int64_t)((2 * i + 1) * n_full / (2 * kChunks)) - kChunkTiles / 2;
-        tile0 = std::max<int64_t>(0, std::min<int64_t>(tile0, n_full - kChunkTiles));
-        TileArgs a = base;
-        for (int k = 0; k < kMaxTileCols; ++k)
-            if (a.kinds[k] != TK_NONE) a.cols[k].data = (const uint8_t *)a.cols[k].data + tile0 * kTileRows * widths[k];
-        a.n_rows = kChunkTiles * kTileRows;
-        a.n_words = kChunkTiles * kTileWords;
-        a.n_tiles = kChunkTiles;
-        a.bitmap = nullptr; // count-only
-        a.block_partials = q->d_block_partials;
-        a.finish = (unsigned long long *)((uint8_t *)d + block * (size_t)i);
-        const int grid = filter_grid(a.n_tiles, false, any_i32, 0);
-        if (!launch_filter_tile(a, grid, ctx->stream, nullptr, nullptr)) return IMM3_OK;
-    }
-    // (one strided copy: word 0 of every block)
-    HIPCHK(hipMemcpy2DAsync(counts, sizeof(unsigned long long), d, block, sizeof(unsigned long long), kChunks, hipMemcpyDeviceToHost, ctx->stream));
+    a.n_rows = (int64_t)kSampleTiles * kTileRows;
+    a.n_words = (int64_t)kSampleTiles * kTileWords;
+    a.n_tiles = kSampleTiles;
+    a.bitmap = nullptr; // count-only
+    a.block_partials = q->d_block_partials;
+    a.finish = nullptr;
+    constexpr int kGrid = kSampleTiles / kWavesPerBlock; // 128: wave w of the launch takes tile w
+    if (!launch_filter_tile(a, kGrid, ctx->stream, nullptr, nullptr)) return IMM3_OK;
+    HIPCHK(hipGetLastError());
+    uint32_t partials[kGrid] = {0};
+    HIPCHK(hipMemcpyAsync(partials, q->d_block_partials, sizeof(partials), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    const double chunk_rows = (double)(kChunkTiles * kTileRows);
+    const double chunk_rows = (double)(kSampleChunkTiles * kTileRows);
     double sum = 0.0, sum_sq = 0.0;
-    for (int i = 0; i < kChunks; ++i) {
-        sum += (double)counts[i];
-        sum_sq += (double)counts[i] * (double)counts[i];
+    for (int i = 0; i < kSampleChunks; ++i) {
+        double c = 0.0;
+        for (int b = 0; b < kGrid / kSampleChunks; ++b) c += (double)partials[i * (kGrid / kSampleChunks) + b];
+        sum += c;
+        sum_sq += c * c;
     }
     if (sum <= 0.0) return IMM3_OK; // (nothing in the sample: the plan for few survivors stands)
-    const double sigma = sum / (chunk_rows * kChunks), sigma_local = sum_sq / (sum * chunk_rows);
+    const double sigma = sum / (chunk_rows * kSampleChunks), sigma_local = sum_sq / (sum * chunk_rows);
     const int rc = single_pass_stream_columns(q, (uint64_t)(sigma * (double)q->n_rows));
     if (rc) return rc;
     records_drop_if_narrow(q, (uint64_t)(sigma * (double)q->n_rows));
@@ -1324,13 +1379,10 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
     //     on a fresh tile of the virtual row space
     int32_t nb = 0;
     if (!table) {
-        SegLayout L;
-        const int lrc = segment_layout(seg, q->used, table_block_size, L);
+        const int lrc = segment_layout(seg, q->used, q->layout);
         if (lrc) return lrc;
+        const SegLayout &L = *q->layout;
         nb = (int32_t)L.size.size();
-        q->batch_size = L.size;
-        q->batch_oid = L.oid;
-        q->batch_word_off = L.word_off;
         q->n_rows = L.rows;
         q->n_words = L.words;
         q->ragged = L.ragged;
@@ -1457,19 +1509,29 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
     q->d_block_partials = (uint32_t *)p;
     HIPCHK(pool_alloc(ctx, &p, kFinishWords * sizeof(unsigned long long))); // {total, n_emit, status, limit, tally, log, log index, log capacity}, then the sub-tallies (imm3_device.h)
     q->d_total = (unsigned long long *)p;
-    HIPCHK(hipMemsetAsync(q->d_total, 0, kFinishWords * sizeof(unsigned long long), ctx->stream));
     q->d_n_emit = q->d_total + 1;
-    std::memset(q->h_init, 0, sizeof(q->h_init)); // lives as long as the query; creation ends with a stream sync anyway
+    // Creation enqueues and returns: nothing below waits for the device (round 3 ended every creation with a stream
+    // synchronisation, behind a 12.5 MB memset of the bitmap -- a query cost four times what running it did).  What the copies
+    // read lives in the query handle.  The finish block = zeros + the limit, ONE copy; of the bitmap only the words behind
+    // n_words in its last tile need to be zero (the offsets scan and the aggregation read whole tiles): every run writes all the
+    // others before anything reads them.
+    q->h_init.assign((size_t)kFinishWords, 0ULL);
     q->h_init[3] = (unsigned long long)limit;
-    HIPCHK(hipMemcpyAsync(q->d_total, q->h_init, sizeof(q->h_init), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemsetAsync(q->d_bitmap, 0, words_alloc * sizeof(uint64_t), ctx->stream));
+    HIPCHK(hipMemcpyAsync(q->d_total, q->h_init.data(), (size_t)kFinishWords * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
+    {
+        const size_t first_pad = (size_t)std::min<int64_t>(std::max<int64_t>(q->n_words, 0), (int64_t)words_alloc);
+        const size_t from = first_pad; // (words [n_words, words_alloc): at most one tile's worth)
+        if (from < words_alloc) HIPCHK(hipMemsetAsync(q->d_bitmap + from, 0, (words_alloc - from) * sizeof(uint64_t), ctx->stream));
+    }
     if (q->ragged) {
-        std::vector<uint32_t> base((size_t)q->n_tiles * kTileWords, 0u);
-        std::vector<uint8_t> nvalid((size_t)q->n_tiles * kTileWords, 0);
+        std::vector<uint32_t> &base = q->h_word_row_base;
+        std::vector<uint8_t> &nvalid = q->h_word_nvalid;
+        base.assign((size_t)q->n_tiles * kTileWords, 0u);
+        nvalid.assign((size_t)q->n_tiles * kTileWords, 0);
         int64_t row = 0;
         size_t w = 0;
         for (int32_t k = 0; k < nb; ++k) {
-            const int64_t n = q->batch_size[(size_t)k];
+            const int64_t n = q->layout->size[(size_t)k];
             for (int64_t r = 0; r < n; r += 64) {
                 base[w] = (uint32_t)(row + r);
                 nvalid[w] = (uint8_t)std::min<int64_t>(64, n - r);
@@ -1485,7 +1547,6 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
             HIPCHK(hipMemcpyAsync(q->d_word_row_base, base.data(), base.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
             HIPCHK(hipMemcpyAsync(q->d_word_nvalid, nvalid.data(), nvalid.size(), hipMemcpyHostToDevice, ctx->stream));
         }
-        HIPCHK(hipStreamSynchronize(ctx->stream)); // the host vectors die at scope end
     }
     if (n_proj > 0 && limit > 0) {
         const int rc = ensure_row_capacity(q.get(), (uint64_t)std::min<int64_t>(limit, std::max<int64_t>(q->n_rows, 1)));
@@ -1595,10 +1656,9 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
         }
     }
     {
-        const int src = single_pass_sample(q.get());
+        const int src = single_pass_sample(q.get()); // (the one synchronisation a creation may contain: segments of 4 M rows and more, undecided plans)
         if (src) return src;
     }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
     *out = q.release();
     return IMM3_OK;
 }
@@ -1658,9 +1718,10 @@ extern "C" int imm3_table_create(imm3_ctx *ctx, const imm3_segment *const *segs,
         for (size_t c = 0; c < ncols; ++c)
             if (sg->cols[c].codec != segs[0]->cols[c].codec || sg->cols[c].width != segs[0]->cols[c].width)
                 return fail(IMM3_ERR_ARG, "segments of one table must have the same column types");
-        SegLayout L;
-        const int rc = segment_layout(sg, all_cols, 0, L);
+        std::shared_ptr<const SegLayout> Lp;
+        const int rc = segment_layout(sg, all_cols, Lp);
         if (rc) return rc;
+        const SegLayout &L = *Lp;
         if (L.ragged) return fail(IMM3_ERR_LAYOUT, "segment " + std::to_string(si) + ": a non-final block is not a multiple of 64 rows (ragged layout); use per-segment queries");
         for (size_t c = 0; c < ncols; ++c) { // the tile table addresses flat columns: decode PFOR_INT ones now
             const int drc = ensure_dense(ctx, sg, (int32_t)c);
@@ -1729,7 +1790,7 @@ extern "C" int imm3_query_segment_starts(const imm3_query *q, int32_t *n_segment
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
     if (!q->table) { // one segment
         if (n_segments) *n_segments = 1;
-        if (first_batch) { first_batch[0] = 0; first_batch[1] = (int32_t)q->batch_size.size(); }
+        if (first_batch) { first_batch[0] = 0; first_batch[1] = (int32_t)q->layout->size.size(); }
         if (first_word) { first_word[0] = 0; first_word[1] = q->n_words; }
         return IMM3_OK;
     }
@@ -2433,7 +2494,7 @@ extern "C" int imm3_query_sync(imm3_query *q) {
 // ---------------------------------------------------------------------------------------------
 extern "C" int imm3_query_layout(const imm3_query *q, int32_t *n_batches, int64_t *total_words, int64_t *n_rows) {
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
-    if (n_batches) *n_batches = (int32_t)(q->table ? q->table->batch_size.size() : q->batch_size.size());
+    if (n_batches) *n_batches = (int32_t)(q->table ? q->table->batch_size.size() : q->layout->size.size());
     if (total_words) *total_words = q->n_words;
     if (n_rows) *n_rows = q->n_rows;
     return IMM3_OK;
@@ -2450,10 +2511,12 @@ extern "C" int imm3_query_batches(const imm3_query *q, int32_t *batch_size, int3
         if (batch_word_off && nb) std::memcpy(batch_word_off, t->batch_word_off.data(), nb * sizeof(int64_t));
         return IMM3_OK;
     }
-    const size_t nb = q->batch_size.size();
-    if (batch_size && nb) std::memcpy(batch_size, q->batch_size.data(), nb * sizeof(int32_t));
-    if (batch_oid && nb) std::memcpy(batch_oid, q->batch_oid.data(), nb * sizeof(int32_t));
-    if (batch_word_off && nb) std::memcpy(batch_word_off, q->batch_word_off.data(), nb * sizeof(int64_t));
+    const SegLayout &L = *q->layout;
+    const size_t nb = L.size.size();
+    if (batch_size && nb) std::memcpy(batch_size, L.size.data(), nb * sizeof(int32_t));
+    if (batch_oid)
+        for (size_t k = 0; k < nb; ++k) batch_oid[k] = (int32_t)((uint32_t)k * (uint32_t)q->table_block_size); // vecCounter * table.blockSize (Scan.scala:60)
+    if (batch_word_off && nb) std::memcpy(batch_word_off, L.word_off.data(), nb * sizeof(int64_t));
     return IMM3_OK;
 }
 
@@ -2666,7 +2729,7 @@ static int query_create_agg_impl(imm3_ctx *ctx, const imm3_segment *seg, const i
         key_bytes += seg->cols[(size_t)q->used[(size_t)group_cols[g]]].width;
     }
     if (key_bytes > 8) return fail(IMM3_ERR_ARG, "group key wider than 8 bytes is not supported on the GPU path");
-    const bool has_batches = table ? !table->batch_size.empty() : !q->batch_size.empty();
+    const bool has_batches = table ? !table->batch_size.empty() : !q->layout->size.empty();
     for (int32_t j = 0; j < n_aggs; ++j) {
         if (aggs[j].column < 0 || aggs[j].column >= n_used) return fail(IMM3_ERR_ARG, "aggregate column is not among the used columns");
         const SegCol &sc = seg->cols[(size_t)q->used[(size_t)aggs[j].column]];

@@ -8,6 +8,7 @@
 
 #include <atomic>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -124,6 +125,17 @@ struct SegCol {
     uint8_t *d_dense = nullptr;        // decoded int32 column, made on first need (Project, aggregation, ragged, table)
 };
 
+// Batches of one segment as ScanOp yields them (Scan.scala:55,72; Segment.scala:159-168): block k of the FIRST used column holds
+// size[k] rows, its BitSet starts at word word_off[k] of the segment's bitmap.  The same for every query whose first used column is
+// the same, so it is computed once per (segment, first column) and shared (a 100 M-row segment has 97 657 batches: three vectors
+// of that length per query were most of a query's creation time).  oid = k * table.blockSize is the caller's parameter: not stored.
+struct SegLayout {
+    std::vector<int32_t> size;
+    std::vector<int64_t> word_off; // within the segment's own bitmap
+    int64_t rows = 0, words = 0;
+    bool ragged = false;
+};
+
 struct imm3_segment {
     std::atomic<int> refs{1};
     std::atomic<bool> closed{false};
@@ -134,6 +146,14 @@ struct imm3_segment {
     hipEvent_t ready = nullptr;        // recorded on the context's copy stream behind the last column's copy
     std::atomic<bool> ready_pending{false}; // the copies may still be in flight: consumers make their stream wait for `ready`
     std::mutex decode_mu;              // guards the lazy d_dense of PFOR_INT columns
+    std::mutex layout_mu;              // guards the two caches below
+    std::map<int32_t, std::shared_ptr<const SegLayout>> layouts; // by first used column
+    std::map<std::pair<int32_t, int32_t>, bool> same_blocks;     // (first column, other column) -> holds the same rows in the same blocks (checked once)
+    // the selectivity sample of query creation (single_pass_sample): a tile table over 8 evenly spaced chunks of 64 full tiles, one
+    // pointer array per column (made on first need), so that the sample is ONE launch of the table instance of the scan+select kernel
+    std::map<int32_t, void **> d_sample_ptrs; // by column
+    uint32_t *d_sample_rows = nullptr;        // kSampleTiles x 1024
+    int64_t sample_full_tiles = -1;           // the full tiles the table was laid out for
 };
 
 // the flat, fixed-width form of a column (what every kernel but k_filter_pfor reads)
@@ -174,9 +194,8 @@ struct imm3_query {
     std::vector<int32_t> used;     // segment column index of each used column
     std::vector<int32_t> proj;     // index into `used`
     int64_t limit = 0;
-    // layout (Scan.scala:55-60)
-    std::vector<int32_t> batch_size, batch_oid;
-    std::vector<int64_t> batch_word_off;
+    // layout (Scan.scala:55-60): shared with every query of the segment that has the same first used column (null: table query)
+    std::shared_ptr<const SegLayout> layout;
     int64_t n_rows = 0, n_words = 0, n_tiles = 0, n_chunks = 0;
     bool ragged = false;
     bool always_false = false;
@@ -186,7 +205,9 @@ struct imm3_query {
     uint32_t *d_tile_offsets = nullptr, *d_chunk_sums = nullptr, *d_block_partials = nullptr;
     unsigned long long *d_total = nullptr, *d_n_emit = nullptr; // adjacent: d_n_emit = d_total + 1; d_total + 2 = status word
     bool has_pfor_pass = false;   // a k_filter_pfor pass may flag malformed blocks in the status word
-    unsigned long long h_init[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // host image of the block above at creation
+    std::vector<unsigned long long> h_init; // host image of the whole finish block at creation (copied asynchronously: lives with the query)
+    std::vector<uint32_t> h_word_row_base;  // ragged layouts: host images of the per-word row map (same reason)
+    std::vector<uint8_t> h_word_nvalid;
     uint32_t *d_word_row_base = nullptr;
     uint8_t *d_word_nvalid = nullptr;
     uint32_t *d_row_index = nullptr;

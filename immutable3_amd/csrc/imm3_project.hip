@@ -30,6 +30,7 @@
 #include "imm3_device.h"
 #include "imm3_tile.h"
 #include <hip/hip_ext.h>
+#include <atomic>
 #include <type_traits>
 
 namespace imm3 {
@@ -1228,11 +1229,18 @@ int project_max_grid(const int32_t *kinds, int P) {
     IMM3_PROJECT_KINDS(IMM3_PROJECT_HAVE)
 #undef IMM3_PROJECT_HAVE
     if (!have) return 0;
+    static std::atomic<int> cus_of[kMaxDevices]; // (asked once per device: this sits in every query creation)
     int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    if (hipGetDevice(&dev) != hipSuccess) {
         (void)hipGetLastError();
         return 0;
     }
+    if (dev >= 0 && dev < kMaxDevices && (cus = cus_of[dev].load(std::memory_order_relaxed)) > 0) return cus;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    if (dev >= 0 && dev < kMaxDevices) cus_of[dev].store(cus, std::memory_order_relaxed);
     return cus;
 }
 
