@@ -666,11 +666,66 @@ __device__ __forceinline__ void load_lane_rows(const void *data, int64_t tile, i
 #pragma unroll
     for (int i = 0; i < N; ++i) r[i] = __builtin_nontemporal_load(p + i);
 }
+// A 2-byte column loaded the COALESCED way (round 4): lane l takes bytes [16 l, 16 l + 16) of the tile's first and of its second
+// kilobyte -- two instructions that each cover contiguous bytes -- instead of 32 contiguous bytes per lane, which is two
+// instructions that each use every other 16-byte piece (loads like that run well below the rate of contiguous ones: DESIGN
+// finding 20; this kernel's loads alone took 60 us for 312 MB).  Lane pairs then swap halves (one DPP move per register): the even
+// lane 2 k ends up with rows 16 k .. 16 k + 15, the odd lane 2 k + 1 with rows 512 + 16 k .. -- sixteen consecutive rows per lane as
+// before, in the "pair" lane order that the 1-byte columns and the bitmap bits are loaded in directly (pair_group below).
+__device__ __forceinline__ void load_lane_rows_pair2(const void *data, int64_t tile, int lane, v4i_t (&r)[2]) {
+    const v4i_t *p = (const v4i_t *)((const uint8_t *)data + tile * (int64_t)(kTileRows * 2)) + lane;
+    r[0] = __builtin_nontemporal_load(p);
+    r[1] = __builtin_nontemporal_load(p + 64);
+}
+__device__ __forceinline__ void pair_swap2(v4i_t (&r)[2], bool odd) {
+    v4i_t xa, xb;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        xa[k] = __builtin_amdgcn_update_dpp(0, r[0][k], 0xB1, 0xF, 0xF, true); // quad_perm [1, 0, 3, 2]: the pair neighbour's register
+        xb[k] = __builtin_amdgcn_update_dpp(0, r[1][k], 0xB1, 0xF, 0xF, true);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int a0 = r[0][k], b1 = r[1][k];
+        r[0][k] = odd ? xb[k] : a0;
+        r[1][k] = odd ? b1 : xa[k];
+    }
+}
+// the 16-row group of a tile that lane l owns in pair order: even lanes the first half of the tile, odd lanes the second
+__device__ __forceinline__ int pair_group(int lane) { return (lane >> 1) + 32 * (lane & 1); }
+
 template <int W>
 __device__ __forceinline__ uint32_t lane_row_value(const v4i_t (&r)[W == 4 ? 4 : (W == 2 ? 2 : 1)], int i) { // i: compile time after unrolling
     if constexpr (W == 4) return (uint32_t)r[i >> 2][i & 3];
     else if constexpr (W == 2) return ((uint32_t)r[i >> 3][(i >> 1) & 3] >> (16 * (i & 1))) & 0xFFFFu;
     else return ((uint32_t)r[0][i >> 2] >> (8 * (i & 3))) & 0xFFu;
+}
+
+// The same with a RUN-TIME row index (the sparse walk of k_group_agg_lanes: every lane takes its own next selected row).  Registers
+// cannot be indexed per lane, so the element is picked with byte permutes (v_perm_b32 selects any four bytes of a register pair)
+// and a few conditional moves: 5 vector instructions for a 1-byte column, ~11 for a 2-byte one, ~19 for int32.
+template <int W>
+__device__ __forceinline__ uint32_t lane_row_value_rt(const v4i_t (&r)[W == 4 ? 4 : (W == 2 ? 2 : 1)], uint32_t i) {
+    if constexpr (W == 1) {
+        const uint32_t sel = 0x0C0C0C00u | (i & 7u); // byte i & 7 of the pair, zero-extended
+        const uint32_t lo = __builtin_amdgcn_perm((uint32_t)r[0][1], (uint32_t)r[0][0], sel), hi = __builtin_amdgcn_perm((uint32_t)r[0][3], (uint32_t)r[0][2], sel);
+        return (i & 8u) ? hi : lo;
+    } else if constexpr (W == 2) {
+        const uint32_t e = i & 3u, sel = 0x0C0C0100u + 0x0202u * e; // bytes 2 e, 2 e + 1 of the pair
+        const uint32_t p0 = __builtin_amdgcn_perm((uint32_t)r[0][1], (uint32_t)r[0][0], sel), p1 = __builtin_amdgcn_perm((uint32_t)r[0][3], (uint32_t)r[0][2], sel);
+        const uint32_t p2 = __builtin_amdgcn_perm((uint32_t)r[1][1], (uint32_t)r[1][0], sel), p3 = __builtin_amdgcn_perm((uint32_t)r[1][3], (uint32_t)r[1][2], sel);
+        const uint32_t a = (i & 4u) ? p1 : p0, b = (i & 4u) ? p3 : p2;
+        return (i & 8u) ? b : a;
+    } else {
+        uint32_t q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t a = (i & 1u) ? (uint32_t)r[k][1] : (uint32_t)r[k][0], b = (i & 1u) ? (uint32_t)r[k][3] : (uint32_t)r[k][2];
+            q[k] = (i & 2u) ? b : a;
+        }
+        const uint32_t a = (i & 4u) ? q[1] : q[0], b = (i & 4u) ? q[3] : q[2];
+        return (i & 8u) ? b : a;
+    }
 }
 
 // one byte of a map: its value, or -- when it is free -- an attempt to claim it and fill it from *counter (values >= limit
@@ -781,17 +836,29 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
         v4i_t kr0[KS == 1 ? 2 : 1], kr1[1], vr[NV], vr2[1];
     };
     constexpr int kDepth = VW == 2 ? 3 : 2; // (16-bit entries: 16 waves per CU, two tiles ahead suffice; VW 4: registers)
+    // lane -> rows: 16 consecutive rows per lane; with an int32 value column group `lane`, otherwise group pair_group(lane), which
+    // lets the 2-byte columns be loaded with contiguous instructions (load_lane_rows_pair2)
+    constexpr bool kPair = VW != 4;
+    const int rgroup = kPair ? pair_group(lane) : lane;
+    const bool odd = (lane & 1) != 0;
     const int64_t stride = (int64_t)gridDim.x * n_waves;
     const int64_t first_tile = (int64_t)blockIdx.x * n_waves + wave;
     auto issue = [&](TileRegs &r, int64_t tile) {
         if (tile >= a.n_tiles) tile = a.n_tiles - 1;
-        r.bits = ((const uint16_t *)a.bitmap)[tile * 64 + lane];
-        load_lane_rows<(KS == 1 ? 2 : 1)>(a.groups[0].data, tile, lane, r.kr0);
-        if constexpr (KS == 2) load_lane_rows<1>(a.groups[1].data, tile, lane, r.kr1);
-        if constexpr (VW != 0) load_lane_rows<(VW ? VW : 1)>(a.aggs[vq].data, tile, lane, r.vr);
+        r.bits = ((const uint16_t *)a.bitmap)[tile * 64 + rgroup];
+        if constexpr (KS == 1 && kPair) load_lane_rows_pair2(a.groups[0].data, tile, lane, r.kr0);
+        else load_lane_rows<(KS == 1 ? 2 : 1)>(a.groups[0].data, tile, rgroup, r.kr0);
+        if constexpr (KS == 2) load_lane_rows<1>(a.groups[1].data, tile, rgroup, r.kr1);
+        if constexpr (VW == 2) load_lane_rows_pair2(a.aggs[vq].data, tile, lane, r.vr);
+        else if constexpr (VW != 0) load_lane_rows<(VW ? VW : 1)>(a.aggs[vq].data, tile, rgroup, r.vr);
         if constexpr (V2) {
-            if (!same2) load_lane_rows<1>(a.aggs[vq2].data, tile, lane, r.vr2); // wave-uniform
+            if (!same2) load_lane_rows<1>(a.aggs[vq2].data, tile, rgroup, r.vr2); // wave-uniform
         }
+    };
+    // the pair swap of the 2-byte columns, once their loads have landed (a tile's registers are rewritten by the next issue)
+    auto settle = [&](TileRegs &r) {
+        if constexpr (KS == 1 && kPair) pair_swap2(r.kr0, odd);
+        if constexpr (VW == 2) pair_swap2(r.vr, odd);
     };
     int since_fold = 0; // VW 1: tiles since the 8-bit counts were folded (wave-uniform)
     auto fold_counts = [&]() { // lane = slot (NS / 64 passes): move the 64 lanes' 8-bit counts of its slot into wcnt (rotated: lanes on different banks)
@@ -821,6 +888,98 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
             wcnt[slot] += c;
         }
     };
+    // one row into the lane's private entry of slot s (raw / raw2: the aggregated columns' values as loaded)
+    auto update_entry = [&](const uint32_t s, uint32_t raw, uint32_t raw2) {
+        uint32_t x = 0;
+        if constexpr (VW != 0) {
+            if (vstr) raw = VW == 4 ? __builtin_bswap32(raw) : (VW == 2 ? (uint32_t)__builtin_bswap16((uint16_t)raw) : raw); // big-endian pack: integer order == byte order
+            x = (raw ^ vflip) & vmask;
+        }
+        if constexpr (V2) {
+            const uint32_t x2 = (raw2 ^ vflip2) & 0xFFu; // (1-byte strings need no byte swap)
+            const uint32_t old = tab[s * 64];
+            tab[s * 64] = ((old + 1u) & 0xFFu) | max(old & 0xFF00u, x << 8) | max(old & 0xFF0000u, x2 << 16);
+        } else if constexpr (kE16) {
+            const uint32_t old = t16[s * 64];
+            if constexpr (VW == 0) t16[s * 64] = (uint16_t)(old + 1u); // (a lane's count stays below 2^16: lanes_plan)
+            else t16[s * 64] = (uint16_t)(((old + 1u) & 0xFFu) | (max(old, x << 8) & 0xFF00u));
+        } else if constexpr (kPacked) {
+            const uint32_t old = tab[s * 64];
+            tab[s * 64] = ((old + 1u) & 0xFFFFu) | (max(old, x << 16) & 0xFFFF0000u); // (a lane's count stays below 2^16: lanes_plan)
+        } else {
+            const uint32_t oc = cnt[s * 64], ov = val[s * 64];
+            cnt[s * 64] = (uint16_t)(oc + 1u);
+            val[s * 64] = max(ov, x);
+        }
+    };
+    // ProjectAggIterator visits SELECTED rows only (ProjectAggregate.scala:158-159).  The dense walk below touches all sixteen rows
+    // of every lane (unselected ones update a trash slot: no branches) -- the same ~440 instructions per tile whether 11 % or all of
+    // the rows are selected.  When no lane of the wave has more than kSparseRows selected rows the SPARSE walk takes over: every lane
+    // takes its own next selected row per step (lowest set bit of its 16), the row's key and values are picked out of the loaded
+    // registers with byte permutes, and the wave makes as many steps as its busiest lane has rows: ~6 at 11 % survivors, ~2 at 2 %.
+    constexpr uint32_t kSparseRows = VW == 4 ? 5u : 8u;
+    auto process_sparse = [&](const TileRegs &r, const int64_t tile) {
+        const uint32_t row0 = (uint32_t)(tile * kTileRows + 16 * rgroup);
+        uint32_t rem = r.bits;
+        uint64_t here[kWords] = {}; // slots this lane met in this tile while the wave was behind
+        bool was_behind = false;
+        while (ballot64(rem != 0u)) { // wave-uniform
+            const bool on = rem != 0u;
+            const uint32_t i = (uint32_t)__builtin_ctz(rem | 0x10000u) & 15u; // this lane's next selected row (row 0 for a lane that has none left: its update goes to the trash slot)
+            rem &= rem - 1u;
+            uint32_t key = lane_row_value_rt<(KS == 1 ? 2 : 1)>(r.kr0, i);
+            if constexpr (KS == 2) key = (key << sh0) | (lane_row_value_rt<1>(r.kr1, i) << sh1);
+            uint32_t sid;
+            if constexpr (KS == 0) sid = S.l2[256 + key];
+            else sid = S.l2[(min((uint32_t)S.l1[key & 0xFFu], (uint32_t)kLanePages) << 8) | (key >> 8)];
+            bool pend = on && sid >= (uint32_t)NS;
+            if (ballot64(pend)) { // wave-uniform, warm-up only: the lanes place (or look up again) their new keys
+                for (int rounds = 0; rounds < 1024 && ballot64(pend); ++rounds) {
+                    if (pend) {
+                        const uint32_t id = lanes_slot<KS>(S, key, kTrash, a.overflow);
+                        if (id != kMapFree) {
+                            sid = id;
+                            pend = false;
+                        }
+                    }
+                }
+                if (ballot64(pend)) *a.overflow = 3; // (never seen: a claimed byte is published a few instructions later)
+            }
+            sid = (on && sid < (uint32_t)NS) ? sid : kTrash;
+            {   // first-seen rows (the slot numbers seen above are below the count read here: slots are numbered before they are published)
+                uint32_t ns = __hip_atomic_load(&S.nslots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                ns = ns < kTrash ? ns : kTrash;
+                bool behind = false;
+#pragma unroll
+                for (int p = 0; p < kWords; ++p) {
+                    const uint32_t n = ns > 64u * p ? ns - 64u * p : 0u;
+                    const uint64_t all = n >= 64u ? ~0ULL : ((1ULL << n) - 1ULL);
+                    behind |= (seen[p] & all) != all;
+                }
+                if (behind) { // wave-uniform.  `seen` stays what it was when the tile began: a later step of this walk may bring a
+                    // LOWER row of the same slot (another lane's), so every row of the tile is tested against the slots met in EARLIER tiles
+                    was_behind = true;
+                    const uint64_t bit = 1ULL << (sid & 63u);
+                    uint64_t sw = seen[0];
+                    if constexpr (kWords == 2) sw = (sid & 64u) ? seen[1] : seen[0];
+                    const bool real = on && sid != kTrash;
+                    if (real && !(sw & bit)) atomicMin(&S.first[sid], row0 + i);
+                    if constexpr (kWords == 2) {
+                        here[0] |= (real && !(sid & 64u)) ? bit : 0ULL;
+                        here[1] |= (real && (sid & 64u)) ? bit : 0ULL;
+                    } else here[0] |= real ? bit : 0ULL;
+                }
+            }
+            uint32_t raw = 0, raw2 = 0;
+            if constexpr (VW != 0) raw = lane_row_value_rt<(VW ? VW : 1)>(r.vr, i);
+            if constexpr (V2) raw2 = same2 ? lane_row_value_rt<1>(r.vr, i) : lane_row_value_rt<1>(r.vr2, i);
+            update_entry(sid, raw, raw2);
+        }
+        if (was_behind) { // wave-uniform
+#pragma unroll
+            for (int p = 0; p < kWords; ++p) seen[p] |= wave_or64(here[p]);
+        }
+    };
     auto process = [&](const TileRegs &r, const int64_t tile) {
         const uint32_t bits = r.bits;
         if (!ballot64(bits != 0u)) return; // nothing selected in these 1024 rows
@@ -830,6 +989,10 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
         const auto &vr2 = r.vr2;
         if (IMM3_ABLATED(a, 44)) { // ablation: loads only
             asm volatile("" ::"v"(kr0[0]), "v"(kr0[KS == 1 ? 1 : 0]), "v"(vr[0]), "v"(vr[NV - 1]));
+            return;
+        }
+        if (!IMM3_ABLATED(a, 45) && !ballot64((uint32_t)__popc(bits) > kSparseRows)) { // (ablation 45: always the dense walk)
+            process_sparse(r, tile);
             return;
         }
         uint32_t key[16], sid[16];
@@ -882,7 +1045,7 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
 #pragma unroll
             for (int i = 0; i < 16; ++i) sid[i] = ((bits >> i) & 1u) ? sid[i] : kTrash;
         }
-        const uint32_t row0 = (uint32_t)(tile * kTileRows + 16 * lane);
+        const uint32_t row0 = (uint32_t)(tile * kTileRows + 16 * rgroup);
         // first-seen rows
         {
             uint32_t ns = __hip_atomic_load(&S.nslots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -918,31 +1081,10 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
         // vector work, which is what this kernel is short of.)
 #pragma unroll
         for (int i = 0; i < (IMM3_ABLATED(a, 42) ? 0 : 16); ++i) {
-            const uint32_t s = sid[i];
-            uint32_t x = 0;
-            if constexpr (VW != 0) {
-                uint32_t raw = lane_row_value<(VW ? VW : 1)>(vr, i);
-                if (vstr) raw = VW == 4 ? __builtin_bswap32(raw) : (VW == 2 ? (uint32_t)__builtin_bswap16((uint16_t)raw) : raw); // big-endian pack: integer order == byte order
-                x = (raw ^ vflip) & vmask;
-            }
-            if constexpr (V2) {
-                uint32_t raw2 = lane_row_value<1>(vr2, i);
-                raw2 = same2 ? lane_row_value<1>(vr, i) : raw2;
-                const uint32_t x2 = (raw2 ^ vflip2) & 0xFFu; // (1-byte strings need no byte swap)
-                const uint32_t old = tab[s * 64];
-                tab[s * 64] = ((old + 1u) & 0xFFu) | max(old & 0xFF00u, x << 8) | max(old & 0xFF0000u, x2 << 16);
-            } else if constexpr (kE16) {
-                const uint32_t old = t16[s * 64];
-                if constexpr (VW == 0) t16[s * 64] = (uint16_t)(old + 1u); // (a lane's count stays below 2^16: lanes_plan)
-                else t16[s * 64] = (uint16_t)(((old + 1u) & 0xFFu) | (max(old, x << 8) & 0xFF00u));
-            } else if constexpr (kPacked) {
-                const uint32_t old = tab[s * 64];
-                tab[s * 64] = ((old + 1u) & 0xFFFFu) | (max(old, x << 16) & 0xFFFF0000u); // (a lane's count stays below 2^16: lanes_plan)
-            } else {
-                const uint32_t oc = cnt[s * 64], ov = val[s * 64];
-                cnt[s * 64] = (uint16_t)(oc + 1u);
-                val[s * 64] = max(ov, x);
-            }
+            uint32_t raw = 0, raw2 = 0;
+            if constexpr (VW != 0) raw = lane_row_value<(VW ? VW : 1)>(vr, i);
+            if constexpr (V2) raw2 = same2 ? lane_row_value<1>(vr, i) : lane_row_value<1>(vr2, i);
+            update_entry(sid[i], raw, raw2);
         }
     };
     TileRegs R[kDepth];
@@ -952,7 +1094,10 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
 #pragma unroll
         for (int d = 0; d < kDepth; ++d) {
             const int64_t tile = base + d * stride;
-            if (tile < a.n_tiles) process(R[d], tile); // wave-uniform
+            if (tile < a.n_tiles) { // wave-uniform
+                settle(R[d]);
+                process(R[d], tile);
+            }
             issue(R[d], tile + kDepth * stride);
         }
         if constexpr (VW == 1) { // (with or without a second value)

@@ -257,6 +257,7 @@ extern "C" int imm3_graph_launch(imm3_graph *g) {
         q->has_pfor_pass = st.has_pfor_pass;
         q->ran_agg = st.ran_agg;
         q->offsets_valid = st.offsets_valid;
+        q->select_partial = st.select_partial;
         q->sp_verified = false;
     }
     return IMM3_OK;
@@ -1879,13 +1880,26 @@ static int join_total(imm3_query *q, hipStream_t s) {
     if (q->total_on_aux) HIPCHK(hipStreamWaitEvent(s, q->ev_total_done, 0));
     return IMM3_OK;
 }
-int imm3::join_query_count(imm3_query *q, hipStream_t s) { return join_total(q, s); }
+static int settle_whole_select(imm3_query *q);
+// (imm3_comm_allreduce_count: the word that goes into the collective is the segment's count -- a run that stopped at its limit is
+// followed by the whole select here, enqueued, no host wait)
+int imm3::join_query_count(imm3_query *q, hipStream_t s) {
+    const int rc = settle_whole_select(q);
+    return rc ? rc : join_total(q, s);
+}
 
 static void fill_tile_col(const imm3_query *q, const FoldedPred &fp, TileCol &c, int kind);
 
 // count_in_scan: a projection follows on the same stream; its offsets scan publishes the count (no k_total launch)
 // count_only: the caller wants selected.size alone -- a chain that is ONE tile launch then stores no bitmap
-static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = false, bool count_only = false) {
+// Chunks of a limit scan: they end at tiles 1024, 8192, 32 768, 131 072, ... (x 4) and at the segment's end -- four launches for
+// 100 M rows.  A `limit 10` is usually met in the first megarow: the chunks behind it cost their dispatch only (1 - 4 us each, which
+// is why there are few of them); a limit met at 5 % of the segment stops at 8 %; one met in the second half scans everything, as a
+// whole select would.  Multiples of kChunkTiles (the offsets scan's unit).
+static constexpr int64_t kLimitFirstChunkTiles = 1024, kLimitSecondEndTiles = 8192;
+
+// whole: never in chunks (the getters' full select)
+static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = false, bool count_only = false, bool whole = false) {
     imm3_ctx *ctx = q->ctx;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -1895,6 +1909,7 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
         q->total_on_aux = false;
     }
     q->offsets_valid = false; // (a new bitmap)
+    q->select_partial = false;
     if (q->always_false || q->n_tiles == 0) {
         // an empty interval / empty IN-list clears every bit; nothing to read
         HIPCHK(hipMemsetAsync(q->d_total, 0, 2 * sizeof(unsigned long long), s)); // (an always-false query logs nothing)
@@ -1944,6 +1959,12 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
     const bool single_tile_pass = generic_preds.empty() && pfor_preds.empty() && tile_passes.size() == 1;
     const bool skip_bitmap = count_only && single_tile_pass && !q->table && !overlap_total && ctx->filter_variant != 7;
     q->bitmap_valid = !skip_bitmap;
+    // `limit` stops the scan (Project.scala:73-80; Engine.scala:166,253-258: the reference's workers stall on the full queue once the
+    // consumer has its rows): a projection with a limit whose select chain is one tile launch over one uniform segment runs that
+    // launch as chunks of growing size; every chunk first looks at the rows selected so far (a device word) and leaves at once when
+    // the limit has been reached -- nothing is read, no bitmap line written.  Enqueued blindly: no host wait.  Tuning variant 14: off.
+    const bool chunked = !whole && !q->count_log_on && count_in_scan && q->limit > 0 && single_tile_pass && !q->table && !q->d_stage_rec && !skip_bitmap && !overlap_total &&
+                         ctx->filter_variant != 7 && ctx->filter_variant != 14 && q->n_tiles > kLimitFirstChunkTiles;
     for (const auto &take : tile_passes) {
         TileArgs a;
         std::memset(&a, 0, sizeof(a));
@@ -2003,6 +2024,35 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
             }
         }
         (void)stamped;
+        if (chunked) { // the limit scan: this launch in chunks that end at tiles 1024, 8192, 32 768, ...; each adds to the running count and scanned-tile words
+            int widths[kMaxTileCols] = {0, 0, 0};
+            for (int k = 0; k < kMaxTileCols; ++k) widths[k] = a.kinds[k] == TK_I32 ? 4 : (a.kinds[k] == TK_S2 ? 2 : (a.kinds[k] == TK_I8 ? 1 : 0));
+            int64_t tile0 = 0, len = kLimitFirstChunkTiles;
+            while (tile0 < q->n_tiles) {
+                const int64_t tiles = std::min<int64_t>(len, q->n_tiles - tile0);
+                TileArgs c = a;
+                for (int k = 0; k < kMaxTileCols; ++k)
+                    if (c.kinds[k] != TK_NONE) c.cols[k].data = (const uint8_t *)a.cols[k].data + tile0 * kTileRows * widths[k];
+                c.bitmap = a.bitmap + tile0 * kTileWords;
+                c.n_rows = std::min<int64_t>(tiles * kTileRows, q->n_rows - tile0 * kTileRows);
+                c.n_words = (c.n_rows + 63) / 64;
+                c.n_tiles = (c.n_words + kTileWords - 1) / kTileWords;
+                c.finish = q->d_total;
+                c.chunked = tile0 == 0 ? 2 : 1; // (the first chunk starts the running words over)
+                c.stamps = nullptr;
+                const int cgrid = filter_grid(c.n_tiles, false, any_i32, ctx->grid_blocks);
+                c.defer_lines = ctx->filter_variant == 12 ? 0 : (cgrid <= 1024 ? kDeferLines : 16);
+                LaunchTimer t(ctx, 0);
+                if (!launch_filter_tile(c, cgrid, s, t.start, t.stop)) return fail(IMM3_ERR_ARG, "internal: no tile kernel for this column combination");
+                HIPCHK(hipGetLastError());
+                tile0 += tiles;
+                len = tile0 == kLimitFirstChunkTiles ? kLimitSecondEndTiles - tile0 : tile0 * 3; // (the next chunk ends at 4 x this one's end)
+            }
+            count_done = true;
+            q->select_partial = true;
+            ++pass;
+            continue;
+        }
         LaunchTimer t(ctx, 0);
         if (!launch_filter_tile(a, grid, s, t.start, t.stop)) return fail(IMM3_ERR_ARG, "internal: no tile kernel for this column combination");
         HIPCHK(hipGetLastError());
@@ -2324,6 +2374,7 @@ static int launch_project(imm3_query *q) {
     g.n_staged_tiles = 0;
     g.word_row_base = q->d_word_row_base;
     g.tile_rows = q->table ? q->table->d_tile_rows : nullptr;
+    g.scanned_tiles = q->select_partial ? q->d_total + kFinishLimitTiles : nullptr;
     // more SELECT-list columns than one launch carries: gather in groups (row indices written by the first)
     size_t done = 0;
     const size_t np = q->proj.size();
@@ -2360,6 +2411,7 @@ static int run_project(imm3_query *q) {
         sa.chunk_sums = q->d_chunk_sums;
         sa.n_tiles = q->n_tiles;
         sa.finish = q->count_pending_scan ? q->d_total : nullptr;
+        sa.scanned_tiles = q->select_partial ? q->d_total + kFinishLimitTiles : nullptr;
         {
             LaunchTimer t(ctx, 1);
             launch_scan(sa, s, t.start, t.stop);
@@ -2434,6 +2486,7 @@ static int capture_note(imm3_query *q, int rc) {
     st.has_pfor_pass = q->has_pfor_pass;
     st.ran_agg = q->ran_agg;
     st.offsets_valid = q->offsets_valid;
+    st.select_partial = q->select_partial;
     return rc;
 }
 
@@ -2527,6 +2580,7 @@ extern "C" int imm3_query_log_counts(imm3_query *q, uint64_t *device_log, uint64
     const unsigned long long v[3] = {(unsigned long long)(uintptr_t)device_log, 0ULL, device_log ? (unsigned long long)capacity : 0ULL};
     HIPCHK(hipMemcpyAsync(q->d_total + 5, v, sizeof(v), hipMemcpyHostToDevice, q->ctx->stream));
     HIPCHK(hipStreamSynchronize(q->ctx->stream)); // `v` is a stack array; also orders the switch after earlier runs
+    q->count_log_on = device_log != nullptr;
     return IMM3_OK;
 }
 
@@ -2539,6 +2593,7 @@ static int scan_offsets(imm3_query *q) {
     sa.tile_offsets = q->d_tile_offsets;
     sa.chunk_sums = q->d_chunk_sums;
     sa.n_tiles = q->n_tiles;
+    sa.scanned_tiles = q->select_partial ? q->d_total + kFinishLimitTiles : nullptr;
     launch_scan(sa, q->ctx->stream, nullptr, nullptr); // (finish = null: the count is already published)
     HIPCHK(hipGetLastError());
     q->offsets_valid = true;
@@ -2551,6 +2606,19 @@ static unsigned long long single_pass_flags(const unsigned long long *head) {
     const unsigned long long status = head[kFinishStatus], epoch_run = head[kFinishEpoch] - 1ULL;
     if (((status >> kStatusEpochShift) & kStatusEpochMask) != (epoch_run & kStatusEpochMask)) return 0ULL; // (an earlier run's flags)
     return status & (kStatusAbandoned | kStatusBusy);
+}
+
+// A projection with a limit stops its scan when the limit is reached (run_select, chunks): the bitmap and the count then cover the
+// tiles scanned so far.  The reference never sees the batches behind the limit either (Project.scala:73-80); a caller that asks for
+// the segment's count or bitmap all the same gets them exact: the whole select runs now, once (the rows were emitted from the scanned
+// prefix and stay what they are -- they are the first `limit` survivors either way).
+static int settle_whole_select(imm3_query *q) {
+    if (!q->select_partial) return IMM3_OK;
+    if (q->ctx->capture) return fail(IMM3_ERR_STATE, "a graph capture is open on this context");
+    const int rc = run_select(q, false, false, false, true);
+    if (rc) return rc;
+    q->offsets_valid = false;
+    return IMM3_OK;
 }
 
 // Every getter's first step after a single-pass run: read the run's status word (with the count and the dense-range tally, one
@@ -2598,6 +2666,8 @@ extern "C" int imm3_query_count(imm3_query *q, uint64_t *selected_rows) {
     {
         const int src = settle_single_pass(q);
         if (src) return src;
+        const int wrc = settle_whole_select(q);
+        if (wrc) return wrc;
         const int jrc = join_total(q, q->ctx->stream);
         if (jrc) return jrc;
     }
@@ -2621,6 +2691,8 @@ extern "C" int imm3_query_bitmap(imm3_query *q, uint64_t *words_out, int64_t n_w
     {
         const int src = settle_single_pass(q);
         if (src) return src;
+        const int wrc = settle_whole_select(q);
+        if (wrc) return wrc;
     }
     if (n_words) HIPCHK(hipMemcpyAsync(words_out, q->d_bitmap, (size_t)n_words * sizeof(uint64_t), hipMemcpyDeviceToHost, q->ctx->stream));
     HIPCHK(hipStreamSynchronize(q->ctx->stream));

@@ -103,6 +103,43 @@ __device__ __forceinline__ bool finish_add(unsigned long long *finish, unsigned 
     return false;
 }
 
+// The same for one CHUNK of a limit scan: the launch's last arrival adds the chunk's count to the run's running count
+// (finish[kFinishLimitRows]) and publishes THAT as the count so far; a chunk that ran adds its tiles to finish[kFinishLimitTiles].
+// The run's first chunk starts both words over (no memset node in front of the run).
+__device__ __forceinline__ void finish_add_chunk(unsigned long long *finish, unsigned long long t, unsigned long long tiles_scanned, bool first) {
+    const unsigned int grid = gridDim.x, sub = blockIdx.x % kSubTallies;
+    const unsigned int peers = (grid - sub + kSubTallies - 1) / kSubTallies;
+    unsigned long long *st = finish + 16 + 16 * sub;
+    unsigned long long prev = __hip_atomic_fetch_add(st, t | (1ULL << 40), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((prev >> 40) != (unsigned long long)peers - 1) return;
+    t += prev & ((1ULL << 40) - 1);
+    __hip_atomic_store(st, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int tops = grid < (unsigned int)kSubTallies ? grid : (unsigned int)kSubTallies;
+    prev = __hip_atomic_fetch_add(finish + 4, t | (1ULL << 40), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((prev >> 40) == (unsigned long long)tops - 1) {
+        const unsigned long long running = (first ? 0ULL : finish[kFinishLimitRows]) + (prev & ((1ULL << 40) - 1)) + t;
+        const long long limit = (long long)finish[3];
+        finish[kFinishLimitRows] = running;
+        finish[kFinishLimitTiles] = (first ? 0ULL : finish[kFinishLimitTiles]) + tiles_scanned;
+        finish[0] = running; // (the rows selected in the tiles scanned so far: imm3_query_count runs the whole select when asked)
+        finish[1] = (limit > 0 && running > (unsigned long long)limit) ? (unsigned long long)limit : running;
+        finish[kFinishEpoch] += 1;
+        __hip_atomic_store(finish + 4, 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+__device__ __forceinline__ void block_partial_finish_chunk(unsigned long long *finish, uint32_t wave_total, int lane, int wave, unsigned long long tiles_scanned, bool first) {
+    __shared__ uint32_t s_part[kWavesPerBlock];
+    if (lane == 0) s_part[wave] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+#pragma unroll
+        for (int i = 0; i < kWavesPerBlock; ++i) t += s_part[i];
+        finish_add_chunk(finish, t, tiles_scanned, first);
+    }
+}
+
 __device__ __forceinline__ void block_partial_finish(unsigned long long *finish, uint32_t wave_total, int lane, int wave) {
     __shared__ uint32_t s_part[kWavesPerBlock];
     if (lane == 0) s_part[wave] = wave_total;

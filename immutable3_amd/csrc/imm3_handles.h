@@ -85,7 +85,7 @@ struct imm3_ctx {
 // again, whatever direct runs, fallbacks or getters did to the handle in between.
 struct QueryRunState {
     bool ran_select = false, ran_project = false, bitmap_valid = false, ran_single_pass = false, stage_written = false;
-    bool count_pending_scan = false, has_pfor_pass = false, ran_agg = false, offsets_valid = false;
+    bool count_pending_scan = false, has_pfor_pass = false, ran_agg = false, offsets_valid = false, select_partial = false;
 };
 
 // A recorded sequence of query runs (hipGraph): launching it enqueues every kernel of those runs with one call.
@@ -262,6 +262,9 @@ struct imm3_query {
     bool ran_single_pass = false;           // the last run went through k_filter_project ...
     bool sp_verified = false;               // ... and its status word has been read since (rows complete, or gathered again from the bitmap)
     bool offsets_valid = false;             // d_tile_offsets / d_chunk_sums describe the last run's bitmap (an offsets scan has run since)
+    bool count_log_on = false;              // imm3_query_log_counts is installed: every run logs the segment's count (a limit query then scans whole)
+    bool select_partial = false;            // the last select pass was a limit scan in chunks: the bitmap and the count cover the tiles scanned until the
+                                            // limit was reached (finish[kFinishLimitTiles]); imm3_query_count / _bitmap run the whole select first
     uint32_t sp_abandoned_runs = 0, sp_busy_runs = 0; // single-pass runs whose rows were gathered from the bitmap instead: a prefix never came / the device was busy (imm3_query_plan)
     bool count_pending_scan = false; // the last select run left the count to the projection's offsets scan
 };

@@ -79,7 +79,8 @@ struct TileArgs {
     uint32_t *tile_start;           // [wave * max_slots + i]: where in its arena the wave's i-th staged tile starts
     int64_t wave_cap;               // records per arena
     int32_t max_slots;              // tiles a wave stages at most (<= kMaxArenaSlots)
-    int32_t pad1;
+    int32_t chunked;                // 1 (2: the run's first): this launch is one CHUNK of a limit scan (run_select, imm3_api.cpp): it adds to the running count
+                                    // finish[kFinishLimitRows] / finish[kFinishLimitTiles], and does nothing at all once that count has reached the limit
     unsigned long long *stamps;     // diagnostics only: per work-group {start, end} of the 100 MHz device clock, or null
     // table queries (imm3_table): the tile table replaces cols[k].data / n_rows.  Tile t holds tile_rows[t] valid rows
     // (1024 except the last tile of each segment) starting at tile_ptrs[k][t] in column k.  Null for one segment.
@@ -228,6 +229,11 @@ constexpr int kStatusEpochShift = 8;
 constexpr unsigned long long kStatusEpochMask = 0xFFFFFFULL;
 constexpr int kFinishEpoch = 8;         // finish[8]: run counter of the query (descriptor epochs)
 constexpr int kFinishDense = 9;         // finish[9]: single-pass projection: ranges of the last run that outgrew their LDS ring (finish[10]: the running sum)
+// `limit` stops the scan (ProjectIterator.hasNext returns false at the limit and the bounded queue stalls the workers:
+// Project.scala:73-80, Engine.scala:166,253-258): a projection with a limit runs its select pass as CHUNKS of growing size, each a
+// launch that first looks at the rows selected so far and leaves at once when the limit has been reached.
+constexpr int kFinishLimitRows = 11;    // finish[11]: rows selected by the chunks of this run so far
+constexpr int kFinishLimitTiles = 12;   // finish[12]: tiles those chunks scanned (the offsets scan and the gather stop there)
 constexpr int kDescValueBits = 36, kDescFlagShift = 36, kDescEpochShift = 38;
 constexpr unsigned long long kDescValueMask = (1ULL << kDescValueBits) - 1;
 constexpr unsigned long long kDescEpochMask = (1ULL << (64 - kDescEpochShift)) - 1;
@@ -292,6 +298,7 @@ struct ScanArgs {
     uint32_t *chunk_sums;        // selected rows per chunk of kChunkTiles tiles
     int64_t n_tiles;
     unsigned long long *finish;  // the query's {total, n_emit, status, limit, tally, log ...} block when THIS kernel publishes the count, else null
+    const unsigned long long *scanned_tiles; // a limit scan stopped early: tiles [0, *scanned_tiles) hold this run's bitmap lines, the rest count as empty; null: all
 };
 
 struct ProjCol {
@@ -318,6 +325,7 @@ struct GatherArgs {
     int64_t n_staged_tiles;        // tiles [0, n) have staged values (the full tiles)
     const uint32_t *word_row_base; // ragged layout, else null
     const uint32_t *tile_rows;     // table queries: valid rows per tile (staged iff 1024), else null
+    const unsigned long long *scanned_tiles; // a limit scan stopped early: only spans below *scanned_tiles are walked; null: all
 };
 
 // launchers (imm3_kernels.hip)

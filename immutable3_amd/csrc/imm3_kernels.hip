@@ -275,6 +275,11 @@ __global__ __launch_bounds__(kBlockThreads, tile_min_waves(K0, K1, STAGE)) void 
         if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x + 1] = wall_clock64();
         return;
     } else {
+    // a chunk of a limit scan (a.chunked) whose predecessors have already selected `limit` rows does nothing at all -- no load, no
+    // bitmap line, no arrival at the tally (the count block already holds what the last chunk that ran published): the launch
+    // costs its dispatch and nothing else.  Uniform over the whole grid (the words were written by the previous launch).
+    if (a.chunked == 1 && a.finish[kFinishLimitRows] >= a.finish[3]) return; // (2: the run's first chunk -- the running words are the previous run's)
+    const int64_t n_tiles_here = a.n_tiles;
     const int64_t n_full = a.n_rows / kTileRows;
     const int64_t n_groups = n_full / T;
 
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(kBlockThreads, tile_min_waves(K0, K1, STAGE)) void 
     }
     if (DEFER && parked) flush();
     // leftovers: fewer than T full tiles, then the one partial tile at the end of the segment
-    for (int64_t tile = n_groups * T + wave_id; tile < a.n_tiles; tile += n_waves) {
+    for (int64_t tile = n_groups * T + wave_id; tile < n_tiles_here; tile += n_waves) {
         const int64_t row0 = tile * kTileRows;
         ColRegs<K0> c0;
         ColRegs<K1> c1;
@@ -366,7 +371,8 @@ __global__ __launch_bounds__(kBlockThreads, tile_min_waves(K0, K1, STAGE)) void 
     }
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) lane_total += __shfl_xor(lane_total, d); // lanes 0..15 -> lane 0
-    if (a.finish) block_partial_finish(a.finish, lane_total, lane, wave); // the last pass also reduces the count
+    if (a.chunked) block_partial_finish_chunk(a.finish, lane_total, lane, wave, (unsigned long long)n_tiles_here, a.chunked == 2);
+    else if (a.finish) block_partial_finish(a.finish, lane_total, lane, wave); // the last pass also reduces the count
     else block_partial_store(a.block_partials, lane_total, lane, wave);
     if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x + 1] = wall_clock64(); // after the barrier in the store above
 #ifdef IMM3_ABLATE
@@ -500,7 +506,10 @@ __global__ __launch_bounds__(kChunkTiles) void k_scan(const ScanArgs a) {
     // counts: the chunk's bitmap read in 16-byte pieces, consecutive threads on consecutive pieces (8 threads = one tile's 128
     // bytes).  One thread per tile reading its own 128 bytes was 64 partial lines per load instruction: 8.0 us for 12.5 MB.
     const uint4 *p = (const uint4 *)(a.bitmap + tile0 * kTileWords);
-    const int64_t pieces = (a.n_tiles - tile0 < kChunkTiles ? a.n_tiles - tile0 : (int64_t)kChunkTiles) * (kTileWords / 2); // the bitmap is allocated in whole tiles
+    // (a limit scan that stopped early left the bitmap lines behind *scanned_tiles untouched: those tiles count as empty)
+    const int64_t live_tiles = a.scanned_tiles ? ((int64_t)*a.scanned_tiles < a.n_tiles ? (int64_t)*a.scanned_tiles : a.n_tiles) : a.n_tiles;
+    const int64_t here = live_tiles - tile0 < 0 ? 0 : (live_tiles - tile0 < kChunkTiles ? live_tiles - tile0 : (int64_t)kChunkTiles);
+    const int64_t pieces = here * (kTileWords / 2); // the bitmap is allocated in whole tiles
 #pragma unroll
     for (int i = 0; i < kTileWords / 2; ++i) {
         const int64_t q = (int64_t)i * kChunkTiles + t;
@@ -609,8 +618,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_gather(const GatherArgs a) {
     __shared__ SpanScratch S;
     const int t = threadIdx.x;
     const int64_t n_spans = (a.n_tiles + kSpanTiles - 1) / kSpanTiles;
+    const int64_t scanned = a.scanned_tiles ? (int64_t)*a.scanned_tiles : a.n_tiles; // (a limit scan that stopped early: nothing behind it)
     for (int64_t span = blockIdx.x; span < n_spans; span += gridDim.x) { // block-uniform trip count
         const int64_t tile0 = span * kSpanTiles;
+        if (tile0 >= scanned) break; // block-uniform
         unsigned long long base;
         const uint32_t n_out = span_expand(a, span, S, base);
         for (uint32_t i = t; i < n_out; i += kBlockThreads) {
@@ -662,8 +673,10 @@ __global__ __launch_bounds__(kBlockThreads) void k_gather_plain(const GatherArgs
     __shared__ SpanScratch S;
     const int t = threadIdx.x;
     const int64_t n_spans = (a.n_tiles + kSpanTiles - 1) / kSpanTiles;
+    const int64_t scanned = a.scanned_tiles ? (int64_t)*a.scanned_tiles : a.n_tiles; // (a limit scan that stopped early: nothing behind it)
     for (int64_t span = blockIdx.x; span < n_spans; span += gridDim.x) { // block-uniform trip count
         const int64_t tile0 = span * kSpanTiles;
+        if (tile0 >= scanned) break; // block-uniform
         unsigned long long base;
         const uint32_t n_out = span_expand(a, span, S, base);
         for (uint32_t i0 = t; i0 < n_out; i0 += kGatherUnroll * kBlockThreads) {

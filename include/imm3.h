@@ -276,7 +276,7 @@ int imm3_query_layout(const imm3_query *q, int32_t *n_batches, int64_t *total_wo
 /* per batch: size (rows), oid, and the offset of its BitSet words in the batch-major bitmap
  * (ceil(size/64) words per batch; bit i of a batch <-> word i>>6, bit i&63 = mutable.BitSet) */
 int imm3_query_batches(const imm3_query *q, int32_t *batch_size, int32_t *batch_oid, int64_t *batch_word_off);
-int imm3_query_count(imm3_query *q, uint64_t *selected_rows);               /* sum of selected.size    */
+int imm3_query_count(imm3_query *q, uint64_t *selected_rows);               /* sum of selected.size (the whole segment's, also behind a run that stopped at its limit) */
 int imm3_query_bitmap(imm3_query *q, uint64_t *words_out, int64_t n_words); /* device -> host copy     */
 /* Rows ProjectOp emits for this segment, in emission order (batch order, ascending position): */
 int imm3_query_row_count(imm3_query *q, uint64_t *rows);
@@ -297,7 +297,12 @@ int imm3_query_fetch_rows(imm3_query *q, uint32_t *row_index_out, void *const *c
  *     (run counter - 1) & 0xFFFFFF with the run counter at count pointer + 8 words.  The host getters (imm3_query_row_count /
  *     _fetch_rows) check this themselves and gather the rows from the bitmap when needed; a consumer that reads the row arrays
  *     on the device calls imm3_query_row_count first (it waits for the run) or checks the word.  Pointers 2 and 16+j change
- *     when the output arrays grow (a reservation that was too small): fetch them again after imm3_query_row_count. */
+ *     when the output arrays grow (a reservation that was too small): fetch them again after imm3_query_row_count;
+ *   - a query with limit > 0 stops scanning once `limit` rows are selected (ProjectIterator.hasNext, Project.scala:73-80: the
+ *     reference never looks at batches behind the limit either): behind imm3_query_run its bitmap (0) and count (1) cover the
+ *     scanned prefix of the segment only -- the rows (2, 3, 16+j) are complete.  imm3_query_count, imm3_query_bitmap,
+ *     imm3_query_run_select / _run_count, imm3_query_log_counts and imm3_comm_allreduce_count give the whole segment's: the host
+ *     getters run the whole select when the last run stopped early. */
 int imm3_query_device_ptr(imm3_query *q, int32_t which, void **ptr);
 
 /* ---- multi-GPU: the count reduce.  Segments shard one per GPU -- segment s belongs to GPU s mod G -- and

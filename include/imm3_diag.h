@@ -44,6 +44,7 @@ int imm3_ctx_measure_read_gbps(imm3_ctx *ctx, uint64_t bytes, int32_t iters, dou
  * 6 = projections never use the one-launch kernel, 8 = they use it with gathered SELECT-list columns too, 9 = gathered int32
  * columns are streamed through it whatever the selectivity, 10 = no sampled selectivity estimate at query creation (the plan
  * then adapts from the first run's count on), 11 = survivor records are staged even when no predicate column is projected,
+ * 14 = a `limit` query scans the whole segment in one launch instead of in chunks behind a limit-reached word (decided per run),
  * 200 + P = fixed tiles per range. */
 int imm3_ctx_set_tuning(imm3_ctx *ctx, int32_t filter_variant, int32_t grid_blocks);
 
