@@ -1105,6 +1105,29 @@ static int single_pass_setup(imm3_query *q) {
     return IMM3_OK;
 }
 
+// ---- the cost model's view of a query (imm3_plan.h) ----
+// Where the survivors are, given a count (or an estimate of one): the sample taken at creation knows how they are spread (survivors
+// per row where there are survivors, and how many sit in fully surviving stretches); without it they are taken as spread evenly.
+static PlanDensity plan_density_for(const imm3_query *q, uint64_t survivors) {
+    PlanDensity d;
+    d.sigma = q->n_rows > 0 ? std::min(1.0, (double)survivors / (double)q->n_rows) : 0.0;
+    d.sloc = d.sigma;
+    d.full = 0.0;
+    if (q->plan_have_density) { // (how densely the survivors sit where they sit is the data's property: a better count does not change it)
+        d.sloc = std::min(1.0, std::max(d.sigma, q->plan_density.sloc));
+        d.full = q->plan_density.full;
+    }
+    return d;
+}
+// the plan a query would fall back to from the one launch, and its predicted cost: records when a predicate column is projected
+// and they are predicted cheaper than the bitmap path
+static double plan_cost_three_launches(const imm3_query *q, const PlanDensity &d, bool records_possible, bool *use_records) {
+    const double c = plan_cost('C', q->plan_shape, d);
+    const double b = records_possible ? plan_cost('B', q->plan_shape, d) : 1e30;
+    if (use_records) *use_records = b < c;
+    return std::min(b, c);
+}
+
 // A projection with gathered SELECT-list columns was planned as three launches (records -> k_scan -> k_emit).  Now the host
 // knows how many rows survive: when that is enough for a gather to touch most 128-byte lines of the column anyway, the
 // column is STREAMED instead -- it joins the one-launch kernel as a tile column whose predicate every value passes, and its
@@ -1114,8 +1137,12 @@ static int single_pass_setup(imm3_query *q) {
 static int single_pass_stream_columns(imm3_query *q, uint64_t survivors) {
     imm3_ctx *ctx = q->ctx;
     if (!q->alt_ok || q->single_pass || ctx->capture || q->n_rows <= 0) return IMM3_OK;
-    const double sigma = (double)survivors / (double)q->n_rows;
-    if (ctx->filter_variant != 9 && sigma < q->alt_min_sigma) return IMM3_OK;
+    if (ctx->filter_variant != 9) { // (9: streamed whatever the prediction)
+        if (q->plan_pinned) return IMM3_OK;
+        const PlanDensity d = plan_density_for(q, survivors);
+        const double now = q->d_stage_rec ? std::min(plan_cost('B', q->plan_shape, d), plan_cost('C', q->plan_shape, d)) : plan_cost('C', q->plan_shape, d);
+        if (!(plan_cost('A', q->plan_shape, d) < kPlanKeepMargin * now)) return IMM3_OK;
+    }
     int32_t keep_kinds[kMaxTileCols], keep_cols[kMaxTileCols];
     for (int k = 0; k < kMaxTileCols; ++k) {
         keep_kinds[k] = q->stage_kinds[k];
@@ -1143,13 +1170,15 @@ static int single_pass_stream_columns(imm3_query *q, uint64_t survivors) {
     return IMM3_OK;
 }
 
-// Survivor records planned, but the projected predicate columns are all one byte wide and few rows survive: gathering those
-// bytes from the bitmap costs less than the staging instance of the filter kernel does (age > 97 -> id, age: 1 % 75 us with
-// records, 65 without; 3 % 106 / 95; at 11 % the columns are streamed anyway).  The records' buffers go back to the pool.
+// Survivor records planned, but the bitmap path is predicted cheaper for this many survivors (the staging instance of the filter
+// kernel costs 10-35 us per 100 M rows more than the plain one, plus the records' bytes; it buys the emit kernel the projected
+// predicate columns: age > 97 -> id, age at 1 %: 75 us with records, 65 without; id > 9e7 -> id, age: 152 / 140; state in (8
+// values) -> id, state, age: 277 / 243).  The records' buffers go back to the pool.
 static void records_drop_if_narrow(imm3_query *q, uint64_t survivors) {
     imm3_ctx *ctx = q->ctx;
-    if (q->single_pass || !q->d_stage_rec || !q->records_narrow_only || ctx->capture || ctx->filter_variant == 11 || q->n_rows <= 0) return;
-    if ((double)survivors > 0.08 * (double)q->n_rows) return;
+    if (q->single_pass || !q->d_stage_rec || q->plan_pinned || ctx->capture || ctx->filter_variant == 11 || ctx->filter_variant == 6 || q->n_rows <= 0) return;
+    const PlanDensity d = plan_density_for(q, survivors);
+    if (!(plan_cost('C', q->plan_shape, d) < kPlanKeepMargin * plan_cost('B', q->plan_shape, d))) return;
     graphs_mark_stale(ctx, q);
     pool_release(ctx, q->d_stage_rec);
     pool_release(ctx, q->d_tile_start);
@@ -1190,33 +1219,63 @@ static int records_setup(imm3_query *q) {
     return IMM3_OK;
 }
 
-// The one-launch kernel costs ~85 us per 100 M rows whatever the columns' widths (it is bound by instructions per row, DESIGN
-// finding 21); the plain filter over 1- and 2-byte columns takes 21-45 us.  A projection of narrow predicate columns alone is
-// therefore better off with filter -> offsets scan -> gather from the bitmap until many rows survive (select age ... where
-// age > 98, 1 %: 89 us in one launch, 53 in three; 3 %: 97 / 58).  Decided on the sample, or on the first count.
-constexpr double kNarrowOneLaunchMinSigma = 0.30;
+// The one launch planned, but three launches are predicted cheaper for this many survivors.  The one-launch kernel costs ~23 us +
+// 0.6-0.85 us per million rows whatever the columns' widths (it is bound by instructions per row, DESIGN finding 21), and its
+// writers walk stretches of mostly-surviving rows at ~1.5 us per million rows and column; the plain filter over 1- and 2-byte
+// columns takes 21-45 us per 100 M rows and k_gather ~2.5 us per million survivors.  So: narrow predicate columns alone take
+// filter -> offsets scan -> gather until many rows survive (select age ... where age > 98, 1 %: 89 us in one launch, 53 in three);
+// small segments take it nearly always (4 M rows: 27 us against 16-20); and C3's shape takes it again above ~50 % survivors spread
+// evenly (60 %: 373 us in one launch, 329 in three).  A projected string column with few survivors is better staged in records than
+// gathered (state = CA -> state, 2 %: 62 us with records, 75 from the bitmap): the cheaper of the two is taken.
 static void single_pass_drop_if_narrow(imm3_query *q, uint64_t survivors) {
     imm3_ctx *ctx = q->ctx;
-    if (!q->single_pass || !q->sp_pass.empty() || q->sp_P_fixed || ctx->capture || ctx->filter_variant == 8 || ctx->filter_variant == 11 || q->n_rows <= 0) return;
-    bool any = false;
-    for (int k = 0; k < kMaxTileCols; ++k) {
-        if (q->stage_kinds[k] == TK_I32) return;
-        any |= q->stage_kinds[k] != TK_NONE;
-    }
-    if (!any || (double)survivors >= kNarrowOneLaunchMinSigma * (double)q->n_rows) return;
+    if (!q->single_pass || !q->sp_pass.empty() || q->sp_P_fixed || q->plan_pinned || ctx->capture || ctx->filter_variant == 8 || ctx->filter_variant == 11 || q->n_rows <= 0) return;
+    const PlanDensity d = plan_density_for(q, survivors);
+    bool use_records = false;
+    const double other = plan_cost_three_launches(q, d, ctx->filter_variant != 3, &use_records);
+    if (!(other < kPlanKeepMargin * plan_cost('A', q->plan_shape, d))) return;
     graphs_mark_stale(ctx, q);
     q->single_pass = false;
+    q->sp_model_dropped = true; // (the first count may bring it back: single_pass_restore)
     pool_release(ctx, q->d_desc);
     q->d_desc = nullptr;
-    // a projected string column and few survivors: its two bytes are better staged than gathered (state = CA -> state, 2 %: 62 us
-    // with records, 75 from the bitmap; at 10 % 108 / 106)
-    if (!q->records_narrow_only && !q->d_stage_rec && (double)survivors < 0.06 * (double)q->n_rows) {
+    if (use_records && !q->d_stage_rec) {
         if (records_setup(q) != IMM3_OK || !q->d_tile_start) { // (no memory for the records: the bitmap path needs none)
             pool_release(ctx, q->d_stage_rec);
             q->d_stage_rec = nullptr;
             (void)hipGetLastError();
         }
     }
+}
+
+// ... and back: the one launch was left on an estimate (the sample, or the guess made for a segment too small to sample), and the
+// first run's count says it is the cheaper plan after all (a small segment most of whose rows survive: 4 M rows, 60 %: 27 us in
+// one launch, 37 in three; a range of the sorted key that the sample's chunks missed).
+static bool single_pass_restore_wanted(const imm3_query *q, uint64_t survivors) {
+    const imm3_ctx *ctx = q->ctx;
+    if (q->single_pass || !q->sp_model_dropped || q->plan_pinned || ctx->capture || ctx->filter_variant == 6 || ctx->filter_variant == 3 || q->n_rows <= 0) return false;
+    const PlanDensity d = plan_density_for(q, survivors);
+    const double now = q->d_stage_rec ? plan_cost('B', q->plan_shape, d) : plan_cost('C', q->plan_shape, d);
+    return plan_cost('A', q->plan_shape, d) < kPlanKeepMargin * now;
+}
+// (the run that read the count finishes on the plan it started with -- its filter and offsets scan are done, the gather is the
+// smaller part -- and the NEXT run takes the one launch: the switch happens at the start of that run)
+static int single_pass_restore(imm3_query *q, uint64_t survivors) {
+    imm3_ctx *ctx = q->ctx;
+    q->sp_restore_pending = false;
+    if (q->single_pass || !q->sp_model_dropped || q->plan_pinned || ctx->capture) return IMM3_OK;
+    const int rc = single_pass_setup(q);
+    if (rc || !q->single_pass) return rc; // (cannot run here: the three launches stay)
+    graphs_mark_stale(ctx, q);
+    pool_release(ctx, q->d_stage_rec);
+    pool_release(ctx, q->d_tile_start);
+    q->d_stage_rec = nullptr;
+    q->d_tile_start = nullptr;
+    q->stage_written = false;
+    q->sp_model_dropped = false;
+    q->sp_narrow_checked = true; // (decided on a count: no second look)
+    single_pass_adapt(q, survivors, -1);
+    return IMM3_OK;
 }
 
 // A look at the data before the first run: the select chain's count over eight evenly spaced chunks of 64 tiles (0.5 % of
@@ -1270,8 +1329,8 @@ static int sample_tile_ptrs(imm3_ctx *ctx, const imm3_segment *cseg, int32_t col
 static int single_pass_sample(imm3_query *q) {
     imm3_ctx *ctx = q->ctx;
     const int64_t n_full = q->n_rows / kTileRows;
-    const bool undecided = q->single_pass || q->alt_ok || (q->d_stage_rec && q->records_narrow_only);
-    if (!undecided || q->sp_P_fixed || ctx->filter_variant == 10 || n_full < 4096) return IMM3_OK; // (below ~4 M rows the sample costs what it saves)
+    const bool undecided = q->single_pass || q->alt_ok || q->d_stage_rec;
+    if (!undecided || q->sp_P_fixed || q->plan_pinned || ctx->filter_variant == 10 || n_full < 4096) return IMM3_OK; // (below ~4 M rows the sample costs what it saves)
     // ONE count-only launch of the scan+select kernel's table instance over the sample's tile table (round 3: eight launches, a
     // memset and a strided copy): 128 work-groups, one tile per wave, so that work-groups 16 i .. 16 i + 15 hold chunk i's count
     // in their partials.
@@ -1309,20 +1368,30 @@ static int single_pass_sample(imm3_query *q) {
     HIPCHK(hipMemcpyAsync(partials, q->d_block_partials, sizeof(partials), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const double chunk_rows = (double)(kSampleChunkTiles * kTileRows);
-    double sum = 0.0, sum_sq = 0.0;
+    double sum = 0.0, sum_sq = 0.0, sum_full = 0.0;
     for (int i = 0; i < kSampleChunks; ++i) {
         double c = 0.0;
-        for (int b = 0; b < kGrid / kSampleChunks; ++b) c += (double)partials[i * (kGrid / kSampleChunks) + b];
+        for (int b = 0; b < kGrid / kSampleChunks; ++b) {
+            const double part = (double)partials[i * (kGrid / kSampleChunks) + b];
+            c += part;
+            if (part >= (double)(kWavesPerBlock * kTileRows)) sum_full += part; // (a work-group's eight tiles, every row of them)
+        }
         sum += c;
         sum_sq += c * c;
     }
-    if (sum <= 0.0) return IMM3_OK; // (nothing in the sample: the plan for few survivors stands)
-    const double sigma = sum / (chunk_rows * kSampleChunks), sigma_local = sum_sq / (sum * chunk_rows);
-    const int rc = single_pass_stream_columns(q, (uint64_t)(sigma * (double)q->n_rows));
+    // (nothing in the sample: fewer than one row in 130 000 survives, or they all sit between the sample's chunks -- the plans for
+    // very few survivors are compared; the first count corrects a miss)
+    const double sigma = std::max(sum, 0.5) / (chunk_rows * kSampleChunks), sigma_local = sum > 0.0 ? sum_sq / (sum * chunk_rows) : sigma;
+    q->plan_density.sigma = sigma;
+    q->plan_density.sloc = std::max(sigma, std::min(1.0, sigma_local));
+    q->plan_density.full = sum > 0.0 ? sum_full / sum : 0.0;
+    q->plan_have_density = true;
+    const uint64_t estimate = (uint64_t)(sigma * (double)q->n_rows);
+    const int rc = single_pass_stream_columns(q, estimate);
     if (rc) return rc;
-    records_drop_if_narrow(q, (uint64_t)(sigma * (double)q->n_rows));
-    single_pass_drop_if_narrow(q, (uint64_t)(sigma * (double)q->n_rows));
-    single_pass_pick_P(q, sigma_local, false);
+    records_drop_if_narrow(q, estimate);
+    single_pass_drop_if_narrow(q, estimate);
+    if (sum > 0.0) single_pass_pick_P(q, sigma_local, false);
     return IMM3_OK;
 }
 
@@ -1593,6 +1662,31 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
                 q->stage_kinds[k] = tile_kind(*order[k]);
                 q->stage_seg_col[k] = order[k]->seg_col;
             }
+            {   // what the cost model needs to know (imm3_plan.h)
+                PlanShape &ps = q->plan_shape;
+                ps = PlanShape();
+                ps.n_rows = q->n_rows;
+                for (const FoldedPred *fp : order) {
+                    if (ps.n_pred >= kPlanMaxCols) break;
+                    ps.pred_width[ps.n_pred] = fp->width;
+                    ps.pred_match[ps.n_pred] = tile_kind(*fp) == TK_S2 ? (int32_t)fp->match.size() : 0;
+                    ++ps.n_pred;
+                }
+                std::vector<int32_t> first; // predicate columns already mentioned (a second mention is gathered)
+                for (int32_t pj : q->proj) {
+                    if (ps.n_proj >= kPlanMaxCols) break;
+                    const int32_t sci = q->used[(size_t)pj];
+                    bool is_pred = false;
+                    for (const FoldedPred *fp : order) is_pred |= fp->seg_col == sci;
+                    if (is_pred && std::find(first.begin(), first.end(), sci) != first.end()) is_pred = false;
+                    if (is_pred) first.push_back(sci);
+                    ps.proj_width[ps.n_proj] = seg->cols[(size_t)sci].width;
+                    ps.proj_is_pred[ps.n_proj] = is_pred;
+                    ++ps.n_proj;
+                }
+                ps.rec_bytes = 4 * rec_layout(q->stage_kinds, -1).dwords;
+                q->plan_pinned = ctx->filter_variant == 12;
+            }
             // Single pass (k_filter_project): the filter kernel writes the rows itself.  Tuning variant 6 keeps the
             // three-launch form (records -> k_scan -> k_emit) for A/B runs.
             // Only when every SELECT-list column is a predicate column (its values ride in the records): gathers issued by the
@@ -1635,13 +1729,12 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
                     for (const FoldedPred &fp : q->sp_pass) any4 |= fp.width == 4;
                     bool any_s2 = false;
                     for (int k = 0; k < kMaxTileCols; ++k) any_s2 |= q->alt_kinds[k] == TK_S2;
-                    // Measured at 100 M rows (tools/proj_bench.py; one launch / three launches): age in (18, 30) -> id, 11 %: 123 / 174 us;
-                    // 5 %: 120 / 145; 3 %: 116 / 107.  Not with a string predicate (the 2-byte match streams at 74 us with the one-launch
-                    // kernel's 8 streaming waves per CU against 47: state in (5 values) -> age, 10 %: 181 / 120), and not for 1-byte
-                    // columns alone (their gather reads every line of the column from ~3 % on and still costs 33 us at 10 %).
-                    // Against the bitmap path (below), which a query takes when none of its predicate columns is projected: age -> id
-                    // 11 % 123 / 122, 5 % 119 / 100: from 12 % on.
-                    q->alt_min_sigma = n_pred_proj == 0 ? 0.12 : 0.04;
+                    // Whether they ARE streamed is the cost model's call once the survivors are known (single_pass_stream_columns: the
+                    // sample at creation, a reservation or the first count).  Measured at 100 M rows (one launch / three launches):
+                    // age < 10 -> id, 10 %: 117 / 123 us; 3 %: 107 / 79; 30 %: 204 / 168; 99 %: 534 / 372 -- a window around 10 %.
+                    // Not with a string predicate (the 2-byte match streams at 74 us with the one-launch kernel's 8 streaming waves per
+                    // CU against 47), and not for 1-byte columns alone (their gather reads every line of the column from ~3 % on and
+                    // still costs 33 us at 10 %).
                     q->alt_ok = any4 && !any_s2;
                 }
             }
@@ -1659,8 +1752,43 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
     {
         const int src = single_pass_sample(q.get()); // (the one synchronisation a creation may contain: segments of 4 M rows and more, undecided plans)
         if (src) return src;
+        // No sample (a segment below 4 M rows -- there the sample costs what it saves): the plans are compared for one survivor in
+        // ten, spread evenly; the first count corrects it.  (At 4 M rows the bitmap path wins nearly every shape: the one launch
+        // starts at ~27 us, three small launches at 16-20.)
+        imm3_query *qq = q.get();
+        if (!qq->plan_have_density && !qq->plan_pinned && !qq->sp_P_fixed && ctx->filter_variant != 10 && qq->plan_shape.n_rows > 0 &&
+            (qq->single_pass || qq->alt_ok || qq->d_stage_rec)) {
+            const uint64_t guess = (uint64_t)(qq->n_rows / 10);
+            const int rc2 = single_pass_stream_columns(qq, guess);
+            if (rc2) return rc2;
+            records_drop_if_narrow(qq, guess);
+            single_pass_drop_if_narrow(qq, guess);
+        }
     }
     *out = q.release();
+    return IMM3_OK;
+}
+
+// diagnostics: the cost model's prediction for a shape (tests hold it against immutable3_amd/plan_model.py; tools print it)
+extern "C" int imm3_plan_predict(int64_t n_rows, const int32_t *pred_width, const int32_t *pred_match, int32_t n_pred, const int32_t *proj_width,
+                                 const int32_t *proj_is_pred, int32_t n_proj, int32_t rec_bytes, double sigma, double sloc, double full, double *out_abc) {
+    if (n_pred < 0 || n_pred > kPlanMaxCols || n_proj < 0 || n_proj > kPlanMaxCols || !out_abc || (n_pred > 0 && (!pred_width || !pred_match)) ||
+        (n_proj > 0 && (!proj_width || !proj_is_pred)))
+        return fail(IMM3_ERR_ARG, "bad argument");
+    PlanShape ps;
+    ps.n_rows = n_rows;
+    ps.n_pred = n_pred;
+    for (int i = 0; i < n_pred; ++i) { ps.pred_width[i] = pred_width[i]; ps.pred_match[i] = pred_match[i]; }
+    ps.n_proj = n_proj;
+    for (int i = 0; i < n_proj; ++i) { ps.proj_width[i] = proj_width[i]; ps.proj_is_pred[i] = proj_is_pred[i] != 0; }
+    ps.rec_bytes = rec_bytes;
+    PlanDensity d;
+    d.sigma = sigma;
+    d.sloc = sloc;
+    d.full = full;
+    out_abc[0] = plan_cost('A', ps, d);
+    out_abc[1] = plan_cost('B', ps, d);
+    out_abc[2] = plan_cost('C', ps, d);
     return IMM3_OK;
 }
 
@@ -2289,7 +2417,7 @@ static int run_single_pass(imm3_query *q) {
         a.n_gather = ng;
     }
     const int fv = ctx->filter_variant;
-    a.ablate = (fv >= 50 && fv <= 50 + 255) ? fv - 50 : 0; // (tools' build only: a mask -- 1 no unpack, 2 no chained scan, 4 no records, 16 no output stores, 32 output stores cache resident)
+    a.ablate = (fv >= 50 && fv <= 50 + 255) ? fv - 50 : 0; // (tools' build only: a mask -- 1 no unpack, 2 no chained scan, 4 no records, 16 no output stores, 32 plain instead of non-temporal stores in the straight copy of fully surviving dense ranges)
     a.max_polls = ctx->fault_max_polls; // (tools' build only: imm3_ctx_inject_fault)
     a.fault_wg = ctx->fault_wg;
     a.fault_span = ctx->fault_span;
@@ -2425,12 +2553,40 @@ static int run_project(imm3_query *q) {
         // query never synchronises (a run that outgrows them is detected when its rows are fetched, and emitted again).
         unsigned long long total = 0;
         HIPCHK(hipMemcpyAsync(&total, q->d_total, sizeof(total), hipMemcpyDeviceToHost, s));
+        // ... and, for the cost model, where the survivors are: the offsets scan's per-chunk counts (256 tiles each; 1.5 KB for 100 M
+        // rows) say how densely they sit where they sit and how many of them in fully surviving chunks -- the whole segment, where
+        // the sample at creation saw 0.5 % of it (a range of a sorted key between two sample chunks showed it nothing)
+        std::vector<uint32_t> chunk_counts;
+        if (!q->plan_pinned && !q->table && q->n_chunks > 0 && q->n_chunks <= (1 << 20) && q->offsets_valid) {
+            chunk_counts.resize((size_t)q->n_chunks);
+            HIPCHK(hipMemcpyAsync(chunk_counts.data(), q->d_chunk_sums, chunk_counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        }
         HIPCHK(hipStreamSynchronize(s));
         ++q->run_syncs;
+        if (!chunk_counts.empty() && total > 0) {
+            const double chunk_rows = (double)kChunkTiles * kTileRows;
+            double sum = 0.0, sum_sq = 0.0, sum_full = 0.0;
+            for (size_t i = 0; i < chunk_counts.size(); ++i) {
+                const double c = (double)chunk_counts[i];
+                sum += c;
+                sum_sq += c * c;
+                if (c >= chunk_rows) sum_full += c;
+            }
+            if (sum > 0.0) {
+                q->plan_density.sigma = (double)total / (double)std::max<int64_t>(q->n_rows, 1);
+                q->plan_density.sloc = std::min(1.0, std::max(q->plan_density.sigma, sum_sq / (sum * chunk_rows)));
+                q->plan_density.full = sum_full / sum;
+                q->plan_have_density = true;
+            }
+        }
         {   // enough survivors for the gathered columns to be streamed instead?  Then this run is done again as one launch
             const int src = single_pass_stream_columns(q, total);
             if (src) return src;
             if (q->single_pass) return run_single_pass(q);
+            if (single_pass_restore_wanted(q, total)) {
+                q->sp_restore_pending = true; // (from the next run on)
+                q->sp_restore_survivors = total;
+            }
             records_drop_if_narrow(q, total); // (this run's rows then come from the bitmap the staging launch wrote as well)
         }
         const unsigned long long want = std::min<unsigned long long>((unsigned long long)std::max<int64_t>(q->n_rows, 1), total + total / 8 + 1024);
@@ -2524,6 +2680,10 @@ extern "C" int imm3_query_run(imm3_query *q) {
     // Reducing the count on the aux stream (tuning variant 2) measured SLOWER on MI355X / ROCm 7.2 (75.6 vs 67.1 us
     // per step: the cross-queue event packets cost more than the two same-queue launch gaps they remove), so the
     // default keeps the reduce on the main stream.
+    if (q->sp_restore_pending && !q->ctx->capture) {
+        const int rrc = single_pass_restore(q, q->sp_restore_survivors);
+        if (rrc) return rrc;
+    }
     if (q->single_pass && !q->proj.empty() && !q->always_false && q->n_tiles > 0) return capture_note(q, run_single_pass(q));
     const bool select_only = q->proj.empty() && !q->is_agg && q->ctx->filter_variant == 2;
     int rc = run_select(q, select_only, !q->proj.empty() && q->n_tiles > 0 && !q->always_false && q->ctx->filter_variant != 7);
@@ -2637,6 +2797,13 @@ static int settle_single_pass(imm3_query *q) {
     q->sp_verified = true;
     const unsigned long long flags = single_pass_flags(head);
     if (!flags) {
+        if (!q->plan_have_density && head[0] > 0 && q->n_rows > 0) { // no sample: what this run saw -- ranges that outgrew their ring mean dense stretches
+            const double sigma = (double)head[0] / (double)q->n_rows, n_ranges = (double)q->sp_spans * kProjectStreamers, dense = (double)head[kFinishDense];
+            q->plan_density.sigma = sigma;
+            q->plan_density.sloc = dense > 0.02 * n_ranges ? std::min(1.0, sigma * n_ranges / dense) : sigma;
+            q->plan_density.full = q->plan_density.sloc >= 0.95 && q->plan_density.sloc > 1.5 * sigma ? 1.0 : 0.0;
+            q->plan_have_density = true;
+        }
         single_pass_adapt(q, head[0], (int64_t)head[kFinishDense]); // (later runs: P from the selectivity this run saw)
         if (!q->sp_narrow_checked) { // (once: the data do not change)
             q->sp_narrow_checked = true;

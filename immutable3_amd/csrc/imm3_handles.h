@@ -4,6 +4,7 @@
 
 #include "../../include/imm3.h"
 #include "imm3_internal.h"
+#include "imm3_plan.h"
 #include "imm3_sync.h"
 
 #include <atomic>
@@ -251,9 +252,15 @@ struct imm3_query {
     std::vector<FoldedPred> sp_pass;        // (once switched: part of the single-pass plan)
     bool alt_ok = false;
     int32_t alt_kinds[3] = {3, 3, 3}, alt_seg_col[3] = {-1, -1, -1};
-    double alt_min_sigma = 1.0;             // survivors / rows from which the alternative is the faster plan
     bool records_narrow_only = false;       // the projected predicate columns are all 1 byte wide (few survivors: the bitmap path beats the records)
-    bool sp_narrow_checked = false;         // the first count has been looked at for "narrow columns, few survivors: three launches"
+    bool sp_narrow_checked = false;         // the first count has been looked at by the cost model ("leave the one launch?")
+    imm3::PlanShape plan_shape;             // what the cost model (imm3_plan.h) needs to know of this query
+    imm3::PlanDensity plan_density;         // where the survivors are: from the sample at creation (plan_have_density), else a default
+    bool plan_have_density = false;
+    bool sp_restore_pending = false;        // ... and it does: the next run sets the one launch up again
+    uint64_t sp_restore_survivors = 0;
+    bool sp_model_dropped = false;          // the cost model took this query off the one launch on an estimate: the first count may bring it back
+    bool plan_pinned = false;               // tuning 12 at creation: the plan made there stands whatever the cost model says (tests of one plan's kernels)
     bool sp_have_stats = false;             // a run's count and dense-range tally have been seen (a reservation's estimate no longer moves P)
     size_t sp_rounds_max = 0;               // rounds at the smallest P: d_desc = {round totals, round counters, span descriptors (smallest P), trash lines}
     size_t sp_desc_off = 0;                 // byte offset of the span descriptors in d_desc's allocation

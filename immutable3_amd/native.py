@@ -48,7 +48,7 @@ EXPORTS = [
 DIAG_EXPORTS = [
     "imm3_ctx_timing_enable", "imm3_ctx_timing_reset", "imm3_ctx_timing_mask", "imm3_ctx_timing_collect", "imm3_ctx_set_tuning",
     "imm3_ctx_measure_read_gbps", "imm3_ctx_devclock_enable", "imm3_ctx_devclock_collect", "imm3_ctx_devclock_raw", "imm3_query_plan",
-    "imm3_ctx_inject_fault", "imm3_ctx_debug_device_lock",
+    "imm3_ctx_inject_fault", "imm3_ctx_debug_device_lock", "imm3_plan_predict",
 ]
 COMM_ID_BYTES = 128
 
@@ -636,6 +636,20 @@ class DeviceQuery:
             self.close()
         except Exception:
             pass
+
+
+def plan_predict(n_rows, pred, proj, rec_bytes, sigma, sloc, full):
+    """The planner's cost model (csrc/imm3_plan.h): predicted us of plans A, B, C.  pred = [(width, n_match)], proj = [(width, is_pred)]."""
+    lib = load()
+    pw = (C.c_int32 * max(1, len(pred)))(*[w for w, _ in pred])
+    pm = (C.c_int32 * max(1, len(pred)))(*[m for _, m in pred])
+    jw = (C.c_int32 * max(1, len(proj)))(*[w for w, _ in proj])
+    jp = (C.c_int32 * max(1, len(proj)))(*[1 if p else 0 for _, p in proj])
+    out = (C.c_double * 3)()
+    lib.imm3_plan_predict.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_void_p]
+    lib.imm3_plan_predict.restype = C.c_int
+    _check(lib.imm3_plan_predict(n_rows, pw, pm, len(pred), jw, jp, len(proj), rec_bytes, sigma, sloc, full, out))
+    return {"A": out[0], "B": out[1], "C": out[2]}
 
 
 def comm_unique_id() -> bytes:

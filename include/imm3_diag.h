@@ -44,9 +44,17 @@ int imm3_ctx_measure_read_gbps(imm3_ctx *ctx, uint64_t bytes, int32_t iters, dou
  * 6 = projections never use the one-launch kernel, 8 = they use it with gathered SELECT-list columns too, 9 = gathered int32
  * columns are streamed through it whatever the selectivity, 10 = no sampled selectivity estimate at query creation (the plan
  * then adapts from the first run's count on), 11 = survivor records are staged even when no predicate column is projected,
+ * 12 = the plan made at creation stands whatever the cost model predicts (tests of one plan's kernels; P still adapts),
  * 14 = a `limit` query scans the whole segment in one launch instead of in chunks behind a limit-reached word (decided per run),
  * 200 + P = fixed tiles per range. */
 int imm3_ctx_set_tuning(imm3_ctx *ctx, int32_t filter_variant, int32_t grid_blocks);
+
+/* The projection planner's cost model (csrc/imm3_plan.h): predicted microseconds of one run's kernels under plan A (one launch), B
+ * (survivor records) and C (the bitmap path) for a query shape -- predicate columns' widths and IN-list sizes, the SELECT list's
+ * widths and which of its entries are predicate columns, the bytes of a survivor record -- with sigma = survivors per row, sloc =
+ * survivors per row where there are survivors, full = share of the survivors in fully surviving stretches.  out_abc: 3 values. */
+int imm3_plan_predict(int64_t n_rows, const int32_t *pred_width, const int32_t *pred_match, int32_t n_pred, const int32_t *proj_width,
+                      const int32_t *proj_is_pred, int32_t n_proj, int32_t rec_bytes, double sigma, double sloc, double full, double *out_abc);
 
 /* How the library planned a query (tests assert the path they mean to exercise; tools print it).
  * out[0] = 1 when an unlimited projection runs as ONE launch (k_filter_project: the filter kernel writes the rows), else 0;

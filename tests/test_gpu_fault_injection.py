@@ -226,7 +226,11 @@ def test_the_shipped_library_refuses_fault_injection_but_knows_a_busy_device():
     br = blocks_of(n, 1024)
     seg = native.DeviceSegment(ctx, [RawColumn(DENSE_INT, 4, a, br).native(), RawColumn(DENSE_TINYINT, 1, c, br).native()])
     rows = np.flatnonzero((c > 79) & (a > 5))
-    q = native.DeviceQuery(ctx, seg, [1, 0], [(0, GT, 79.0), (1, GT, 5.0)], [1, 0], 0)
+    ctx.set_tuning(12, 0)          # (the one launch, whatever the cost model makes of 300 K rows)
+    try:
+        q = native.DeviceQuery(ctx, seg, [1, 0], [(0, GT, 79.0), (1, GT, 5.0)], [1, 0], 0)
+    finally:
+        ctx.set_tuning(0, 0)
     assert q.plan()["single_pass"]
     prev = ctx.debug_device_lock(0xBEEF0001)
     try:

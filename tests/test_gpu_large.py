@@ -37,6 +37,7 @@ def test_c3_range_and_project_100m(big, oracle):
     ctx, seg, ids, age, st = big
     sels = [(0, GT, 18.0), (0, LT, 30.0), (1, GT, 1e6), (1, LT, 9e7)]
     q = native.DeviceQuery(ctx, seg, [1, 0], sels, [1, 0], 0)     # used = [age, id]; project (id, age)
+    assert q.plan()["single_pass"], q.plan()                       # BASELINE's C3 at its full size: ONE launch (the cost model's choice from the sample)
     q.run()
     count = q.count()
     words = q.bitmap()

@@ -23,6 +23,53 @@ pytestmark = pytest.mark.gpu
 SHAPES = [[0], [2], [4], [0, 1], [0, 2], [2, 3], [0, 4], [2, 4], [0, 1, 2], [0, 2, 3], [2, 3, 4], [0, 1, 4], [0, 2, 4]]
 
 
+def pinned_query(ctx, *args):
+    """A query on the plan made at creation -- the one launch where the SELECT list allows it -- whatever the cost model predicts for
+    its size and survivors (tuning variant 12: the tests of that kernel's own paths)."""
+    ctx.set_tuning(12, 0)
+    try:
+        return native.DeviceQuery(ctx, *args)
+    finally:
+        ctx.set_tuning(0, 0)
+
+
+def plan_kind(p):
+    return "one launch" if p["single_pass"] else ("records" if p["records"] else "bitmap")
+
+
+def model_accepts(kind, n, data, used, sels, proj, keep, clustered=False, slack=1.10):
+    """Is `kind` a plan the cost model (immutable3_amd/plan_model.py = csrc/imm3_plan.h) could have picked for this query?  Its
+    predicted cost must be within `slack` of the cheapest plan's (the library decides on a sampled estimate of the survivors and
+    keeps a plan in use unless another is predicted 3 % cheaper, so near ties go either way)."""
+    from immutable3_amd import plan_model
+    width = lambda u: 2 if data[u].ndim == 2 else data[u].dtype.itemsize
+    pred_cols = list(dict.fromkeys(used[i] for i, _, _ in sels))
+    pred = [(width(u), max([len(v) for i, op, v in sels if used[i] == u and op == MATCH] + [0])) for u in pred_cols]
+    seen, pj = [], []
+    for j in proj:
+        u = used[j]
+        first = u in pred_cols and u not in seen
+        if first:
+            seen.append(u)
+        pj.append((width(u), first))
+    n32 = sum(1 for w, _ in pred if w == 4)
+    dwords = 1 + n32
+    rec_bytes = 4 * (dwords if dwords <= 2 else 4)
+    sigma = float(keep.mean())
+    sloc, full = (1.0, 1.0) if clustered else (sigma, 0.0)
+    letters = {"one launch": "A", "records": "B", "bitmap": "C"}
+    cost = {k: plan_model.cost(l, n, sigma, sloc, full, pred, pj, rec_bytes) for k, l in letters.items()}
+    eligible = dict(cost)
+    gathers = not all(f for _, f in pj)
+    if gathers and (not any(w == 4 and not f for w, f in pj) or any(w == 2 for w, _ in pred)):
+        eligible.pop("one launch")                      # gathered columns, and none of them int32 (nothing to stream) or a string predicate
+    if not any(f for _, f in pj):
+        eligible.pop("records")                         # no predicate column projected: records buy nothing
+    return kind in eligible and cost[kind] <= slack * min(eligible.values()), cost
+
+
+
+
 @pytest.fixture(scope="module")
 def ctx():
     c = native.Context(0)
@@ -81,7 +128,7 @@ def test_every_instance_at_every_fill_level(ctx, big, pred_cols):
     pos = {u: i for i, u in enumerate(used)}
     for level in ("none", "few", "some", "most", "all"):
         sels, keep = _predicates(data, pred_cols, level, pos)
-        ctx.set_tuning(10, 0)        # (no sample at creation: with few survivors of narrow columns the planner would pick three launches)
+        ctx.set_tuning(12, 0)        # (the plan made at creation stands: this file is about the one launch, which the cost model would leave for few survivors of narrow columns)
         try:
             q = native.DeviceQuery(ctx, seg, used, sels, list(range(len(used))), 0)
         finally:
@@ -121,12 +168,16 @@ def test_against_the_oracle_with_ragged_tail_and_second_mentions(ctx, oracle):
 
 def test_plan_only_when_every_select_list_column_is_a_predicate_column(ctx, big):
     n, data, seg = big
-    q = native.DeviceQuery(ctx, seg, [2, 0], [(0, GT, 18.0), (0, LT, 30.0), (1, GT, 5.0)], [1, 0], 0)
-    assert q.plan()["single_pass"]
-    q.close()
-    q = native.DeviceQuery(ctx, seg, [4, 0], [(0, MATCH, [b"CA"])], [1, 0], 0)                 # id is gathered, the string predicate column projected: records + k_emit
-    assert not q.plan()["single_pass"] and q.plan()["records"]
-    q.close()
+    ctx.set_tuning(12, 0)      # (which plans a SELECT list is eligible for: the plan made at creation, before the cost model looks at the survivors)
+    try:
+        q = native.DeviceQuery(ctx, seg, [2, 0], [(0, GT, 18.0), (0, LT, 30.0), (1, GT, 5.0)], [1, 0], 0)
+        assert q.plan()["single_pass"]
+        q.close()
+        q = native.DeviceQuery(ctx, seg, [4, 0], [(0, MATCH, [b"CA"])], [1, 0], 0)             # id is gathered, the string predicate column projected: records + k_emit
+        assert not q.plan()["single_pass"] and q.plan()["records"]
+        q.close()
+    finally:
+        ctx.set_tuning(0, 0)
     q = native.DeviceQuery(ctx, seg, [4, 0], [(0, MATCH, [b"CA"])], [1], 0)                    # no predicate column projected: records would buy nothing
     assert not q.plan()["single_pass"] and not q.plan()["records"]
     q.close()
@@ -141,7 +192,7 @@ def test_reservation_too_small_and_abandoned_run_are_answered_from_the_bitmap(ct
     keep = (c > 89) & (a > 0.5 * 2 ** 30)
     rows = np.flatnonzero(keep)
     sels = [(0, GT, 89.0), (1, GT, float(0.5 * 2 ** 30))]
-    q = native.DeviceQuery(ctx, seg, [2, 0], sels, [1, 0], 0)
+    q = pinned_query(ctx, seg, [2, 0], sels, [1, 0], 0)
     q.reserve_rows(1000)                          # far too small: the kernel stops writing at the capacity, the count stays exact
     q.run()
     assert q.count() == rows.size
@@ -180,7 +231,7 @@ def test_graph_replays_and_counts_in_the_log(ctx, big):
     c, b = data[2], data[1]
     keep = (c > 18) & (c < 30) & (b > 1000)
     rows = np.flatnonzero(keep)
-    q = native.DeviceQuery(ctx, seg, [2, 1], [(0, GT, 18.0), (0, LT, 30.0), (1, GT, 1000.0)], [1, 0], 0)
+    q = pinned_query(ctx, seg, [2, 1], [(0, GT, 18.0), (0, LT, 30.0), (1, GT, 1000.0)], [1, 0], 0)
     q.run()                                        # allocates the row arrays (room for every row: no reservation needed)
     with ctx.capture() as cap:
         q.run()
@@ -203,6 +254,7 @@ def test_two_contexts_launch_the_kernel_at_once(big):
     def worker(t):
         try:
             cx = native.Context(0)
+            cx.set_tuning(12, 0)             # (the one launch, whatever the cost model makes of 13 M rows)
             lo = 10.0 + 7 * t
             keep = (c > lo) & (c < lo + 12) & (a > 1000)
             rows = np.flatnonzero(keep)
@@ -237,6 +289,7 @@ def test_steady_state_projections_never_wait_for_the_device(ctx, big):
               "bitmap": ([2, 0, 4], [(0, GT, 18.0), (2, MATCH, [b"CA", b"NY", b"TX", b"WA", b"VA", b"DC", b"CT", b"AL", b"AK"])], [1, 0], 1)}
     for name, (used, sels, proj, first_run_syncs) in shapes.items():
         q = native.DeviceQuery(ctx, seg, used, sels, proj, 0)
+        first_run_syncs = 0 if q.plan()["single_pass"] else 1           # (the one launch has room for every row; the others size their arrays from the first count)
         for _ in range(6):
             q.run()
         assert q.plan()["run_syncs"] == first_run_syncs, (name, q.plan())
@@ -262,7 +315,7 @@ def test_tiles_per_range_follow_the_selectivity(ctx, big):
     for name, (used, sels, keep, expect) in cases.items():
         rows = np.flatnonzero(keep)
         sampled = native.DeviceQuery(ctx, seg, used, sels, list(range(len(used))), 0)     # the plan from the sample taken at creation ...
-        ctx.set_tuning(10, 0)                                                              # ... and without it: what the first count teaches
+        ctx.set_tuning(12, 0)                                                              # ... and the one launch pinned, without a sample: what the first count teaches P
         try:
             q = native.DeviceQuery(ctx, seg, used, sels, list(range(len(used))), 0)
         finally:
@@ -295,14 +348,61 @@ def test_tiles_per_range_follow_the_selectivity(ctx, big):
                 assert vals[j].tobytes() == np.ascontiguousarray(data[u][rows]).tobytes(), (name, rnd, u)
         assert q.plan()["P"] == p1["P"], (name, "P keeps still once it fits")
         ps = sampled.plan()
-        assert (ps["P"] < p0["P"]) == (expect == "smaller"), (name, p0, ps)           # the sample leads to the same side of the planned P
+        ok, cost = model_accepts(plan_kind(ps), n, data, used, sels, list(range(len(used))), keep, clustered=name.startswith("clustered"))
+        assert ok, (name, ps, cost)                                                    # (at 13 M rows the cost model takes several of these off the one launch)
+        if ps["single_pass"]:
+            assert (ps["P"] < p0["P"]) == (expect == "smaller"), (name, p0, ps)       # the sample leads to the same side of the planned P
         sampled.run()
         idx, vals = sampled.fetch_rows()
-        assert sampled.plan()["ran_single_pass"] and idx.size == rows.size and (idx == rows).all(), name
+        assert sampled.plan()["ran_single_pass"] == ps["single_pass"] and idx.size == rows.size and (idx == rows).all(), name
         sampled.close()
         if g is not None:
             g.close()
         q.close()
+
+
+def test_fully_surviving_ranges_are_copied_whatever_the_first_slot(ctx):
+    """unpack_dense's straight copy: a range all of whose rows survive is moved with 16-byte loads and stores.  The output slot of its
+    first row is arbitrary (the survivors before it): every residue mod 4, with int32, int8 and 2-byte columns in the SELECT list
+    (a narrow column whose first output byte is not dword-aligned takes the general walk), a reservation that ends inside a copied
+    range, and the segment's partial last tile at the end of the run of survivors."""
+    n = 3_000 * 1024 - 77
+    rng = np.random.default_rng(21)
+    key = np.arange(n, dtype=np.int32)
+    a = rng.integers(0, 2 ** 30, size=n).astype(np.int32)
+    c = rng.integers(0, 100, size=n).astype(np.int8)
+    codes = [b"CA", b"NY", b"TX"]
+    s = np.array([list(x) for x in codes], dtype=np.uint8)[rng.integers(0, 3, size=n)]
+    data = [key, a, c, s]
+    br = blocks_of(n, 1024)
+    cols = [RawColumn(DENSE_INT, 4, key, br), RawColumn(DENSE_INT, 4, a, br), RawColumn(DENSE_TINYINT, 1, c, br), RawColumn(DENSE_STRING, 2, s, br)]
+    seg = native.DeviceSegment(ctx, [x.native() for x in cols])
+    shapes = [([0], [], None),
+              ([0, 2], [(1, GT, -1.0)], None),                                          # + int8, every row passes it
+              ([0, 3, 2], [(1, MATCH, codes), (2, GT, -1.0)], None),                    # + 2-byte codes + int8, every row passes both
+              ([0, 1], [(1, GT, float(0.001 * 2 ** 30))], a > 0.001 * 2 ** 30)]         # a few holes: ranges with and without them
+    for shift in (0, 1, 2, 3, 1024 * 7 + 5):
+        thr = n // 3 + shift                                           # key > thr: everything behind row thr, one long run
+        for used, extra, extra_keep in shapes:
+            sels = [(0, GT, float(thr))] + extra
+            keep = key > thr
+            if extra_keep is not None:
+                keep = keep & extra_keep
+            rows = np.flatnonzero(keep)
+            for reserve in (0, rows.size // 2 + 3):
+                q = pinned_query(ctx, seg, used, sels, list(range(len(used))), 0)
+                if reserve:
+                    q.reserve_rows(reserve)
+                assert q.plan()["single_pass"], (used, q.plan())
+                for _ in range(2):
+                    q.run()
+                assert q.count() == rows.size, (shift, used, reserve)
+                idx, vals = q.fetch_rows()
+                assert idx.size == rows.size and (idx == rows).all(), (shift, used, reserve)
+                for j, u in enumerate(used):
+                    assert vals[j].tobytes() == np.ascontiguousarray(data[u][rows]).tobytes(), (shift, used, reserve, u)
+                q.close()
+    seg.close()
 
 
 def test_gathered_columns_in_the_one_launch_when_the_tuning_hook_forces_it(big):
@@ -344,65 +444,80 @@ def test_gathered_columns_in_the_one_launch_when_the_tuning_hook_forces_it(big):
         ctx8.close()
 
 
-def test_gathered_int32_columns_are_streamed_once_the_count_says_so(ctx, big):
+def test_gathered_int32_columns_are_streamed_when_the_cost_model_says_so(ctx, big):
     """`select id, age ... where age > 18 and age < 30` (the reference README's example): id is not a predicate column.  Three plans
     exist for such a projection -- survivor records -> offsets scan -> emit (the predicate columns' values ride in the records),
     the same from the bitmap alone (no records: the plain filter kernel, the gather reads every SELECT-list column), and the one
     launch with the gathered int32 columns streamed through it as tile columns that let every value pass.  Which one is the
-    fastest depends on how many rows survive and on which predicate columns are projected; the library decides from a sample
-    counted at query creation and, without one (small segments; here: tuning variant 10), from the first run's count.  Same rows
-    whatever the plan."""
+    fastest depends on the rows, on how many survive and on which predicate columns are projected (csrc/imm3_plan.h); the library
+    decides from a sample counted at query creation and, without one (small segments; here: tuning variant 10), from the first run's
+    count.  Same rows whatever the plan; tuning variant 9 forces the streamed plan, so its transition runs here whatever the model
+    makes of 13 M rows."""
     n, data, seg = big
     a, b, c, d, s2 = data
     cases = {
-        # name: used, sels, proj, keep, plan with the sample / plan at creation without it / plan after the first run without it
-        "11 %, id gathered":         ([2, 0], [(0, GT, 18.0), (0, LT, 30.0)], [1, 0], (c > 18) & (c < 30), "one launch", "records", "one launch"),
-        "10 %, two int32 gathered":  ([2, 0, 1], [(0, GT, 89.0)], [2, 0, 1], c > 89, "one launch", "records", "one launch"),
-        "second mention stays a gather": ([3, 0], [(0, GT, 30.0)], [1, 0, 1], d > 30, "one launch", "records", "one launch"),
-        "2 %, int8 predicate projected": ([2, 0], [(0, GT, 97.0)], [1, 0], c > 97, "bitmap", "records", "bitmap"),
-        "2 %, string predicate projected": ([4, 0], [(0, MATCH, [b"CA"])], [1, 0], None, "records", "records", "records"),
-        "string predicate, not projected": ([4, 0], [(0, MATCH, [b"CA", b"NY", b"TX", b"WA", b"VA"])], [1], None, "bitmap", "bitmap", "bitmap"),
-        "only a 1-byte column gathered": ([0, 2], [(0, GT, float(0.8 * 2 ** 30))], [1], a > 0.8 * 2 ** 30, "bitmap", "bitmap", "bitmap"),
-        "20 %, no predicate column projected": ([2, 0], [(0, GT, 79.0)], [1], c > 79, "one launch", "bitmap", "one launch"),
-        "5 %, no predicate column projected": ([2, 0], [(0, GT, 94.0)], [1], c > 94, "bitmap", "bitmap", "bitmap"),
+        # name: used, sels, proj, keep, plan at creation without the sample
+        "11 %, id gathered":         ([2, 0], [(0, GT, 18.0), (0, LT, 30.0)], [1, 0], (c > 18) & (c < 30), "records"),
+        "10 %, two int32 gathered":  ([2, 0, 1], [(0, GT, 89.0)], [2, 0, 1], c > 89, "records"),
+        "second mention stays a gather": ([3, 0], [(0, GT, 30.0)], [1, 0, 1], d > 30, "records"),
+        "2 %, int8 predicate projected": ([2, 0], [(0, GT, 97.0)], [1, 0], c > 97, "records"),
+        "2 %, string predicate projected": ([4, 0], [(0, MATCH, [b"CA"])], [1, 0], None, "records"),
+        "string predicate, not projected": ([4, 0], [(0, MATCH, [b"CA", b"NY", b"TX", b"WA", b"VA"])], [1], None, "bitmap"),
+        "only a 1-byte column gathered": ([0, 2], [(0, GT, float(0.8 * 2 ** 30))], [1], a > 0.8 * 2 ** 30, "bitmap"),
+        "20 %, no predicate column projected": ([2, 0], [(0, GT, 79.0)], [1], c > 79, "bitmap"),
+        "5 %, no predicate column projected": ([2, 0], [(0, GT, 94.0)], [1], c > 94, "bitmap"),
     }
 
-    def kind(p):
-        return "one launch" if p["single_pass"] else ("records" if p["records"] else "bitmap")
+    def check_rows(q, rows, used, proj, tag):
+        idx, vals = q.fetch_rows()
+        assert idx.size == rows.size and (idx == rows).all(), tag
+        for j, pj in enumerate(proj):
+            assert vals[j].tobytes() == np.ascontiguousarray(data[used[pj]][rows]).tobytes(), (tag, j)
 
-    for name, (used, sels, proj, keep, want_sampled, want_created, want_run) in cases.items():
+    for name, (used, sels, proj, keep, want_created) in cases.items():
         if keep is None:
             keep = np.zeros(n, bool)
             for v in sels[0][2]:
                 keep |= (s2[:, 0] == v[0]) & (s2[:, 1] == v[1])
         rows = np.flatnonzero(keep)
         sampled = native.DeviceQuery(ctx, seg, used, sels, proj, 0)    # the sample taken at creation decides before the first run ...
-        assert kind(sampled.plan()) == want_sampled, (name, sampled.plan())
+        k0 = plan_kind(sampled.plan())
+        ok, cost = model_accepts(k0, n, data, used, sels, proj, keep)
+        assert ok, (name, sampled.plan(), cost)
         sampled.run()
-        idx, vals = sampled.fetch_rows()
-        assert kind(sampled.plan()) == want_sampled and sampled.plan()["run_syncs"] == (0 if want_sampled == "one launch" else 1), (name, sampled.plan())
-        assert idx.size == rows.size and (idx == rows).all(), name
-        for j, pj in enumerate(proj):
-            assert vals[j].tobytes() == np.ascontiguousarray(data[used[pj]][rows]).tobytes(), (name, j)
+        check_rows(sampled, rows, used, proj, name)
+        ok, cost = model_accepts(plan_kind(sampled.plan()), n, data, used, sels, proj, keep)
+        assert ok and sampled.plan()["run_syncs"] == (0 if k0 == "one launch" else 1), (name, sampled.plan(), cost)
         sampled.close()
         ctx.set_tuning(10, 0)                                           # ... without it, the first run's count does
         try:
             q = native.DeviceQuery(ctx, seg, used, sels, proj, 0)
         finally:
             ctx.set_tuning(0, 0)
-        assert kind(q.plan()) == want_created, (name, q.plan())
+        assert plan_kind(q.plan()) == want_created, (name, q.plan())
         for rnd in range(3):
             q.run()
             p = q.plan()
-            assert kind(p) == want_run and p["ran_single_pass"] == (want_run == "one launch"), (name, rnd, p)
+            ok, cost = model_accepts(plan_kind(p), n, data, used, sels, proj, keep)
+            assert ok and p["ran_single_pass"] == p["single_pass"], (name, rnd, p, cost)
             assert p["run_syncs"] == 1, (name, rnd, p)           # the first run's look at the count, never again
             assert q.count() == rows.size, (name, rnd)
-            idx, vals = q.fetch_rows()
-            assert idx.size == rows.size and (idx == rows).all(), (name, rnd)
-            for j, pj in enumerate(proj):
-                assert vals[j].tobytes() == np.ascontiguousarray(data[used[pj]][rows]).tobytes(), (name, rnd, j)
+            check_rows(q, rows, used, proj, (name, rnd))
         q.close()
-    # a reservation stands in for the count the first run would have read
+        # forced: the gathered int32 columns are streamed whatever the prediction (where there is one to stream and no string predicate)
+        ctx.set_tuning(9, 0)
+        try:
+            q = native.DeviceQuery(ctx, seg, used, sels, proj, 0)
+            for rnd in range(2):
+                q.run()
+                assert q.count() == rows.size, (name, "forced", rnd)
+                check_rows(q, rows, used, proj, (name, "forced", rnd))
+            if name in ("11 %, id gathered", "10 %, two int32 gathered", "second mention stays a gather", "20 %, no predicate column projected"):
+                assert q.plan()["ran_single_pass"], (name, q.plan())
+            q.close()
+        finally:
+            ctx.set_tuning(0, 0)
+    # a reservation stands in for the count the first run would have read: forced to the streamed plan here, it switches before the first run
     ctx.set_tuning(10, 0)
     try:
         q = native.DeviceQuery(ctx, seg, [2, 0], [(0, GT, 18.0), (0, LT, 30.0)], [1, 0], 0)
@@ -410,7 +525,11 @@ def test_gathered_int32_columns_are_streamed_once_the_count_says_so(ctx, big):
         ctx.set_tuning(0, 0)
     assert not q.plan()["single_pass"] and q.plan()["records"]
     rows = np.flatnonzero((c > 18) & (c < 30))
-    q.reserve_rows(rows.size + 100)
+    ctx.set_tuning(9, 0)
+    try:
+        q.reserve_rows(rows.size + 100)
+    finally:
+        ctx.set_tuning(0, 0)
     assert q.plan()["single_pass"] and not q.plan()["records"]
     q.run()
     assert q.plan()["run_syncs"] == 0 and q.plan()["ran_single_pass"]
@@ -461,26 +580,26 @@ def test_random_sizes_predicates_and_select_lists(ctx):
         seg.close()
 
 
-def test_narrow_columns_alone_take_three_launches_until_many_rows_survive(ctx, big):
+def test_the_plan_follows_the_cost_model_with_and_without_the_sample(ctx, big):
     """The one-launch kernel costs about the same per row whatever the columns' widths; the plain filter over 1- and 2-byte columns
-    is four times cheaper than over an int32 column.  `select age ... where age > 98` is therefore planned as filter -> offsets
-    scan -> gather from the bitmap when the sample taken at creation shows few survivors (< 30 %), and as one launch when it
-    shows many; without a sample the first count decides for the runs after it."""
+    is four times cheaper than over an int32 column, and three small launches start cheaper than the one.  `select age ... where
+    age > 98` is therefore planned as filter -> offsets scan -> gather from the bitmap when the sample taken at creation shows few
+    survivors, a projected string column with few survivors is staged in records, and so on: whatever csrc/imm3_plan.h predicts
+    cheapest.  Without a sample (tuning variant 10) the query starts on the one launch and the first count brings it to a plan the
+    model accepts.  Same rows whatever the plan."""
     n, data, seg = big
     a, b, c, d, s2 = data
-
-    def kind(p):
-        return "one launch" if p["single_pass"] else ("records" if p["records"] else "bitmap")
-
     cases = {
-        "int8, 10 %":        ([2], [(0, GT, 89.0)], c > 89, "bitmap"),
-        "int8, 50 %":        ([2], [(0, GT, 49.0)], c > 49, "one launch"),
-        "int8 + int8, 5 %":  ([2, 3], [(0, GT, 89.0), (1, GT, 0.0)], (c > 89) & (d > 0), "bitmap"),
-        "string, 2 %":       ([4], [(0, MATCH, [b"CA"])], (s2[:, 0] == ord("C")) & (s2[:, 1] == ord("A")), "records"),   # (two bytes per survivor: staged, not gathered)
-        "string, 10 %":      ([4], [(0, MATCH, [b"CA", b"NY", b"TX", b"WA", b"VA"])], None, "bitmap"),
-        "int8 + int32, 10 %": ([2, 0], [(0, GT, 89.0), (1, GT, -1.0)], (c > 89) & (a > -1), "one launch"),    # an int32 column: the one launch at any selectivity
+        "int8, 10 %":        ([2], [(0, GT, 89.0)], c > 89, False),
+        "int8, 50 %":        ([2], [(0, GT, 49.0)], c > 49, False),
+        "int8 + int8, 5 %":  ([2, 3], [(0, GT, 89.0), (1, GT, 0.0)], (c > 89) & (d > 0), False),
+        "string, 2 %":       ([4], [(0, MATCH, [b"CA"])], (s2[:, 0] == ord("C")) & (s2[:, 1] == ord("A")), False),
+        "string, 10 %":      ([4], [(0, MATCH, [b"CA", b"NY", b"TX", b"WA", b"VA"])], None, False),
+        "int8 + int32, 10 %": ([2, 0], [(0, GT, 89.0), (1, GT, -1.0)], (c > 89) & (a > -1), False),
+        "int8 + int32, 99 %": ([2, 0], [(0, GT, 0.0), (1, GT, -1.0)], (c > 0) & (a > -1), False),
+        "sorted key, 40 %":  ([1], [(0, GT, float(0.6 * n))], b > 0.6 * n, True),
     }
-    for name, (used, sels, keep, want) in cases.items():
+    for name, (used, sels, keep, clustered) in cases.items():
         if keep is None:
             keep = np.zeros(n, bool)
             for v in sels[0][2]:
@@ -488,13 +607,14 @@ def test_narrow_columns_alone_take_three_launches_until_many_rows_survive(ctx, b
         rows = np.flatnonzero(keep)
         proj = list(range(len(used)))
         q = native.DeviceQuery(ctx, seg, used, sels, proj, 0)
-        assert kind(q.plan()) == want, (name, q.plan())
+        ok, cost = model_accepts(plan_kind(q.plan()), n, data, used, sels, proj, keep, clustered)
+        assert ok, (name, q.plan(), cost)
         ctx.set_tuning(10, 0)
         try:
             late = native.DeviceQuery(ctx, seg, used, sels, proj, 0)
         finally:
             ctx.set_tuning(0, 0)
-        assert kind(late.plan()) == "one launch", (name, late.plan())
+        assert plan_kind(late.plan()) == "one launch", (name, late.plan())
         for qq in (q, late):
             for rnd in range(3):
                 qq.run()
@@ -503,5 +623,35 @@ def test_narrow_columns_alone_take_three_launches_until_many_rows_survive(ctx, b
                 assert idx.size == rows.size and (idx == rows).all(), (name, rnd)
                 for j, u in enumerate(used):
                     assert vals[j].tobytes() == np.ascontiguousarray(data[u][rows]).tobytes(), (name, rnd, j)
-            assert kind(qq.plan()) == want, (name, qq.plan())        # the first count brought `late` to the same plan
+            ok, cost = model_accepts(plan_kind(qq.plan()), n, data, used, sels, proj, keep, clustered)
+            assert ok, (name, qq.plan(), cost)                         # (the first count brought `late` to a plan the model accepts)
             qq.close()
+
+
+def test_survivors_between_the_sample_points(ctx, big):
+    """The sample at creation looks at eight chunks of 64 tiles; a range of the sorted key that lies between two of them shows it no
+    survivor at all.  The answer is exact all the same, and the first count puts the query on a plan the cost model accepts for the
+    survivors that are really there (1300 fully surviving tiles: 10 % of the rows, in one run)."""
+    n, data, seg = big
+    a, b, c, d, s2 = data
+    n_full = n // 1024
+    centres = [(2 * i + 1) * n_full // 16 for i in range(8)]          # the sample's chunks: 64 tiles around each (imm3_api.cpp: sample_tile_ptrs)
+    lo_tile, hi_tile = centres[0] + 100, centres[1] - 100
+    assert hi_tile - lo_tile > 1000
+    lo, hi = lo_tile * 1024 + 7, hi_tile * 1024 - 9
+    keep = (b > lo) & (b < hi)
+    rows = np.flatnonzero(keep)
+    for used, extra, proj in (([1], [], [0]), ([1, 2], [], [0, 1]), ([1, 0], [(1, GT, -1.0)], [1, 0])):
+        sels = [(0, GT, float(lo)), (0, LT, float(hi))] + extra
+        q = native.DeviceQuery(ctx, seg, used, sels, proj, 0)
+        first = plan_kind(q.plan())
+        for rnd in range(3):
+            q.run()
+            assert q.count() == rows.size, (used, rnd)
+            idx, vals = q.fetch_rows()
+            assert idx.size == rows.size and (idx == rows).all(), (used, rnd)
+            for j, pj in enumerate(proj):
+                assert vals[j].tobytes() == np.ascontiguousarray(data[used[pj]][rows]).tobytes(), (used, rnd, j)
+        ok, cost = model_accepts(plan_kind(q.plan()), n, data, used, sels, proj, keep, clustered=True, slack=1.25)
+        assert ok, (used, first, q.plan(), cost)
+        q.close()

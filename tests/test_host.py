@@ -291,3 +291,31 @@ def test_the_single_pass_kernel_instances_that_count_their_own_loads_do_not_spil
             seen_deep += 1
             assert scratch == 0, (kinds, vgprs, scratch)
     assert seen_deep >= 9
+
+
+def test_the_planners_cost_model_is_the_same_in_cpp_and_python():
+    """csrc/imm3_plan.h (what the library decides with) and immutable3_amd/plan_model.py (what tools/plan_fit.py fits) are one model:
+    same features, same coefficients (the header tools/plan_fit.py writes), on a grid of shapes, sizes and densities.  And the model
+    says what the sweep it was fitted to says at its corners (profiles/r04_plan_sweep*): a small segment takes the bitmap path, C3's
+    shape the one launch at 10 % survivors and three launches at 99 %, a sorted key's run the one launch."""
+    from immutable3_amd import native, plan_model
+    from immutable3_amd.build import build_native
+    build_native()
+    coef = plan_model.coefficients()
+    shapes = [([(1, 0)], [(1, True)], 4), ([(1, 0), (4, 0)], [(4, True), (1, True)], 8), ([(2, 3)], [(4, False), (2, True), (1, False)], 4),
+              ([(1, 0)], [(4, False)], 4), ([(4, 0)], [(4, True), (4, True)], 8), ([(2, 8), (1, 0)], [(2, True)], 4)]
+    for pred, proj, rec in shapes:
+        for n in (100_000, 4_000_000, 100_000_000):
+            for sigma, sloc, full in ((0.0, 0.0, 0.0), (0.01, 0.01, 0.0), (0.1, 1.0, 1.0), (0.5, 0.5, 0.0), (0.99, 1.0, 0.3), (1.0, 1.0, 1.0)):
+                got = native.plan_predict(n, pred, proj, rec, sigma, sloc, full)
+                for plan in "ABC":
+                    want = plan_model.cost(plan, n, sigma, sloc, full, pred, proj, rec, coef)
+                    assert abs(got[plan] - want) <= 1e-6 * max(1.0, abs(want)), (plan, pred, proj, n, sigma, sloc, full, got[plan], want)
+    c3 = ([(4, 0), (1, 0)], [(4, True), (1, True)], 8)
+    def best(shape, n, sigma, sloc, full):
+        c = native.plan_predict(n, shape[0], shape[1], shape[2], sigma, sloc, full)
+        return min(c, key=c.get)
+    assert best(c3, 100_000_000, 0.10, 0.10, 0.0) == "A"
+    assert best(c3, 100_000_000, 0.99, 0.99, 0.0) == "C"
+    assert best(c3, 4_000_000, 0.10, 0.10, 0.0) == "C"
+    assert best(([(4, 0)], [(4, True)], 8), 100_000_000, 0.5, 1.0, 1.0) == "A"

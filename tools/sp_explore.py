@@ -19,6 +19,7 @@ seg = native.DeviceSegment(ctx, [
 cases = {
     "C3": ([2, 0], [(0, native.GT, 18.0), (0, native.LT, 30.0), (1, native.GT, 1e6), (1, native.LT, 9e7)], [1, 0]),
     "C4": ([1, 0, 2], [(0, native.MATCH, [b"CA"])], [1, 0, 2]),
+    "C4-id-age": ([1, 0, 2], [(0, native.MATCH, [b"CA"])], [1, 2]),       # (the same without the matched column in the SELECT list)
     "age->id": ([2, 0], [(0, native.GT, 18.0), (0, native.LT, 30.0)], [1]),
     "id2%": ([0], [(0, native.GT, 9.8e7)], [0]),
     "id50%": ([0], [(0, native.GT, 5e7)], [0]),

@@ -22,6 +22,8 @@ if case == "C4":
                                      (native.DENSE_STRING, 2, st.reshape(-1), n * 2, synth.block_offsets(n, 2)),
                                      (native.DENSE_TINYINT, 1, age.view(np.uint8), n, synth.block_offsets(n, 1))])
     q = native.DeviceQuery(ctx, seg, [1, 0, 2], [(0, native.MATCH, [b"CA"])], [1, 0, 2], 0, 1024)
+elif case == "id50%":
+    q = native.DeviceQuery(ctx, seg, [0], [(0, native.GT, 5e7)], [0], 0, 1024)
 else:
     q = native.DeviceQuery(ctx, seg, [1, 0], [(0, native.GT, 18.0), (0, native.LT, 30.0), (1, native.GT, 1e6), (1, native.LT, 9e7)], [1, 0], 0, 1024)
 ctx.set_tuning(variant, 0)
