@@ -505,7 +505,16 @@ def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True, solo: 
     per_query = {KERNEL_NAMES[i]: (v / len(queries) if v is not None else None) for i, v in k.items()}
     sel = sum(expect) / (n * len(mine))
     kernel_ms_per_query = sum(v for v in per_query.values() if v)
-    per_rank = env.gather_objects({"rank": env.rank, "segments": mine, "selected_rows": sum(expect), "kernel_ms_per_query": per_query})
+    # What became of the one-launch runs on this rank: a getter reads the last run's status word (bit 1: a look-back wait ran into its
+    # poll cap -- not every work-group resident? -- and the rows came from the bitmap instead; bit 2: another launch of the kernel
+    # owned the device).  Non-zero here on ANY rank means that rank's timings are those of the fallback, not of the plan.
+    for q in queries:
+        q.row_count()
+    plans = [q.plan() for q in queries]
+    per_rank = env.gather_objects({"rank": env.rank, "segments": mine, "selected_rows": sum(expect), "kernel_ms_per_query": per_query,
+                                   "single_pass_queries": sum(1 for p in plans if p.get("single_pass")),
+                                   "abandoned_runs": sum(int(p.get("abandoned_runs", 0)) for p in plans),
+                                   "busy_runs": sum(int(p.get("busy_runs", 0)) for p in plans)})
 
     out = None
     if env.rank == 0:
@@ -538,6 +547,8 @@ def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True, solo: 
                 "timing": "HIP events on the launching stream, second pass; frac = SURVEY 8d C3 bytes/row x rows / sum of kernel durations",
             },
             "staging": {"host_to_hbm_s_per_segment": stage_s / max(len(mine), 1), "note": "incl. synthetic generation and the parity gate; never part of value"},
+            "abandoned_runs": sum(int(r.get("abandoned_runs", 0)) for r in per_rank) if per_rank else None,
+            "busy_runs": sum(int(r.get("busy_runs", 0)) for r in per_rank) if per_rank else None,
             "per_rank": per_rank,
         }
     if graph is not None:
@@ -635,6 +646,18 @@ def extra_workloads(env: Env, steps: int = 20):
                      "kernel_ms": {KERNEL_NAMES[i]: v for i, v in k.items()}, "algorithmic_bytes": algo,
                      "frac": algo / (sum(v for v in k.values() if v) * 1e-3) / 1e9 / HBM_PEAK_GBS}
         q.close()
+    # `limit` stops the scan (Project.scala:73-80): select id from t where id > T limit 10 -- met in the first megarow (T = 5), and in
+    # the second half of the sorted key (T = 5e7: 200 MB of id lie before the first survivor, for the reference as for this path)
+    for name, thr in (() if env.args.no_limit else (("limit10_met_in_the_first_rows", 5.0), ("limit10_met_in_the_second_half", float(n // 2)))):
+        q = native.DeviceQuery(ctx, seg, [0], [(0, native.GT, thr)], [0], 10, 1024)
+        dt = env.timed_steps(lambda i: q.run(), 10, 3) / 10
+        k = env.kernel_times(q.run, 10, ids=(0, 1, 2), launches_per_run=16)
+        idx, _ = q.fetch_rows()
+        assert (idx == np.arange(int(thr) + 1, int(thr) + 11)).all()
+        out[name] = {"query": f"select id from t where id > {int(thr)} limit 10", "ms_per_query": dt * 1e3,
+                     "kernel_ms": {KERNEL_NAMES[i]: v for i, v in k.items()}, "kernel_ms_sum": sum(v for v in k.values() if v),
+                     "note": "HIP events read ~3 us high per launch on launches that leave at once; profiles/ holds the rocprofv3 dispatch durations"}
+        q.close()
     seg.close()
     # host -> HBM staging of 400 MB columns (the step before the path): synchronous create, and three asynchronous creates on
     # the context's copy stream while the query stream keeps scanning (what SegmentManager's start-up looks like here)
@@ -695,6 +718,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="C5: launch every pass kernel by kernel instead of replaying the recorded hipGraph")
     ap.add_argument("--no-g1", action="store_true", help="N > 1: skip the solo leg (every rank runs the whole C5 job on its own GPU: the G = 1 point)")
     ap.add_argument("--no-c5", action="store_true", help="leave the C5 leg out of the extra block (profiling runs: its kernels are C3's instances)")
+    ap.add_argument("--no-limit", action="store_true", help="leave the `limit` queries out of the extra block (profiling runs: their chunks are launches of the headline kernel's instance)")
     ap.add_argument("--extra", action="store_true", help="(kept for compatibility: the extra block is on by default)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--grid", type=int, default=0)
@@ -717,7 +741,7 @@ def main():
     if env.rank == 0:
         result = dict(base, scaling="weak", dtype="i32", **{k: c2[k] for k in ("value", "ms_per_step", "ms_per_step_with_kernel_events", "config", "roofline", "staging", "per_rank")})
         result["cpu_baseline"] = c2.get("cpu_baseline") if env.world == 1 else None     # timed at N = 1 only (contract)
-    c5_keys = ("value", "ms_per_step", "launch", "ms_per_step_kernel_by_kernel", "global_selected_rows_per_pass", "count_allreduce", "config", "roofline", "per_rank")
+    c5_keys = ("value", "ms_per_step", "launch", "ms_per_step_kernel_by_kernel", "global_selected_rows_per_pass", "count_allreduce", "config", "roofline", "abandoned_runs", "busy_runs", "per_rank")
     if env.world == 1:
         if not args.no_extra:
             extra = extra_workloads(env)
