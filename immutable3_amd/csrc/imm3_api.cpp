@@ -871,6 +871,7 @@ static void query_free(imm3_query *q) {
     pool_release(ctx, q->d_tile_offsets);
     pool_release(ctx, q->d_chunk_sums);
     pool_release(ctx, q->d_block_partials);
+    pool_release(ctx, q->d_limit_state);
     pool_release(ctx, q->d_total);
     pool_release(ctx, q->d_word_row_base);
     pool_release(ctx, q->d_word_nvalid);
@@ -1577,6 +1578,11 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
     q->d_chunk_sums = (uint32_t *)p;
     HIPCHK(pool_alloc(ctx, &p, kMaxFilterGrid * sizeof(uint32_t)));
     q->d_block_partials = (uint32_t *)p;
+    if (limit > 0 && limit <= kLimitGatherMaxRows && !table) { // (k_limit_gather's per-work-group counts: pooled memory, so cleared -- a run's tag is never zero)
+        HIPCHK(pool_alloc(ctx, &p, 256 * sizeof(unsigned long long)));
+        q->d_limit_state = (unsigned long long *)p;
+        HIPCHK(hipMemsetAsync(q->d_limit_state, 0, 256 * sizeof(unsigned long long), ctx->stream));
+    }
     HIPCHK(pool_alloc(ctx, &p, kFinishWords * sizeof(unsigned long long))); // {total, n_emit, status, limit, tally, log, log index, log capacity}, then the sub-tallies (imm3_device.h)
     q->d_total = (unsigned long long *)p;
     q->d_n_emit = q->d_total + 1;
@@ -2528,9 +2534,56 @@ static int launch_project(imm3_query *q) {
     return IMM3_OK;
 }
 
+// A small limit behind a limit scan: the offsets scan and the gather in ONE launch over the scanned tiles (k_limit_gather).
+// `select id ... limit 10`: 7 + 9 us of k_scan + k_gather -> ~5.  Tuning variant 15: off.
+constexpr int kLimitGatherGrid = 256;
+static bool limit_gather_applies(const imm3_query *q) {
+    if (!q->select_partial || !(q->limit > 0) || q->limit > kLimitGatherMaxRows || q->table || q->d_word_row_base || q->stage_written || q->ctx->filter_variant == 15) return false;
+    if (q->n_chunks > (int64_t)kLimitGatherGrid * kLimitGatherMaxChunks || q->proj.size() > (size_t)kMaxProj || !q->d_limit_state) return false;
+    for (int32_t pj : q->proj) {
+        const SegCol &sc = q->seg->cols[(size_t)q->used[(size_t)pj]];
+        if (!col_flat(sc) || (sc.width != 1 && sc.width != 2 && sc.width != 4)) return false;
+    }
+    return true;
+}
+static int launch_limit_gather_for(imm3_query *q) {
+    imm3_ctx *ctx = q->ctx;
+    LimitGatherArgs g;
+    std::memset(&g, 0, sizeof(g));
+    g.bitmap = q->d_bitmap;
+    g.finish = q->d_total;
+    g.wg_state = q->d_limit_state;
+    g.n_tiles = q->n_tiles;
+    g.limit = q->limit;
+    g.cap_rows = q->cap_rows;
+    g.row_index = q->d_row_index;
+    g.n_proj = (int32_t)q->proj.size();
+    for (size_t j = 0; j < q->proj.size(); ++j) {
+        const SegCol &sc = q->seg->cols[(size_t)q->used[(size_t)q->proj[j]]];
+        g.proj[j].src = col_flat(sc);
+        g.proj[j].dst = q->d_proj[j];
+        g.proj[j].width = sc.width;
+    }
+    LaunchTimer t(ctx, 2);
+    launch_limit_gather(g, (int)std::min<int64_t>(kLimitGatherGrid, std::max<int64_t>(q->n_chunks, 1)), ctx->stream, t.start, t.stop);
+    HIPCHK(hipGetLastError());
+    return IMM3_OK;
+}
+
 static int run_project(imm3_query *q) {
     imm3_ctx *ctx = q->ctx;
     hipStream_t s = ctx->stream;
+    if (q->n_tiles > 0 && limit_gather_applies(q)) {
+        if (!q->d_row_index) {
+            const int rc = ensure_row_capacity(q, 1);
+            if (rc) return rc;
+        }
+        const int rc = launch_limit_gather_for(q);
+        if (rc) return rc;
+        q->offsets_valid = false; // (no offsets scan has run on this bitmap)
+        q->ran_project = true;
+        return IMM3_OK;
+    }
     if (q->n_tiles > 0) {
         ScanArgs sa;
         std::memset(&sa, 0, sizeof(sa));

@@ -204,6 +204,7 @@ struct imm3_query {
     // device buffers
     uint64_t *d_bitmap = nullptr;
     uint32_t *d_tile_offsets = nullptr, *d_chunk_sums = nullptr, *d_block_partials = nullptr;
+    unsigned long long *d_limit_state = nullptr; // k_limit_gather: per-work-group survivor counts, tagged with the run (small limits only)
     unsigned long long *d_total = nullptr, *d_n_emit = nullptr; // adjacent: d_n_emit = d_total + 1; d_total + 2 = status word
     bool has_pfor_pass = false;   // a k_filter_pfor pass may flag malformed blocks in the status word
     std::vector<unsigned long long> h_init; // host image of the whole finish block at creation (copied asynchronously: lives with the query)

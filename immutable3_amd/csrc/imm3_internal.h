@@ -328,6 +328,22 @@ struct GatherArgs {
     const unsigned long long *scanned_tiles; // a limit scan stopped early: only spans below *scanned_tiles are walked; null: all
 };
 
+// k_limit_gather: the offsets scan and the gather of a SMALL `limit` in one launch, over the tiles a limit scan got to.
+constexpr int kLimitGatherMaxChunks = 64;   // chunks of 256 tiles per work-group at most (the launch has one work-group per CU)
+constexpr int64_t kLimitGatherMaxRows = 4096;
+struct LimitGatherArgs {
+    const uint64_t *bitmap;
+    const unsigned long long *finish;  // [kFinishLimitTiles] = tiles scanned, [kFinishEpoch] = the run's tag
+    unsigned long long *wg_state;      // [grid]: (tag << 40) | survivors of the work-group's tiles
+    int64_t n_tiles;
+    int64_t limit;
+    uint64_t cap_rows;
+    uint32_t *row_index;
+    ProjCol proj[kMaxProj];
+    int32_t n_proj;
+    int32_t pad;
+};
+
 // launchers (imm3_kernels.hip)
 // ---- group-by aggregation (imm3_agg.hip) ----
 constexpr int kMaxGroupCols = 4;
@@ -463,6 +479,7 @@ void launch_total(const TotalArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t 
 void launch_read_stream(const int32_t *data, int64_t n_tiles, int32_t *sink, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 void launch_scan(const ScanArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 void launch_gather(const GatherArgs &a, int grid_blocks, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+void launch_limit_gather(const LimitGatherArgs &a, int grid_blocks, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
 
 } // namespace imm3
 

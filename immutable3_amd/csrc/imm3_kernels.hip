@@ -987,6 +987,112 @@ void launch_total(const TotalArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t 
     IMM3_LAUNCH(k_total, 1, 64, s, ev0, ev1, a);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_limit_gather: ProjectOp with a small limit, behind a limit scan (run_select's chunks): the first `limit` survivors of the tiles
+// that were scanned, in one launch instead of k_scan + k_gather (7 + 9 us for ten rows).  Work-group b takes a CONTIGUOUS piece of
+// the scanned tiles (K chunks of 256 tiles, K from the scanned-tile word): it counts its survivors, publishes the count tagged with
+// the run, and adds up the counts of the work-groups before it -- which were dispatched before it, so the wait cannot deadlock
+// whatever is resident -- to know its first output row.  A work-group whose first row is already behind the limit leaves; the few
+// that are not walk their tiles again (the lines are in the L2) and emit row numbers and column values row by row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kChunkTiles) void k_limit_gather(const LimitGatherArgs a) {
+    __shared__ uint32_t s_wave[kChunkTiles / 64];
+    __shared__ uint32_t s_chunk_total[kLimitGatherMaxChunks];
+    __shared__ unsigned long long s_base;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t scanned = (int64_t)a.finish[kFinishLimitTiles] < a.n_tiles ? (int64_t)a.finish[kFinishLimitTiles] : a.n_tiles;
+    const unsigned long long tag = ((a.finish[kFinishEpoch] & 0x7FFFFFULL) << 1) | 1ULL; // (24 bits, never zero: the counts start out cleared)
+    const int64_t n_chunks = (scanned + kChunkTiles - 1) / kChunkTiles;
+    const int64_t K = (n_chunks + gridDim.x - 1) / gridDim.x; // (<= kLimitGatherMaxChunks: the host checks n_tiles against the grid)
+    const int64_t chunk0 = (int64_t)blockIdx.x * K;
+    // this work-group's tiles: counts per chunk (block-wide), and the sum
+    auto tile_count = [&](int64_t tile) -> uint32_t {
+        if (tile >= scanned) return 0u;
+        const uint4 *p = (const uint4 *)(a.bitmap + tile * kTileWords);
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < kTileWords / 2; ++i) {
+            const uint4 v = p[i];
+            c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+        }
+        return c;
+    };
+    // inclusive scan of one value per thread over the work-group; returns the thread's exclusive prefix, total in `total`
+    auto block_scan = [&](uint32_t c, uint32_t &total) -> uint32_t {
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        __syncthreads(); // (s_wave of the previous call has been read)
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        total = 0;
+#pragma unroll
+        for (int i = 0; i < kChunkTiles / 64; ++i) {
+            if (i < wave) before += s_wave[i];
+            total += s_wave[i];
+        }
+        return incl - c + before;
+    };
+    unsigned long long mine = 0;
+    for (int64_t k = 0; k < K; ++k) {
+        uint32_t total;
+        (void)block_scan(tile_count((chunk0 + k) * kChunkTiles + t), total);
+        if (t == 0) s_chunk_total[k] = total;
+        mine += total;
+    }
+    if (t == 0) __hip_atomic_store(a.wg_state + blockIdx.x, (tag << 40) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the survivors before this work-group's tiles: the counts of the work-groups before it (enough of them: once the sum has
+    // reached the limit the rest does not matter)
+    if (wave == 0) {
+        unsigned long long base = 0;
+        for (int64_t b0 = 0; b0 < (int64_t)blockIdx.x && base < (unsigned long long)a.limit; b0 += 64) {
+            const int64_t b = b0 + lane;
+            unsigned long long v = 0;
+            if (b < (int64_t)blockIdx.x) {
+                do v = __hip_atomic_load(a.wg_state + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while ((v >> 40) != tag);
+                v &= (1ULL << 40) - 1ULL;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+            base += v;
+        }
+        if (lane == 0) s_base = base;
+    }
+    __syncthreads();
+    unsigned long long base = s_base;
+    const unsigned long long stop = (unsigned long long)a.limit < a.cap_rows ? (unsigned long long)a.limit : a.cap_rows;
+    if (base >= stop || mine == 0) return; // block-uniform
+    for (int64_t k = 0; k < K && base < stop; ++k) {
+        const int64_t tile = (chunk0 + k) * kChunkTiles + t;
+        uint32_t total;
+        const uint32_t cnt = tile_count(tile);
+        unsigned long long out = base + block_scan(cnt, total);
+        if (cnt && out < stop) {
+            for (int w = 0; w < kTileWords && out < stop; ++w) {
+                uint64_t word = a.bitmap[tile * kTileWords + w];
+                while (word && out < stop) {
+                    const int64_t row = tile * kTileRows + 64 * w + __builtin_ctzll(word);
+                    word &= word - 1;
+                    a.row_index[out] = (uint32_t)row;
+                    for (int pj = 0; pj < a.n_proj; ++pj)
+                        store_value_rt(a.proj[pj].dst, a.proj[pj].width, out, load_value_rt(a.proj[pj].src, a.proj[pj].width, row));
+                    ++out;
+                }
+            }
+        }
+        base += total;
+    }
+}
+
+void launch_limit_gather(const LimitGatherArgs &a, int grid_blocks, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    IMM3_LAUNCH(k_limit_gather, grid_blocks < 1 ? 1 : grid_blocks, kChunkTiles, s, ev0, ev1, a);
+}
+
 void launch_scan(const ScanArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     const int grid = (int)((a.n_tiles + kChunkTiles - 1) / kChunkTiles);
     IMM3_LAUNCH(k_scan, grid < 1 ? 1 : grid, kChunkTiles, s, ev0, ev1, a);

@@ -46,6 +46,7 @@ int imm3_ctx_measure_read_gbps(imm3_ctx *ctx, uint64_t bytes, int32_t iters, dou
  * then adapts from the first run's count on), 11 = survivor records are staged even when no predicate column is projected,
  * 12 = the plan made at creation stands whatever the cost model predicts (tests of one plan's kernels; P still adapts),
  * 14 = a `limit` query scans the whole segment in one launch instead of in chunks behind a limit-reached word (decided per run),
+ * 15 = a small limit behind a limit scan takes k_scan + k_gather instead of the one fused launch (k_limit_gather),
  * 200 + P = fixed tiles per range. */
 int imm3_ctx_set_tuning(imm3_ctx *ctx, int32_t filter_variant, int32_t grid_blocks);
 

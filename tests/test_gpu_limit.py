@@ -43,6 +43,7 @@ CASES = {
     "no survivor": ([1, 0], [(0, GT, 100.0)], [1], lambda i, a, s: np.zeros(i.shape[0], bool)),
     "string match, three columns": ([2, 0, 1], [(0, MATCH, [b"CA"])], [1, 0, 2], lambda i, a, s: (s[:, 0] == ord("C")) & (s[:, 1] == ord("A"))),
     "half of the rows": ([1, 0], [(0, GT, 49.0), (1, GT, 5.0)], [1, 0], lambda i, a, s: (a > 49) & (i > 5)),
+    "one row in five thousand": ([1, 2, 0], [(0, GT, 98.0), (1, MATCH, [b"CA"])], [2, 0, 1], lambda i, a, s: (a > 98) & (s[:, 0] == ord("C")) & (s[:, 1] == ord("A"))),
 }
 
 
@@ -53,7 +54,7 @@ def test_rows_are_the_first_survivors_and_count_and_bitmap_stay_exact(ctx, seg13
     used, sels, proj, keepf = CASES[name]
     keep = keepf(ids, age, st)
     rows = np.flatnonzero(keep)
-    for limit in (1, 10, 1_000_000, 5_000_000):
+    for limit in (1, 10, 1000, 4096, 4097, 1_000_000, 5_000_000):     # (up to 4096 rows: the offsets scan and the gather are one launch, k_limit_gather)
         q = native.DeviceQuery(ctx, seg, used, sels, proj, limit)
         want = rows[:limit]
         for rnd in range(2):
@@ -84,7 +85,7 @@ def test_against_the_oracle_and_in_a_graph(ctx, oracle):
     sels = [(0, GT, 18.0), (0, LT, 30.0), (1, GT, 100.0)]
     ocols = [cols[1].ocol(), cols[0].ocol()]
     words, total = oracle.scan_select(ocols, sels, 1024)
-    for limit in (10, 1500, 200_000):
+    for limit in (10, 1500, 4096, 200_000):
         cnt, batch, pos, ovals, _ = oracle.project(ocols, [1, 0], limit, 1024, words)
         pos = batch.astype(np.int64) * 1024 + pos                     # (batch, position in the batch) -> row of the segment: every block holds 1024 rows
         q = native.DeviceQuery(ctx, seg, [1, 0], sels, [1, 0], limit)

@@ -15,7 +15,7 @@ ctx = native.Context(0)
 ids = np.arange(n, dtype=np.int32)
 seg = native.DeviceSegment(ctx, [(native.DENSE_INT, 4, ids.view(np.uint8), n * 4, synth.block_offsets(n, 4))])
 for thr in thresholds:
-    for variant in (0, 14):
+    for variant in (0, 15, 14):
         ctx.set_tuning(variant, 0)            # (chunking is decided when the run is enqueued)
         q = native.DeviceQuery(ctx, seg, [0], [(0, native.GT, thr)], [0], 10)
         for _ in range(3):
@@ -32,7 +32,7 @@ for thr in thresholds:
         idx, _ = q.fetch_rows()
         assert (idx == np.arange(int(thr) + 1, int(thr) + 11)).all()
         per = {i: float(k.sum()) * 1e3 / reps for i, k in ks.items() if k.size}
-        print(f"rows {n} id > {thr:.0f} limit 10, {'whole select' if variant else 'limit scan  '}: "
+        print(f"rows {n} id > {thr:.0f} limit 10, { {0: 'limit scan, fused gather  ', 15: 'limit scan, k_scan + gather', 14: 'whole select               '}[variant] }: "
               + "  ".join(f"slot{i} {v:.1f} us ({ks[i].size // reps} launches)" for i, v in per.items()) + f"  sum {sum(per.values()):.1f} us", flush=True)
         q.close()
         ctx.set_tuning(0, 0)
