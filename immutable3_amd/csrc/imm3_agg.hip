@@ -810,6 +810,7 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
     __syncthreads();
     if (t == 0) S.npages = 1; // page 0 is the null page
     __syncthreads();
+    if (IMM3_ABLATED(a, 46)) return; // (timing only: the launch and the clearing of the tables)
 
     uint32_t vflip = 0, vmask = 0;
     bool vstr = false;
@@ -866,23 +867,33 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
         for (int p = 0; p < kWords; ++p) {
             const int slot = 64 * p + lane;
             uint32_t c = 0;
+            // (eight reads, then their eight writes: with a write behind every read the compiler -- which cannot know that the rotated
+            // indices never collide -- kept the 64 round trips in sequence)
             if constexpr (V2) {
                 uint32_t *row = (uint32_t *)wbase + slot * 64;
-#pragma unroll 4
-                for (int j = 0; j < 64; ++j) {
-                    const int idx = (j + lane) & 63;
-                    const uint32_t e = row[idx];
-                    c += e & 0xFFu;
-                    row[idx] = e & ~0xFFu;
+#pragma unroll 1
+                for (int j0 = 0; j0 < 64; j0 += 8) {
+                    uint32_t e[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) e[k] = row[(j0 + k + lane) & 63];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        c += e[k] & 0xFFu;
+                        row[(j0 + k + lane) & 63] = e[k] & ~0xFFu;
+                    }
                 }
             } else {
                 uint16_t *row = (uint16_t *)wbase + slot * 64;
-#pragma unroll 4
-                for (int j = 0; j < 64; ++j) {
-                    const int idx = (j + lane) & 63;
-                    const uint32_t e = row[idx];
-                    c += e & 0xFFu;
-                    row[idx] = (uint16_t)(e & 0xFF00u);
+#pragma unroll 1
+                for (int j0 = 0; j0 < 64; j0 += 8) {
+                    uint32_t e[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) e[k] = row[(j0 + k + lane) & 63];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        c += e[k] & 0xFFu;
+                        row[(j0 + k + lane) & 63] = (uint16_t)(e[k] & 0xFF00u);
+                    }
                 }
             }
             wcnt[slot] += c;
@@ -1036,6 +1047,22 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
                             }
                     }
                 }
+                // ... and every lane looks its other pending keys up again: the 64 lanes of this wave -- and the other waves of the
+                // work-group -- have just placed up to one key each, which is nearly always all there are (51 states: two rounds
+                // instead of the ~15 a lane needed for the distinct keys of its own sixteen rows, one map update at a time)
+                if (ballot64(pend != 0u) && !IMM3_ABLATED(a, 49)) { // wave-uniform
+                    asm volatile("" ::: "memory"); // (the map is read again, not taken from registers)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        uint32_t again;
+                        if constexpr (KS == 0) again = S.l2[256 + key[i]];
+                        else again = S.l2[(min((uint32_t)S.l1[key[i] & 0xFFu], (uint32_t)kLanePages) << 8) | (key[i] >> 8)];
+                        if (((pend >> i) & 1u) && again < (uint32_t)NS) {
+                            sid[i] = again;
+                            pend &= ~(1u << i);
+                        }
+                    }
+                }
             }
             if (ballot64(pend != 0u)) *a.overflow = 3; // (never seen: a claimed byte is published a few instructions later)
 #pragma unroll
@@ -1090,7 +1117,11 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
     TileRegs R[kDepth];
 #pragma unroll
     for (int d = 0; d < kDepth; ++d) issue(R[d], first_tile + d * stride);
-    for (int64_t base = first_tile; base < a.n_tiles; base += kDepth * stride) {
+    // (Tried: the work-group's first wave takes its first tile alone while the others wait, so that one wave places the keys all
+    // sixteen would otherwise place at once -- slower, 96 -> 104 us at 100 M rows.  What a wave's first tile costs, ~18 us against
+    // ~2.5 for a later one (group by state over 1 M rows: 33 us = 4 launch + clearing, 8 fold, 3 loads, 18 the tiles), is its own
+    // first-seen bookkeeping -- an LDS atomicMin per row until the wave has met every slot -- not the collisions in the map.)
+    for (int64_t base = first_tile; base < (IMM3_ABLATED(a, 47) ? 0 : a.n_tiles); base += kDepth * stride) { // (47, timing only: no tile at all)
 #pragma unroll
         for (int d = 0; d < kDepth; ++d) {
             const int64_t tile = base + d * stride;
@@ -1117,7 +1148,8 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
         const int slot = 64 * p + lane;
         uint32_t c = 0, m = 0, m2 = 0;
         if constexpr (VW == 1) c = wcnt[slot];
-        for (int l = 0; l < 64; ++l) {
+#pragma unroll 8
+        for (int l = 0; l < 64; ++l) { // (eight reads in flight: rolled, this was 64 dependent LDS round trips per wave)
             const int src = (l + lane) & 63;
             if constexpr (V2) {
                 const uint32_t e = ((const uint32_t *)wbase)[slot * 64 + src];
@@ -1145,6 +1177,7 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
     __syncthreads();
     // flush: one atomic set per (work-group, group), widened to what the global table holds
     const uint32_t n_slots = S.nslots < kTrash ? S.nslots : kTrash;
+    if (IMM3_ABLATED(a, 48)) return; // (timing only: no flush to the global table)
     if ((uint32_t)t < n_slots && S.count[t]) {
         const uint32_t g = global_slot(a, (unsigned long long)S.slotkey[t]);
         if (g != 0xFFFFFFFFu) {
