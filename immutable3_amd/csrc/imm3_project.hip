@@ -259,11 +259,24 @@ constexpr int kProjSlots = 4;   // published ranges a streamer may have waiting 
 // written row by row.  (The first version walked run-time column descriptors per row: 2.5 wave instructions per record and
 // pass, 60 % of what the streamers execute -- the writers were the bottleneck at ~50 us per span.)
 // ---------------------------------------------------------------------------------------------
-template <int W>
+// (the rows are written once and read by nobody on the device: non-temporal stores, NT = false for A/B runs)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+template <int W, bool NT = true>
 __device__ __forceinline__ void store_quad_w(void *dst, uint32_t out0, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3) {
-    if constexpr (W == 4) *(uint4 *)((uint32_t *)dst + out0) = make_uint4(v0, v1, v2, v3);
-    else if constexpr (W == 2) *(uint2 *)((uint16_t *)dst + out0) = make_uint2((v0 & 0xFFFFu) | (v1 << 16), (v2 & 0xFFFFu) | (v3 << 16));
-    else *(uint32_t *)((uint8_t *)dst + out0) = (v0 & 0xFFu) | ((v1 & 0xFFu) << 8) | ((v2 & 0xFFu) << 16) | (v3 << 24);
+    if constexpr (W == 4) {
+        const u32x4_t q = {v0, v1, v2, v3};
+        if constexpr (NT) __builtin_nontemporal_store(q, (u32x4_t *)((uint32_t *)dst + out0));
+        else *(u32x4_t *)((uint32_t *)dst + out0) = q;
+    } else if constexpr (W == 2) {
+        const u32x2_t q = {(v0 & 0xFFFFu) | (v1 << 16), (v2 & 0xFFFFu) | (v3 << 16)};
+        if constexpr (NT) __builtin_nontemporal_store(q, (u32x2_t *)((uint16_t *)dst + out0));
+        else *(u32x2_t *)((uint16_t *)dst + out0) = q;
+    } else {
+        const uint32_t q = (v0 & 0xFFu) | ((v1 & 0xFFu) << 8) | ((v2 & 0xFFu) << 16) | (v3 << 24);
+        if constexpr (NT) __builtin_nontemporal_store(q, (uint32_t *)((uint8_t *)dst + out0));
+        else *(uint32_t *)((uint8_t *)dst + out0) = q;
+    }
 }
 constexpr int kind_width(int k) { return k == TK_I32 ? 4 : (k == TK_S2 ? 2 : 1); }
 
@@ -276,7 +289,7 @@ __device__ __forceinline__ void rec_words(const typename RecVec<R>::type &r, uin
 
 // predicate column K (compile time) of a quad of records -> dst
 template <int K0, int K1, int K2, int K>
-__device__ __forceinline__ void store_pred_col(void *dst, const uint32_t (&rw)[4][4], const bool (&ok)[4], bool whole, uint32_t out0) {
+__device__ __forceinline__ void store_pred_col(void *dst, const uint32_t (&rw)[4][4], const bool (&ok)[4], bool whole, uint32_t out0, bool plain = false) {
     constexpr int kinds[3] = {K0, K1, K2};
     if constexpr (kinds[K] != TK_NONE) {
         if (!dst) return; // wave-uniform: the column is not in the SELECT list
@@ -285,8 +298,10 @@ __device__ __forceinline__ void store_pred_col(void *dst, const uint32_t (&rw)[4
         uint32_t v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = rw[e][f.dword] >> f.shift;
-        if (whole) store_quad_w<W>(dst, out0, v[0], v[1], v[2], v[3]);
-        else {
+        if (whole) {
+            if (plain) store_quad_w<W, false>(dst, out0, v[0], v[1], v[2], v[3]);
+            else store_quad_w<W, true>(dst, out0, v[0], v[1], v[2], v[3]);
+        } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (ok[e]) store_value<W>(dst, out0 + e, v[e]);
@@ -390,15 +405,18 @@ __device__ __forceinline__ void unpack_range(const ProjectArgs &a, const typenam
         uint32_t rowv[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) rowv[e] = tile0 * (uint32_t)kTileRows + (rw[e][0] >> 16); // (the record's position in its range rides on top of dword 0)
-        if (whole) *(uint4 *)(row_index + out0) = make_uint4(rowv[0], rowv[1], rowv[2], rowv[3]);
-        else {
+        const bool plain = IMM3_ABLATE_BIT(a, 32); // (A/B: plain instead of non-temporal stores)
+        if (whole) {
+            if (plain) store_quad_w<4, false>(row_index, out0, rowv[0], rowv[1], rowv[2], rowv[3]);
+            else store_quad_w<4, true>(row_index, out0, rowv[0], rowv[1], rowv[2], rowv[3]);
+        } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
                 if (ok[e]) row_index[out0 + e] = rowv[e];
         }
-        store_pred_col<K0, K1, K2, 0>(d0, rw, ok, whole, out0);
-        store_pred_col<K0, K1, K2, 1>(d1, rw, ok, whole, out0);
-        store_pred_col<K0, K1, K2, 2>(d2, rw, ok, whole, out0);
+        store_pred_col<K0, K1, K2, 0>(d0, rw, ok, whole, out0, plain);
+        store_pred_col<K0, K1, K2, 1>(d1, rw, ok, whole, out0, plain);
+        store_pred_col<K0, K1, K2, 2>(d2, rw, ok, whole, out0, plain);
     }
     // ---- SELECT-list columns that are not predicate columns: gathered at the records' rows
     switch (a.n_gather) { // wave-uniform

@@ -1,6 +1,6 @@
 # the round's profiling session (profiles/README.md): kernel trace + stats, FETCH_SIZE and WRITE_SIZE passes of the bench command,
 # the un-profiled tools.  usage: bash tools/gpu/r4_profile.sh <tag>
-TAG=${1:-r04a}
+TAG=${1:-r04b}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 G=gpurun_out
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $G/${TAG}_trace -o $TAG -- python3 bench.py --no-cpu-baseline --no-c5 --no-limit > $G/${TAG}_trace.log 2>$G/${TAG}_trace.err || { tail -5 $G/${TAG}_trace.err; exit 1; }
