@@ -655,3 +655,43 @@ def test_survivors_between_the_sample_points(ctx, big):
         ok, cost = model_accepts(plan_kind(q.plan()), n, data, used, sels, proj, keep, clustered=True, slack=1.25)
         assert ok, (used, first, q.plan(), cost)
         q.close()
+
+
+def test_string_records_sparse_and_dense_tiles(big):
+    """Survivor records of a lone 2-byte string column (C4's shape: state in (...) -> id, state, ...): tiles with few survivors are
+    staged lane-consecutively (s2_sparse_tile, csrc/imm3_kernels.hip), tiles with many the row-strided way, in the same launch --
+    one value (2 %), three (6 %: both forms side by side around 60 survivors per tile... all sparse), eight (16 %: mostly the
+    row-strided form).  Rows, values and their order against numpy; the records plan forced (tuning variant 6)."""
+    n, data, seg0 = big
+    a, b, c, d, s2 = data
+    ctx6 = native.Context(0)
+    br = blocks_of(n, 1024)
+    cols = [RawColumn(DENSE_INT, 4, a, br), RawColumn(DENSE_INT, 4, b, br), RawColumn(DENSE_TINYINT, 1, c, br),
+            RawColumn(DENSE_TINYINT, 1, d, br), RawColumn(DENSE_STRING, 2, s2, br)]
+    seg = native.DeviceSegment(ctx6, [x.native() for x in cols])
+    uniq = [bytes(x) for x in np.unique(s2, axis=0)]
+    try:
+        ctx6.set_tuning(6, 0)
+        for m in (1, 3, 5, 8):
+            lst = uniq[3:3 + m]
+            keep = np.zeros(n, bool)
+            for v in lst:
+                keep |= (s2[:, 0] == v[0]) & (s2[:, 1] == v[1])
+            rows = np.flatnonzero(keep)
+            for used, proj in (([4, 1], [1, 0]), ([4, 0, 2], [0, 2, 1, 0])):
+                q = native.DeviceQuery(ctx6, seg, used, [(0, MATCH, lst)], proj, 0)
+                assert q.plan()["records"] and not q.plan()["single_pass"], q.plan()
+                for rnd in range(2):
+                    q.run()
+                    assert q.count() == rows.size, (m, rnd)
+                    assert q.bitmap().tobytes() == np.packbits(keep, bitorder="little").tobytes()[: q.total_words * 8].ljust(q.total_words * 8, b"\0"), (m, rnd)
+                    idx, vals = q.fetch_rows()
+                    assert idx.size == rows.size and (idx == rows).all(), (m, rnd)
+                    for j, pj in enumerate(proj):
+                        assert vals[j].tobytes() == np.ascontiguousarray(data[used[pj]][rows]).tobytes(), (m, rnd, j)
+                assert q.plan()["records"], q.plan()
+                q.close()
+    finally:
+        ctx6.set_tuning(0, 0)
+        seg.close()
+        ctx6.close()
