@@ -658,10 +658,9 @@ def test_survivors_between_the_sample_points(ctx, big):
 
 
 def test_string_records_sparse_and_dense_tiles(big):
-    """Survivor records of a lone 2-byte string column (C4's shape: state in (...) -> id, state, ...): tiles with few survivors are
-    staged lane-consecutively (s2_sparse_tile, csrc/imm3_kernels.hip), tiles with many the row-strided way, in the same launch --
-    one value (2 %), three (6 %: both forms side by side around 60 survivors per tile... all sparse), eight (16 %: mostly the
-    row-strided form).  Rows, values and their order against numpy; the records plan forced (tuning variant 6)."""
+    """Survivor records of a lone 2-byte string column (C4's shape: state in (...) -> id, state, ...) from 2 % to 16 % survivors
+    (one, three, five and eight IN-list values), with one and with two gathered columns and a second mention: rows, values and their
+    order against numpy; the records plan forced (tuning variant 6: the cost model would take the bitmap path at this size)."""
     n, data, seg0 = big
     a, b, c, d, s2 = data
     ctx6 = native.Context(0)
