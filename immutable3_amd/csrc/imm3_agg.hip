@@ -1353,31 +1353,80 @@ void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_
     IMM3_LAUNCH(k_group_agg, grid, kAggThreads, s, ev0, ev1, a);
 }
 
-// ---- merge of group tables (imm3_comm_merge_groups): direct-indexed tables for keys of <= 2 bytes ----
+// ---- merge of group tables (imm3_comm_merge_groups): direct-indexed tables for keys of <= 2 bytes, a hash table for wider keys ----
 __global__ __launch_bounds__(kBlockThreads) void k_merge_init(const MergeArgs a) {
     for (uint32_t i = blockIdx.x * kBlockThreads + threadIdx.x; i < a.slots; i += gridDim.x * kBlockThreads) {
         a.t_counts[i] = 0ULL;
         a.t_first[i] = ~0ULL;
+        if (a.t_keys) a.t_keys[i] = kEmptyKey;
         for (int j = 0; j < kMaxAggs; ++j) {
             const int kind = j < a.n_agg ? a.kinds[j] : AGG_COUNT;
             a.t_vals[(size_t)j * a.slots + i] = kind == AGG_MIN ? INT64_MAX : ((j < a.n_agg && a.is_str[j]) ? 0 : INT64_MIN);
         }
     }
+    if (a.out_n && blockIdx.x == 0 && threadIdx.x == 0) *a.out_n = 0ULL;
 }
 
+// the key's slot: the key itself in a direct table; in the hash table the first slot from its hash on that is free (claimed with a
+// compare-and-swap) or already the key's.  The table holds at least twice the entries that can arrive.
+__device__ __forceinline__ uint32_t merge_slot(const MergeArgs &a, unsigned long long key) {
+    if (!a.t_keys) return key < a.slots ? (uint32_t)key : 0xFFFFFFFFu; // (a key is narrower than its direct table)
+    if (key == kEmptyKey) return a.mask + 1;
+    uint32_t g = (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> 32) & a.mask;
+    for (uint32_t probes = 0; probes <= a.mask; ++probes) {
+        const unsigned long long prev = atomicCAS(&a.t_keys[g], kEmptyKey, key);
+        if (prev == kEmptyKey || prev == key) return g;
+        g = (g + 1) & a.mask;
+    }
+    return 0xFFFFFFFFu;
+}
+__device__ __forceinline__ void merge_update(const MergeArgs &a, uint32_t slot, unsigned long long first, unsigned long long count, const long long *vals) {
+    if (slot == 0xFFFFFFFFu) return;
+    atomicAdd(a.t_counts + slot, count);
+    atomicMin(a.t_first + slot, first);
+    for (int j = 0; j < a.n_agg; ++j) {
+        const long long v = vals[j];
+        long long *t = a.t_vals + (size_t)j * a.slots + slot;
+        if (a.kinds[j] == AGG_MAX) {
+            if (a.is_str[j]) atomicMax((unsigned long long *)t, (unsigned long long)v);
+            else atomicMax(t, v);
+        } else if (a.kinds[j] == AGG_MIN) atomicMin(t, v);
+    }
+}
+
+// one query's dense group list (k_group_collect's output) into the table
 __global__ __launch_bounds__(kBlockThreads) void k_merge_scatter(const MergeArgs a) {
+    for (uint32_t g = blockIdx.x * kBlockThreads + threadIdx.x; g < a.n_groups; g += gridDim.x * kBlockThreads)
+        merge_update(a, merge_slot(a, a.keys[g]), a.seg_hi | (unsigned long long)a.first[g], a.counts[g], a.vals + (size_t)g * kMaxAggs);
+}
+// a packed list (the ranks' lists after the all-gather; padding entries have count 0) into the table
+__global__ __launch_bounds__(kBlockThreads) void k_merge_insert_list(const MergeArgs a) {
     for (uint32_t g = blockIdx.x * kBlockThreads + threadIdx.x; g < a.n_groups; g += gridDim.x * kBlockThreads) {
-        const uint32_t slot = (uint32_t)a.keys[g];
-        if (slot >= a.slots) continue; // (cannot happen: the key is narrower than the table)
-        atomicAdd(a.t_counts + slot, a.counts[g]);
-        atomicMin(a.t_first + slot, a.seg_hi | (unsigned long long)a.first[g]);
-        for (int j = 0; j < a.n_agg; ++j) {
-            const long long v = a.vals[(size_t)g * kMaxAggs + j];
-            long long *t = a.t_vals + (size_t)j * a.slots + slot;
-            if (a.kinds[j] == AGG_MAX) {
-                if (a.is_str[j]) atomicMax((unsigned long long *)t, (unsigned long long)v);
-                else atomicMax(t, v);
-            } else if (a.kinds[j] == AGG_MIN) atomicMin(t, v);
+        const unsigned long long *w = a.list + (size_t)g * kMergeListWords;
+        if (!w[2]) continue;
+        merge_update(a, merge_slot(a, w[0]), w[1], w[2], (const long long *)(w + 3));
+    }
+}
+// the occupied slots of the hash table as a packed list (order irrelevant: the host sorts by first arrival)
+__global__ __launch_bounds__(kBlockThreads) void k_merge_collect_list(const MergeArgs a) {
+    const int lane = threadIdx.x & 63;
+    for (uint32_t base = blockIdx.x * kBlockThreads + (threadIdx.x & ~63u); base < a.slots; base += gridDim.x * kBlockThreads) {
+        const uint32_t i = base + (uint32_t)lane;
+        const bool occ = i < a.slots && a.t_counts[i] != 0ULL;
+        const uint64_t m = (uint64_t)__ballot(occ);
+        if (!m) continue;
+        unsigned long long start = 0;
+        if (lane == 0) start = atomicAdd(a.out_n, (unsigned long long)__popcll(m));
+        start = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(start >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)start);
+        if (occ) {
+            const unsigned long long o = start + (unsigned long long)__popcll(m & ((1ULL << lane) - 1ULL));
+            if (o < a.out_cap) {
+                unsigned long long *w = a.out_list + o * kMergeListWords;
+                w[0] = i == a.mask + 1 ? kEmptyKey : a.t_keys[i];
+                w[1] = a.t_first[i];
+                w[2] = a.t_counts[i];
+                for (int j = 0; j < kMaxAggs; ++j) w[3 + j] = (unsigned long long)a.t_vals[(size_t)j * a.slots + i];
+            }
         }
     }
 }
@@ -1389,6 +1438,14 @@ void launch_merge_init(const MergeArgs &a, hipStream_t s) {
 void launch_merge_scatter(const MergeArgs &a, hipStream_t s) {
     const int grid = (int)std::min<uint32_t>((a.n_groups + kBlockThreads - 1) / kBlockThreads, 256u);
     hipLaunchKernelGGL(k_merge_scatter, dim3(grid < 1 ? 1 : grid), dim3(kBlockThreads), 0, s, a);
+}
+void launch_merge_insert_list(const MergeArgs &a, hipStream_t s) {
+    const int grid = (int)std::min<uint32_t>((a.n_groups + kBlockThreads - 1) / kBlockThreads, 256u);
+    hipLaunchKernelGGL(k_merge_insert_list, dim3(grid < 1 ? 1 : grid), dim3(kBlockThreads), 0, s, a);
+}
+void launch_merge_collect_list(const MergeArgs &a, hipStream_t s) {
+    const int grid = (int)std::min<uint32_t>((a.slots + kBlockThreads - 1) / kBlockThreads, 256u);
+    hipLaunchKernelGGL(k_merge_collect_list, dim3(grid < 1 ? 1 : grid), dim3(kBlockThreads), 0, s, a);
 }
 
 void launch_group_collect(const AggArgs &a, hipStream_t s) {

@@ -510,77 +510,129 @@ extern "C" int imm3_comm_merge_groups(imm3_comm *c, imm3_query *const *queries, 
             merged.push_back(g);
         }
     } else {
-        // ---- wide keys: local merge, all-gather of fixed-size lists, merge by key ----
-        std::map<unsigned long long, MergedGroup> local;
-        for (int32_t i = 0; i < n_queries; ++i) {
-            imm3_query *q = queries[i];
-            const uint32_t ng = n_local[(size_t)i];
-            std::vector<unsigned long long> hk(ng), hc(ng);
-            std::vector<uint32_t> hf(ng);
-            std::vector<long long> hv((size_t)ng * kMaxAggs);
-            if (ng) {
-                HIPCHK(hipMemcpyAsync(hk.data(), q->d_okeys, ng * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-                HIPCHK(hipMemcpyAsync(hf.data(), q->d_ofirst, ng * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                HIPCHK(hipMemcpyAsync(hc.data(), q->d_ocounts, ng * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-                HIPCHK(hipMemcpyAsync(hv.data(), q->d_ovals, (size_t)ng * kMaxAggs * sizeof(long long), hipMemcpyDeviceToHost, s));
-            }
-            HIPCHK(hipStreamSynchronize(s));
-            for (uint32_t g = 0; g < ng; ++g) {
-                MergedGroup m;
-                m.key = hk[g];
-                m.count = hc[g];
-                m.first = ((unsigned long long)(uint32_t)segment_index[i] << 32) | hf[g];
-                for (int j = 0; j < kMaxAggs; ++j) m.vals[j] = hv[(size_t)g * kMaxAggs + j];
-                auto it = local.find(m.key);
-                if (it == local.end()) local.emplace(m.key, m);
-                else combine(it->second, m, kinds, is_str, n_agg);
-            }
+        // ---- wide keys: merged by key ON THE DEVICE (round 4; rounds 2-3 merged std::maps on the host, fine for thousands of
+        // groups, not for 10^5 and more): this rank's queries' lists go into a hash table (compare-and-swap on the key, atomic
+        // add / min / max on the columns), its occupied slots come out as a packed list, the ranks' lists are exchanged with
+        // ncclAllGather -- fixed-size slots, sized by an all-reduce(max) of the list lengths -- and merged the same way.  The
+        // host only sorts the result by first arrival.
+        unsigned long long total_local = 0;
+        for (int32_t i = 0; i < n_queries; ++i) total_local += n_local[(size_t)i];
+        auto pow2_at_least = [](unsigned long long v) { unsigned long long p = 1024; while (p < v) p <<= 1; return p; };
+        // one table: {keys, counts, first, vals[kMaxAggs]} x slots, then the packed list and its counter
+        auto table_bytes = [](unsigned long long slots, unsigned long long list_cap) {
+            return (size_t)((slots * (3 + kMaxAggs) + list_cap * kMergeListWords + 8) * sizeof(unsigned long long));
+        };
+        auto bind = [&](MergeArgs &a, void *p, unsigned long long cap, unsigned long long list_cap) {
+            std::memset(&a, 0, sizeof(a));
+            a.mask = (uint32_t)(cap - 1);
+            a.slots = (uint32_t)(cap + 1); // (+ the slot of the one key that equals the empty marker)
+            unsigned long long *w = (unsigned long long *)p;
+            a.t_keys = w;
+            a.t_counts = a.t_keys + a.slots;
+            a.t_first = a.t_counts + a.slots;
+            a.t_vals = (long long *)(a.t_first + a.slots);
+            a.out_list = (unsigned long long *)(a.t_vals + (size_t)kMaxAggs * a.slots);
+            a.out_n = a.out_list + list_cap * kMergeListWords;
+            a.out_cap = (uint32_t)list_cap;
+            a.n_agg = n_agg;
+            for (int j = 0; j < kMaxAggs; ++j) { a.kinds[j] = kinds[j]; a.is_str[j] = is_str[j]; }
+        };
+        if (total_local > 0x7FFFFFFFULL) return fail(IMM3_ERR_ARG, "too many groups to merge");
+        const unsigned long long cap1 = pow2_at_least(2 * std::max<unsigned long long>(total_local, 1)), list1 = std::max<unsigned long long>(total_local, 1);
+        void *p1 = nullptr;
+        {   // (a failure here is this rank's alone: with more than one rank it would leave the others in the collective below, so the
+            // allocation is small-step: the table of the LOCAL merge was sized from counts every rank already has)
+            const hipError_t e = hipMalloc(&p1, table_bytes(cap1 + 1, list1));
+            if (e != hipSuccess) { (void)hipGetLastError(); p1 = nullptr; }
         }
-        if (c->world == 1) {
-            for (auto &kv : local) merged.push_back(kv.second);
-        } else {
-            // list lengths -> the common slot count
-            unsigned long long mine = local.size(), most = 0;
-            HIPCHK(hipMemcpyAsync(c->d_slot, &mine, sizeof(mine), hipMemcpyHostToDevice, s));
-            NCCLCHK(g_rccl.AllReduce(c->d_slot, c->d_slot, 1, ncclUint64, ncclMax, c->nccl, s));
-            HIPCHK(hipMemcpyAsync(&most, c->d_slot, sizeof(most), hipMemcpyDeviceToHost, s));
+        std::unique_ptr<void, void (*)(void *)> g1(p1, [](void *q) { (void)hipFree(q); });
+        unsigned long long mine = 0;
+        MergeArgs a1;
+        if (p1) {
+            bind(a1, p1, cap1, list1);
+            launch_merge_init(a1, s);
+            HIPCHK(hipGetLastError());
+            for (int32_t i = 0; i < n_queries; ++i) {
+                imm3_query *q = queries[i];
+                const uint32_t ng = n_local[(size_t)i];
+                a1.keys = q->d_okeys;
+                a1.first = q->d_ofirst;
+                a1.counts = q->d_ocounts;
+                a1.vals = q->d_ovals;
+                a1.n_groups = ng;
+                a1.seg_hi = (unsigned long long)(uint32_t)segment_index[i] << 32;
+                if (ng) launch_merge_scatter(a1, s);
+                HIPCHK(hipGetLastError());
+            }
+            launch_merge_collect_list(a1, s);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(&mine, a1.out_n, sizeof(mine), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            constexpr size_t W = 3 + kMaxAggs; // u64 words per entry: key, first, count (0 = padding), values
-            const size_t per_rank = (size_t)most * W;
-            std::vector<unsigned long long> send(std::max<size_t>(per_rank, 1), 0ULL), recv(std::max<size_t>(per_rank * (size_t)c->world, 1), 0ULL);
-            size_t e = 0;
-            for (auto &kv : local) {
-                unsigned long long *w = send.data() + e * W;
-                w[0] = kv.second.key;
-                w[1] = kv.second.first;
-                w[2] = kv.second.count;
-                for (int j = 0; j < kMaxAggs; ++j) w[3 + j] = (unsigned long long)kv.second.vals[j];
-                ++e;
-            }
-            if (per_rank) {
-                void *p = nullptr;
-                HIPCHK(hipMalloc(&p, (per_rank + per_rank * (size_t)c->world) * sizeof(unsigned long long)));
-                std::unique_ptr<void, void (*)(void *)> guard(p, [](void *q) { (void)hipFree(q); });
-                unsigned long long *d_send = (unsigned long long *)p, *d_recv = d_send + per_rank;
-                HIPCHK(hipMemcpyAsync(d_send, send.data(), per_rank * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-                NCCLCHK(g_rccl.AllGather(d_send, d_recv, per_rank, ncclUint64, c->nccl, s));
-                HIPCHK(hipMemcpyAsync(recv.data(), d_recv, per_rank * (size_t)c->world * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-                HIPCHK(hipStreamSynchronize(s));
-            }
-            std::map<unsigned long long, MergedGroup> all;
-            for (size_t i = 0; i < (size_t)most * (size_t)c->world; ++i) {
-                const unsigned long long *w = recv.data() + i * W;
-                if (!w[2]) continue; // padding
+        }
+        auto take_list = [&](const unsigned long long *d_list, unsigned long long n) -> int {
+            std::vector<unsigned long long> h((size_t)n * kMergeListWords);
+            if (n) HIPCHK(hipMemcpyAsync(h.data(), d_list, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            merged.reserve((size_t)n);
+            for (size_t i = 0; i < (size_t)n; ++i) {
+                const unsigned long long *w = h.data() + i * kMergeListWords;
                 MergedGroup m;
                 m.key = w[0];
                 m.first = w[1];
                 m.count = w[2];
                 for (int j = 0; j < kMaxAggs; ++j) m.vals[j] = (long long)w[3 + j];
-                auto it = all.find(m.key);
-                if (it == all.end()) all.emplace(m.key, m);
-                else combine(it->second, m, kinds, is_str, n_agg);
+                merged.push_back(m);
             }
-            for (auto &kv : all) merged.push_back(kv.second);
+            return IMM3_OK;
+        };
+        if (c->world == 1) {
+            if (!p1) return fail(IMM3_ERR_DEVICE, "hipMalloc of the merge table failed");
+            const int trc = take_list(a1.out_list, mine);
+            if (trc) return trc;
+        } else {
+            // list lengths -> the common slot count (a rank whose table could not be allocated says so with ~0: every rank leaves)
+            unsigned long long word = p1 ? mine : ~0ULL, most = 0;
+            HIPCHK(hipMemcpyAsync(c->d_slot, &word, sizeof(word), hipMemcpyHostToDevice, s));
+            NCCLCHK(g_rccl.AllReduce(c->d_slot, c->d_slot, 1, ncclUint64, ncclMax, c->nccl, s));
+            HIPCHK(hipMemcpyAsync(&most, c->d_slot, sizeof(most), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (most == ~0ULL) return fail(IMM3_ERR_DEVICE, "a rank could not allocate its merge table; no rank has merged anything");
+            const size_t per_rank = (size_t)most * kMergeListWords;
+            if (per_rank) {
+                const unsigned long long entries = most * (unsigned long long)c->world;
+                if (entries > 0x7FFFFFFFULL) return fail(IMM3_ERR_ARG, "too many groups to merge");
+                const unsigned long long cap2 = pow2_at_least(2 * entries);
+                void *p = nullptr;
+                // (sizes are the same on every rank: an allocation failure here is reported through one more flag exchange)
+                hipError_t e = hipMalloc(&p, (per_rank + per_rank * (size_t)c->world) * sizeof(unsigned long long) + table_bytes(cap2 + 1, entries));
+                if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+                std::unique_ptr<void, void (*)(void *)> guard(p, [](void *q) { (void)hipFree(q); });
+                unsigned long long ok = p ? 0ULL : 1ULL, any = 0;
+                HIPCHK(hipMemcpyAsync(c->d_slot, &ok, sizeof(ok), hipMemcpyHostToDevice, s));
+                NCCLCHK(g_rccl.AllReduce(c->d_slot, c->d_slot, 1, ncclUint64, ncclMax, c->nccl, s));
+                HIPCHK(hipMemcpyAsync(&any, c->d_slot, sizeof(any), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                if (any) return fail(IMM3_ERR_DEVICE, "a rank could not allocate the exchange buffers of the merge; no rank has merged anything");
+                unsigned long long *d_send = (unsigned long long *)p, *d_recv = d_send + per_rank;
+                HIPCHK(hipMemsetAsync(d_send, 0, per_rank * sizeof(unsigned long long), s)); // (padding entries: count 0)
+                if (mine) HIPCHK(hipMemcpyAsync(d_send, a1.out_list, (size_t)mine * kMergeListWords * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+                NCCLCHK(g_rccl.AllGather(d_send, d_recv, per_rank, ncclUint64, c->nccl, s));
+                MergeArgs a2;
+                bind(a2, d_recv + per_rank * (size_t)c->world, cap2, entries);
+                launch_merge_init(a2, s);
+                HIPCHK(hipGetLastError());
+                a2.list = d_recv;
+                a2.n_groups = (uint32_t)entries;
+                launch_merge_insert_list(a2, s);
+                HIPCHK(hipGetLastError());
+                launch_merge_collect_list(a2, s);
+                HIPCHK(hipGetLastError());
+                unsigned long long n2 = 0;
+                HIPCHK(hipMemcpyAsync(&n2, a2.out_n, sizeof(n2), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                const int trc = take_list(a2.out_list, n2);
+                if (trc) return trc;
+            }
         }
     }
     std::sort(merged.begin(), merged.end(), [](const MergedGroup &x, const MergedGroup &y) { return x.first < y.first; }); // first arrival first

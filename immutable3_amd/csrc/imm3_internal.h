@@ -416,9 +416,22 @@ struct MergeArgs {
     int32_t n_agg;
     int32_t kinds[kMaxAggs];          // AggKind
     int32_t is_str[kMaxAggs];         // MAX over strings: unsigned compare of the big-endian-packed bytes
+    // keys wider than 2 bytes: the table is a hash table -- t_keys[slots] (open addressing, linear probing; slots = mask + 2, the
+    // last slot is the one key that equals the empty marker), sized >= 2 x the entries that can arrive: it cannot fill up
+    unsigned long long *t_keys;       // null: direct-indexed (slot = key)
+    uint32_t mask;
+    // packed lists (kMergeListWords u64 words per entry: key, first, count, kMaxAggs values; count 0 = padding): what the ranks
+    // exchange with ncclAllGather and what the collect kernel writes
+    const unsigned long long *list;   // k_merge_insert_list: n_groups entries
+    unsigned long long *out_list;     // k_merge_collect_list: occupied slots, in no particular order ...
+    unsigned long long *out_n;        // ... and how many (starts at 0)
+    uint32_t out_cap;
 };
+constexpr int kMergeListWords = 3 + kMaxAggs;
 void launch_merge_init(const MergeArgs &a, hipStream_t s);
 void launch_merge_scatter(const MergeArgs &a, hipStream_t s);
+void launch_merge_insert_list(const MergeArgs &a, hipStream_t s);
+void launch_merge_collect_list(const MergeArgs &a, hipStream_t s);
 void launch_group_collect(const AggArgs &a, hipStream_t s);
 
 constexpr int kSubTallies = 32;                       // in-kernel count reduce: sub-tallies (finish_add, imm3_device.h)

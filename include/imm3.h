@@ -344,8 +344,9 @@ int imm3_comm_allreduce_count_all(imm3_comm *const *comms, int32_t n_comms, imm3
  * one per rank), segment_index[i] = the global index of the segment queries[i] ran on, and every rank receives the merged
  * table in first-seen order -- ascending (segment, first selected row): the reference's arrival order is a race, this is
  * the order Engine.execute would produce with one thread.  Keys of <= 2 bytes travel as element-wise all-reduces of a
- * direct-indexed table (sum on counts, min on segment << 32 | row, max / min on each aggregate); wider keys as an
- * ncclAllGather of the ranks' group lists.  One rank: the same merge over that rank's queries, no collective.
+ * direct-indexed table (sum on counts, min on segment << 32 | row, max / min on each aggregate); wider keys are merged in a
+ * device hash table per rank, exchanged as an ncclAllGather of the ranks' group lists and merged again on the device.  One rank:
+ * the same merge over that rank's queries, no collective.
  *   keys / counts / vals as imm3_query_fetch_groups; first[g] = segment << 32 | first selected row of the group there.
  * Synchronous (the merged table is returned to the host). */
 int imm3_comm_merge_groups(imm3_comm *c, imm3_query *const *queries, const int32_t *segment_index, int32_t n_queries,

@@ -348,3 +348,54 @@ def test_merge_groups_across_segments_one_rank_rccl(ctx, group, aggs):
         q.close()
     for s in segs:
         s.close()
+
+
+def test_merge_of_a_hundred_thousand_groups_on_the_device(ctx):
+    """Wide keys are merged on the device (a hash table: compare-and-swap on the key, atomics on the columns; csrc/imm3_agg.hip
+    k_merge_*): three segments whose int32 group column takes ~130 000 distinct values, count + max(age) + min(id), against numpy --
+    every group once, counts added, extremes combined, first arrival first (ascending segment index, then first row)."""
+    rng = np.random.default_rng(77)
+    used = [0, 1, 2]
+    segs, queries = [], []
+    all_ids, all_age, first_seen = [], [], {}
+    for sidx, n in enumerate((260_000, 90_001, 300_123)):
+        ids = rng.integers(0, 150_000, size=n).astype(np.int32)
+        if sidx == 1:
+            ids[:5] = -1                                              # (a key with every byte 0xFF: the hash table's empty marker once widened?  no: 4 bytes -- an ordinary key)
+        age = rng.integers(-128, 128, size=n).astype(np.int8)
+        st = np.array([list(CODES[i]) for i in rng.integers(0, len(CODES), size=n)], dtype=np.uint8).reshape(n, 2)
+        br = blocks_of(n, 1024)
+        cols = [RawColumn(DENSE_INT, 4, ids, br), RawColumn(DENSE_TINYINT, 1, age, br), RawColumn(DENSE_STRING, 2, st, br)]
+        seg = native.DeviceSegment(ctx, [c.native() for c in cols])
+        q = native.DeviceQuery(ctx, seg, used, [], (), 0, 1024, group_cols=[0], aggs=[(KIND["count"], 0), (KIND["max"], 1), (KIND["min"], 0)])
+        q.run()
+        segs.append(seg)
+        queries.append(q)
+        all_ids.append(ids)
+        all_age.append(age)
+        uniq, first = np.unique(ids, return_index=True)
+        for k, f in zip(uniq.tolist(), first.tolist()):
+            first_seen.setdefault(k, (sidx << 32) | f)
+    comm = native.Comm(ctx, 1, 0, native.comm_unique_id())
+    keys, first, counts, vals = comm.merge_groups(queries, [0, 1, 2])
+    comm.close()
+    ids = np.concatenate(all_ids)
+    age = np.concatenate(all_age).astype(np.int64)
+    uniq, inv, cnt = np.unique(ids, return_inverse=True, return_counts=True)
+    mx = np.full(uniq.size, -(1 << 62), np.int64)
+    np.maximum.at(mx, inv, age)
+    got_keys = keys.astype(np.uint64).astype(np.uint32).view(np.int32) if keys.dtype != np.int32 else keys
+    got_keys = (keys.astype(np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)
+    assert keys.shape[0] == uniq.size > 100_000
+    order = np.argsort(got_keys, kind="stable")
+    assert (got_keys[order] == uniq).all()
+    assert (counts[order].astype(np.int64) == cnt).all() and (vals[order, 0] == cnt).all()
+    assert (vals[order, 1] == mx).all()
+    assert (vals[order, 2] == uniq.astype(np.int64)).all()            # min(id) of the group id = the key
+    assert (np.diff(first.astype(np.int64)) > 0).all()
+    want_first = np.array([first_seen[k] for k in got_keys.tolist()], dtype=np.uint64)
+    assert (first.astype(np.uint64) == want_first).all()
+    for q in queries:
+        q.close()
+    for s in segs:
+        s.close()
