@@ -881,6 +881,7 @@ static void query_free(imm3_query *q) {
     pool_release(ctx, q->d_stage_rec);
     pool_release(ctx, q->d_tile_start);
     pool_release(ctx, q->d_desc);
+    pool_release(ctx, q->d_tile_desc);
     pool_release(ctx, q->d_akeys); pool_release(ctx, q->d_acounts); pool_release(ctx, q->d_okeys); pool_release(ctx, q->d_ocounts);
     pool_release(ctx, q->d_afirst); pool_release(ctx, q->d_ofirst); pool_release(ctx, q->d_ameta);
     pool_release(ctx, q->d_avals); pool_release(ctx, q->d_ovals);
@@ -1094,6 +1095,25 @@ static int single_pass_setup(imm3_query *q) {
         pool_release(ctx, d);
         HIPCHK(me);
     }
+    if (q->table && !q->d_tile_desc) { // the launch's view of the tile table: one descriptor per tile (built on the device from the table's per-column pointers)
+        void *td = nullptr;
+        const hipError_t te = pool_alloc(ctx, &td, (size_t)q->n_tiles * sizeof(ProjectTile));
+        if (te != hipSuccess) {
+            pool_release(ctx, d);
+            HIPCHK(te);
+        }
+        const void *const *tp[kMaxTileCols] = {nullptr, nullptr, nullptr};
+        for (int k = 0; k < kMaxTileCols; ++k)
+            if (q->stage_kinds[k] != TK_NONE && q->stage_seg_col[k] >= 0) tp[k] = (const void *const *)q->table->d_tile_ptrs[(size_t)q->stage_seg_col[k]];
+        launch_project_tile_desc(q->table->d_tile_rows, tp[0], tp[1], tp[2], (ProjectTile *)td, q->n_tiles, ctx->stream);
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {
+            pool_release(ctx, d);
+            pool_release(ctx, td);
+            HIPCHK(le);
+        }
+        q->d_tile_desc = (ProjectTile *)td;
+    }
     q->d_desc = (unsigned long long *)d;
     q->sp_rounds_max = rounds_max;
     q->sp_desc_off = desc_off;
@@ -1233,13 +1253,15 @@ static void single_pass_drop_if_narrow(imm3_query *q, uint64_t survivors) {
     if (!q->single_pass || !q->sp_pass.empty() || q->sp_P_fixed || q->plan_pinned || ctx->capture || ctx->filter_variant == 8 || ctx->filter_variant == 11 || q->n_rows <= 0) return;
     const PlanDensity d = plan_density_for(q, survivors);
     bool use_records = false;
-    const double other = plan_cost_three_launches(q, d, ctx->filter_variant != 3, &use_records);
+    const double other = plan_cost_three_launches(q, d, ctx->filter_variant != 3 && !q->table, &use_records); // (a table has no survivor records: the bitmap path)
     if (!(other < kPlanKeepMargin * plan_cost('A', q->plan_shape, d))) return;
     graphs_mark_stale(ctx, q);
     q->single_pass = false;
     q->sp_model_dropped = true; // (the first count may bring it back: single_pass_restore)
     pool_release(ctx, q->d_desc);
     q->d_desc = nullptr;
+    pool_release(ctx, q->d_tile_desc);
+    q->d_tile_desc = nullptr;
     if (use_records && !q->d_stage_rec) {
         if (records_setup(q) != IMM3_OK || !q->d_tile_start) { // (no memory for the records: the bitmap path needs none)
             pool_release(ctx, q->d_stage_rec);
@@ -1329,9 +1351,10 @@ static int sample_tile_ptrs(imm3_ctx *ctx, const imm3_segment *cseg, int32_t col
 
 static int single_pass_sample(imm3_query *q) {
     imm3_ctx *ctx = q->ctx;
-    const int64_t n_full = q->n_rows / kTileRows;
+    const int64_t n_full = q->table ? q->n_tiles : q->n_rows / kTileRows; // (a table's sample may hold a segment's partial last tile: the kernel's rolled path)
     const bool undecided = q->single_pass || q->alt_ok || q->d_stage_rec;
     if (!undecided || q->sp_P_fixed || q->plan_pinned || ctx->filter_variant == 10 || n_full < 4096) return IMM3_OK; // (below ~4 M rows the sample costs what it saves)
+    if (q->table && !q->table->d_sample_rows) return IMM3_OK;
     // ONE count-only launch of the scan+select kernel's table instance over the sample's tile table (round 3: eight launches, a
     // memset and a strided copy): 128 work-groups, one tile per wave, so that work-groups 16 i .. 16 i + 15 hold chunk i's count
     // in their partials.
@@ -1349,8 +1372,13 @@ static int single_pass_sample(imm3_query *q) {
         fill_tile_col(q, *fp, a.cols[k], a.kinds[k]);
         void **ptrs = nullptr;
         uint32_t *rows = nullptr;
-        const int rc = sample_tile_ptrs(ctx, q->seg, fp->seg_col, n_full, &ptrs, &rows);
-        if (rc) return rc;
+        if (q->table) { // (made with the table: imm3_table_create)
+            ptrs = q->table->d_sample_ptrs[(size_t)fp->seg_col];
+            rows = q->table->d_sample_rows;
+        } else {
+            const int rc = sample_tile_ptrs(ctx, q->seg, fp->seg_col, n_full, &ptrs, &rows);
+            if (rc) return rc;
+        }
         a.tile_ptrs[k] = (const void *const *)ptrs;
         a.tile_rows = rows;
         any = true;
@@ -1632,7 +1660,10 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
     // is ONE tile launch (<= 3 predicate columns of int32 / int8 / 2-byte string, at most one string; none is also fine:
     // the record is then the position alone) and whose SELECT list is 1-, 2- and 4-byte columns, at most kMaxEmitGather of
     // them not predicate columns.
-    if (n_proj > 0 && limit <= 0 && !table && !q->ragged && !q->always_false && nb >= 1 && q->n_rows > 0 && ctx->filter_variant != 1 &&
+    // A table query (every segment the GPU owns as one scan unit) takes the ONE-LAUNCH plan under the same conditions when no
+    // SELECT-list column has to be gathered (round 5; its TABLE instances walk the tile table); survivor records and streamed
+    // gathers are one-segment plans, the bitmap path is a table's other plan.
+    if (n_proj > 0 && limit <= 0 && !q->ragged && !q->always_false && nb >= 1 && q->n_rows > 0 && ctx->filter_variant != 1 &&
         ctx->filter_variant != 3 && q->preds.size() <= (size_t)kMaxTileCols && n_proj <= kMaxProj) {
         std::vector<const FoldedPred *> order;
         int n_s2 = 0;
@@ -1663,7 +1694,7 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
             }
             n_gather += !is_pred;
         }
-        if (ok && n_gather <= kMaxEmitGather) {
+        if (ok && n_gather <= kMaxEmitGather && (!table || (n_gather == 0 && ctx->filter_variant != 6))) {
             for (size_t k = 0; k < order.size(); ++k) {
                 q->stage_kinds[k] = tile_kind(*order[k]);
                 q->stage_seg_col[k] = order[k]->seg_col;
@@ -1701,7 +1732,7 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
                 const int rc = single_pass_setup(q.get());
                 if (rc) return rc;
             }
-            if (!q->single_pass && n_gather > 0 && ctx->filter_variant != 6) {
+            if (!q->single_pass && n_gather > 0 && ctx->filter_variant != 6 && !table) {
                 // The alternative the first count may switch to (single_pass_stream_columns): every gathered column of the SELECT list
                 // (first mentions; dense int32 / int8) as a tile column that lets every value pass.
                 std::vector<FoldedPred> pass;
@@ -1749,7 +1780,7 @@ static int query_create_impl(imm3_ctx *ctx, const imm3_segment *seg, const imm3_
             // columns.  When none is projected they buy nothing -- state in (5 values) -> age, 10 %: 120 us with records, 87 without
             // (filter -> offsets scan -> gather from the bitmap); age in (18, 30) -> id, 11 %: 167 / 122; 3 %: 106 / 79.
             q->records_narrow_only = n_pred_proj > 0 && !pred_proj_wide;
-            if (q->single_pass || (n_gather > 0 && n_pred_proj == 0 && ctx->filter_variant != 11)) { /* no survivor records in HBM */ } else {
+            if (q->single_pass || table || (n_gather > 0 && n_pred_proj == 0 && ctx->filter_variant != 11)) { /* no survivor records in HBM */ } else {
                 const int rc = records_setup(q.get());
                 if (rc) return rc;
             }
@@ -1823,6 +1854,8 @@ static void table_free(imm3_table *t) {
     if (t->ctx) (void)hipSetDevice(t->ctx->device);
     (void)hipFree(t->d_tile_rows);
     for (auto p : t->d_tile_ptrs) (void)hipFree(p);
+    (void)hipFree(t->d_sample_rows);
+    for (auto p : t->d_sample_ptrs) (void)hipFree(p);
     for (auto sg : t->segs) segment_release(sg);
     if (t->ctx) ctx_release(t->ctx);
     delete t;
@@ -1898,6 +1931,30 @@ extern "C" int imm3_table_create(imm3_ctx *ctx, const imm3_segment *const *segs,
         HIPCHK(hipMalloc(&p, ptrs[c].size() * sizeof(void *)));
         t->d_tile_ptrs[c] = (void **)p;
         HIPCHK(hipMemcpyAsync(t->d_tile_ptrs[c], ptrs[c].data(), ptrs[c].size() * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+    }
+    // the sample a query's plan is made on (single_pass_sample): eight chunks of 64 tiles spread evenly over the table
+    std::vector<uint32_t> srows;
+    std::vector<std::vector<const void *>> sptrs;
+    if (t->n_tiles >= 4096) {
+        srows.resize((size_t)kSampleTiles);
+        sptrs.assign(ncols, std::vector<const void *>((size_t)kSampleTiles, nullptr));
+        for (int i = 0; i < kSampleChunks; ++i) {
+            int64_t tile0 = (int64_t)((2 * i + 1) * t->n_tiles / (2 * kSampleChunks)) - kSampleChunkTiles / 2;
+            tile0 = std::max<int64_t>(0, std::min<int64_t>(tile0, t->n_tiles - kSampleChunkTiles));
+            for (int64_t k = 0; k < kSampleChunkTiles; ++k) {
+                srows[(size_t)(i * kSampleChunkTiles + k)] = rows[(size_t)(tile0 + k)];
+                for (size_t c = 0; c < ncols; ++c) sptrs[c][(size_t)(i * kSampleChunkTiles + k)] = ptrs[c][(size_t)(tile0 + k)];
+            }
+        }
+        HIPCHK(hipMalloc(&p, srows.size() * sizeof(uint32_t)));
+        t->d_sample_rows = (uint32_t *)p;
+        HIPCHK(hipMemcpyAsync(t->d_sample_rows, srows.data(), srows.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        t->d_sample_ptrs.assign(ncols, nullptr);
+        for (size_t c = 0; c < ncols; ++c) {
+            HIPCHK(hipMalloc(&p, sptrs[c].size() * sizeof(void *)));
+            t->d_sample_ptrs[c] = (void **)p;
+            HIPCHK(hipMemcpyAsync(t->d_sample_ptrs[c], sptrs[c].data(), sptrs[c].size() * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+        }
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *out = t.release();
@@ -2392,6 +2449,11 @@ static int run_single_pass(imm3_query *q) {
     }
     a.P = q->sp_P;
     a.n_rows = q->n_rows;
+    if (q->table) {
+        if (!q->d_tile_desc) return fail(IMM3_ERR_STATE, "internal: table query planned as one launch without its tile descriptors");
+        a.tile_desc = q->d_tile_desc;
+        a.n_rows = q->n_tiles * kTileRows; // (virtual rows: what the tiles span; the kernel takes a tile's valid rows from its descriptor)
+    }
     a.n_tiles = q->n_tiles;
     a.n_spans = q->sp_spans;
     a.n_rounds = (q->sp_spans + q->sp_grid - 1) / q->sp_grid;
@@ -2413,7 +2475,7 @@ static int run_single_pass(imm3_query *q) {
                 if (q->stage_seg_col[k] == sci && !a.pred_dst[k]) { k_pred = k; break; }
             if (k_pred >= 0) a.pred_dst[k_pred] = q->d_proj[j];
             else {
-                if (ng >= kMaxEmitGather) return fail(IMM3_ERR_ARG, "internal: single-pass plan has too many gathered columns");
+                if (ng >= kMaxEmitGather || q->table) return fail(IMM3_ERR_ARG, "internal: single-pass plan has too many gathered columns");
                 a.gather[ng].dst = q->d_proj[j];
                 a.gather[ng].src = col_flat(sc);
                 a.gather[ng].width = sc.width;
@@ -2447,7 +2509,8 @@ static int run_single_pass(imm3_query *q) {
         if (chained) HIPCHK(hipStreamWaitEvent(s, dev->last, 0));
         {
             LaunchTimer t(ctx, 0);
-            if (!launch_filter_project(a, q->sp_grid, s, t.start, t.stop)) return fail(IMM3_ERR_ARG, "internal: no single-pass kernel for this column combination");
+            const bool launched = q->table ? launch_filter_project_table(a, q->sp_grid, s, t.start, t.stop) : launch_filter_project(a, q->sp_grid, s, t.start, t.stop);
+            if (!launched) return fail(IMM3_ERR_ARG, "internal: no single-pass kernel for this column combination");
         }
         HIPCHK(hipGetLastError());
         if (chained) HIPCHK(hipEventRecord(dev->last, s));

@@ -170,6 +170,9 @@ struct imm3_table { // all segments of one table as one scan unit: the tile tabl
     int64_t n_tiles = 0, n_rows = 0;
     uint32_t *d_tile_rows = nullptr;   // valid rows per tile
     std::vector<void **> d_tile_ptrs;  // per column: device array of per-tile pointers
+    // the sample a query's plan is made on (single_pass_sample, imm3_api.cpp): eight chunks of 64 tiles spread over the table
+    uint32_t *d_sample_rows = nullptr;     // valid rows of the sampled tiles (null: the table is too small to sample)
+    std::vector<void **> d_sample_ptrs;    // per column: the sampled tiles' pointers
     // batches of all segments (every column shares one block layout: checked at creation), built once: a query over 98
     // README-style segments otherwise spends ~0.4 ms of host time re-deriving them
     std::vector<int32_t> batch_size, batch_k; // rows; index of the batch within its segment (oid = k * table.blockSize)
@@ -267,6 +270,7 @@ struct imm3_query {
     size_t sp_desc_off = 0;                 // byte offset of the span descriptors in d_desc's allocation
     unsigned long long *d_desc = nullptr;   // per-span descriptors of the chained scan
     size_t sp_trash_off = 0;                // byte offset of the writers' trash lines in d_desc's allocation
+    imm3::ProjectTile *d_tile_desc = nullptr; // table queries: one descriptor per tile of the table for the launch's columns (k_filter_project's TABLE instances)
     bool ran_single_pass = false;           // the last run went through k_filter_project ...
     bool sp_verified = false;               // ... and its status word has been read since (rows complete, or gathered again from the bitmap)
     bool offsets_valid = false;             // d_tile_offsets / d_chunk_sums describe the last run's bitmap (an offsets scan has run since)

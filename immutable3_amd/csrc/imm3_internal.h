@@ -238,6 +238,11 @@ constexpr int kDescValueBits = 36, kDescFlagShift = 36, kDescEpochShift = 38;
 constexpr unsigned long long kDescValueMask = (1ULL << kDescValueBits) - 1;
 constexpr unsigned long long kDescEpochMask = (1ULL << (64 - kDescEpochShift)) - 1;
 constexpr uint32_t kProjectMaxPolls = 1u << 17; // polls of a look-back wait (~0.1-0.2 s) before the run's rows are given up
+struct ProjectTile {                // 32 bytes: one scalar load (s_load_dwordx8) per tile, issued a tile ahead of its use
+    const void *p[kMaxTileCols];    // the tile's first value in each tile column of the launch (kinds order)
+    uint32_t rows;                  // valid rows (kTileRows: a full tile)
+    uint32_t pad;
+};
 struct ProjectArgs {
     TileCol cols[kMaxTileCols];
     int32_t kinds[kMaxTileCols];    // sorted ascending, TK_NONE last
@@ -262,9 +267,16 @@ struct ProjectArgs {
     uint32_t max_polls;             // polls before a look-back wait gives up (0: kProjectMaxPolls)
     int32_t fault_wg, fault_span;   // work-group fault_wg never announces its fault_span-th span (-1: none)
     int32_t pad2;
+    // table queries (imm3_table; the TABLE instances, imm3_project_table.hip): one descriptor per tile of the table's virtual row
+    // space -- where the tile starts in each of the launch's columns and how many of its 1024 rows exist (1024 except the last tile
+    // of each segment) -- replaces cols[k].data / n_rows.  Null for one segment.
+    const ProjectTile *tile_desc;
 };
 // false: no instance for these kinds.  grid <= project_max_grid(): every work-group must be resident (they wait on each other)
 bool launch_filter_project(const ProjectArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+bool launch_filter_project_table(const ProjectArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1); // a.tile_desc set
+// the per-query tile descriptors of a table query, from the table's per-column tile pointers (null pointer: no such column)
+void launch_project_tile_desc(const uint32_t *tile_rows, const void *const *p0, const void *const *p1, const void *const *p2, ProjectTile *out, int64_t n_tiles, hipStream_t s);
 int project_max_grid(const int32_t *kinds, int P);   // resident work-groups of the instance on the current device (0: none)
 int project_rec_dwords(const int32_t *kinds);
 

@@ -453,9 +453,11 @@ struct DenseSet {
 // branch per predicated access the compiler waits for ALL outstanding loads (s_waitcnt vmcnt(0)) before every store --
 // one unit in flight whatever the source says.  (Tile by tile, with the tile's bitmap line fetched first and its stores
 // behind its loads, a dense tile cost a writer three dependent round trips: 5 us; with two units and vmcnt(0): 3.5 us.)
-template <int K0, int K1, int K2>
+// TABLE (table queries): a tile's columns start where its descriptor says (a range may straddle two segments), rows are virtual
+// (tile * 1024 + position), and every tile's bitmap line exists in full (bits past a segment's last row are zero).
+template <int K0, int K1, int K2, bool TABLE>
 __device__ __forceinline__ void unpack_dense(const ProjectArgs &a, int64_t tile0, int P, unsigned long long base, int lane, void *trash) {
-    const int64_t n_words = (a.n_rows + 63) / 64;
+    const int64_t n_words = TABLE ? a.n_tiles * kTileWords : (a.n_rows + 63) / 64;
     int n_t = P;
     if ((int64_t)n_t > a.n_tiles - tile0) n_t = (int)(a.n_tiles - tile0);
     const int n_units = 2 * n_t;
@@ -498,7 +500,17 @@ __device__ __forceinline__ void unpack_dense(const ProjectArgs &a, int64_t tile0
         unit_words(t, m);
         S.ubase = base;
         const int tt = t < n_units ? t : 0;             // (an empty unit loads tile 0's rows: valid addresses)
-        const uint32_t row0 = row_of(tt), safe = row_of(tt & ~1) - (uint32_t)lane; // safe: the tile's first row
+        // where the unit's rows are read: rows of the segment's flat columns, or (table) rows of the unit's TILE behind its descriptor's pointers
+        const void *s0 = a.cols[0].data, *s1 = a.cols[1].data, *s2 = a.cols[2].data;
+        uint32_t row0 = row_of(tt), safe = row_of(tt & ~1) - (uint32_t)lane; // safe: the tile's first row
+        if constexpr (TABLE) {
+            const ProjectTile &d = a.tile_desc[tile0 + (tt >> 1)]; // (wave-uniform: scalar loads)
+            s0 = d.p[0];
+            s1 = d.p[1];
+            s2 = d.p[2];
+            row0 = (uint32_t)((tt & 1) * kDenseWords * 64) + (uint32_t)lane;
+            safe = 0u;
+        }
         auto load_col = [&](auto kind, const void *src, uint32_t (&v)[kDenseWords]) __attribute__((always_inline)) {
             constexpr int K = decltype(kind)::value;
             if constexpr (K != TK_NONE) {
@@ -512,9 +524,9 @@ __device__ __forceinline__ void unpack_dense(const ProjectArgs &a, int64_t tile0
                 }
             }
         };
-        load_col(std::integral_constant<int, K0>(), a.cols[0].data, S.v[0]);
-        load_col(std::integral_constant<int, K1>(), a.cols[1].data, S.v[1]);
-        load_col(std::integral_constant<int, K2>(), a.cols[2].data, S.v[2]);
+        load_col(std::integral_constant<int, K0>(), s0, S.v[0]);
+        load_col(std::integral_constant<int, K1>(), s1, S.v[1]);
+        load_col(std::integral_constant<int, K2>(), s2, S.v[2]);
 #pragma unroll
         for (int w = 0; w < kDenseWords; ++w) base += (uint32_t)__popcll(m[w]);
     };
@@ -557,7 +569,7 @@ __device__ __forceinline__ void unpack_dense(const ProjectArgs &a, int64_t tile0
     // ~540: the general walk computes every row's slot from the bitmap line, per column.
     bool copied = false;
     {
-        bool ok = (tile0 + n_t) * (int64_t)kTileRows <= a.n_rows && base + (unsigned long long)n_t * kTileRows <= cap_rows;
+        bool ok = (TABLE || (tile0 + n_t) * (int64_t)kTileRows <= a.n_rows) && base + (unsigned long long)n_t * kTileRows <= cap_rows; // (table: a partial tile's line has zero bits, found below)
         if (K0 != TK_NONE && !t0) ok = ok && ((base * kind_width(K0)) & 3ULL) == 0ULL;
         if (K1 != TK_NONE && !t1) ok = ok && ((base * kind_width(K1)) & 3ULL) == 0ULL;
         if (K2 != TK_NONE && !t2) ok = ok && ((base * kind_width(K2)) & 3ULL) == 0ULL;
@@ -583,7 +595,7 @@ __device__ __forceinline__ void unpack_dense(const ProjectArgs &a, int64_t tile0
             constexpr int W = decltype(width)::value;
             if constexpr (W != 0) {
                 if (to_trash) return; // (wave-uniform: the column is not in the SELECT list)
-                const u32x4 *from = (const u32x4 *)((const uint8_t *)src + ((int64_t)first_row + (int64_t)j * kTileRows) * W);
+                const u32x4 *from = TABLE ? (const u32x4 *)src : (const u32x4 *)((const uint8_t *)src + ((int64_t)first_row + (int64_t)j * kTileRows) * W); // (table: src is the tile's own pointer)
 #pragma unroll
                 for (int i = 0; i < W; ++i) v[i] = __builtin_nontemporal_load(from + 64 * i + lane);
             }
@@ -602,9 +614,16 @@ __device__ __forceinline__ void unpack_dense(const ProjectArgs &a, int64_t tile0
         };
         auto load_tile = [&](CopySet &S, int j) __attribute__((always_inline)) { // (a tile past the range: the range's last one again -- no branch around loads)
             const int jj = j < n_t ? j : n_t - 1;
-            load_col(std::integral_constant<int, W0>(), a.cols[0].data, t0, jj, S.v0);
-            load_col(std::integral_constant<int, W1>(), a.cols[1].data, t1, jj, S.v1);
-            load_col(std::integral_constant<int, W2>(), a.cols[2].data, t2, jj, S.v2);
+            const void *s0 = a.cols[0].data, *s1 = a.cols[1].data, *s2 = a.cols[2].data;
+            if constexpr (TABLE) {
+                const ProjectTile &d = a.tile_desc[tile0 + jj];
+                s0 = d.p[0];
+                s1 = d.p[1];
+                s2 = d.p[2];
+            }
+            load_col(std::integral_constant<int, W0>(), s0, t0, jj, S.v0);
+            load_col(std::integral_constant<int, W1>(), s1, t1, jj, S.v1);
+            load_col(std::integral_constant<int, W2>(), s2, t2, jj, S.v2);
         };
         auto store_tile = [&](const CopySet &S, int j) __attribute__((always_inline)) {
             u32x4 *rows = (u32x4 *)(a.row_index + base + (unsigned long long)j * kTileRows);
@@ -655,7 +674,7 @@ __device__ __forceinline__ void unpack_dense(const ProjectArgs &a, int64_t tile0
             issue(S[i], t + i);
         }
     }
-    if (a.n_gather == 0) return;
+    if (TABLE || a.n_gather == 0) return; // (table queries are planned as one launch only without gathered columns)
     // ---- SELECT-list columns that are not predicate columns (only when the tuning forces this kernel on such a query): a
     // second walk over the range, unit by unit
     unsigned long long gbase = base;
@@ -828,7 +847,12 @@ __device__ __forceinline__ void compact_tile_at(const uint64_t (&acc)[kTileWords
 // (Tried and not kept: an unpredicated form in which every lane stores -- survivors at their rank, the others into a trash
 // slot of their own behind the ring, v_cndmask on the word instead of s_and_saveexec / branch / restore -- was 5 us slower
 // on C3: sixteen full-width ds_write_b64 per tile cost more than the five scalar instructions per word they save.)
-template <int K0, int K1, int K2>
+// TABLE: the launch covers a tile TABLE -- every segment a GPU owns, each starting on a fresh tile of one virtual row space
+// (imm3_table; Engine.scala:176-196: one result over all the per-segment pipelines) -- instead of one segment: a tile's columns
+// start where its descriptor says, the last tile of every segment is partial (rolled path, its range a dense one), spans and
+// descriptors run over the virtual tile space.  One launch ramp and one exposed prefix chain for the whole table instead of one
+// per segment (C5 at one GPU: eight launches of ~125 us each paid 13-25 us of tail).
+template <int K0, int K1, int K2, bool TABLE>
 __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectArgs a) {
     typedef RingRec<K0, K1, K2> L;
     typedef typename L::vec vec;
@@ -837,7 +861,7 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
     constexpr bool kS2 = K0 == TK_S2 || K1 == TK_S2 || K2 == TK_S2;
     constexpr bool kXpose = kS2 || K0 == TK_I8 || K1 == TK_I8 || K2 == TK_I8;
     constexpr int kTileLoads = ColRegs<K0>::kLoads + ColRegs<K1>::kLoads + ColRegs<K2>::kLoads; // vector-memory instructions per tile
-    constexpr int kProjDepth = project_depth(K0, K1, K2);
+    constexpr int kProjDepth = TABLE ? 1 : project_depth(K0, K1, K2);
     constexpr int kI32 = (K0 == TK_I32) + (K1 == TK_I32) + (K2 == TK_I32);
     // (the three-column instances with two wide columns have no registers to spare for compact_tile_at's four words at a time:
     // they keep the compiler's word-by-word form, wrap-around test included)
@@ -921,7 +945,49 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
         int64_t head_t = ((int64_t)blockIdx.x * kProjStreamers + wave) * P, head_last = 0;
         const int64_t head_jump = ((int64_t)gridDim.x * kProjStreamers - 1) * P; // from the end of a range to the wave's next one
         int head_j = 0;
-        auto head_load = [&](ColRegs<K0> &r0, ColRegs<K1> &r1, ColRegs<K2> &r2) {
+        auto head_next = [&]() -> int64_t { // the next tile of the wave's sequence (range by range, span by span)
+            const int64_t t = head_t;
+            ++head_t;
+            if (++head_j == P) {
+                head_j = 0;
+                head_t += head_jump;
+            }
+            return t;
+        };
+        // Table queries: the head's next tile and its descriptor, fetched ONE TILE AHEAD of the loads that need it (a scalar load in
+        // front of every tile's loads would hold them back by its latency); the head skips partial tiles -- they take the rolled
+        // path and no register set -- so the sets always hold consecutive FULL tiles, and tile_in[] says which (what the consuming
+        // side checks: a tile of its sequence that is not the one loaded is a partial one).
+        int64_t nx_t = 0;
+        ProjectTile nx = {};
+        const void *last_p[kMaxTileCols] = {nullptr, nullptr, nullptr};
+        auto fetch_desc = [&]() {
+            nx_t = head_next();
+            nx = a.tile_desc[nx_t < a.n_tiles ? nx_t : a.n_tiles - 1];
+        };
+        if constexpr (TABLE) {
+            const ProjectTile &d0 = a.tile_desc[0]; // (an address that is always readable as a whole tile: the columns carry slack)
+            last_p[0] = d0.p[0];
+            last_p[1] = d0.p[1];
+            last_p[2] = d0.p[2];
+            fetch_desc();
+        }
+        auto head_load = [&](ColRegs<K0> &r0, ColRegs<K1> &r1, ColRegs<K2> &r2) -> int64_t { // -> the tile loaded (-1: none left)
+            if constexpr (TABLE) {
+                while (nx_t < a.n_tiles && nx.rows != (uint32_t)kTileRows) fetch_desc(); // (one partial tile per segment)
+                int64_t got = -1;
+                if (nx_t < a.n_tiles) {
+                    got = nx_t;
+                    last_p[0] = nx.p[0];
+                    last_p[1] = nx.p[1];
+                    last_p[2] = nx.p[2];
+                } // (nothing left: the last tile again -- a load the compiler sees on every path)
+                r0.load(last_p[0], 0, lane);
+                r1.load(last_p[1], 0, lane);
+                r2.load(last_p[2], 0, lane);
+                if (nx_t < a.n_tiles) fetch_desc();
+                return got;
+            } else {
             int64_t t = head_t;
             if (IMM3_ABLATE_BIT(a, 8)) { // (timing only: all tiles dealt grid-stride -- every wave of the launch reads one contiguous window, as k_filter_tile)
                 const int64_t span = t / ((int64_t)P * kProjStreamers), round = span / gridDim.x;
@@ -938,13 +1004,12 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
                 r1.load(a.cols[1].data, t * kTileRows, lane);
                 r2.load(a.cols[2].data, t * kTileRows, lane);
             }
-            ++head_t;
-            if (++head_j == P) {
-                head_j = 0;
-                head_t += head_jump;
+            (void)head_next();
+            return t;
             }
         };
-        head_load(A0, A1, A2);
+        int64_t tile_in[2] = {-1, -1}; // (table) the tile whose columns are in register set A / B
+        tile_in[0] = head_load(A0, A1, A2);
         if constexpr (kProjDepth == 2) head_load(B0, B1, B2);
         // ---- the wave's running state: its current span (s, the work-group's i-th), the ring, whether the rows have been given up
         int64_t s = blockIdx.x;
@@ -1021,14 +1086,14 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
         };
         // one full tile: its columns are in (c0, c1, c2); the loads of the tile kProjDepth tiles ahead go to (n0, n1, n2), the set
         // that was worked on last
-        auto full_tile = [&](ColRegs<K0> &c0, ColRegs<K1> &c1, ColRegs<K2> &c2, ColRegs<K0> &n0, ColRegs<K1> &n1, ColRegs<K2> &n2) {
+        auto full_tile = [&](ColRegs<K0> &c0, ColRegs<K1> &c1, ColRegs<K2> &c2, ColRegs<K0> &n0, ColRegs<K1> &n1, ColRegs<K2> &n2, int64_t &next_in) {
             // software pipeline (k_filter_tile, finding 11): the wait for this tile's loads sits BEFORE the next loads are issued (vmcnt
             // retires in order: what is in flight behind this tile's loads -- the next tile's, at depth 2 -- is not waited for)
             if constexpr (kProjDepth == 2) wait_tile<kTileLoads>(); // this tile's loads have landed; the next tile's stay in flight
             c0.touch();
             c1.touch();
             c2.touch();
-            head_load(n0, n1, n2);
+            next_in = head_load(n0, n1, n2);
             uint64_t acc[kTileWords]; // wave-uniform words (SGPR pairs)
 #pragma unroll
             for (int w = 0; w < kTileWords; ++w) acc[w] = ~0ULL;
@@ -1091,11 +1156,21 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
             tail_pos += cnt;
             if (tail_pos >= kCap) tail_pos -= kCap;
         };
-        // the one partial tile at the end of the segment: rolled, bounds-checked; its range is a dense one
+        // the one partial tile at the end of the segment (of every segment of a table): rolled, bounds-checked; its range is a dense one
         auto partial_tile = [&](int64_t tile) {
             flush_park();
+            ++first_parked; // (this tile's line is stored below, not parked: the range's later lines -- a table's next segment -- start behind it)
             if (!dense) to_dense();
-            const int64_t row0 = tile * kTileRows, valid_rows = a.n_rows - row0;
+            int64_t row0 = tile * kTileRows, valid_rows = a.n_rows - row0;
+            const void *d0 = a.cols[0].data, *d1 = a.cols[1].data, *d2 = a.cols[2].data;
+            if constexpr (TABLE) { // (rare: a blocking scalar load)
+                const ProjectTile &d = a.tile_desc[tile];
+                d0 = d.p[0];
+                d1 = d.p[1];
+                d2 = d.p[2];
+                row0 = 0;
+                valid_rows = d.rows;
+            }
             ColRegs<K0> c0;
             ColRegs<K1> c1;
             ColRegs<K2> c2;
@@ -1106,7 +1181,7 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
                 const bool valid = r_in < valid_rows;
                 const int64_t r = row0 + (valid ? r_in : 0);
                 bool keep = valid;
-                if (valid) keep = c0.row(a.cols[0].data, a.cols[0], r) && c1.row(a.cols[1].data, a.cols[1], r) && c2.row(a.cols[2].data, a.cols[2], r);
+                if (valid) keep = c0.row(d0, a.cols[0], r) && c1.row(d1, a.cols[1], r) && c2.row(d2, a.cols[2], r);
                 const uint64_t m = ballot64(keep);
                 if (lane == w) mine &= m;
                 range_cnt += (uint32_t)__popcll(m);
@@ -1114,13 +1189,13 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
             mine &= low_mask(valid_rows - 64 * (int64_t)lane);
             if (lane >= kTileWords) mine = 0;
             const int64_t word = tile * kTileWords + lane;
-            if (lane < kTileWords && word < (a.n_rows + 63) / 64) a.bitmap[word] = mine;
+            if (lane < kTileWords && (TABLE || word < (a.n_rows + 63) / 64)) a.bitmap[word] = mine; // (table: every tile's line exists in full)
             lane_total += (uint32_t)__popcll(mine);
         };
-        // One tile of the wave's sequence -- range by range, span by span; false: the wave has no tile left.  The loop below calls it
-        // with the register sets in rotating roles (an explicit unroll by their number: no register copies).  A partial tile, or a
-        // range that starts behind the segment's end, consumes no register set; both only occur in the wave's last range, so the
-        // strict alternation holds wherever it matters.
+        // One tile of the wave's sequence -- range by range, span by span.  The loop below calls it with the register sets in
+        // rotating roles (an explicit unroll by their number: no register copies).  A partial tile, or a range that starts behind
+        // the data's end, consumes no register set (kStepKept): the same set is offered to the next step.  In one segment both only
+        // occur in the wave's last range; a table has a partial tile at the end of every segment, in the middle of a wave's work.
         // every untracked tile load has landed, and up to here the register sets were the columns' (ColRegs::keep says why)
         auto drain_loads = [&]() {
             wait_tile<0>();
@@ -1129,34 +1204,44 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
             C0.keep(); C1.keep(); C2.keep();
             __builtin_amdgcn_sched_barrier(0);
         };
-        auto step = [&](ColRegs<K0> &c0, ColRegs<K1> &c1, ColRegs<K2> &c2, ColRegs<K0> &n0, ColRegs<K1> &n1, ColRegs<K2> &n2) -> bool {
+        constexpr int kStepDone = 0, kStepUsed = 1, kStepKept = 2;
+        // `in`: (table) the tile whose columns are in (c0, c1, c2); `next_in`: where the tile loaded into (n0, n1, n2) is noted
+        auto step = [&](ColRegs<K0> &c0, ColRegs<K1> &c1, ColRegs<K2> &c2, ColRegs<K0> &n0, ColRegs<K1> &n1, ColRegs<K2> &n2, int64_t in, int64_t &next_in) -> int {
             const int64_t tile = t0 + j;
-            if (tile < n_full) full_tile(c0, c1, c2, n0, n1, n2);
+            int rc = kStepUsed;
+            if (TABLE ? tile == in : tile < n_full) full_tile(c0, c1, c2, n0, n1, n2, next_in);
             else {
                 if constexpr (kProjDepth == 2) drain_loads(); // (a step that consumes no register set: what was prefetched is dead from here on)
                 if (tile < a.n_tiles) partial_tile(tile);
+                rc = kStepKept;
             }
             ++j;
-            if (j < P && tile + 1 < a.n_tiles) return true; // (wave-uniform)
+            if (j < P && tile + 1 < a.n_tiles) return rc; // (wave-uniform)
             end_range();
             s += gridDim.x;
             ++i;
-            if (s >= a.n_spans) return false;
+            if (s >= a.n_spans) return kStepDone;
             begin_range();
-            return true;
+            return rc;
         };
         if (s < a.n_spans) {
             begin_range();
             if constexpr (kProjDepth == 2) {
-                for (;;) {
-                    if (!step(A0, A1, A2, C0, C1, C2)) break;
-                    if (!step(B0, B1, B2, A0, A1, A2)) break;
-                    if (!step(C0, C1, C2, B0, B1, B2)) break;
+                int64_t unused = 0;
+                for (;;) { // (one segment: a step that keeps its set only occurs in the wave's last range)
+                    if (!step(A0, A1, A2, C0, C1, C2, 0, unused)) break;
+                    if (!step(B0, B1, B2, A0, A1, A2, 0, unused)) break;
+                    if (!step(C0, C1, C2, B0, B1, B2, 0, unused)) break;
                 }
             } else {
-                for (;;) {
-                    if (!step(A0, A1, A2, B0, B1, B2)) break;
-                    if (!step(B0, B1, B2, A0, A1, A2)) break;
+                for (bool more = true; more;) {
+                    int rc;
+                    do rc = step(A0, A1, A2, B0, B1, B2, tile_in[0], tile_in[1]);
+                    while (TABLE && rc == kStepKept);
+                    if (rc == kStepDone) break;
+                    do rc = step(B0, B1, B2, A0, A1, A2, tile_in[1], tile_in[0]);
+                    while (TABLE && rc == kStepKept);
+                    more = rc != kStepDone;
                 }
             }
         }
@@ -1255,7 +1340,7 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
                     const uint32_t b32 = base > 0xFFFFFFFFULL ? 0xFFFFFFFFu : (uint32_t)base;
                     if (dense) {
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                        unpack_dense<K0, K1, K2>(a, (int64_t)tile0, P, base, lane, a.trash + ((size_t)blockIdx.x * kProjWriters + wr) * 64);
+                        unpack_dense<K0, K1, K2, TABLE>(a, (int64_t)tile0, P, base, lane, a.trash + ((size_t)blockIdx.x * kProjWriters + wr) * 64);
                     } else {
                         unpack_range<K0, K1, K2>(a, (const vec *)&s_ring[w][0], start, kCap, cnt, b32, tile0, lane);
                     }
@@ -1300,7 +1385,9 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
 }
 
 // ---------------------------------------------------------------------------------------------
-// launchers
+// launchers.  Two translation units share this file: imm3_project.hip holds the one-segment instances and the host-side
+// helpers, imm3_project_table.hip (which defines IMM3_PROJECT_TABLE_TU and includes this file) the table instances -- sixteen
+// kernels of ~17 000 instructions each per unit, compiled side by side.
 // ---------------------------------------------------------------------------------------------
 #define IMM3_PROJECT_KINDS(X)                                                                       \
     X(TK_NONE, TK_NONE, TK_NONE)                                                                    \
@@ -1310,10 +1397,40 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
     X(TK_I32, TK_I32, TK_I32) X(TK_I32, TK_I32, TK_I8) X(TK_I32, TK_I8, TK_I8)                      \
     X(TK_I8, TK_I8, TK_I8) X(TK_I32, TK_I32, TK_S2) X(TK_I32, TK_I8, TK_S2) X(TK_I8, TK_I8, TK_S2)
 
+#ifdef IMM3_PROJECT_TABLE_TU
+bool launch_filter_project_table(const ProjectArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    if (!a.tile_desc) return false;
+#define IMM3_PROJECT_CASE(k0, k1, k2)                                                               \
+    if (a.kinds[0] == k0 && a.kinds[1] == k1 && a.kinds[2] == k2) {                                 \
+        IMM3_LAUNCH((k_filter_project<k0, k1, k2, true>), grid, kProjThreads, s, ev0, ev1, a);     \
+        return true;                                                                                \
+    }
+    IMM3_PROJECT_KINDS(IMM3_PROJECT_CASE)
+#undef IMM3_PROJECT_CASE
+    return false;
+}
+
+// one descriptor per tile: the tile's address in each of the launch's columns and its valid rows
+__global__ __launch_bounds__(256) void k_project_tile_desc(const uint32_t *tile_rows, const void *const *p0, const void *const *p1, const void *const *p2, ProjectTile *out, int64_t n_tiles) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    ProjectTile d;
+    d.p[0] = p0 ? p0[t] : nullptr;
+    d.p[1] = p1 ? p1[t] : nullptr;
+    d.p[2] = p2 ? p2[t] : nullptr;
+    d.rows = tile_rows[t];
+    d.pad = 0u;
+    out[t] = d;
+}
+void launch_project_tile_desc(const uint32_t *tile_rows, const void *const *p0, const void *const *p1, const void *const *p2, ProjectTile *out, int64_t n_tiles, hipStream_t s) {
+    if (n_tiles <= 0) return;
+    hipLaunchKernelGGL(k_project_tile_desc, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, s, tile_rows, p0, p1, p2, out, n_tiles);
+}
+#else
 bool launch_filter_project(const ProjectArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
 #define IMM3_PROJECT_CASE(k0, k1, k2)                                                               \
     if (a.kinds[0] == k0 && a.kinds[1] == k1 && a.kinds[2] == k2) {                                 \
-        IMM3_LAUNCH((k_filter_project<k0, k1, k2>), grid, kProjThreads, s, ev0, ev1, a);           \
+        IMM3_LAUNCH((k_filter_project<k0, k1, k2, false>), grid, kProjThreads, s, ev0, ev1, a);    \
         return true;                                                                                \
     }
     IMM3_PROJECT_KINDS(IMM3_PROJECT_CASE)
@@ -1349,5 +1466,6 @@ int project_max_grid(const int32_t *kinds, int P) {
     if (dev >= 0 && dev < kMaxDevices) cus_of[dev].store(cus, std::memory_order_relaxed);
     return cus;
 }
+#endif
 
 } // namespace imm3
