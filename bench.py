@@ -66,6 +66,38 @@ def headline_source_sha16() -> str:
     return h.hexdigest()[:16]
 
 
+EXTRA_SOURCES = ("immutable3_amd/csrc/imm3_kernels.hip", "immutable3_amd/csrc/imm3_project.hip", "immutable3_amd/csrc/imm3_project_table.hip",
+                 "immutable3_amd/csrc/imm3_agg.hip", "immutable3_amd/csrc/imm3_tile.h", "immutable3_amd/csrc/imm3_device.h", "immutable3_amd/csrc/imm3_internal.h")
+
+
+def extra_source_sha16() -> str:
+    """Hash of the kernel sources behind the extra block's configs (C3, C4, C5, the README-shaped table): the stamp of their
+    entries in profiles/traffic.json."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in EXTRA_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def stamped_traffic(name: str) -> dict:
+    """HBM bytes of one config from profiles/traffic.json["extra"][name] (2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc
+    passes of this command, summed over the config's kernels; tools/summarize_prof5.py writes it) -- only when the entry was
+    measured on these kernel sources.  {} / {"source": why not} otherwise: a counter figure is never re-used across builds."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        e = json.load(open(path)).get("extra", {}).get(name)
+    except Exception:
+        return {"source": "profiles/traffic.json missing or unreadable"}
+    if not e:
+        return {"source": f"profiles/traffic.json has no entry '{name}'"}
+    if e.get("source_sha16") != extra_source_sha16():
+        return {"source": f"profiles/traffic.json['{name}'] REFUSED: measured on sources {e.get('source_sha16')}, this build is {extra_source_sha16()} -- re-run the --pmc passes (tools/gpu/r5_profile.sh)"}
+    return dict(e, source=f"from profiles/traffic.json['{name}'] (tag {e.get('tag')}): 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes of this command over "
+                          f"kernels {e.get('kernels')}, on these kernel sources (hash matches), committed; NOT re-measured in this run")
+
+
 def c3_bytes_per_row(sel: float) -> float:
     """(4+1) predicate columns + 1/8 bitmap + sigma x [4 B index + (4+1) gathered + (4+1) written]."""
     return 5 + 0.125 + sel * (4 + 5 + 5)
@@ -176,6 +208,68 @@ def cpu_baseline(values: np.ndarray, offsets: np.ndarray, sels, budget_s: float 
         "all_cores": {"value": all_cores, "cores": workers, "segments": len(bounds),
                       "note": "faithful flavour, one thread per segment, README-style segments (1024 x 1000 rows) of the same rows"},
     }
+
+
+def _ocols(cols):
+    from oracle import oracle_c
+    return [oracle_c.OColumn(np.ascontiguousarray(v).view(np.uint8).reshape(-1), offs, codec, width) for (codec, width, v, offs) in cols]
+
+
+def _select_project(ocols, sels, proj, flavour):
+    """ScanOp -> SelectOp* -> ProjectOp of one segment on the CPU (the oracle: imm3o_scan_select + imm3o_project); -> rows emitted."""
+    from oracle import oracle_c
+    words, count = oracle_c.scan_select(ocols, sels, 1024, flavour)
+    n_out = oracle_c.project(ocols, proj, 0, 1024, words, cap_rows=count)[0]
+    assert n_out == count, (n_out, count)
+    return count
+
+
+def cpu_baseline_project(cols, sels, proj, n: int, want_rows: int, budget_s: float = 10.0):
+    """The reference's CPU operators for a projecting config (C3, C4) on ONE thread -- one pipeline thread per segment,
+    Engine.scala:176-180 -- restated by the oracle: SelectOp chain (faithful flavour = the reference's per-block copy / per-element
+    decode / per-row BitSet cost structure; tight flavour also given) then ProjectOp (Project.scala:37-80) over the whole 100 M-row
+    segment, the same data and query as the GPU leg."""
+    ocols = _ocols(cols)
+    out = {}
+    for name, flavour in (("faithful", 0), ("tight", 1)):
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            got = _select_project(ocols, sels, proj, flavour)
+            assert got == want_rows, (got, want_rows)
+            reps += 1
+            if time.perf_counter() - t0 >= budget_s / 2 or reps >= 2:
+                break
+        out[name] = (n * reps / (time.perf_counter() - t0), reps)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return {"value": out["faithful"][0], "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": f"{out['faithful'][1]} full pass(es) of imm3o_scan_select + imm3o_project over the same {n}-row segment and query as the GPU leg, "
+                      f"oracle/imm3_oracle.c faithful flavour, gcc -O2, 1 thread (host: {os.cpu_count()} logical CPUs, {cores} usable)",
+            "selected_rows": int(want_rows), "tight_flavour_1_thread": out["tight"][0], "nproc": os.cpu_count()}
+
+
+def cpu_baseline_c5(host_cols, n: int):
+    """C5 on the CPU: the reference runs one pipeline thread per segment (Engine.scala:176-180) -- 8 segments, 8 threads, each the
+    oracle's faithful SelectOp chain + ProjectOp over its 100 M-row segment (ctypes releases the GIL inside the C calls)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle_c
+    sels = [(0, 3, 18.0), (0, 4, 30.0), (1, 3, C5_ID_LO), (1, 4, C5_ID_HI)]
+    per_seg = [_ocols([(oracle_c.DENSE_TINYINT, 1, c["age"], _block_offsets(n, 1)), (oracle_c.DENSE_INT, 4, c["id"], _block_offsets(n, 4))]) for c in host_cols]
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    workers = max(1, min(cores, len(per_seg)))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        counts = list(ex.map(lambda oc: _select_project(oc, sels, [1, 0], 0), per_seg))
+    dt = time.perf_counter() - t0
+    return {"value": n * len(per_seg) / dt, "unit": "rows/s", "cores": workers, "kind": "port",
+            "sample": f"one full pass of imm3o_scan_select + imm3o_project over all {len(per_seg)} segments of {n} rows (the GPU leg's data and query), one thread per "
+                      f"segment as Engine.scala:176-180 runs them ({workers} threads; host: {os.cpu_count()} logical CPUs, {cores} usable), faithful flavour, gcc -O2",
+            "selected_rows": int(sum(counts)), "seconds": dt, "nproc": os.cpu_count()}
+
+
+def _block_offsets(n: int, width: int):
+    from immutable3_amd import synth
+    return synth.block_offsets(n, width)
 
 
 # =====================================================================================================================
@@ -424,39 +518,71 @@ def measure_c2(env: Env, steps: int, warmup: int, with_cpu_baseline: bool):
 C5_ID_LO, C5_ID_HI = 1.0e6, 7.9e8        # the C3 id range stretched over the 8-segment id space [0, 8e8)
 
 
-def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True, solo: bool = False):
+def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True, solo: bool = False, with_cpu_baseline: bool = False):
     """solo: EVERY rank runs the whole job (all 8 segments) alone on its own GPU -- the G = 1 point of the strong-scaling curve
-    measured inside an N > 1 run (time = max over ranks); no count collective, the counts are checked locally."""
+    measured inside an N > 1 run (time = max over ranks); no count collective, the counts are checked locally.
+
+    The segments a rank owns are ONE scan unit (imm3_table, round 5): one table query -- one launch of k_filter_project's table
+    instance per pass whatever the number of owned segments (Engine.scala:176-196 merges the per-segment pipelines into one
+    result); --c5-per-segment keeps round 4's one query (one launch) per segment for A/B runs."""
     torch, native, synth, ctx, args = env.torch, env.native, env.synth, env.ctx, env.args
     from immutable3_amd.distributed import owned_segments
     n = args.rows
+    as_table = not args.c5_per_segment
     if not solo:
         env.make_comm()
     comm = None if solo else env.comm
     mine = list(range(C5_SEGMENTS)) if solo else owned_segments(C5_SEGMENTS, env.rank, env.world)
     sels = [(0, native.GT, 18.0), (0, native.LT, 30.0), (1, native.GT, C5_ID_LO), (1, native.LT, C5_ID_HI)]
-    segs, queries, expect = [], [], []
+    segs, queries, expect, host_cols = [], [], [], []
+    exp_seg, exp_row, exp_id, exp_age = [], [], [], []
     t_stage = time.perf_counter()
-    for s in mine:
+    for k, s in enumerate(mine):
         c = synth.c3_segment(n, seed=100 + s, id_base=s * n)
         seg = native.DeviceSegment(ctx, [(native.DENSE_INT, 4, c["id"].view(np.uint8), n * 4, synth.block_offsets(n, 4)),
                                          (native.DENSE_TINYINT, 1, c["age"].view(np.uint8), n, synth.block_offsets(n, 1))])
-        q = native.DeviceQuery(ctx, seg, [1, 0], sels, [1, 0], 0, 1024)     # used columns [age, id] (Engine.getColumns), SELECT id, age
         keep = (c["age"] > 18) & (c["age"] < 30) & (c["id"] > C5_ID_LO) & (c["id"] < C5_ID_HI)
         want = int(keep.sum())
-        # parity gate: count, ordered rows and values of every owned segment against numpy
-        q.run()
-        assert q.count() == want, (s, q.count(), want)
-        q.reserve_rows(want + 1024)
-        q.run()
-        idx, vals = q.fetch_rows()
         rows = np.flatnonzero(keep)
-        assert idx.size == want and (idx == rows).all(), f"segment {s}: row order"
-        assert (vals[0].view("<i4").reshape(-1) == c["id"][rows]).all() and (vals[1].view(np.int8).reshape(-1) == c["age"][rows]).all(), f"segment {s}: values"
+        if as_table:                                    # gated below, once the table query exists
+            exp_seg.append(np.full(rows.size, k, np.uint32))
+            exp_row.append(rows.astype(np.uint32))
+            exp_id.append(c["id"][rows])
+            exp_age.append(c["age"][rows])
+        else:
+            q = native.DeviceQuery(ctx, seg, [1, 0], sels, [1, 0], 0, 1024)     # used columns [age, id] (Engine.getColumns), SELECT id, age
+            # parity gate: count, ordered rows and values of every owned segment against numpy
+            q.run()
+            assert q.count() == want, (s, q.count(), want)
+            q.reserve_rows(want + 1024)
+            q.run()
+            idx, vals = q.fetch_rows()
+            assert idx.size == want and (idx == rows).all(), f"segment {s}: row order"
+            assert (vals[0].view("<i4").reshape(-1) == c["id"][rows]).all() and (vals[1].view(np.int8).reshape(-1) == c["age"][rows]).all(), f"segment {s}: values"
+            queries.append(q)
+            del idx, vals
+        if with_cpu_baseline:
+            host_cols.append(c)
         expect.append(want)
         segs.append(seg)
+        del c, keep, rows
+    table = None
+    if as_table and segs:
+        table = native.DeviceTable(ctx, segs)
+        q = native.DeviceQuery(ctx, table, [1, 0], sels, [1, 0], 0, 1024)
+        # parity gate: count, rows in (segment, row) order and values of every owned segment against numpy
+        q.run()
+        assert q.count() == sum(expect), (q.count(), sum(expect))
+        q.reserve_rows(sum(expect) + 1024)
+        q.run()
+        idx, vals = q.fetch_rows()
+        seg_of, row_of = q.locate_rows(idx)
+        assert idx.size == sum(expect), (idx.size, sum(expect))
+        assert (seg_of == np.concatenate(exp_seg)).all() and (row_of == np.concatenate(exp_row)).all(), "table query: row order"
+        assert (vals[0].view("<i4").reshape(-1) == np.concatenate(exp_id)).all() and (vals[1].view(np.int8).reshape(-1) == np.concatenate(exp_age)).all(), "table query: values"
         queries.append(q)
-        del c, keep, rows, idx, vals
+        del idx, vals, seg_of, row_of
+    del exp_seg, exp_row, exp_id, exp_age
     stage_s = time.perf_counter() - t_stage
     expect_total = sum(expect) if solo else env.sum_over_ranks(sum(expect))     # over gloo: independent of the collective under test
 
@@ -466,8 +592,8 @@ def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True, solo: 
 
     plan = queries[0].plan() if queries else {}
     kernels_per_query = 1 if plan.get("single_pass") else 3
-    # One pass = the runs of every owned segment's query.  They are recorded once (imm3_ctx_capture_begin / _end: a hipGraph of
-    # the kernels of every segment's query) and replayed with one call per pass; `--no-graph` issues the runs one by one instead.
+    # One pass = the runs of this rank's queries (one table query; or one per owned segment).  They are recorded once
+    # (imm3_ctx_capture_begin / _end: a hipGraph) and replayed with one call per pass; `--no-graph` issues the runs one by one.
     graph = None
     if use_graph:
         with ctx.capture() as cap:
@@ -480,7 +606,7 @@ def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True, solo: 
             graph.launch()
         else:
             for q in queries:
-                q.run()                                 # scan+select(+stage) -> offsets scan -> compact+gather, per owned segment
+                q.run()                                 # scan + select + project of every owned segment
         if comm is not None:
             comm.allreduce_count(queries, device_out=log.data_ptr() + 8 * i, wait=False)
         elif solo:                                      # no collective: the counts are summed once the loop is over
@@ -491,6 +617,20 @@ def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True, solo: 
     elapsed = env.timed_steps(step, steps, warmup)
     got = log[:steps].tolist() if comm is not None else ([sum(q.count() for q in queries)] if solo else host_counts[-steps:])
     assert all(g == expect_total for g in got), (got[:4], expect_total)
+    # How far behind the pass's last scan the collective ends: the all-reduce sits on the communicator's stream behind the scans, the
+    # next pass's scans do not wait for it -- on the host.  On the device a one-launch pass wants every CU; what a co-resident kernel
+    # of the communicator costs it is measured by tools/overlap_probe.py (profiles/r05_overlap.txt).  Here: the wall time of K passes
+    # with the collective against K passes without it, per pass.
+    allreduce_gap_ms = None
+    if comm is not None:
+        def step_no_collective(i: int):
+            if graph is not None:
+                graph.launch()
+            else:
+                for q in queries:
+                    q.run()
+        bare = env.timed_steps(step_no_collective, steps, min(warmup, 2))
+        allreduce_gap_ms = (elapsed - bare) / steps * 1e3
     elapsed_plain = None
     if graph is not None:                               # the same passes launched kernel by kernel, for the record
         elapsed_plain = env.timed_steps(lambda i: step(i, graphed=False), steps, min(warmup, 2))
@@ -501,8 +641,9 @@ def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True, solo: 
     def one_pass():
         for q in queries:
             q.run()
-    k = env.kernel_times(one_pass, max(3, min(steps, 20)), launches_per_run=8 * len(queries))
-    per_query = {KERNEL_NAMES[i]: (v / len(queries) if v is not None else None) for i, v in k.items()}
+    k = env.kernel_times(one_pass, max(3, min(steps, 20)), launches_per_run=8 * max(len(queries), 1))
+    per_pass = {KERNEL_NAMES[i]: v for i, v in k.items()}
+    per_query = {name: (v / len(mine) if v is not None else None) for name, v in per_pass.items()}   # per owned SEGMENT
     sel = sum(expect) / (n * len(mine))
     kernel_ms_per_query = sum(v for v in per_query.values() if v)
     # What became of the one-launch runs on this rank: a getter reads the last run's status word (bit 1: a look-back wait ran into its
@@ -511,7 +652,8 @@ def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True, solo: 
     for q in queries:
         q.row_count()
     plans = [q.plan() for q in queries]
-    per_rank = env.gather_objects({"rank": env.rank, "segments": mine, "selected_rows": sum(expect), "kernel_ms_per_query": per_query,
+    per_rank = env.gather_objects({"rank": env.rank, "segments": mine, "selected_rows": sum(expect), "kernel_ms_per_segment": per_query,
+                                   "kernel_ms_per_pass": per_pass, "queries": len(queries),
                                    "single_pass_queries": sum(1 for p in plans if p.get("single_pass")),
                                    "abandoned_runs": sum(int(p.get("abandoned_runs", 0)) for p in plans),
                                    "busy_runs": sum(int(p.get("busy_runs", 0)) for p in plans)})
@@ -520,12 +662,18 @@ def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True, solo: 
     if env.rank == 0:
         algo = c3_bytes_per_row(sel) * n
         achieved = algo / (kernel_ms_per_query * 1e-3) / 1e9
+        traffic = stamped_traffic("c5_table" if as_table else "c5_per_segment")
+        t_bytes = traffic.get("hbm_bytes_per_pass") if traffic.get("hbm_bytes_per_pass") and len(mine) == C5_SEGMENTS else None
+        pass_ms = kernel_ms_per_query * len(mine)
         out = {
             "value": float(n) * C5_SEGMENTS * steps / elapsed,
             "ms_per_step": elapsed / steps * 1e3,
-            "launch": (f"one hipGraph launch per pass ({kernels_per_query * len(queries)} kernels, imm3_graph_launch) + the count all-reduce"
+            "launch": (f"one hipGraph launch per pass ({kernels_per_query * len(queries)} kernel(s), imm3_graph_launch) + the count all-reduce"
                        if graph is not None else "kernel by kernel (--no-graph)"),
             "ms_per_step_kernel_by_kernel": elapsed_plain / steps * 1e3 if elapsed_plain is not None else None,
+            "allreduce_gap_ms_per_pass": allreduce_gap_ms,
+            "allreduce_gap_note": "wall time per pass with the count all-reduce minus without it (same K passes, same graph): what the collective adds "
+                                  "behind the last scan of a pass, net of what the next pass's scans hide",
             "global_selected_rows_per_pass": int(expect_total),
             "count_allreduce": ({"collective": "none (solo: every rank runs all 8 segments on its own GPU)", "checked": f"local count == {expect_total} (numpy)"} if solo else
                                 {"collective": env.count_reduce, "checked": f"all {steps} per-pass global counts == {expect_total} (numpy, summed over ranks via gloo)"}),
@@ -534,27 +682,39 @@ def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True, solo: 
                             "RangeFilter(age > 18 AND age < 30) AND RangeFilter(id > 1e6 AND id < 7.9e8) + Project(id, age), "
                             "one count all-reduce per pass",
                 "rows_per_step": n * C5_SEGMENTS, "segments": C5_SEGMENTS, "segments_per_gpu": len(mine), "block_rows": 1024,
+                "queries_per_gpu": len(queries),
+                "scan_unit": ("the rank's segments as ONE table query (imm3_table): one launch per pass" if as_table else "one query (one launch) per owned segment"),
                 "selectivity": sel, "parallelism": f"segment-sharded x{env.world} (s mod G), no data-path collective but the count",
             },
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": ("per-segment query: ONE launch, imm3::k_filter_project (scan + select + project; rank 0)" if plan.get("single_pass") else
-                           "per-segment query: scan+select(+stage) -> offsets scan -> compact+gather (rank 0)"),
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": t_bytes, "traffic_source": traffic.get("source"),
+                "traffic_ratio": (t_bytes / (algo * len(mine))) if t_bytes else None,
+                "frac_traffic": (t_bytes / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_bytes and pass_ms else None,
+                "kernel": (("one table query per rank: ONE launch of imm3::k_filter_project's table instance over all owned segments (scan + select + project; rank 0)"
+                            if as_table else "per-segment query: ONE launch, imm3::k_filter_project (scan + select + project; rank 0)") if plan.get("single_pass") else
+                           "scan+select -> offsets scan -> compact+gather (rank 0)"),
                 "plan": plan,
+                "kernel_ms_per_pass": per_pass,
                 "kernel_ms_per_query": per_query, "kernel_ms_sum_per_query": kernel_ms_per_query,
                 "algorithmic_bytes_per_query": algo,
                 "algorithmic_bytes_per_row": c3_bytes_per_row(sel),
-                "timing": "HIP events on the launching stream, second pass; frac = SURVEY 8d C3 bytes/row x rows / sum of kernel durations",
+                "timing": "HIP events on the launching stream, second pass; per query = per owned 100M-row segment (the pass's kernel time / segments); "
+                          "frac = SURVEY 8d C3 bytes/row x rows / kernel time",
             },
             "staging": {"host_to_hbm_s_per_segment": stage_s / max(len(mine), 1), "note": "incl. synthetic generation and the parity gate; never part of value"},
             "abandoned_runs": sum(int(r.get("abandoned_runs", 0)) for r in per_rank) if per_rank else None,
             "busy_runs": sum(int(r.get("busy_runs", 0)) for r in per_rank) if per_rank else None,
             "per_rank": per_rank,
         }
+        if with_cpu_baseline and host_cols:
+            out["cpu_baseline"] = cpu_baseline_c5(host_cols, n)
     if graph is not None:
         graph.close()
     for q in queries:
         q.close()
+    if table is not None:
+        table.close()
     for s in segs:
         s.close()
     return out
@@ -563,7 +723,67 @@ def measure_c5(env: Env, steps: int, warmup: int, use_graph: bool = True, solo: 
 # =====================================================================================================================
 # extra block of the N = 1 line: C3, C4, aggregation (the other BASELINE configs at full size), staging
 # =====================================================================================================================
-def extra_workloads(env: Env, steps: int = 20):
+def readme_table_c3(env: Env, ids: np.ndarray, age: np.ndarray, steps: int):
+    """C3's query over the reference's own on-disk shape: `LoaderCli --block-size 1024 --segment-size 1000` (README.md:10) cuts
+    100 M rows into 98 segments, each a "full" loader segment of 1000 * 1024 + 1 rows whose last block holds ONE row,
+    the last one shorter.  The reference fans out one pipeline per segment and merges the rows (Engine.scala:176-196); here the 98
+    resident segments are one scan unit (imm3_table) and the query is ONE launch over its tile table."""
+    native, synth, ctx = env.native, env.synth, env.ctx
+    n = ids.shape[0]
+    seg_rows = 1000 * 1024 + 1
+    bounds = [(a, min(a + seg_rows, n)) for a in range(0, n, seg_rows)]
+    segs = []
+    t0 = time.perf_counter()
+    for a, b in bounds:
+        m = b - a
+        segs.append(native.DeviceSegment(ctx, [(native.DENSE_TINYINT, 1, age[a:b].view(np.uint8), m, synth.block_offsets(m, 1)),
+                                               (native.DENSE_INT, 4, ids[a:b].view(np.uint8), m * 4, synth.block_offsets(m, 4))]))
+    table = native.DeviceTable(ctx, segs)
+    stage_s = time.perf_counter() - t0
+    lo, hi = 1e6 * n / 1e8, 9e7 * n / 1e8
+    sels = [(0, native.GT, 18.0), (0, native.LT, 30.0), (1, native.GT, lo), (1, native.LT, hi)]
+    keep = (age > 18) & (age < 30) & (ids > lo) & (ids < hi)
+    rows = np.flatnonzero(keep)
+    t0 = time.perf_counter()
+    q = native.DeviceQuery(ctx, table, [0, 1], sels, [1, 0], 0, 1024)
+    create_ms = (time.perf_counter() - t0) * 1e3
+    q.run()
+    cnt = q.count()
+    assert cnt == rows.size, (cnt, rows.size)
+    q.reserve_rows(cnt + 1024)
+    q.run()
+    idx, vals = q.fetch_rows()
+    seg_of, row_of = q.locate_rows(idx)
+    starts = np.array([a for a, _ in bounds], dtype=np.int64)
+    assert idx.size == rows.size and (starts[seg_of] + row_of == rows).all(), "README-shaped table: rows in (segment, row) order"
+    assert (vals[0].view("<i4").reshape(-1) == ids[rows]).all() and (vals[1].view(np.int8).reshape(-1) == age[rows]).all(), "README-shaped table: values"
+    del idx, vals, seg_of, row_of, keep
+    dt = env.timed_steps(lambda i: q.run(), steps, 3) / steps
+    k = env.kernel_times(q.run, steps)
+    kms = {KERNEL_NAMES[i]: v for i, v in k.items()}
+    ksum = sum(v for v in kms.values() if v)
+    sel = cnt / n
+    algo = c3_bytes_per_row(sel) * n
+    q.row_count()
+    tr = stamped_traffic("readme_table_c3")
+    tb = tr.get("hbm_bytes_per_query")
+    out = {"config": {"workload": "C3's query over 98 loader-made segments (README.md:10: block 1024 x segment 1000 -> 1 024 001 rows each, a one-row last block) "
+                                  "as ONE table query (imm3_table)", "segments": len(bounds), "rows": n, "rows_per_segment": seg_rows},
+           "plan": q.plan(), "create_ms": create_ms, "rows_per_s": n / dt, "ms_per_query": dt * 1e3, "selected_rows": int(cnt), "selectivity": sel,
+           "algorithmic_bytes_per_row": c3_bytes_per_row(sel), "algorithmic_bytes": algo, "kernel_ms": kms, "kernel_ms_sum": ksum,
+           "achieved_GBps": algo / (ksum * 1e-3) / 1e9, "frac": algo / (ksum * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_wall": algo / dt / 1e9 / HBM_PEAK_GBS,
+           "roofline": {"bound": "hbm", "achieved": algo / (ksum * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algo / (ksum * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": tb, "traffic_source": tr.get("source"), "traffic_ratio": tb / algo if tb else None,
+                        "frac_traffic": tb / (ksum * 1e-3) / 1e9 / HBM_PEAK_GBS if tb else None},
+           "staging_s_98_segments": stage_s}
+    q.close()
+    table.close()
+    for sg in segs:
+        sg.close()
+    return out
+
+
+def extra_workloads(env: Env, steps: int = 20, with_cpu_baseline: bool = True):
     """C3 (conjunctive RangeFilter on age and id + Project(id, age)) and C4 (MatchFilter(state)=='CA' +
     Project(id, state, age)) over one 100 M-row segment, group-by aggregation, PFOR_INT: per config the algorithmic
     bytes, every kernel's mean duration (HIP events) and the fraction of the 8 TB/s peak."""
@@ -586,6 +806,8 @@ def extra_workloads(env: Env, steps: int = 20):
                                     c3_bytes_per_row, keep3),
         "c4_match_state_project": ([1, 0, 2], [(0, native.MATCH, [b"CA"])], [1, 0, 2], c4_bytes_per_row, keep4),
     }
+    host_cols = [(native.DENSE_INT, 4, ids, synth.block_offsets(n, 4)), (native.DENSE_STRING, 2, st, synth.block_offsets(n, 2)),
+                 (native.DENSE_TINYINT, 1, age, synth.block_offsets(n, 1))]
     for name, (used, sels, proj, bytes_per_row, keep) in cases.items():
         q = native.DeviceQuery(ctx, seg, used, sels, proj, 0, 1024)
         q.run()
@@ -631,8 +853,21 @@ def extra_workloads(env: Env, steps: int = 20):
             "frac": algo / (ksum * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "frac_wall": algo / dt / 1e9 / HBM_PEAK_GBS,
         }
+        # HBM bytes really moved (counters of a committed profiling session on these sources) next to the algorithmic ones: C4's
+        # gathers fetch a 128-byte line per value, so its traffic-based fraction says how close its kernels are to what the memory
+        # system can do, the algorithmic one what the query is worth
+        tr = stamped_traffic(name)
+        tb = tr.get("hbm_bytes_per_query")
+        out[name]["roofline"] = {"bound": "hbm", "achieved": algo / (ksum * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": algo / (ksum * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tb, "traffic_source": tr.get("source"),
+                                 "traffic_ratio": tb / algo if tb else None,
+                                 "frac_traffic": tb / (ksum * 1e-3) / 1e9 / HBM_PEAK_GBS if tb else None}
+        if with_cpu_baseline:
+            out[name]["cpu_baseline"] = cpu_baseline_project([host_cols[u] for u in used], sels, proj, n, cnt)
         q.close()
     del keep3, keep4
+    if not env.args.no_readme_table:
+        out["readme_table_c3"] = readme_table_c3(env, ids, age, steps)
     # group-by aggregation: select count(id), max(age) from t [where age > 18 and age < 30] group by state
     for name, sels in (("agg_group_by_state_all_rows", []),
                        ("agg_group_by_state_range_age", [(1, native.GT, 18.0), (1, native.LT, 30.0)])):
@@ -718,6 +953,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="C5: launch every pass kernel by kernel instead of replaying the recorded hipGraph")
     ap.add_argument("--no-g1", action="store_true", help="N > 1: skip the solo leg (every rank runs the whole C5 job on its own GPU: the G = 1 point)")
     ap.add_argument("--no-c5", action="store_true", help="leave the C5 leg out of the extra block (profiling runs: its kernels are C3's instances)")
+    ap.add_argument("--c5-per-segment", action="store_true", help="C5: one query (one launch) per owned segment, as round 4 ran it, instead of one table query per rank")
+    ap.add_argument("--no-readme-table", action="store_true", help="leave the README-shaped 98-segment table out of the extra block")
     ap.add_argument("--no-limit", action="store_true", help="leave the `limit` queries out of the extra block (profiling runs: their chunks are launches of the headline kernel's instance)")
     ap.add_argument("--extra", action="store_true", help="(kept for compatibility: the extra block is on by default)")
     ap.add_argument("--variant", type=int, default=0)
@@ -741,13 +978,15 @@ def main():
     if env.rank == 0:
         result = dict(base, scaling="weak", dtype="i32", **{k: c2[k] for k in ("value", "ms_per_step", "ms_per_step_with_kernel_events", "config", "roofline", "staging", "per_rank")})
         result["cpu_baseline"] = c2.get("cpu_baseline") if env.world == 1 else None     # timed at N = 1 only (contract)
-    c5_keys = ("value", "ms_per_step", "launch", "ms_per_step_kernel_by_kernel", "global_selected_rows_per_pass", "count_allreduce", "config", "roofline", "abandoned_runs", "busy_runs", "per_rank")
+    c5_keys = ("value", "ms_per_step", "launch", "ms_per_step_kernel_by_kernel", "allreduce_gap_ms_per_pass", "allreduce_gap_note", "global_selected_rows_per_pass", "count_allreduce",
+               "config", "roofline", "abandoned_runs", "busy_runs", "per_rank")
     if env.world == 1:
         if not args.no_extra:
-            extra = extra_workloads(env)
+            extra = extra_workloads(env, with_cpu_baseline=not args.no_cpu_baseline)
             if not args.no_c5:
-                c5 = measure_c5(env, max(3, min(args.steps, 10)), 2, use_graph=not args.no_graph)
+                c5 = measure_c5(env, max(3, min(args.steps, 10)), 2, use_graph=not args.no_graph, with_cpu_baseline=not args.no_cpu_baseline)
                 extra["c5"] = {k: c5[k] for k in c5_keys}
+                extra["c5"]["cpu_baseline"] = c5.get("cpu_baseline")
                 extra["c5"]["scaling"] = "strong"
                 extra["c5"]["note"] = "BASELINE config C5 at G = 1: the first point of the strong-scaling curve whose G > 1 points are extra.c5.value of the --gpus N lines"
             result["extra"] = extra

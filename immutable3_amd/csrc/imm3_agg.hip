@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kAggThreads) void k_group_agg(const AggArgs a) {
             unsigned long long key[4] = {0, 0, 0, 0};
             for (int g = 0; g < a.n_group; ++g) {
                 unsigned long long raw[4];
-                if (a.groups[g].tile_ptrs) load4_raw(a.groups[g].tile_ptrs[tile], in_tile, a.groups[g].width, raw);
+                if (a.groups[g].tile_ptrs) load4_raw(as_global(a.groups[g].tile_ptrs[tile]), in_tile, a.groups[g].width, raw);
                 else load4_raw(a.groups[g].data, row0, a.groups[g].width, raw);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) key[k] |= raw[k] << (8 * a.groups[g].shift);
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kAggThreads) void k_group_agg(const AggArgs a) {
             for (int q = 0; q < a.n_agg; ++q) {
                 if (a.aggs[q].kind == AGG_COUNT) continue;
                 unsigned long long raw[4];
-                if (a.aggs[q].tile_ptrs) load4_raw(a.aggs[q].tile_ptrs[tile], in_tile, a.aggs[q].width, raw);
+                if (a.aggs[q].tile_ptrs) load4_raw(as_global(a.aggs[q].tile_ptrs[tile]), in_tile, a.aggs[q].width, raw);
                 else load4_raw(a.aggs[q].data, row0, a.aggs[q].width, raw);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)

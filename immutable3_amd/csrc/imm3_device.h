@@ -21,6 +21,16 @@ __device__ __forceinline__ uint64_t ballot64(bool p) { return (uint64_t)__ballot
 // clang has no __builtin_amdgcn_writelane; bind the LLVM intrinsic directly (emits v_writelane_b32).
 extern "C" __device__ int imm3_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 
+// A pointer READ FROM MEMORY (a tile table's per-tile column pointer) has no known address space, and every access through it
+// becomes a FLAT instruction: slower per access than a global one, and counted by BOTH wait counters -- a wave's LDS waits then
+// also wait for its outstanding column loads, which serialises exactly the loads / LDS-transpose overlap the tile kernels are
+// built on (round 5: the table instance of k_filter_project ran C3 at 164 us against 122 until its tile pointers went through
+// this).  The round trip through address space 1 tells the compiler the pointer is a global one; nothing is emitted.
+template <class T>
+__device__ __forceinline__ T *as_global(T *p) {
+    return (T *)(__attribute__((address_space(1))) T *)p;
+}
+
 // mask of the first `rem` bits (rem may be <= 0 or >= 64)
 __device__ __forceinline__ uint64_t low_mask(int64_t rem) {
     return rem >= 64 ? ~0ULL : (rem <= 0 ? 0ULL : ((1ULL << rem) - 1ULL));

@@ -244,9 +244,9 @@ __global__ __launch_bounds__(kBlockThreads, tile_min_waves(K0, K1, STAGE)) void 
         };
         for (int64_t tile = wave_id; tile < a.n_tiles; tile += n_waves) {
             const uint32_t rows_here = a.tile_rows[tile];
-            const void *d0 = K0 != TK_NONE ? a.tile_ptrs[0][tile] : nullptr;
-            const void *d1 = K1 != TK_NONE ? a.tile_ptrs[1][tile] : nullptr;
-            const void *d2 = K2 != TK_NONE ? a.tile_ptrs[2][tile] : nullptr;
+            const void *d0 = K0 != TK_NONE ? as_global(a.tile_ptrs[0][tile]) : nullptr; // (as_global: no flat loads through a pointer read from memory)
+            const void *d1 = K1 != TK_NONE ? as_global(a.tile_ptrs[1][tile]) : nullptr;
+            const void *d2 = K2 != TK_NONE ? as_global(a.tile_ptrs[2][tile]) : nullptr;
             ColRegs<K0> c0;
             ColRegs<K1> c1;
             ColRegs<K2> c2;
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(kBlockThreads) void k_gather(const GatherArgs a) {
             for (int pj = 0; pj < a.n_proj; ++pj) {
                 ProjCol pc2 = a.proj[pj];
                 if (pc2.tile_ptrs) { // table query: the column of this tile's segment, position within the tile
-                    pc2.src = pc2.tile_ptrs[tile];
+                    pc2.src = as_global(pc2.tile_ptrs[tile]);
                     row = r & (kTileRows - 1);
                 }
                 if (pc2.staged && staged_tile) { // survivors' values were compacted per tile by the filter kernel

@@ -280,6 +280,24 @@ __device__ __forceinline__ void store_quad_w(void *dst, uint32_t out0, uint32_t 
 }
 constexpr int kind_width(int k) { return k == TK_I32 ? 4 : (k == TK_S2 ? 2 : 1); }
 
+// One tile descriptor of a table query, read through a CONSTANT-address-space pointer: the descriptors were written before the
+// launch and nothing writes them during it, and only so may the compiler use a scalar load (s_load, lgkmcnt) for a wave-uniform
+// index.  As plain global memory it must assume that this kernel's own stores could alias them and emits vector loads -- which sit
+// in vmcnt BEHIND the tile loads just issued, so the wait for the descriptor drained the streamers' prefetch (C3 over a table:
+// 160 us against 120).
+__device__ __forceinline__ ProjectTile load_tile_desc(const ProjectTile *base, int64_t idx) {
+    typedef const __attribute__((address_space(4))) unsigned long long *cptr;
+    const cptr w = (cptr)(base + idx);
+    ProjectTile d;
+    d.p[0] = (const void *)w[0];
+    d.p[1] = (const void *)w[1];
+    d.p[2] = (const void *)w[2];
+    const unsigned long long r = w[3];
+    d.rows = (uint32_t)r;
+    d.pad = (uint32_t)(r >> 32);
+    return d;
+}
+
 template <int R>
 __device__ __forceinline__ void rec_words(const typename RecVec<R>::type &r, uint32_t (&w)[4]) {
     if constexpr (R == 1) { w[0] = r; w[1] = w[2] = w[3] = 0u; }
@@ -504,10 +522,10 @@ __device__ __forceinline__ void unpack_dense(const ProjectArgs &a, int64_t tile0
         const void *s0 = a.cols[0].data, *s1 = a.cols[1].data, *s2 = a.cols[2].data;
         uint32_t row0 = row_of(tt), safe = row_of(tt & ~1) - (uint32_t)lane; // safe: the tile's first row
         if constexpr (TABLE) {
-            const ProjectTile &d = a.tile_desc[tile0 + (tt >> 1)]; // (wave-uniform: scalar loads)
-            s0 = d.p[0];
-            s1 = d.p[1];
-            s2 = d.p[2];
+            const ProjectTile d = load_tile_desc(a.tile_desc, __builtin_amdgcn_readfirstlane((int)(tile0 + (tt >> 1)))); // (wave-uniform, read-only: scalar loads)
+            s0 = as_global(d.p[0]);
+            s1 = as_global(d.p[1]);
+            s2 = as_global(d.p[2]);
             row0 = (uint32_t)((tt & 1) * kDenseWords * 64) + (uint32_t)lane;
             safe = 0u;
         }
@@ -595,7 +613,8 @@ __device__ __forceinline__ void unpack_dense(const ProjectArgs &a, int64_t tile0
             constexpr int W = decltype(width)::value;
             if constexpr (W != 0) {
                 if (to_trash) return; // (wave-uniform: the column is not in the SELECT list)
-                const u32x4 *from = TABLE ? (const u32x4 *)src : (const u32x4 *)((const uint8_t *)src + ((int64_t)first_row + (int64_t)j * kTileRows) * W); // (table: src is the tile's own pointer)
+                typedef IMM3_GLOBAL u32x4 gvec; // (a global pointer by type: no flat loads through a tile descriptor's pointer)
+                const gvec *from = TABLE ? (const gvec *)src : (const gvec *)((const IMM3_GLOBAL uint8_t *)src + ((int64_t)first_row + (int64_t)j * kTileRows) * W); // (table: src is the tile's own pointer)
 #pragma unroll
                 for (int i = 0; i < W; ++i) v[i] = __builtin_nontemporal_load(from + 64 * i + lane);
             }
@@ -616,10 +635,10 @@ __device__ __forceinline__ void unpack_dense(const ProjectArgs &a, int64_t tile0
             const int jj = j < n_t ? j : n_t - 1;
             const void *s0 = a.cols[0].data, *s1 = a.cols[1].data, *s2 = a.cols[2].data;
             if constexpr (TABLE) {
-                const ProjectTile &d = a.tile_desc[tile0 + jj];
-                s0 = d.p[0];
-                s1 = d.p[1];
-                s2 = d.p[2];
+                const ProjectTile d = load_tile_desc(a.tile_desc, __builtin_amdgcn_readfirstlane((int)(tile0 + jj)));
+                s0 = as_global(d.p[0]);
+                s1 = as_global(d.p[1]);
+                s2 = as_global(d.p[2]);
             }
             load_col(std::integral_constant<int, W0>(), s0, t0, jj, S.v0);
             load_col(std::integral_constant<int, W1>(), s1, t1, jj, S.v1);
@@ -955,38 +974,33 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
             return t;
         };
         // Table queries: the head's next tile and its descriptor, fetched ONE TILE AHEAD of the loads that need it (a scalar load in
-        // front of every tile's loads would hold them back by its latency); the head skips partial tiles -- they take the rolled
-        // path and no register set -- so the sets always hold consecutive FULL tiles, and tile_in[] says which (what the consuming
-        // side checks: a tile of its sequence that is not the one loaded is a partial one).
-        int64_t nx_t = 0;
+        // front of every tile's loads would hold them back by its latency).  A segment's PARTIAL last tile is loaded and evaluated as
+        // a whole one -- every column carries 16 KiB of readable slack behind its last row (imm3_api.cpp: kPad) -- and the bits of
+        // the rows that do not exist are masked off the words before anything is counted or compacted (rows_in[] says how many
+        // exist): a partial tile in the middle of the table costs sixteen scalar ANDs, not a rolled walk and a dense range.  (First
+        // version: rolled path + dense range per partial tile -- 98 loader-made segments per 100 M rows took 187 us against 123.)
+        // (SGPRs are what this loop is short of -- the sixteen bitmap words alone are 32 -- and every spilled one is a v_readlane per
+        // use: the table's head keeps ONE descriptor, 32-bit tile numbers, and no "last valid pointer": behind the table's end it
+        // reads the LAST tile's descriptor again, so that the loads the compiler sees on every path stay on readable addresses.)
+        int32_t nx_t = 0;
         ProjectTile nx = {};
-        const void *last_p[kMaxTileCols] = {nullptr, nullptr, nullptr};
-        auto fetch_desc = [&]() {
-            nx_t = head_next();
-            nx = a.tile_desc[nx_t < a.n_tiles ? nx_t : a.n_tiles - 1];
+        auto fetch_desc = [&]() { // (load_tile_desc: a scalar load)
+            nx_t = (int32_t)head_next();
+            nx = load_tile_desc(a.tile_desc, nx_t < (int32_t)a.n_tiles ? nx_t : (int32_t)a.n_tiles - 1);
         };
-        if constexpr (TABLE) {
-            const ProjectTile &d0 = a.tile_desc[0]; // (an address that is always readable as a whole tile: the columns carry slack)
-            last_p[0] = d0.p[0];
-            last_p[1] = d0.p[1];
-            last_p[2] = d0.p[2];
-            fetch_desc();
-        }
-        auto head_load = [&](ColRegs<K0> &r0, ColRegs<K1> &r1, ColRegs<K2> &r2) -> int64_t { // -> the tile loaded (-1: none left)
+        if constexpr (TABLE) fetch_desc();
+        auto head_load = [&](ColRegs<K0> &r0, ColRegs<K1> &r1, ColRegs<K2> &r2, uint32_t &rows_loaded) -> int32_t { // -> the tile loaded (-1: none left)
             if constexpr (TABLE) {
-                while (nx_t < a.n_tiles && nx.rows != (uint32_t)kTileRows) fetch_desc(); // (one partial tile per segment)
-                int64_t got = -1;
-                if (nx_t < a.n_tiles) {
-                    got = nx_t;
-                    last_p[0] = nx.p[0];
-                    last_p[1] = nx.p[1];
-                    last_p[2] = nx.p[2];
-                } // (nothing left: the last tile again -- a load the compiler sees on every path)
-                r0.load(last_p[0], 0, lane);
-                r1.load(last_p[1], 0, lane);
-                r2.load(last_p[2], 0, lane);
-                if (nx_t < a.n_tiles) fetch_desc();
-                return got;
+                // (the scalar load of the descriptor AFTER this one is issued first: its latency passes while this tile's seventeen
+                // vector loads are issued)
+                const int32_t this_t = nx_t;
+                const ProjectTile cur = nx;
+                fetch_desc();
+                rows_loaded = cur.rows;
+                r0.load(as_global(cur.p[0]), 0, lane);
+                r1.load(as_global(cur.p[1]), 0, lane);
+                r2.load(as_global(cur.p[2]), 0, lane);
+                return this_t < (int32_t)a.n_tiles ? this_t : -1;
             } else {
             int64_t t = head_t;
             if (IMM3_ABLATE_BIT(a, 8)) { // (timing only: all tiles dealt grid-stride -- every wave of the launch reads one contiguous window, as k_filter_tile)
@@ -1005,12 +1019,14 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
                 r2.load(a.cols[2].data, t * kTileRows, lane);
             }
             (void)head_next();
-            return t;
+            (void)rows_loaded;
+            return (int32_t)t;
             }
         };
-        int64_t tile_in[2] = {-1, -1}; // (table) the tile whose columns are in register set A / B
-        tile_in[0] = head_load(A0, A1, A2);
-        if constexpr (kProjDepth == 2) head_load(B0, B1, B2);
+        int32_t tile_in[2] = {-1, -1};        // (table) the tile whose columns are in register set A / B ...
+        uint32_t rows_in[2] = {kTileRows, kTileRows}; // ... and how many of its rows exist
+        tile_in[0] = head_load(A0, A1, A2, rows_in[0]);
+        if constexpr (kProjDepth == 2) head_load(B0, B1, B2, rows_in[1]);
         // ---- the wave's running state: its current span (s, the work-group's i-th), the ring, whether the rows have been given up
         int64_t s = blockIdx.x;
         uint32_t i = 0;
@@ -1086,14 +1102,14 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
         };
         // one full tile: its columns are in (c0, c1, c2); the loads of the tile kProjDepth tiles ahead go to (n0, n1, n2), the set
         // that was worked on last
-        auto full_tile = [&](ColRegs<K0> &c0, ColRegs<K1> &c1, ColRegs<K2> &c2, ColRegs<K0> &n0, ColRegs<K1> &n1, ColRegs<K2> &n2, int64_t &next_in) {
+        auto full_tile = [&](ColRegs<K0> &c0, ColRegs<K1> &c1, ColRegs<K2> &c2, ColRegs<K0> &n0, ColRegs<K1> &n1, ColRegs<K2> &n2, uint32_t rows_here, int32_t &next_in, uint32_t &next_rows) {
             // software pipeline (k_filter_tile, finding 11): the wait for this tile's loads sits BEFORE the next loads are issued (vmcnt
             // retires in order: what is in flight behind this tile's loads -- the next tile's, at depth 2 -- is not waited for)
             if constexpr (kProjDepth == 2) wait_tile<kTileLoads>(); // this tile's loads have landed; the next tile's stay in flight
             c0.touch();
             c1.touch();
             c2.touch();
-            next_in = head_load(n0, n1, n2);
+            next_in = head_load(n0, n1, n2, next_rows);
             uint64_t acc[kTileWords]; // wave-uniform words (SGPR pairs)
 #pragma unroll
             for (int w = 0; w < kTileWords; ++w) acc[w] = ~0ULL;
@@ -1113,6 +1129,12 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
                 if constexpr (K0 != TK_I32) c0.test(a.cols[0], acc);
                 if constexpr (K1 != TK_I32) c1.test(a.cols[1], acc);
                 if constexpr (K2 != TK_I32) c2.test(a.cols[2], acc);
+            }
+            if constexpr (TABLE) {
+                if (rows_here < (uint32_t)kTileRows) { // (wave-uniform) a segment's last tile: the rows behind its end are no rows
+#pragma unroll
+                    for (int w = 0; w < kTileWords; ++w) acc[w] &= low_mask((int64_t)rows_here - 64 * w);
+                }
             }
             uint64_t mine = words_to_lanes(acc);
             if (lane >= kTileWords) mine = 0;
@@ -1164,10 +1186,10 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
             int64_t row0 = tile * kTileRows, valid_rows = a.n_rows - row0;
             const void *d0 = a.cols[0].data, *d1 = a.cols[1].data, *d2 = a.cols[2].data;
             if constexpr (TABLE) { // (rare: a blocking scalar load)
-                const ProjectTile &d = a.tile_desc[tile];
-                d0 = d.p[0];
-                d1 = d.p[1];
-                d2 = d.p[2];
+                const ProjectTile d = load_tile_desc(a.tile_desc, tile);
+                d0 = as_global(d.p[0]);
+                d1 = as_global(d.p[1]);
+                d2 = as_global(d.p[2]);
                 row0 = 0;
                 valid_rows = d.rows;
             }
@@ -1192,10 +1214,10 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
             if (lane < kTileWords && (TABLE || word < (a.n_rows + 63) / 64)) a.bitmap[word] = mine; // (table: every tile's line exists in full)
             lane_total += (uint32_t)__popcll(mine);
         };
-        // One tile of the wave's sequence -- range by range, span by span.  The loop below calls it with the register sets in
-        // rotating roles (an explicit unroll by their number: no register copies).  A partial tile, or a range that starts behind
-        // the data's end, consumes no register set (kStepKept): the same set is offered to the next step.  In one segment both only
-        // occur in the wave's last range; a table has a partial tile at the end of every segment, in the middle of a wave's work.
+        // One tile of the wave's sequence -- range by range, span by span; false: the wave has no tile left.  The loop below calls it
+        // with the register sets in rotating roles (an explicit unroll by their number: no register copies).  A partial tile, or a
+        // range that starts behind the data's end, consumes no register set; both only occur in the wave's last range, so the
+        // strict alternation holds wherever it matters (a table's partial tiles are whole tiles to this loop).
         // every untracked tile load has landed, and up to here the register sets were the columns' (ColRegs::keep says why)
         auto drain_loads = [&]() {
             wait_tile<0>();
@@ -1204,44 +1226,44 @@ __global__ __launch_bounds__(kProjThreads) void k_filter_project(const ProjectAr
             C0.keep(); C1.keep(); C2.keep();
             __builtin_amdgcn_sched_barrier(0);
         };
-        constexpr int kStepDone = 0, kStepUsed = 1, kStepKept = 2;
-        // `in`: (table) the tile whose columns are in (c0, c1, c2); `next_in`: where the tile loaded into (n0, n1, n2) is noted
-        auto step = [&](ColRegs<K0> &c0, ColRegs<K1> &c1, ColRegs<K2> &c2, ColRegs<K0> &n0, ColRegs<K1> &n1, ColRegs<K2> &n2, int64_t in, int64_t &next_in) -> int {
+        // `in` / `rows_here`: (table) the tile whose columns are in (c0, c1, c2) and its valid rows; `next_in` / `next_rows`: where the
+        // same is noted for the tile loaded into (n0, n1, n2)
+        auto step = [&](ColRegs<K0> &c0, ColRegs<K1> &c1, ColRegs<K2> &c2, ColRegs<K0> &n0, ColRegs<K1> &n1, ColRegs<K2> &n2, int32_t in, uint32_t rows_here, int32_t &next_in,
+                        uint32_t &next_rows) -> bool {
             const int64_t tile = t0 + j;
-            int rc = kStepUsed;
-            if (TABLE ? tile == in : tile < n_full) full_tile(c0, c1, c2, n0, n1, n2, next_in);
-            else {
-                if constexpr (kProjDepth == 2) drain_loads(); // (a step that consumes no register set: what was prefetched is dead from here on)
-                if (tile < a.n_tiles) partial_tile(tile);
-                rc = kStepKept;
+            if constexpr (TABLE) { // (every tile of the table is loaded and evaluated as a whole one; a tile that is not the one loaded lies
+                // behind the table's end, and so does everything after it: the sets' alternation no longer matters)
+                if ((int32_t)tile == in) full_tile(c0, c1, c2, n0, n1, n2, rows_here, next_in, next_rows);
+            } else {
+                if (tile < n_full) full_tile(c0, c1, c2, n0, n1, n2, rows_here, next_in, next_rows);
+                else {
+                    if constexpr (kProjDepth == 2) drain_loads(); // (a step that consumes no register set: what was prefetched is dead from here on)
+                    if (tile < a.n_tiles) partial_tile(tile);
+                }
             }
             ++j;
-            if (j < P && tile + 1 < a.n_tiles) return rc; // (wave-uniform)
+            if (j < P && tile + 1 < a.n_tiles) return true; // (wave-uniform)
             end_range();
             s += gridDim.x;
             ++i;
-            if (s >= a.n_spans) return kStepDone;
+            if (s >= a.n_spans) return false;
             begin_range();
-            return rc;
+            return true;
         };
         if (s < a.n_spans) {
             begin_range();
             if constexpr (kProjDepth == 2) {
-                int64_t unused = 0;
+                int32_t unused = 0;
+                uint32_t unused_rows = 0;
                 for (;;) { // (one segment: a step that keeps its set only occurs in the wave's last range)
-                    if (!step(A0, A1, A2, C0, C1, C2, 0, unused)) break;
-                    if (!step(B0, B1, B2, A0, A1, A2, 0, unused)) break;
-                    if (!step(C0, C1, C2, B0, B1, B2, 0, unused)) break;
+                    if (!step(A0, A1, A2, C0, C1, C2, 0, kTileRows, unused, unused_rows)) break;
+                    if (!step(B0, B1, B2, A0, A1, A2, 0, kTileRows, unused, unused_rows)) break;
+                    if (!step(C0, C1, C2, B0, B1, B2, 0, kTileRows, unused, unused_rows)) break;
                 }
             } else {
-                for (bool more = true; more;) {
-                    int rc;
-                    do rc = step(A0, A1, A2, B0, B1, B2, tile_in[0], tile_in[1]);
-                    while (TABLE && rc == kStepKept);
-                    if (rc == kStepDone) break;
-                    do rc = step(B0, B1, B2, A0, A1, A2, tile_in[1], tile_in[0]);
-                    while (TABLE && rc == kStepKept);
-                    more = rc != kStepDone;
+                for (;;) {
+                    if (!step(A0, A1, A2, B0, B1, B2, tile_in[0], rows_in[0], tile_in[1], rows_in[1])) break;
+                    if (!step(B0, B1, B2, A0, A1, A2, tile_in[1], rows_in[1], tile_in[0], rows_in[0])) break;
                 }
             }
         }

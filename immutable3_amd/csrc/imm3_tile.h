@@ -23,6 +23,10 @@ __device__ __forceinline__ void lds_reads_landed() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// Column bytes are read through pointers TYPED as global (address space 1): a pointer whose provenance the compiler cannot see --
+// one read from a tile table -- otherwise makes every access a FLAT instruction (imm3_device.h: as_global says what that costs).
+#define IMM3_GLOBAL __attribute__((address_space(1)))
+
 template <int KIND>
 struct ColRegs { // TK_NONE: no column
     __device__ __forceinline__ void load(const void *, int64_t, int) {}
@@ -42,7 +46,7 @@ template <>
 struct ColRegs<TK_I32> {
     int32_t v[kTileWords];
     __device__ __forceinline__ void load(const void *data, int64_t row0, int lane) {
-        const int32_t *p = (const int32_t *)data + row0 + lane;
+        const IMM3_GLOBAL int32_t *p = (const IMM3_GLOBAL int32_t *)data + row0 + lane;
 #pragma unroll
         for (int j = 0; j < kTileWords; ++j) v[j] = __builtin_nontemporal_load(p + 64 * j);
     }
@@ -85,9 +89,9 @@ struct ColRegs<TK_I32> {
     // eval() in two steps (k_filter_project): stage() = the LDS traffic of a narrow column's transpose, test() = the compares
     __device__ __forceinline__ void stage(int, uint8_t *) {}
     __device__ __forceinline__ void test(const TileCol &c, uint64_t (&acc)[kTileWords]) { eval(c, acc, 0, nullptr); }
-    __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return in_closed(((const int32_t *)data)[r], c.lo, c.hi); }
+    __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return in_closed(((const IMM3_GLOBAL int32_t *)data)[r], c.lo, c.hi); }
     __device__ __forceinline__ uint32_t value(int j) const { return (uint32_t)v[j]; }
-    __device__ __forceinline__ uint32_t rowval(const void *data, int64_t r) const { return ((const uint32_t *)data)[r]; }
+    __device__ __forceinline__ uint32_t rowval(const void *data, int64_t r) const { return ((const IMM3_GLOBAL uint32_t *)data)[r]; }
 };
 
 template <>
@@ -95,7 +99,7 @@ struct ColRegs<TK_I8> {
     v4i raw;
     uint32_t v[kTileWords]; // after eval(): the byte of row 64j + lane, zero-extended (what a survivor record carries)
     __device__ __forceinline__ void load(const void *data, int64_t row0, int lane) {
-        raw = __builtin_nontemporal_load((const v4i *)((const int8_t *)data + row0) + lane);
+        raw = __builtin_nontemporal_load((const IMM3_GLOBAL v4i *)((const IMM3_GLOBAL int8_t *)data + row0) + lane);
     }
     __device__ __forceinline__ void touch() { asm volatile("" : "+v"(raw)); }
     static constexpr int kLoads = 1;
@@ -119,9 +123,9 @@ struct ColRegs<TK_I8> {
         stage(lane, xp);
         test(c, acc);
     }
-    __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return in_closed((int32_t)((const int8_t *)data)[r], c.lo, c.hi); }
+    __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return in_closed((int32_t)((const IMM3_GLOBAL int8_t *)data)[r], c.lo, c.hi); }
     __device__ __forceinline__ uint32_t value(int j) const { return v[j]; }
-    __device__ __forceinline__ uint32_t rowval(const void *data, int64_t r) const { return ((const uint8_t *)data)[r]; }
+    __device__ __forceinline__ uint32_t rowval(const void *data, int64_t r) const { return ((const IMM3_GLOBAL uint8_t *)data)[r]; }
 };
 
 template <>
@@ -129,7 +133,7 @@ struct ColRegs<TK_S2> {
     v4i raw[2];
     uint32_t v[kTileWords]; // after eval(): the two bytes of row 64j + lane, little-endian
     __device__ __forceinline__ void load(const void *data, int64_t row0, int lane) {
-        const v4i *p = (const v4i *)((const uint16_t *)data + row0) + lane;
+        const IMM3_GLOBAL v4i *p = (const IMM3_GLOBAL v4i *)((const IMM3_GLOBAL uint16_t *)data + row0) + lane;
         raw[0] = __builtin_nontemporal_load(p);
         raw[1] = __builtin_nontemporal_load(p + 64);
     }
@@ -181,9 +185,9 @@ struct ColRegs<TK_S2> {
             }
         }
     }
-    __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return hit(c, ((const uint16_t *)data)[r]); }
+    __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return hit(c, ((const IMM3_GLOBAL uint16_t *)data)[r]); }
     __device__ __forceinline__ uint32_t value(int j) const { return v[j]; }
-    __device__ __forceinline__ uint32_t rowval(const void *data, int64_t r) const { return ((const uint16_t *)data)[r]; }
+    __device__ __forceinline__ uint32_t rowval(const void *data, int64_t r) const { return ((const IMM3_GLOBAL uint16_t *)data)[r]; }
 };
 
 // ---- survivor records ---------------------------------------------------------------------------------------
@@ -226,9 +230,10 @@ struct Rec {
 // The store truncates.
 template <int W>
 __device__ __forceinline__ uint32_t load_value(const void *src, int64_t idx) {
-    if constexpr (W == 4) return ((const uint32_t *)src)[idx];
-    else if constexpr (W == 2) return ((const uint32_t *)src)[idx >> 1] >> (16 * ((uint32_t)idx & 1u));
-    else return ((const uint32_t *)src)[idx >> 2] >> (8 * ((uint32_t)idx & 3u));
+    const IMM3_GLOBAL uint32_t *g = (const IMM3_GLOBAL uint32_t *)src; // (every source of these helpers is a column in HBM)
+    if constexpr (W == 4) return g[idx];
+    else if constexpr (W == 2) return g[idx >> 1] >> (16 * ((uint32_t)idx & 1u));
+    else return g[idx >> 2] >> (8 * ((uint32_t)idx & 3u));
 }
 template <int W>
 __device__ __forceinline__ void store_value(void *dst, uint64_t out, uint32_t v) {

@@ -50,6 +50,11 @@ def test_bench_cpu_baseline_and_extra_block():
         for k in ("algorithmic_bytes", "kernel_ms", "frac", "selected_rows", "ms_per_query"):
             assert k in e, (name, k)
         assert e["kernel_ms"]["scan_select"] > 0 and 0 < e["frac"] < 1.2
+        # round 5: the reference's CPU operators timed beside every config, and counter traffic next to the algorithmic bytes
+        cb = e["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["selected_rows"] == e["selected_rows"] and cb["nproc"] >= 1
+        for k in ("traffic", "traffic_ratio", "frac_traffic", "traffic_source", "frac", "achieved", "peak"):
+            assert k in e["roofline"], (name, k)
         if e["plan"]["single_pass"]:     # ONE launch: the filter kernel writes the rows (imm3_project.hip)
             assert e["plan"]["ran_single_pass"] and e["kernel_ms"]["compact_gather"] is None and e["kernel_ms"]["offsets_scan"] is None
         else:
@@ -58,6 +63,11 @@ def test_bench_cpu_baseline_and_extra_block():
     assert x["agg_group_by_state_all_rows"]["groups"] == 51
     c5 = x["c5"]
     assert c5["config"]["segments"] == 8 and c5["value"] > 0 and "ncclAllReduce" in c5["count_allreduce"]["collective"] and c5["scaling"] == "strong"
+    assert c5["config"]["queries_per_gpu"] == 1                     # the rank's eight segments are ONE table query
+    assert c5["cpu_baseline"]["cores"] >= 1 and c5["cpu_baseline"]["selected_rows"] == c5["global_selected_rows_per_pass"]
+    assert "allreduce_gap_ms_per_pass" in c5 and "traffic" in c5["roofline"] and "frac_traffic" in c5["roofline"]
+    rt = x["readme_table_c3"]
+    assert rt["selected_rows"] == x["c3_range_age_id_project"]["selected_rows"] and rt["kernel_ms"]["scan_select"] > 0
 
 
 def test_bench_gpus_2_launches_its_own_ranks():
