@@ -309,12 +309,20 @@ extern "C" int imm3_ctx_inject_fault(imm3_ctx *ctx, int32_t work_group, int32_t 
     return IMM3_OK;
 }
 
+#ifdef IMM3_ABLATE
 static int single_pass_lock_word(int device, unsigned long long **out);
+#endif
 
 // The device's ticket word of the single-pass kernel (0 = free).  Tests put a foreign ticket there to make every launch find the
 // device busy, deterministically; imm3_project.hip and run_single_pass say what the word is for.
 extern "C" int imm3_ctx_debug_device_lock(imm3_ctx *ctx, uint64_t value, uint64_t *previous) {
     CTX_LIVE(ctx);
+#ifndef IMM3_ABLATE
+    // (the shipped library does not hand out a way to park every one-launch query of a device, in every context, on its fallback)
+    (void)value;
+    (void)previous;
+    return fail(IMM3_ERR_STATE, "the device-lock hook exists only in the tools' build of the library (make -C csrc ablate)");
+#else
     HIPCHK(hipSetDevice(ctx->device));
     unsigned long long *word = nullptr;
     const int rc = single_pass_lock_word(ctx->device, &word);
@@ -325,6 +333,7 @@ extern "C" int imm3_ctx_debug_device_lock(imm3_ctx *ctx, uint64_t value, uint64_
     HIPCHK(hipMemcpy(word, &v, sizeof(v), hipMemcpyHostToDevice));
     if (previous) *previous = old;
     return IMM3_OK;
+#endif
 }
 
 extern "C" int imm3_ctx_devclock_enable(imm3_ctx *ctx, int32_t max_launches) {
@@ -1316,19 +1325,24 @@ constexpr int kSampleTiles = kSampleChunks * (int)kSampleChunkTiles;
 // the sample's tile table for one column of the segment (cached on the segment: the sampled tiles are the segment's, not the query's)
 static int sample_tile_ptrs(imm3_ctx *ctx, const imm3_segment *cseg, int32_t col, int64_t n_full, void ***out, uint32_t **rows_out) {
     imm3_segment *seg = const_cast<imm3_segment *>(cseg);
-    std::lock_guard<std::mutex> g(seg->layout_mu);
-    if (seg->sample_full_tiles >= 0 && seg->sample_full_tiles != n_full) return fail(IMM3_ERR_STATE, "internal: the segment's sample was laid out for another row count");
-    if (!seg->d_sample_rows) {
-        std::vector<uint32_t> rows((size_t)kSampleTiles, (uint32_t)kTileRows);
-        void *p = nullptr;
-        HIPCHK(hipMalloc(&p, rows.size() * sizeof(uint32_t)));
-        const hipError_t e = hipMemcpy(p, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e != hipSuccess) { (void)hipFree(p); HIPCHK(e); }
-        seg->d_sample_rows = (uint32_t *)p;
-        seg->sample_full_tiles = n_full;
+    // The device allocations and copies happen OUTSIDE the segment's lock (they wait for the device: query creations on one
+    // segment would queue up behind them); the lock only covers looking the tables up and publishing them.  Two creations that
+    // race for the same column both build a table and the loser's is freed.
+    bool have_rows = false, have_ptrs = false;
+    {
+        std::lock_guard<std::mutex> g(seg->layout_mu);
+        if (seg->sample_full_tiles >= 0 && seg->sample_full_tiles != n_full) return fail(IMM3_ERR_STATE, "internal: the segment's sample was laid out for another row count");
+        have_rows = seg->d_sample_rows != nullptr;
+        have_ptrs = seg->d_sample_ptrs.find(col) != seg->d_sample_ptrs.end();
     }
-    auto it = seg->d_sample_ptrs.find(col);
-    if (it == seg->d_sample_ptrs.end()) {
+    void *new_rows = nullptr, *new_ptrs = nullptr;
+    if (!have_rows) {
+        std::vector<uint32_t> rows((size_t)kSampleTiles, (uint32_t)kTileRows);
+        HIPCHK(hipMalloc(&new_rows, rows.size() * sizeof(uint32_t)));
+        const hipError_t e = hipMemcpy(new_rows, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(new_rows); HIPCHK(e); }
+    }
+    if (!have_ptrs) {
         const SegCol &sc = seg->cols[(size_t)col];
         std::vector<const void *> ptrs((size_t)kSampleTiles);
         for (int i = 0; i < kSampleChunks; ++i) {
@@ -1337,15 +1351,28 @@ static int sample_tile_ptrs(imm3_ctx *ctx, const imm3_segment *cseg, int32_t col
             for (int64_t t = 0; t < kSampleChunkTiles; ++t)
                 ptrs[(size_t)(i * kSampleChunkTiles + t)] = col_flat(sc) + (size_t)(tile0 + t) * kTileRows * (size_t)sc.width;
         }
-        void *p = nullptr;
-        HIPCHK(hipMalloc(&p, ptrs.size() * sizeof(void *)));
-        const hipError_t e = hipMemcpy(p, ptrs.data(), ptrs.size() * sizeof(void *), hipMemcpyHostToDevice);
-        if (e != hipSuccess) { (void)hipFree(p); HIPCHK(e); }
-        it = seg->d_sample_ptrs.emplace(col, (void **)p).first;
+        hipError_t e = hipMalloc(&new_ptrs, ptrs.size() * sizeof(void *));
+        if (e == hipSuccess) e = hipMemcpy(new_ptrs, ptrs.data(), ptrs.size() * sizeof(void *), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(new_rows); (void)hipFree(new_ptrs); HIPCHK(e); }
     }
+    void *drop_rows = nullptr, *drop_ptrs = nullptr;
+    {
+        std::lock_guard<std::mutex> g(seg->layout_mu);
+        if (new_rows) {
+            if (!seg->d_sample_rows) { seg->d_sample_rows = (uint32_t *)new_rows; seg->sample_full_tiles = n_full; }
+            else drop_rows = new_rows;
+        }
+        auto it = seg->d_sample_ptrs.find(col);
+        if (new_ptrs) {
+            if (it == seg->d_sample_ptrs.end()) it = seg->d_sample_ptrs.emplace(col, (void **)new_ptrs).first;
+            else drop_ptrs = new_ptrs;
+        }
+        *out = it->second;
+        *rows_out = seg->d_sample_rows;
+    }
+    (void)hipFree(drop_rows);
+    (void)hipFree(drop_ptrs);
     (void)ctx;
-    *out = it->second;
-    *rows_out = seg->d_sample_rows;
     return IMM3_OK;
 }
 
@@ -2409,6 +2436,7 @@ static int single_pass_device(int device, SinglePassDevice **out) {
     return IMM3_OK;
 }
 
+#ifdef IMM3_ABLATE
 static int single_pass_lock_word(int device, unsigned long long **out) {
     SinglePassDevice *dev = nullptr;
     const int rc = single_pass_device(device, &dev);
@@ -2416,6 +2444,7 @@ static int single_pass_lock_word(int device, unsigned long long **out) {
     *out = dev->d_lock;
     return IMM3_OK;
 }
+#endif
 
 // ScanOp -> SelectOp* -> ProjectOp in one launch (k_filter_project): bitmap, count and the projected rows
 static int run_single_pass(imm3_query *q) {
@@ -2784,6 +2813,10 @@ extern "C" int imm3_query_join_count(imm3_query *q) {
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
     CTX_LIVE(q->ctx);
     HIPCHK(hipSetDevice(q->ctx->device));
+    // (the hand-off to device-side consumers of the count word: after a limit scan that stopped early the word holds the scanned
+    // prefix's count -- the whole select runs first, as for imm3_query_count and the count all-reduce)
+    const int wrc = settle_whole_select(q);
+    if (wrc) return wrc;
     return join_total(q, q->ctx->stream);
 }
 

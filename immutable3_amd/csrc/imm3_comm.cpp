@@ -13,6 +13,7 @@
 #include <rccl/rccl.h> // types and enums only; every call goes through the table below
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -40,10 +41,19 @@ Rccl g_rccl;
 std::once_flag g_rccl_once;
 
 void rccl_bind() {
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // IMM3_RCCL_LIB: another library that exports the nine nccl* entry points bound below, tried first.  The test suite's
+    // loopback transport (tests/native/loopback_rccl.cpp: two ranks of ONE process on ONE device, which RCCL itself refuses)
+    // comes in this way, so that the world > 1 paths of this file run where no second GPU exists.
+    const char *override_path = getenv("IMM3_RCCL_LIB");
+    const char *names[] = {override_path && *override_path ? override_path : "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *n : names) {
         g_rccl.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (g_rccl.so) break;
+        if (override_path && *override_path && n == names[0]) { // (an override that does not load is an error, not a silent fall-back)
+            const char *e = dlerror();
+            g_rccl.error = std::string("cannot load IMM3_RCCL_LIB=") + override_path + ": " + (e ? e : "?");
+            return;
+        }
     }
     if (!g_rccl.so) {
         const char *e = dlerror();
@@ -430,6 +440,12 @@ extern "C" int imm3_comm_merge_groups(imm3_comm *c, imm3_query *const *queries, 
             if (grc) local_fail(grc, imm3_last_error());
         }
     }
+    // (wide keys: this rank's entries must leave room for a table of twice their number + 1 slots in the kernels' 32-bit slot
+    // fields -- 2^30 entries: checked HERE, before the first collective, like everything else that can fail on one rank alone)
+    constexpr unsigned long long kMaxMergeEntries = 1ULL << 30;
+    unsigned long long total_local = 0;
+    for (int32_t i = 0; i < n_queries; ++i) total_local += n_local[(size_t)i];
+    if (local_rc == IMM3_OK && key_bytes > 2 && total_local > kMaxMergeEntries) local_fail(IMM3_ERR_ARG, "too many groups to merge");
     hipStream_t s = ctx->stream;
     // the direct table of narrow keys (allocated before the exchange: a failure here is this rank's to report)
     void *table = nullptr;
@@ -515,8 +531,6 @@ extern "C" int imm3_comm_merge_groups(imm3_comm *c, imm3_query *const *queries, 
         // add / min / max on the columns), its occupied slots come out as a packed list, the ranks' lists are exchanged with
         // ncclAllGather -- fixed-size slots, sized by an all-reduce(max) of the list lengths -- and merged the same way.  The
         // host only sorts the result by first arrival.
-        unsigned long long total_local = 0;
-        for (int32_t i = 0; i < n_queries; ++i) total_local += n_local[(size_t)i];
         auto pow2_at_least = [](unsigned long long v) { unsigned long long p = 1024; while (p < v) p <<= 1; return p; };
         // one table: {keys, counts, first, vals[kMaxAggs]} x slots, then the packed list and its counter
         auto table_bytes = [](unsigned long long slots, unsigned long long list_cap) {
@@ -537,7 +551,7 @@ extern "C" int imm3_comm_merge_groups(imm3_comm *c, imm3_query *const *queries, 
             a.n_agg = n_agg;
             for (int j = 0; j < kMaxAggs; ++j) { a.kinds[j] = kinds[j]; a.is_str[j] = is_str[j]; }
         };
-        if (total_local > 0x7FFFFFFFULL) return fail(IMM3_ERR_ARG, "too many groups to merge");
+        if (c->world == 1 && total_local > kMaxMergeEntries) return fail(IMM3_ERR_ARG, "too many groups to merge"); // (world > 1: refused before the shape exchange)
         const unsigned long long cap1 = pow2_at_least(2 * std::max<unsigned long long>(total_local, 1)), list1 = std::max<unsigned long long>(total_local, 1);
         void *p1 = nullptr;
         {   // (a failure here is this rank's alone: with more than one rank it would leave the others in the collective below, so the
@@ -548,11 +562,22 @@ extern "C" int imm3_comm_merge_groups(imm3_comm *c, imm3_query *const *queries, 
         std::unique_ptr<void, void (*)(void *)> g1(p1, [](void *q) { (void)hipFree(q); });
         unsigned long long mine = 0;
         MergeArgs a1;
+        std::memset(&a1, 0, sizeof(a1));
+        std::string p1_why = "hipMalloc of the merge table failed";
         if (p1) {
+            // Device work of THIS rank between two collectives: whatever fails here must not return -- the other ranks are on
+            // their way to the list-length all-reduce below and would wait there for good.  A failure clears p1 instead: the
+            // rank then says ~0 in that all-reduce and every rank leaves together.
+            auto local_step = [&](hipError_t e, const char *what) {
+                if (e == hipSuccess || !p1) return;
+                (void)hipGetLastError();
+                p1_why = std::string(what) + ": " + hipGetErrorString(e);
+                p1 = nullptr;
+            };
             bind(a1, p1, cap1, list1);
             launch_merge_init(a1, s);
-            HIPCHK(hipGetLastError());
-            for (int32_t i = 0; i < n_queries; ++i) {
+            local_step(hipGetLastError(), "merge table init");
+            for (int32_t i = 0; i < n_queries && p1; ++i) {
                 imm3_query *q = queries[i];
                 const uint32_t ng = n_local[(size_t)i];
                 a1.keys = q->d_okeys;
@@ -562,12 +587,14 @@ extern "C" int imm3_comm_merge_groups(imm3_comm *c, imm3_query *const *queries, 
                 a1.n_groups = ng;
                 a1.seg_hi = (unsigned long long)(uint32_t)segment_index[i] << 32;
                 if (ng) launch_merge_scatter(a1, s);
-                HIPCHK(hipGetLastError());
+                local_step(hipGetLastError(), "merge scatter");
             }
-            launch_merge_collect_list(a1, s);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(&mine, a1.out_n, sizeof(mine), hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
+            if (p1) {
+                launch_merge_collect_list(a1, s);
+                local_step(hipGetLastError(), "merge collect");
+            }
+            if (p1) local_step(hipMemcpyAsync(&mine, a1.out_n, sizeof(mine), hipMemcpyDeviceToHost, s), "merge list length");
+            if (p1) local_step(hipStreamSynchronize(s), "merge list length");
         }
         auto take_list = [&](const unsigned long long *d_list, unsigned long long n) -> int {
             std::vector<unsigned long long> h((size_t)n * kMergeListWords);
@@ -586,7 +613,7 @@ extern "C" int imm3_comm_merge_groups(imm3_comm *c, imm3_query *const *queries, 
             return IMM3_OK;
         };
         if (c->world == 1) {
-            if (!p1) return fail(IMM3_ERR_DEVICE, "hipMalloc of the merge table failed");
+            if (!p1) return fail(IMM3_ERR_DEVICE, p1_why);
             const int trc = take_list(a1.out_list, mine);
             if (trc) return trc;
         } else {
@@ -596,11 +623,11 @@ extern "C" int imm3_comm_merge_groups(imm3_comm *c, imm3_query *const *queries, 
             NCCLCHK(g_rccl.AllReduce(c->d_slot, c->d_slot, 1, ncclUint64, ncclMax, c->nccl, s));
             HIPCHK(hipMemcpyAsync(&most, c->d_slot, sizeof(most), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            if (most == ~0ULL) return fail(IMM3_ERR_DEVICE, "a rank could not allocate its merge table; no rank has merged anything");
+            if (most == ~0ULL) return fail(IMM3_ERR_DEVICE, p1 ? std::string("a rank could not build its merge table; no rank has merged anything") : p1_why + "; no rank has merged anything");
             const size_t per_rank = (size_t)most * kMergeListWords;
             if (per_rank) {
                 const unsigned long long entries = most * (unsigned long long)c->world;
-                if (entries > 0x7FFFFFFFULL) return fail(IMM3_ERR_ARG, "too many groups to merge");
+                if (entries > kMaxMergeEntries) return fail(IMM3_ERR_ARG, "too many groups to merge"); // (the same figure on every rank: every rank leaves here)
                 const unsigned long long cap2 = pow2_at_least(2 * entries);
                 void *p = nullptr;
                 // (sizes are the same on every rank: an allocation failure here is reported through one more flag exchange)

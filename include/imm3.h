@@ -261,7 +261,10 @@ int imm3_query_run_count(imm3_query *q);
 int imm3_query_sync(imm3_query *q);
 /* The selected-row count of a select-only run is reduced on the context's auxiliary stream so that it overlaps the
  * next scan.  Host getters wait for it by themselves; a DEVICE consumer of imm3_query_device_ptr(q, 1) that runs on
- * the context's main stream calls this first: it makes the main stream wait (stream-side, no host block). */
+ * the context's main stream calls this first: it makes the main stream wait (stream-side, no host block).  After a projection
+ * with a `limit` whose scan stopped early (imm3_query_run on a limit query) the count word holds the scanned prefix's count: this
+ * call then runs the whole select first, like imm3_query_count and imm3_comm_allreduce_count, so that what the device consumer reads
+ * behind it is the segment's count. */
 int imm3_query_join_count(imm3_query *q);
 
 /* Device-side log of the selected-row count of every later run of this query: run k (counted from this call) stores its

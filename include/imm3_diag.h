@@ -77,7 +77,8 @@ int imm3_query_plan(const imm3_query *q, int64_t *out, int32_t n);
  * but "off".
  * imm3_ctx_debug_device_lock: overwrites the per-device ticket word that keeps two launches of the kernel from sharing the
  * device (0 = free) and returns what it held; with a foreign ticket in place every launch finds the device busy.  Synchronises
- * the context's stream first.  Works in every build (it only touches the word). */
+ * the context's stream first.  TOOLS' build only, like the fault injection (round 4 shipped it: any caller could have parked every
+ * one-launch query of a device, in every context, on its fallback); the shipped library answers IMM3_ERR_STATE. */
 int imm3_ctx_inject_fault(imm3_ctx *ctx, int32_t work_group, int32_t span, uint32_t max_polls);
 int imm3_ctx_debug_device_lock(imm3_ctx *ctx, uint64_t value, uint64_t *previous);
 

@@ -192,6 +192,79 @@ print("two graphs ok; launches that found the device busy:", busy, "of", 24, flu
 ca.graph.close(); cb.graph.close()
 qa.close(); qb.close()
 seg2.close(); ctx2.close()
+
+# ---- 5. a TABLE query (one launch over three segments, csrc/imm3_project_table.hip): the same failure paths -- a span that is never
+# announced, a busy device -- leave count and bitmap exact, and the rows come back through the table's bitmap path
+cuts = [0, 4_000 * 1024 + 1, 4_000 * 1024 + 1 + 5_000 * 1024 + 777, n]
+tsegs = []
+for lo_, hi_ in zip(cuts[:-1], cuts[1:]):
+    m = hi_ - lo_
+    tsegs.append(native.DeviceSegment(ctx, [RawColumn(DENSE_INT, 4, a[lo_:hi_], blocks_of(m, 1024)).native(), RawColumn(DENSE_TINYINT, 1, c[lo_:hi_], blocks_of(m, 1024)).native()]))
+table = native.DeviceTable(ctx, tsegs)
+starts = np.array(cuts[:-1], dtype=np.int64)
+
+def check_table_rows(q, tag):
+    idx, vals = q.fetch_rows()
+    seg_of, row_of = q.locate_rows(idx)
+    assert idx.size == rows.size and (starts[seg_of] + row_of == rows).all(), tag
+    assert vals[0].tobytes() == np.ascontiguousarray(a[rows]).tobytes() and vals[1].tobytes() == np.ascontiguousarray(c[rows]).tobytes(), tag
+    words = q.bitmap()
+    fb, fw = q.segment_starts()
+    for si in range(3):
+        want = np.packbits(keep[cuts[si]: cuts[si + 1]], bitorder="little")
+        want = np.concatenate([want, np.zeros((-want.size) % 8, np.uint8)]).view("<u8")
+        assert words[int(fw[si]): int(fw[si]) + want.size].tolist() == want.tolist(), (tag, si)
+
+def fresh_table():
+    ctx.set_tuning(202, 0)
+    try:
+        q = native.DeviceQuery(ctx, table, [1, 0], sels, [1, 0], 0, 1024)
+    finally:
+        ctx.set_tuning(0, 0)
+    assert q.plan()["single_pass"] and q.plan()["P"] == 2, q.plan()
+    q.reserve_rows(n)
+    ctx.sync()
+    poison(q)
+    return q
+
+q = fresh_table()
+q.run(); ctx.sync()
+assert run_flags(q) == (rows.size, 0)
+check_table_rows(q, "table baseline")
+assert q.plan()["ran_single_pass"]
+q.close()
+for wg, span in ((7, 1), (0, 0)):
+    ctx.inject_fault(wg, span, 3000)
+    q = fresh_table()
+    q.run(); ctx.sync()
+    cnt, flags = run_flags(q)
+    assert cnt == rows.size and flags & ABANDONED and not flags & BUSY, (wg, span, cnt, flags)
+    assert comm.allreduce_count([q]) == rows.size
+    ctx.inject_fault(-1, -1, 0)
+    check_table_rows(q, ("table abandoned", wg, span))
+    p = q.plan()
+    assert p["abandoned_runs"] == 1 and not p["single_pass"] and not p["ran_single_pass"], p
+    q.run()
+    check_table_rows(q, ("table after abandoned", wg, span))
+    q.close()
+q = fresh_table()
+assert ctx.debug_device_lock(0xDEAD0005) == 0
+q.run(); ctx.sync()
+cnt, flags = run_flags(q)
+assert cnt == rows.size and flags & BUSY, (cnt, flags)
+check_table_rows(q, "table busy")
+assert q.plan()["busy_runs"] == 1 and q.plan()["single_pass"], q.plan()
+assert ctx.debug_device_lock(0) == 0xDEAD0005
+poison(q)
+q.run(); ctx.sync()
+assert run_flags(q) == (rows.size, 0)
+check_table_rows(q, "table after busy")
+assert q.plan()["ran_single_pass"]
+q.close()
+table.close()
+for t_ in tsegs:
+    t_.close()
+print("table ok", flush=True)
 comm.close(); seg.close(); ctx.close()
 print("FAULT-INJECTION-OK", flush=True)
 '''
@@ -211,8 +284,10 @@ def test_abandoned_and_busy_runs_on_the_device(tmp_path):
     assert r.returncode == 0 and "FAULT-INJECTION-OK" in r.stdout
 
 
-def test_the_shipped_library_refuses_fault_injection_but_knows_a_busy_device():
-    """The fault-injection argument is inert in the shipped kernel (the hook says so); the busy path needs no special build."""
+def test_the_shipped_library_refuses_the_fault_hooks():
+    """The fault-injection argument is inert in the shipped kernel and the device-lock hook is not in the shipped library at all
+    (round 4 shipped it: any caller could park every one-launch query of a device on its fallback); both say so.  The busy path
+    itself is run by the worker above, on the tools' build."""
     import numpy as np
     from conftest import DENSE_INT, DENSE_TINYINT, GT, RawColumn, blocks_of
     from immutable3_amd import native, synth
@@ -220,6 +295,8 @@ def test_the_shipped_library_refuses_fault_injection_but_knows_a_busy_device():
     with pytest.raises(native.Imm3Error):
         ctx.inject_fault(3, 0, 100)
     ctx.inject_fault(-1, -1, 0)
+    with pytest.raises(native.Imm3Error):
+        ctx.debug_device_lock(0xBEEF0001)
     n = 300 * 1024 + 17
     a = synth.uniform_int30(5, n)
     c = synth.uniform_below(6, n, 100, np.int8)
@@ -232,18 +309,10 @@ def test_the_shipped_library_refuses_fault_injection_but_knows_a_busy_device():
     finally:
         ctx.set_tuning(0, 0)
     assert q.plan()["single_pass"]
-    prev = ctx.debug_device_lock(0xBEEF0001)
-    try:
-        q.run()
-        assert q.count() == rows.size
-        idx, vals = q.fetch_rows()
-        assert (idx == rows).all() and vals[0].tobytes() == np.ascontiguousarray(a[rows]).tobytes()
-        assert q.plan()["busy_runs"] == 1 and q.plan()["single_pass"]
-    finally:
-        ctx.debug_device_lock(prev)
-    q.run()
-    idx, _ = q.fetch_rows()
-    assert (idx == rows).all() and q.plan()["ran_single_pass"] and q.plan()["busy_runs"] == 1
+    q.run()                        # (the refused hook left the device's ticket word alone)
+    idx, vals = q.fetch_rows()
+    assert (idx == rows).all() and vals[0].tobytes() == np.ascontiguousarray(a[rows]).tobytes()
+    assert q.plan()["ran_single_pass"] and q.plan()["busy_runs"] == 0
     q.close()
     seg.close()
     ctx.close()
