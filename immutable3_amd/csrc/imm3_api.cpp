@@ -1008,11 +1008,28 @@ static int tile_kind(const FoldedPred &fp) {
 }
 
 // ---- single-pass projection: tiles per wave and span (P) ----
+// CUs a one-launch plan leaves free while a communicator is attached to its context: ONE PER XCD.  The kernel wants every CU (one
+// work-group per CU, all resident); the kernel RCCL launches for the count all-reduce of the pass before cannot share a CU with such
+// a work-group (ncclDevKernel_Generic for gfx950: 512 threads x 256 vector registers and 37 664 bytes of LDS, beside 3 waves x 131
+// registers per SIMD and 140 KB) -- so with all 256 CUs taken it waits until a work-group LEAVES, i.e. for the whole pass, and when
+// it wins the race instead, one work-group of the pass starts late by the collective's duration and the pass ends that much later.
+// Work-groups go to the XCDs round-robin BEFORE the dispatcher knows where there is room, so a free CU only helps on the XCD the
+// collective's work-group is sent to: four free CUs (grid 252: XCDs 0-3 full) changed nothing, one per XCD does (tools/overlap_probe.py,
+// profiles/r05_overlap.txt; the table is in DESIGN section 8).
+constexpr int kXcds = 8;
+constexpr int kCommReservedCUs = kXcds;
+static bool single_pass_reserves(const imm3_query *q) {
+    return q->ctx->comms_attached.load(std::memory_order_relaxed) > 0 && q->ctx->filter_variant != 16 && q->sp_max_grid > 4 * kCommReservedCUs; // (tuning 16: no reservation, for A/B runs)
+}
+static int32_t single_pass_run_grid(const imm3_query *q) {
+    const int64_t g = single_pass_reserves(q) ? q->sp_max_grid - kCommReservedCUs : q->sp_max_grid;
+    return (int32_t)std::max<int64_t>(1, std::min<int64_t>(g, q->sp_spans));
+}
 static void single_pass_set_P(imm3_query *q, int32_t P) {
     const int64_t tiles_per_span = (int64_t)P * kProjectStreamers;
     q->sp_P = P;
     q->sp_spans = (q->n_tiles + tiles_per_span - 1) / tiles_per_span;
-    q->sp_grid = (int32_t)std::min<int64_t>(q->sp_max_grid, q->sp_spans);
+    q->sp_grid = single_pass_run_grid(q);
 }
 // The host has learnt how many rows survive (a count it fetched together with the number of ranges that outgrew their LDS
 // ring, dense_ranges; or a reservation, dense_ranges < 0): later runs use a P at which a range's survivors fill about 45 %
@@ -1076,15 +1093,24 @@ static int single_pass_setup(imm3_query *q) {
     const int64_t ring_records = kProjectRingBytes / (4 * R);
     int64_t p_hi = std::max<int64_t>(4, std::min<int64_t>(16, ring_records / 3 / 85));
     if (tile_bytes > 0) p_hi = std::max<int64_t>(4, std::min<int64_t>(p_hi, (60 * 1024) / tile_bytes));
-    const int64_t p_lo = std::max<int64_t>(4, p_hi - 1);
-    int64_t P = p_hi;
-    double best = -1.0;
-    for (int64_t p = p_hi; p >= p_lo && maxg > 0; --p) {
-        const int64_t spans = (q->n_tiles + p * kProjectStreamers - 1) / (p * kProjectStreamers);
-        const int64_t rounds = (spans + maxg - 1) / maxg;
-        const double fill = (double)spans / (double)(rounds * maxg);
-        if (fill > best + 0.02) { best = fill; P = p; }
-    }
+    // Spans go to the work-groups in ROUNDS of one span each, and a round takes the time of its P tiles whether all work-groups have a
+    // span in it or one: the launch costs rounds x P tile times (+ a prefix chain per round), and the rounds are quantised by the
+    // grid.  100 M rows on 256 CUs: P = 6 -> 7.95 rounds -> 8 x 6 = 48 tile times (47.7 is the floor); on 248 CUs (a CU per XCD left
+    // to a communicator) P = 6 -> 8.2 rounds -> 9 x 6 = 54, P = 5 -> 9.85 -> 10 x 5 = 50.  So P is planned per grid: the candidate
+    // (two below the ceiling the ring and the register sets allow, never under 4) with the fewest tile times, the larger P on a tie.
+    auto plan_P = [&](int64_t grid) -> int64_t {
+        int64_t best_P = p_hi;
+        double best = 1e300;
+        for (int64_t p = p_hi; p >= std::max<int64_t>(4, p_hi - 2) && grid > 0; --p) {
+            const int64_t spans = (q->n_tiles + p * kProjectStreamers - 1) / (p * kProjectStreamers);
+            const int64_t rounds = (spans + grid - 1) / grid;
+            const double cost = (double)rounds * ((double)p + 0.35); // (+ the part of a round's prefix chain and ring hand-offs that nothing hides)
+            if (cost < best - 1e-9) { best = cost; best_P = p; }
+        }
+        return best_P;
+    };
+    int64_t P = plan_P(maxg);
+    const int64_t P_reserved = plan_P(maxg > 4 * kCommReservedCUs ? maxg - kCommReservedCUs : maxg);
     const bool fixed = ctx->filter_variant > 200 && ctx->filter_variant <= 200 + kProjectMaxP;
     if (fixed) P = ctx->filter_variant - 200; // tuning: variant 200 + P
     if (maxg < 1 || q->n_tiles < 1) return IMM3_OK;
@@ -1092,7 +1118,7 @@ static int single_pass_setup(imm3_query *q) {
     // descriptors of the smallest P a run may use, then one 64-byte trash line per writer wave.  The plan is committed only
     // once the allocation stands (a query whose descriptors could not be allocated keeps the three launches).
     const int64_t spans_max = (q->n_tiles + kProjectMinP * kProjectStreamers - 1) / (kProjectMinP * kProjectStreamers);
-    const int64_t grid_min = std::min<int64_t>(maxg, spans_max);
+    const int64_t grid_min = std::max<int64_t>(1, std::min<int64_t>(maxg > 4 * kCommReservedCUs ? maxg - kCommReservedCUs : maxg, spans_max)); // (the smallest grid a run may use: single_pass_run_grid)
     const size_t rounds_max = (size_t)((spans_max + grid_min - 1) / grid_min);
     const size_t desc_off = (rounds_max * (sizeof(unsigned long long) + sizeof(uint32_t)) + 255) / 256 * 256;
     const size_t desc_bytes = desc_off + (size_t)spans_max * sizeof(unsigned long long);
@@ -1128,10 +1154,12 @@ static int single_pass_setup(imm3_query *q) {
     q->sp_desc_off = desc_off;
     q->sp_trash_off = trash_off;
     q->single_pass = true;
-    q->sp_P_plan = (int32_t)P;
     q->sp_P_fixed = fixed;
     q->sp_max_grid = maxg;
-    single_pass_set_P(q, (int32_t)P);
+    q->sp_P_plan_for[0] = (int32_t)P;
+    q->sp_P_plan_for[1] = fixed ? (int32_t)P : (int32_t)P_reserved;
+    q->sp_P_plan = q->sp_P_plan_for[single_pass_reserves(q) ? 1 : 0];
+    single_pass_set_P(q, q->sp_P_plan);
     return IMM3_OK;
 }
 
@@ -2475,6 +2503,19 @@ static int run_single_pass(imm3_query *q) {
             if (p.seg_col == q->stage_seg_col[k]) fp = &p;
         if (!fp) return fail(IMM3_ERR_ARG, "internal: single-pass plan lost a predicate column");
         fill_tile_col(q, *fp, a.cols[k], a.kinds[k]);
+    }
+    {   // a communicator may have been attached or destroyed since the plan was made: the grid follows, and so does the planned P
+        // (a P the host has lowered for dense survivors stays: it is below either plan)
+        const int32_t want_plan = q->sp_P_plan_for[single_pass_reserves(q) ? 1 : 0];
+        if (!q->sp_P_fixed && !ctx->capture && want_plan > 0 && want_plan != q->sp_P_plan) {
+            const bool at_plan = q->sp_P == q->sp_P_plan;
+            q->sp_P_plan = want_plan;
+            if (at_plan || q->sp_P > want_plan) {
+                if (hipMemsetAsync(q->d_desc, 0, q->sp_trash_off, s) == hipSuccess) single_pass_set_P(q, want_plan); // (hygiene, as in single_pass_pick_P)
+                else (void)hipGetLastError();
+            }
+        }
+        q->sp_grid = single_pass_run_grid(q);
     }
     a.P = q->sp_P;
     a.n_rows = q->n_rows;

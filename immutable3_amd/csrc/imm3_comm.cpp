@@ -103,7 +103,26 @@ struct imm3_comm {
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
     bool in_flight = false;       // a collective has been enqueued since the last join / sync
     unsigned long long *d_slot = nullptr; // send/receive word of imm3_comm_allreduce_count when the caller passes no buffer
+    // tools' build (imm3_comm_debug_standin): a kernel with the footprint of RCCL's, in front of every count all-reduce
+    int32_t standin_wgs = 0;
+    uint32_t standin_ticks = 0;   // how long each of its work-groups spins, in ticks of the 100 MHz device clock
 };
+
+#ifdef IMM3_ABLATE
+// A stand-in for the kernel RCCL launches for the count all-reduce when there are other ranks: same footprint -- 512 threads,
+// 37 664 bytes of LDS, 256 vector registers per lane, as ncclDevKernel_Generic_* is built for gfx950 in ROCm 7.2 (read from
+// librccl.so's code object) -- so it takes a CU the way that kernel does: it cannot share one with a work-group of the one-launch
+// projection (LDS and registers), which is what decides whether the next pass waits for the collective or the collective for
+// the pass.  Spins on the device clock.  One GPU is enough to measure that (tools/overlap_probe.py).
+__global__ __launch_bounds__(512) void k_comm_standin(uint32_t ticks, unsigned long long *sink) {
+    __shared__ unsigned char s_fill[37664];
+    asm volatile("; footprint" ::: "v255");   // (256 vector registers per lane, like the kernel it stands for)
+    if (threadIdx.x < 64) s_fill[threadIdx.x] = (unsigned char)threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(8);
+    if (s_fill[threadIdx.x & 63] == 255 && sink) *sink = t0;
+}
+#endif
 
 // the collective on `buf` may start once the context's stream has reached this point
 static int fence_in(imm3_comm *c) {
@@ -140,7 +159,19 @@ static int comm_finish(imm3_ctx *ctx, ncclComm_t nc, int32_t world, int32_t rank
     c->d_slot = (unsigned long long *)p;
     c->ctx = ctx;
     ctx_retain(ctx);
+    ctx->comms_attached.fetch_add(1, std::memory_order_relaxed); // (one-launch plans of this context now leave CUs for the collective's kernel)
     *out = c.release();
+    return IMM3_OK;
+}
+
+extern "C" int imm3_comm_debug_standin(imm3_comm *c, int32_t work_groups, uint32_t spin_us) {
+    if (!c) return fail(IMM3_ERR_ARG, "comm is null");
+#ifndef IMM3_ABLATE
+    if (work_groups > 0) return fail(IMM3_ERR_STATE, "the collective's stand-in kernel exists only in the tools' build of the library (make -C csrc ablate)");
+#endif
+    if (work_groups < 0 || work_groups > 64) return fail(IMM3_ERR_ARG, "0..64 work-groups");
+    c->standin_wgs = work_groups;
+    c->standin_ticks = spin_us * 100u;
     return IMM3_OK;
 }
 
@@ -215,6 +246,7 @@ extern "C" int imm3_comm_destroy(imm3_comm *c) {
     (void)hipEventDestroy(c->ev_ready);
     (void)hipEventDestroy(c->ev_done);
     (void)hipFree(c->d_slot);
+    c->ctx->comms_attached.fetch_sub(1, std::memory_order_relaxed);
     ctx_release(c->ctx);
     delete c;
     return IMM3_OK;
@@ -298,6 +330,12 @@ extern "C" int imm3_comm_allreduce_count(imm3_comm *c, imm3_query *const *querie
     if (rc) return rc;
     rc = fence_in(c);
     if (rc) return rc;
+#ifdef IMM3_ABLATE
+    if (c->standin_wgs > 0) { // (tools: what a real multi-rank all-reduce puts on the device at this point)
+        hipLaunchKernelGGL(k_comm_standin, dim3((unsigned)c->standin_wgs), dim3(512), 0, c->stream, c->standin_ticks, (unsigned long long *)nullptr);
+        HIPCHK(hipGetLastError());
+    }
+#endif
     NCCLCHK(g_rccl.AllReduce(dst, dst, 1, ncclUint64, ncclSum, c->nccl, c->stream));
     rc = fence_out(c);
     if (rc) return rc;

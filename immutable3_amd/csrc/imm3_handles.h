@@ -77,6 +77,7 @@ struct imm3_ctx {
     imm3_graph *capture = nullptr;  // open stream capture (imm3_ctx_capture_begin .. _end), else null; owned by the capturing thread (gate)
     std::vector<imm3_graph *> graphs; // graphs recorded on this context that have not been destroyed yet (mu)
     // fault injection into k_filter_project (imm3_ctx_inject_fault, imm3_diag.h): read by the tools' build of the kernel only
+    std::atomic<int> comms_attached{0}; // communicators created on this context and not yet destroyed: one-launch plans leave CUs for their kernels (imm3_api.cpp: single_pass_run_grid)
     std::atomic<int> fault_wg{-1}, fault_span{-1};
     std::atomic<uint32_t> fault_max_polls{0};
 };
@@ -251,6 +252,7 @@ struct imm3_query {
     int32_t sp_P = 0, sp_grid = 0;          // tiles per wave per span; work-groups (all resident: they wait on each other)
     int64_t sp_spans = 0;                   // spans of 8 * P tiles
     int32_t sp_P_plan = 0, sp_max_grid = 0; // P as planned without knowing the selectivity (the ceiling of the adapted P); resident work-groups
+    int32_t sp_P_plan_for[2] = {0, 0};      // ... for the whole chip / with a CU per XCD left to a communicator's kernels (single_pass_run_grid): the rounds of spans are quantised by the grid
     bool sp_P_fixed = false;                // P was set by the tuning hook: never adapted
     // the alternative plan of a projection with gathered columns: those columns streamed as always-true tile columns
     std::vector<FoldedPred> sp_pass;        // (once switched: part of the single-pass plan)

@@ -48,7 +48,7 @@ EXPORTS = [
 DIAG_EXPORTS = [
     "imm3_ctx_timing_enable", "imm3_ctx_timing_reset", "imm3_ctx_timing_mask", "imm3_ctx_timing_collect", "imm3_ctx_set_tuning",
     "imm3_ctx_measure_read_gbps", "imm3_ctx_devclock_enable", "imm3_ctx_devclock_collect", "imm3_ctx_devclock_raw", "imm3_query_plan",
-    "imm3_ctx_inject_fault", "imm3_ctx_debug_device_lock", "imm3_plan_predict",
+    "imm3_ctx_inject_fault", "imm3_ctx_debug_device_lock", "imm3_plan_predict", "imm3_comm_debug_standin",
 ]
 COMM_ID_BYTES = 128
 
@@ -180,6 +180,7 @@ def load() -> C.CDLL:
     L.imm3_comm_sync.argtypes = [vp]
     L.imm3_comm_join.argtypes = [vp]
     L.imm3_comm_allreduce_u64.argtypes = [vp, vp, u64]
+    L.imm3_comm_debug_standin.argtypes = [vp, i32, C.c_uint32]
     L.imm3_comm_allreduce_count.argtypes = [vp, P(vp), i32, vp, P(u64)]
     L.imm3_comm_allreduce_count_all.argtypes = [P(vp), i32, P(P(vp)), P(i32), P(u64)]
     L.imm3_comm_merge_groups.argtypes = [vp, P(vp), vp, i32, vp, vp, vp, vp, C.c_uint32, P(C.c_uint32)]
@@ -691,6 +692,10 @@ class Comm:
     def join(self):
         """The context's stream waits (stream side) for the last collective."""
         _check(load().imm3_comm_join(self._h))
+
+    def debug_standin(self, work_groups: int, spin_us: int):
+        """Tools' build: a kernel with RCCL's footprint in front of every count all-reduce (include/imm3_diag.h)."""
+        _check(load().imm3_comm_debug_standin(self._h, work_groups, spin_us))
 
     def allreduce_u64(self, device_ptr: int, n: int):
         _check(load().imm3_comm_allreduce_u64(self._h, C.c_void_p(device_ptr), n))

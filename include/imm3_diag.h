@@ -79,6 +79,13 @@ int imm3_query_plan(const imm3_query *q, int64_t *out, int32_t n);
  * device (0 = free) and returns what it held; with a foreign ticket in place every launch finds the device busy.  Synchronises
  * the context's stream first.  TOOLS' build only, like the fault injection (round 4 shipped it: any caller could have parked every
  * one-launch query of a device, in every context, on its fallback); the shipped library answers IMM3_ERR_STATE. */
+/* imm3_comm_debug_standin (tools' build; the shipped library answers IMM3_ERR_STATE to anything but "off"): from now on every
+ * imm3_comm_allreduce_count of this communicator first launches, on the communicator's stream, `work_groups` work-groups of a kernel
+ * with the footprint of RCCL's all-reduce kernel (512 threads, 256 vector registers per lane, 37 664 bytes of LDS) that spin for
+ * `spin_us` microseconds: what a multi-rank collective puts on the device beside the next pass's scans, measurable on one GPU
+ * (tools/overlap_probe.py).  work_groups = 0 switches it off. */
+struct imm3_comm;
+int imm3_comm_debug_standin(struct imm3_comm *comm, int32_t work_groups, uint32_t spin_us);
 int imm3_ctx_inject_fault(imm3_ctx *ctx, int32_t work_group, int32_t span, uint32_t max_polls);
 int imm3_ctx_debug_device_lock(imm3_ctx *ctx, uint64_t value, uint64_t *previous);
 

@@ -265,6 +265,43 @@ table.close()
 for t_ in tsegs:
     t_.close()
 print("table ok", flush=True)
+
+# ---- 6. a co-resident kernel on the communicator's stream (the G > 1 shape: one launch per pass + one collective per pass).  The
+# stand-in has the footprint of RCCL's all-reduce kernel and cannot share a CU with a work-group of the one-launch projection; while a
+# communicator is attached the projection leaves one CU per XCD free for it (imm3_api.cpp: single_pass_run_grid).  Passes under
+# it: exact counts on the device, exact rows, no abandoned and no busy run -- with the reservation and (tuning 16) without it.
+import torch
+PASSES = 40
+dlog = torch.zeros(PASSES + 4, dtype=torch.int64, device="cuda")
+cus = torch.cuda.get_device_properties(0).multi_processor_count
+for variant, want_grid in ((0, cus - 8), (16, cus)):
+    ctx.set_tuning(variant, 0)
+    try:
+        ctx.set_tuning(204 if variant == 0 else 16, 0)      # (P = 4: more spans than CUs, so the grid is the reservation's to decide)
+        q = native.DeviceQuery(ctx, seg, [1, 0], sels, [1, 0], 0)
+        ctx.set_tuning(variant, 0)
+        q.run(); assert q.count() == rows.size
+        q.reserve_rows(rows.size + 1024)
+        q.run(); ctx.sync()
+        assert q.plan()["single_pass"] and q.plan()["grid"] == min(want_grid, q.plan()["spans"]), (variant, q.plan(), want_grid)
+        poison(q)
+        for wgs, us in ((1, 20), (4, 60)):
+            comm.debug_standin(wgs, us)
+            dlog.zero_(); torch.cuda.synchronize()
+            for i in range(PASSES):
+                q.run()
+                comm.allreduce_count([q], device_out=dlog.data_ptr() + 8 * i, wait=False)
+            torch.cuda.synchronize()
+            assert dlog[:PASSES].tolist() == [rows.size] * PASSES, (variant, wgs, us)
+            assert run_flags(q) == (rows.size, 0)
+            check_rows(q, ("under the stand-in", variant, wgs, us))
+            p = q.plan()
+            assert p["ran_single_pass"] and p["abandoned_runs"] == 0 and p["busy_runs"] == 0, p
+        comm.debug_standin(0, 0)
+        q.close()
+    finally:
+        ctx.set_tuning(0, 0)
+print("co-resident kernel ok", flush=True)
 comm.close(); seg.close(); ctx.close()
 print("FAULT-INJECTION-OK", flush=True)
 '''

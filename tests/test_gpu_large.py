@@ -137,28 +137,6 @@ def test_maximum_segment_size():
     ctx.close()
 
 
-def test_headline_kernel_meets_the_north_star_roofline_target(big):
-    """North star: >= 60 % of the MI355X HBM-read roofline on RangeFilter over a 100 M-row DENSE_INT column.  Guards against
-    kernel regressions (the int32 tile kernel has run at 78-82 % of 8 TB/s on every box so far; 60 % = 85.9 us for the
-    412.5 MB of algorithmic bytes)."""
-    from immutable3_amd import native
-    ctx, seg, ids, age, st = big
-    q = native.DeviceQuery(ctx, seg, [0], [(0, GT, float(2 ** 25)), (0, LT, float(2 ** 26))])
-    for _ in range(5):
-        q.run_select()
-    ctx.sync()
-    ctx.timing_enable(64); ctx.timing_mask(1); ctx.timing_reset()
-    for _ in range(30):
-        q.run_select()
-    ctx.sync()
-    ms = float(np.median(ctx.timing_collect(0)))
-    ctx.timing_enable(0)
-    assert q.count() == 2 ** 26 - 2 ** 25 - 1
-    q.close()
-    gbps = 4.125 * N / (ms * 1e-3) / 1e9
-    assert gbps >= 0.60 * 8000.0, f"scan+select kernel at {gbps:.0f} GB/s ({ms * 1e3:.1f} us)"
-
-
 def test_group_by_state_100m(big):
     """Group-by aggregation at the bench's size (k_group_agg_lanes), all rows and under a range predicate, against a numpy
     evaluation: group keys in first-seen order, counts, max / min of the int8 column, first rows."""
