@@ -779,7 +779,12 @@ __device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
 // KS: key shape -- 0: one 1-byte column, 1: one 2-byte column, 2: two 1-byte columns.  VW: bytes of the aggregated column (0: counts only).
 // V2: a second min / max aggregate, both over 1-byte columns (e.g. max(age), min(age)).
 // NS: rows of a lane's table (64 or 128, the last one the trash slot): 63 or 127 distinct keys per work-group.
-template <int KS, int VW, bool V2, int NS>
+// FUSED: the select chain is evaluated HERE, on the sixteen rows a lane holds -- a.fused[] closed intervals over int8 / int32
+// columns (a predicate on the value aggregate's own column reads nothing more), or no predicate at all -- instead of being read
+// from the bitmap a filter launch wrote: SelectOp fused into ProjectAggOp (ProjectAggregate.scala:158-177 walks the selected
+// positions of the batch it was handed).  Round 4 ran `group by state where age in (18, 30)` as filter 22 us + aggregation 82 us
+// with the bitmap written and read back and `age` read twice.
+template <int KS, int VW, bool V2, int NS, bool FUSED>
 __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const int vq, const int vq2) {
     static_assert(!V2 || VW == 1, "two value aggregates: 1-byte columns only");
     static_assert(NS == 64 || NS == 128, "the map's markers (253 .. 255) must have a bit set that no slot number has");
@@ -835,6 +840,7 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
     struct TileRegs {
         uint32_t bits; // rows 16 * lane ..: bits 16 * lane .. of the tile's 1024
         v4i_t kr0[KS == 1 ? 2 : 1], kr1[1], vr[NV], vr2[1];
+        v4i_t pr[1]; // FUSED: the rows of the ONE int8 predicate column that is not the value aggregate's (registers: the kernel sits at its 128)
     };
     constexpr int kDepth = VW == 2 ? 3 : 2; // (16-bit entries: 16 waves per CU, two tiles ahead suffice; VW 4: registers)
     // lane -> rows: 16 consecutive rows per lane; with an int32 value column group `lane`, otherwise group pair_group(lane), which
@@ -844,9 +850,16 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
     const bool odd = (lane & 1) != 0;
     const int64_t stride = (int64_t)gridDim.x * n_waves;
     const int64_t first_tile = (int64_t)blockIdx.x * n_waves + wave;
+    int own_pred = -1; // FUSED: the predicate whose int8 column is loaded for it alone (at most one: fused_args_ok)
+    if constexpr (FUSED) {
+        for (int f = 0; f < kMaxAggPreds; ++f)
+            if (f < a.n_fused && !a.fused[f].share) own_pred = f;
+    }
     auto issue = [&](TileRegs &r, int64_t tile) {
         if (tile >= a.n_tiles) tile = a.n_tiles - 1;
-        r.bits = ((const uint16_t *)a.bitmap)[tile * 64 + rgroup];
+        if constexpr (FUSED) {
+            if (own_pred >= 0) load_lane_rows<1>(a.fused[own_pred].data, tile, rgroup, r.pr); // (wave-uniform: a kernel argument)
+        } else r.bits = ((const uint16_t *)a.bitmap)[tile * 64 + rgroup];
         if constexpr (KS == 1 && kPair) load_lane_rows_pair2(a.groups[0].data, tile, lane, r.kr0);
         else load_lane_rows<(KS == 1 ? 2 : 1)>(a.groups[0].data, tile, rgroup, r.kr0);
         if constexpr (KS == 2) load_lane_rows<1>(a.groups[1].data, tile, rgroup, r.kr1);
@@ -857,9 +870,34 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
         }
     };
     // the pair swap of the 2-byte columns, once their loads have landed (a tile's registers are rewritten by the next issue)
-    auto settle = [&](TileRegs &r) {
+    auto settle = [&](TileRegs &r, int64_t tile) {
         if constexpr (KS == 1 && kPair) pair_swap2(r.kr0, odd);
         if constexpr (VW == 2) pair_swap2(r.vr, odd);
+        if constexpr (FUSED) { // the lane's sixteen selection bits from the rows it holds (SelectIteratorGT / LT / EQ folded: Select.scala:53-162)
+            const int64_t left = a.n_rows - (tile * kTileRows + 16 * (int64_t)rgroup); // rows of the segment from this lane's first on
+            uint32_t bits = left >= 16 ? 0xFFFFu : (left <= 0 ? 0u : ((1u << (uint32_t)left) - 1u));
+#pragma unroll
+            for (int f = 0; f < kMaxAggPreds; ++f) {
+                if (f < a.n_fused) { // (wave-uniform)
+                    const uint32_t lo = (uint32_t)a.fused[f].lo, span = (uint32_t)a.fused[f].hi - (uint32_t)a.fused[f].lo;
+                    uint32_t ok = 0;
+                    if (a.fused[f].share) { // the value aggregate's own rows
+                        if constexpr (VW == 4) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) ok |= ((lane_row_value<4>(r.vr, i) - lo) <= span ? 1u : 0u) << i;
+                        } else if constexpr (VW == 1) {
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) ok |= (((uint32_t)(int32_t)(int8_t)lane_row_value<1>(r.vr, i) - lo) <= span ? 1u : 0u) << i;
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) ok |= (((uint32_t)(int32_t)(int8_t)lane_row_value<1>(r.pr, i) - lo) <= span ? 1u : 0u) << i;
+                    }
+                    bits &= ok;
+                }
+            }
+            r.bits = bits;
+        }
     };
     int since_fold = 0; // VW 1: tiles since the 8-bit counts were folded (wave-uniform)
     auto fold_counts = [&]() { // lane = slot (NS / 64 passes): move the 64 lanes' 8-bit counts of its slot into wcnt (rotated: lanes on different banks)
@@ -1126,7 +1164,7 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
         for (int d = 0; d < kDepth; ++d) {
             const int64_t tile = base + d * stride;
             if (tile < a.n_tiles) { // wave-uniform
-                settle(R[d]);
+                settle(R[d], tile);
                 process(R[d], tile);
             }
             issue(R[d], tile + kDepth * stride);
@@ -1293,7 +1331,7 @@ static bool lanes_plan(const AggArgs &a, int ns, LanesPlan &p) {
 }
 
 // false: the device refused the kernel's dynamic LDS size (the caller falls through to the next form)
-template <int KS, int VW, bool V2, int NS>
+template <int KS, int VW, bool V2, int NS, bool FUSED>
 static bool launch_lanes(const AggArgs &a, const LanesPlan &p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     // The dynamic-LDS limit of a kernel function is raised once per DEVICE (a process may drive all eight GPUs, one
     // context each, from several threads): 0 = not yet, 1 = raised, 2 = refused.
@@ -1302,14 +1340,36 @@ static bool launch_lanes(const AggArgs &a, const LanesPlan &p, hipStream_t s, hi
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return false;
     int st = raised[dev].load(std::memory_order_acquire);
     if (st == 0) { // (two threads may both get here: the call is idempotent)
-        const hipError_t e = hipFuncSetAttribute((const void *)k_group_agg_lanes<KS, VW, V2, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - kLanesFixedBytes);
+        const hipError_t e = hipFuncSetAttribute((const void *)k_group_agg_lanes<KS, VW, V2, NS, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - kLanesFixedBytes);
         if (e != hipSuccess) (void)hipGetLastError();
         st = e == hipSuccess ? 1 : 2;
         raised[dev].store(st, std::memory_order_release);
     }
     if (st != 1) return false;
     const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((a.n_tiles + p.waves - 1) / p.waves, 256)); // one work-group per CU
-    IMM3_LAUNCH_LDS((k_group_agg_lanes<KS, VW, V2, NS>), (unsigned)grid, p.waves * 64, (size_t)p.lds_bytes, s, ev0, ev1, a, p.vq, p.vq2);
+    IMM3_LAUNCH_LDS((k_group_agg_lanes<KS, VW, V2, NS, FUSED>), (unsigned)grid, p.waves * 64, (size_t)p.lds_bytes, s, ev0, ev1, a, p.vq, p.vq2);
+    return true;
+}
+
+// The select chain rides in the aggregation launch when the 63-key lanes form takes the query and every predicate is a closed interval
+// over an int8 / int32 column (at most kMaxAggPreds of them, or none at all): the FUSED instances exist for NS = 64 only.
+static bool fused_args_ok(const AggArgs &a) {
+    if (a.n_fused < 0 || a.n_fused > kMaxAggPreds || (a.n_fused == 0 && !a.fused_all)) return false;
+    int own = 0;
+    for (int f = 0; f < a.n_fused; ++f) {
+        if (a.fused[f].width != 1 && a.fused[f].width != 4) return false;
+        if (a.fused[f].share) continue;
+        // a predicate column of its own: ONE int8 column (four registers per tile in flight; an int32 column would be sixteen, and
+        // the kernel sits at the 128 registers its sixteen waves per CU leave it -- such a query keeps the filter launch)
+        if (!a.fused[f].data || a.fused[f].width != 1 || ++own > 1) return false;
+    }
+    return true;
+}
+bool group_agg_fuses_select(const AggArgs &a) {
+    LanesPlan lp;
+    if (!fused_args_ok(a) || a.first_form != AGG_FORM_LANES || !lanes_plan(a, 64, lp)) return false;
+    for (int f = 0; f < a.n_fused; ++f) // (a shared predicate column is the first value aggregate's, at its width)
+        if (a.fused[f].share && (lp.vw != a.fused[f].width || a.aggs[lp.vq].data == nullptr)) return false;
     return true;
 }
 
@@ -1324,10 +1384,12 @@ void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_
     // table overflowed on this query's keys: AggForm in imm3_internal.h).
     // private per-lane tables, no atomics: 63 keys per work-group, then 127
     if (a.first_form <= AGG_FORM_LANES_WIDE && lanes_plan(a, a.first_form == AGG_FORM_LANES_WIDE ? 128 : 64, lp)) {
+        const bool fuse = group_agg_fuses_select(a); // (the host has then skipped the select launch: imm3_api.cpp, run_agg)
 #define IMM3_LANES(KS, VW, V2)                                                                       \
     if (lp.ks == KS && lp.vw == VW && (lp.v2 != 0) == V2) {                                          \
-        const bool ok = lp.ns == 64 ? launch_lanes<KS, VW, V2, 64>(a, lp, s, ev0, ev1)               \
-                                    : launch_lanes<KS, VW, V2, 128>(a, lp, s, ev0, ev1);             \
+        const bool ok = fuse ? launch_lanes<KS, VW, V2, 64, true>(a, lp, s, ev0, ev1)                \
+                             : (lp.ns == 64 ? launch_lanes<KS, VW, V2, 64, false>(a, lp, s, ev0, ev1) \
+                                            : launch_lanes<KS, VW, V2, 128, false>(a, lp, s, ev0, ev1)); \
         if (ok) return;                                                                              \
     }
         IMM3_LANES(0, 0, false) IMM3_LANES(0, 1, false) IMM3_LANES(0, 2, false) IMM3_LANES(0, 4, false) IMM3_LANES(0, 1, true)

@@ -2129,8 +2129,10 @@ static int join_total(imm3_query *q, hipStream_t s) {
 static int settle_whole_select(imm3_query *q);
 // (imm3_comm_allreduce_count: the word that goes into the collective is the segment's count -- a run that stopped at its limit is
 // followed by the whole select here, enqueued, no host wait)
+static int settle_agg_select(imm3_query *q);
 int imm3::join_query_count(imm3_query *q, hipStream_t s) {
-    const int rc = settle_whole_select(q);
+    int rc = settle_agg_select(q);
+    if (!rc) rc = settle_whole_select(q);
     return rc ? rc : join_total(q, s);
 }
 
@@ -2791,6 +2793,7 @@ static int run_project(imm3_query *q) {
 }
 
 static int run_agg(imm3_query *q);
+static bool agg_run_fuses(const imm3_query *q);
 
 // a run recorded into an open capture: nothing in it may synchronise, allocate or use a second stream
 static int capture_admit(imm3_query *q) {
@@ -2856,6 +2859,8 @@ extern "C" int imm3_query_join_count(imm3_query *q) {
     HIPCHK(hipSetDevice(q->ctx->device));
     // (the hand-off to device-side consumers of the count word: after a limit scan that stopped early the word holds the scanned
     // prefix's count -- the whole select runs first, as for imm3_query_count and the count all-reduce)
+    const int arc = settle_agg_select(q);
+    if (arc) return arc;
     const int wrc = settle_whole_select(q);
     if (wrc) return wrc;
     return join_total(q, q->ctx->stream);
@@ -2876,7 +2881,10 @@ extern "C" int imm3_query_run(imm3_query *q) {
     }
     if (q->single_pass && !q->proj.empty() && !q->always_false && q->n_tiles > 0) return capture_note(q, run_single_pass(q));
     const bool select_only = q->proj.empty() && !q->is_agg && q->ctx->filter_variant == 2;
-    int rc = run_select(q, select_only, !q->proj.empty() && q->n_tiles > 0 && !q->always_false && q->ctx->filter_variant != 7);
+    int rc = IMM3_OK;
+    q->agg_select_skipped = agg_run_fuses(q);
+    if (q->agg_select_skipped) q->ran_select = true; // (bitmap and count on demand: settle_agg_select)
+    else rc = run_select(q, select_only, !q->proj.empty() && q->n_tiles > 0 && !q->always_false && q->ctx->filter_variant != 7);
     if (rc) return rc;
     if (!q->proj.empty()) rc = run_project(q);
     if (!rc && q->is_agg) rc = run_agg(q);
@@ -3021,6 +3029,8 @@ extern "C" int imm3_query_count(imm3_query *q, uint64_t *selected_rows) {
     HIPCHK(hipSetDevice(q->ctx->device));
     unsigned long long total = 0;
     {
+        const int arc = settle_agg_select(q);
+        if (arc) return arc;
         const int src = settle_single_pass(q);
         if (src) return src;
         const int wrc = settle_whole_select(q);
@@ -3046,6 +3056,8 @@ extern "C" int imm3_query_bitmap(imm3_query *q, uint64_t *words_out, int64_t n_w
     if (n_words && !words_out) return fail(IMM3_ERR_ARG, "words_out is null");
     HIPCHK(hipSetDevice(q->ctx->device));
     {
+        const int arc = settle_agg_select(q);
+        if (arc) return arc;
         const int src = settle_single_pass(q);
         if (src) return src;
         const int wrc = settle_whole_select(q);
@@ -3183,6 +3195,13 @@ static int query_create_agg_impl(imm3_ctx *ctx, const imm3_segment *seg, const i
     q->is_agg = true;
     q->group_cols.assign(group_cols, group_cols + n_group);
     q->aggs.assign(aggs, aggs + n_aggs);
+    {   // SelectOp fused into the aggregation launch (k_group_agg_lanes' FUSED instances; whether the lanes form takes the query is
+        // the launcher's call at run time)
+        bool ok = !table && !q->ragged && !q->always_false && has_batches && q->n_rows > 0 && q->preds.size() <= (size_t)kMaxAggPreds;
+        for (const auto &fp : q->preds)
+            ok = ok && !fp.pfor && (fp.kind == KIND_I8 || fp.kind == KIND_I32) && col_flat(seg->cols[(size_t)fp.seg_col]) != nullptr;
+        q->agg_fusable = ok;
+    }
     // table capacity: twice the number of possible groups, bounded by the rows and by 2^27 slots
     double domain = 1.0;
     for (int b = 0; b < key_bytes; ++b) domain *= 256.0;
@@ -3247,6 +3266,21 @@ static void fill_agg_args(const imm3_query *q, AggArgs &a) {
         a.aggs[j].is_str = sc.vcodec == IMM3_DENSE_STRING;
     }
     a.n_agg = (int32_t)q->aggs.size();
+    if (q->agg_fusable && q->ctx->filter_variant != 17) { // (tuning 17: filter launch + aggregation launch, as before round 5)
+        int first_value = -1; // the aggregate whose rows the lanes form keeps in registers: the first one that is not a count
+        for (size_t j = 0; j < q->aggs.size() && first_value < 0; ++j)
+            if (q->aggs[j].kind != IMM3_AGG_COUNT) first_value = (int)j;
+        for (const auto &fp : q->preds) {
+            AggPred &f = a.fused[a.n_fused++];
+            const SegCol &sc = q->seg->cols[(size_t)fp.seg_col];
+            f.data = col_flat(sc);
+            f.width = sc.width;
+            f.lo = (int32_t)fp.lo;
+            f.hi = (int32_t)fp.hi;
+            f.share = first_value >= 0 && q->used[(size_t)q->aggs[(size_t)first_value].column] == fp.seg_col ? 1 : 0;
+        }
+        a.fused_all = q->preds.empty() ? 1 : 0;
+    }
     a.keys = q->d_akeys;
     a.first = q->d_afirst;
     a.counts = q->d_acounts;
@@ -3261,14 +3295,35 @@ static void fill_agg_args(const imm3_query *q, AggArgs &a) {
     a.out_vals = q->d_ovals;
 }
 
+static void agg_launch_args(const imm3_query *q, AggArgs &a) {
+    fill_agg_args(q, a);
+    // tuning variants 100 + AggForm start the chain at that form (tools/aggexp.py); 140 + x: ablation x of the tools' build
+    const int fv = q->ctx->filter_variant;
+    a.first_form = (fv >= 100 && fv <= 100 + AGG_FORM_GENERAL) ? fv - 100 : q->agg_first_form; // (agg_first_form: past the forms this query's keys overflowed)
+    a.ablate = fv >= 140 ? fv - 100 : 0;
+}
+// will this run's aggregation launch evaluate the select chain itself?  (then no select launch precedes it)
+static bool agg_run_fuses(const imm3_query *q) {
+    if (!q->is_agg || !q->agg_fusable || q->count_log_on) return false; // (a count log wants every run's count on the device: the select launch produces it)
+    AggArgs a;
+    agg_launch_args(q, a);
+    return group_agg_fuses_select(a);
+}
+// A getter wants the bitmap or the selected-row count of an aggregation whose last run fused the select: the select chain runs now.
+static int settle_agg_select(imm3_query *q) {
+    if (!q->agg_select_skipped) return IMM3_OK;
+    if (q->ctx->capture) return fail(IMM3_ERR_STATE, "a graph capture is open on this context");
+    const int rc = run_select(q, false);
+    if (rc) return rc;
+    q->agg_select_skipped = false;
+    return IMM3_OK;
+}
+
 static int run_agg(imm3_query *q) {
     imm3_ctx *ctx = q->ctx;
     AggArgs a;
-    fill_agg_args(q, a);
-    // tuning variants 100 + AggForm start the chain at that form (tools/aggexp.py); 140 + x: ablation x of the tools' build
-    const int fv = ctx->filter_variant;
-    a.first_form = (fv >= 100 && fv <= 100 + AGG_FORM_GENERAL) ? fv - 100 : q->agg_first_form; // (agg_first_form: past the forms this query's keys overflowed)
-    a.ablate = fv >= 140 ? fv - 100 : 0;
+    agg_launch_args(q, a);
+    if (!q->agg_select_skipped) { a.n_fused = 0; a.fused_all = 0; } // (the select ran: the bitmap is what this launch reads)
     LaunchTimer t(ctx, 4);
     launch_group_agg(a, ctx->stream, t.start, t.stop);
     HIPCHK(hipGetLastError());
@@ -3298,6 +3353,12 @@ static int settle_groups(imm3_query *q, uint32_t *n_groups) {
             // lanes (63 keys) -> lanes (127 keys) -> direct -> general
             q->agg_first_form = meta[1] == 3 ? (q->agg_first_form == AGG_FORM_LANES ? AGG_FORM_LANES_WIDE : AGG_FORM_DIRECT) : AGG_FORM_GENERAL;
             g.first_form = q->agg_first_form;
+            {   // (the forms behind the 63-key lanes form read the bitmap: a run that fused the select has none yet)
+                const int arc = settle_agg_select(q);
+                if (arc) return arc;
+                g.n_fused = 0;
+                g.fused_all = 0;
+            }
             launch_group_agg(g, s, nullptr, nullptr);
             HIPCHK(hipGetLastError());
             continue;

@@ -233,6 +233,8 @@ struct imm3_query {
     long long *d_avals = nullptr, *d_ovals = nullptr;
     uint32_t out_cap = 0;
     bool ran_agg = false;
+    bool agg_fusable = false;          // the select chain is closed intervals over <= 2 dense int8 / int32 columns of one uniform segment (or empty): the aggregation kernel can evaluate it itself
+    bool agg_select_skipped = false;   // the last run fused the select into the aggregation launch: bitmap and count do not exist until a getter asks (settle_agg_select)
     int32_t agg_first_form = imm3::AGG_FORM_LANES; // first kernel form to try: raised past the forms this query's keys overflowed
     // select-only runs: the count reduce goes to ctx->aux, fenced by these events
     hipEvent_t ev_filter_done = nullptr, ev_total_done = nullptr;

@@ -383,6 +383,16 @@ struct AggCol {
     int32_t pad;
 };
 
+// SelectOp fused into the aggregation (k_group_agg_lanes' FUSED instances): ProjectAggIterator walks the selected positions of the
+// batch it is handed (ProjectAggregate.scala:158-177); with the predicates evaluated on the rows the aggregation kernel already holds
+// there is no bitmap to store and to read back, and a column that is both predicate and aggregate is read once.
+constexpr int kMaxAggPreds = 2;
+struct AggPred {
+    const void *data;            // flat column (int8 or int32), or null: the predicate is on the value aggregate's own column (share = 1)
+    int32_t width;               // 1 or 4
+    int32_t lo, hi;              // closed interval (int8 values sign-extended)
+    int32_t share;               // 1: the rows are the first value aggregate's, already in registers
+};
 struct AggArgs {
     const uint64_t *bitmap;
     int64_t n_words, n_tiles, n_rows;
@@ -392,6 +402,9 @@ struct AggArgs {
     int32_t n_group, n_agg;
     int32_t first_form;          // AggForm: where the chain of kernel forms starts for this query
     int32_t ablate;              // read only by the tools' build (IMM3_ABLATED); 0 otherwise
+    AggPred fused[kMaxAggPreds]; // n_fused > 0: the select chain, evaluated by the aggregation kernel itself (no bitmap is read)
+    int32_t n_fused;
+    int32_t fused_all;           // 1: no predicate at all -- every row of the segment is selected (n_fused == 0, no bitmap either)
     // global open-addressing table: mask + 1 slots, plus one for the all-ones key
     unsigned long long *keys;
     uint32_t *first;             // first (lowest) selected row of the group
@@ -409,6 +422,7 @@ struct AggArgs {
 };
 
 void launch_group_agg(const AggArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1);
+bool group_agg_fuses_select(const AggArgs &a); // would launch_group_agg run a form that evaluates a.fused[] itself (no select launch needed)?
 
 // ---- cross-segment / cross-GPU merge of group tables (ProjectAggregateQueueOp, ProjectAggregateQueue.scala:9-55) ----
 // Keys of <= 2 bytes index a DIRECT table (256 or 65 536 slots; one slot for no group column): every query's dense group
