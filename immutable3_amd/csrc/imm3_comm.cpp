@@ -106,7 +106,17 @@ struct imm3_comm {
     // tools' build (imm3_comm_debug_standin): a kernel with the footprint of RCCL's, in front of every count all-reduce
     int32_t standin_wgs = 0;
     uint32_t standin_ticks = 0;   // how long each of its work-groups spins, in ticks of the 100 MHz device clock
+    bool reserves = false;        // counted in ctx->comms_attached: its collectives launch kernels (more than one rank, or the stand-in)
 };
+
+// A communicator whose collectives put KERNELS on the device -- more than one rank (a one-rank all-reduce launches none), or the
+// tools' stand-in -- makes the one-launch plans of its context leave a CU per XCD free (imm3_api.cpp: single_pass_run_grid).
+static void comm_reserve(imm3_comm *c, bool on) {
+    if (on == c->reserves) return;
+    c->reserves = on;
+    if (on) c->ctx->comms_attached.fetch_add(1, std::memory_order_relaxed);
+    else c->ctx->comms_attached.fetch_sub(1, std::memory_order_relaxed);
+}
 
 #ifdef IMM3_ABLATE
 // A stand-in for the kernel RCCL launches for the count all-reduce when there are other ranks: same footprint -- 512 threads,
@@ -159,7 +169,7 @@ static int comm_finish(imm3_ctx *ctx, ncclComm_t nc, int32_t world, int32_t rank
     c->d_slot = (unsigned long long *)p;
     c->ctx = ctx;
     ctx_retain(ctx);
-    ctx->comms_attached.fetch_add(1, std::memory_order_relaxed); // (one-launch plans of this context now leave CUs for the collective's kernel)
+    comm_reserve(c.get(), world > 1);
     *out = c.release();
     return IMM3_OK;
 }
@@ -172,6 +182,7 @@ extern "C" int imm3_comm_debug_standin(imm3_comm *c, int32_t work_groups, uint32
     if (work_groups < 0 || work_groups > 64) return fail(IMM3_ERR_ARG, "0..64 work-groups");
     c->standin_wgs = work_groups;
     c->standin_ticks = spin_us * 100u;
+    comm_reserve(c, c->world > 1 || work_groups > 0);
     return IMM3_OK;
 }
 
@@ -246,7 +257,7 @@ extern "C" int imm3_comm_destroy(imm3_comm *c) {
     (void)hipEventDestroy(c->ev_ready);
     (void)hipEventDestroy(c->ev_done);
     (void)hipFree(c->d_slot);
-    c->ctx->comms_attached.fetch_sub(1, std::memory_order_relaxed);
+    comm_reserve(c, false);
     ctx_release(c->ctx);
     delete c;
     return IMM3_OK;

@@ -277,6 +277,7 @@ cus = torch.cuda.get_device_properties(0).multi_processor_count
 for variant, want_grid in ((0, cus - 8), (16, cus)):
     ctx.set_tuning(variant, 0)
     try:
+        comm.debug_standin(1, 20)      # (a communicator whose collectives launch kernels: a one-rank RCCL all-reduce launches none)
         ctx.set_tuning(204 if variant == 0 else 16, 0)      # (P = 4: more spans than CUs, so the grid is the reservation's to decide)
         q = native.DeviceQuery(ctx, seg, [1, 0], sels, [1, 0], 0)
         ctx.set_tuning(variant, 0)

@@ -46,6 +46,12 @@ sd = raw[26 * g: 27 * g]
 if (sd > 0).any():
     sdu = (sd[sd > 0] - t0) / 100.0
     print(f"streamers through by us: min {sdu.min():.1f} p50 {np.median(sdu):.1f} max {sdu.max():.1f};  work-group end - streamers through: p50 {np.median(end[sd > 0] - sdu):.1f} max {(end[sd > 0] - sdu).max():.1f}")
+if (sd > 0).all():
+    sdu_all = (sd - t0) / 100.0
+    print("streamers through, mean us by blockIdx % 8 (XCD under round-robin placement):", " ".join(f"{x}:{sdu_all[x::8].mean():.1f}" for x in range(8)))
+    print("streamers through, mean us by blockIdx // 32:", " ".join(f"{x}:{sdu_all[32 * x: 32 * x + 32].mean():.1f}" for x in range(g // 32)))
+    srt = np.sort(sdu_all)
+    print("streamers through, percentiles us:", " ".join(f"p{p}:{srt[int(p / 100 * (g - 1))]:.1f}" for p in (0, 10, 25, 50, 75, 90, 100)))
 for i in range(6):
     r = ext[:, i]; d = ext[:, 6 + i]; pk = ext[:, 12 + i]; an = ext[:, 18 + i]
     if (an > 0).any():
