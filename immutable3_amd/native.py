@@ -48,7 +48,7 @@ EXPORTS = [
 DIAG_EXPORTS = [
     "imm3_ctx_timing_enable", "imm3_ctx_timing_reset", "imm3_ctx_timing_mask", "imm3_ctx_timing_collect", "imm3_ctx_set_tuning",
     "imm3_ctx_measure_read_gbps", "imm3_ctx_devclock_enable", "imm3_ctx_devclock_collect", "imm3_ctx_devclock_raw", "imm3_query_plan",
-    "imm3_ctx_inject_fault", "imm3_ctx_debug_device_lock", "imm3_plan_predict", "imm3_comm_debug_standin",
+    "imm3_ctx_inject_fault", "imm3_ctx_debug_device_lock", "imm3_plan_predict", "imm3_comm_debug_standin", "imm3_plan_limit_scan",
 ]
 COMM_ID_BYTES = 128
 

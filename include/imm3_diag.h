@@ -84,6 +84,11 @@ int imm3_query_plan(const imm3_query *q, int64_t *out, int32_t n);
  * with the footprint of RCCL's all-reduce kernel (512 threads, 256 vector registers per lane, 37 664 bytes of LDS) that spin for
  * `spin_us` microseconds: what a multi-rank collective puts on the device beside the next pass's scans, measurable on one GPU
  * (tools/overlap_probe.py).  work_groups = 0 switches it off. */
+/* imm3_plan_limit_scan: does a projection with a `limit` scan in chunks that stop once the limit is reached (1) or as one whole
+ * select (0)?  The library's own decision (csrc/imm3_planner.cpp: limit_scan_applies) as a pure function of its inputs -- no device,
+ * no handle: tests walk it. */
+int imm3_plan_limit_scan(int32_t whole, int32_t count_log_on, int32_t count_in_scan, int64_t limit, int32_t single_tile_pass, int32_t table, int32_t records,
+                         int32_t skip_bitmap, int32_t overlap_total, int32_t filter_variant, int64_t n_tiles);
 struct imm3_comm;
 int imm3_comm_debug_standin(struct imm3_comm *comm, int32_t work_groups, uint32_t spin_us);
 int imm3_ctx_inject_fault(imm3_ctx *ctx, int32_t work_group, int32_t span, uint32_t max_polls);

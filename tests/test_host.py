@@ -319,3 +319,41 @@ def test_the_planners_cost_model_is_the_same_in_cpp_and_python():
     assert best(c3, 100_000_000, 0.99, 0.99, 0.0) == "C"
     assert best(c3, 4_000_000, 0.10, 0.10, 0.0) == "C"
     assert best(([(4, 0)], [(4, True)], 8), 100_000_000, 0.5, 1.0, 1.0) == "A"
+
+
+def test_limit_scan_decision_is_a_named_function():
+    """csrc/imm3_planner.cpp::limit_scan_applies (round 4 had it as an eleven-term boolean inside run_select): a projection with a
+    `limit` scans in chunks that stop at the limit (Project.scala:73-80) exactly when its select chain is ONE tile launch over one
+    uniform segment, a projection follows, and nothing wants the whole segment's count."""
+    L = native.load()
+    L.imm3_plan_limit_scan.restype = ctypes.c_int
+    L.imm3_plan_limit_scan.argtypes = [ctypes.c_int32] * 3 + [ctypes.c_int64] + [ctypes.c_int32] * 6 + [ctypes.c_int64]
+    base = dict(whole=0, count_log_on=0, count_in_scan=1, limit=10, single_tile_pass=1, table=0, records=0, skip_bitmap=0, overlap_total=0, filter_variant=0, n_tiles=97657)
+    call = lambda **kw: L.imm3_plan_limit_scan(*[{**base, **kw}[k] for k in base])
+    assert call() == 1
+    for veto in (dict(whole=1), dict(count_log_on=1), dict(count_in_scan=0), dict(limit=0), dict(limit=-3), dict(single_tile_pass=0), dict(table=1), dict(records=1),
+                 dict(skip_bitmap=1), dict(overlap_total=1), dict(filter_variant=7), dict(filter_variant=14), dict(n_tiles=1024), dict(n_tiles=5)):
+        assert call(**veto) == 0, veto
+    assert call(n_tiles=1025) == 1 and call(filter_variant=12) == 1 and call(limit=10 ** 9) == 1
+
+
+def test_bench_traffic_entries_are_stamped_with_the_kernel_sources(tmp_path, monkeypatch):
+    """bench.py only reports counter traffic (roofline.traffic, traffic_ratio, frac_traffic of C3 / C4 / C5 / the README-shaped table)
+    from a profiles/traffic.json entry that was measured on THESE kernel sources; anything else is refused with the reason."""
+    import json
+    import bench
+    sha = bench.extra_source_sha16()
+    assert re.fullmatch(r"[0-9a-f]{16}", sha) and sha == bench.extra_source_sha16()
+    good = {"extra": {"c3_range_age_id_project": {"kernels": ["k"], "hbm_bytes_per_query": 6.1e8, "source_sha16": sha, "tag": "t"},
+                      "c5_table": {"kernels": ["k"], "hbm_bytes_per_pass": 5.0e9, "source_sha16": "0" * 16, "tag": "t"}}}
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "profiles" / "traffic.json").write_text(json.dumps(good))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "extra_source_sha16", lambda: sha)
+    e = bench.stamped_traffic("c3_range_age_id_project")
+    assert e["hbm_bytes_per_query"] == 6.1e8 and "hash matches" in e["source"]
+    stale = bench.stamped_traffic("c5_table")
+    assert "hbm_bytes_per_pass" not in stale and "REFUSED" in stale["source"]
+    assert "no entry" in bench.stamped_traffic("readme_table_c3")["source"]
+    (tmp_path / "profiles" / "traffic.json").unlink()
+    assert "missing" in bench.stamped_traffic("c3_range_age_id_project")["source"]
