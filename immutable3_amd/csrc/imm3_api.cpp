@@ -254,6 +254,8 @@ extern "C" int imm3_graph_launch(imm3_graph *g) {
         q->bitmap_valid = st.bitmap_valid;
         q->ran_single_pass = st.ran_single_pass;
         q->stage_written = st.stage_written;
+        q->bitmap_lazy = st.bitmap_lazy;
+        q->agg_select_skipped = st.agg_select_skipped;
         q->count_pending_scan = st.count_pending_scan;
         q->has_pfor_pass = st.has_pfor_pass;
         q->ran_agg = st.ran_agg;
@@ -1699,6 +1701,7 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
     int grid = 1;
     bool count_done = false; // the filter kernel's last work-group has written total / n_emit
     q->stage_written = false;
+    q->bitmap_lazy = false;
     q->ran_single_pass = false;
     // exactly ONE launch in the whole select chain: only then may that launch publish the count (and append to the count
     // log) itself, and only then are the survivors' values staged
@@ -1733,7 +1736,7 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
             a.kinds[k] = tile_kind(fp);
             fill_tile_col(q, fp, a.cols[k], a.kinds[k]);
         }
-        if (single_tile_pass && q->d_stage_rec && !skip_bitmap) { // the columns are in the order the records were laid out for (same sort)
+        if (single_tile_pass && q->d_stage_rec && !skip_bitmap && !q->force_plain_select) { // the columns are in the order the records were laid out for (same sort)
             bool same = true;
             for (int k = 0; k < kMaxTileCols; ++k) same = same && a.kinds[k] == q->stage_kinds[k] && (k >= n || take[(size_t)k]->seg_col == q->stage_seg_col[k]);
             if (!same) return fail(IMM3_ERR_ARG, "internal: staged record layout does not match the tile launch");
@@ -1749,6 +1752,14 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
         a.n_words = q->n_words;
         a.n_tiles = q->n_tiles;
         a.bitmap = q->d_bitmap;
+        // A records run whose offsets scan follows (imm3_query_run of a projection) stores NO bitmap: the records carry the positions
+        // and the scan takes the tiles' counts from the arenas (round 5: 12.5 MB of 128-byte line stores in between the streaming
+        // loads, and 12.5 MB read back by k_scan -- C4 107 -> 100 us).  imm3_query_bitmap materialises it on demand.  Tuning 19: off.
+        q->bitmap_lazy = q->stage_written && count_in_scan && !q->count_log_on && ctx->filter_variant != 19;
+        if (q->bitmap_lazy) {
+            a.bitmap = nullptr;
+            q->bitmap_valid = false;
+        }
         a.block_partials = q->d_block_partials;
         a.tile_rows = q->table ? q->table->d_tile_rows : nullptr; // table query: address the columns through the tile table
         bool any_i32 = false;
@@ -1766,7 +1777,7 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
         // bitmap lines parked in LDS and stored in bursts: no staging (whose LDS and 2048 work-groups
         // leave no room for 32 KiB more per group); tuning variant 12 switches it off
         // (64 lines = 32 KiB per work-group at <= 4 groups per CU; 16 lines = 8 KiB for the 1536-group narrow-column kernels)
-        a.defer_lines = ctx->filter_variant == 12 ? 0 : (q->stage_written ? 16 : (grid <= 1024 ? kDeferLines : 16));
+        a.defer_lines = (ctx->filter_variant == 12 || q->bitmap_lazy) ? 0 : (q->stage_written ? 16 : (grid <= 1024 ? kDeferLines : 16)); // (no bitmap, no lines to park)
         if (skip_bitmap) { // count-only: the kernel instance that stores nothing (the count is reduced in the kernel)
             a.bitmap = nullptr;
             a.defer_lines = 0;
@@ -2237,6 +2248,13 @@ static int run_project(imm3_query *q) {
         sa.n_tiles = q->n_tiles;
         sa.finish = q->count_pending_scan ? q->d_total : nullptr;
         sa.scanned_tiles = q->select_partial ? q->d_total + kFinishLimitTiles : nullptr;
+        if (q->stage_written && q->bitmap_lazy) { // no bitmap was stored: the tiles' counts come from the records' start table
+            sa.rec_tile_start = q->d_tile_start;
+            sa.rec_n_waves = (int64_t)q->stage_grid * kWavesPerBlock;
+            sa.rec_main_tiles = q->stage_main_tiles;
+            sa.rec_max_slots = q->stage_max_slots;
+            sa.rec_T = q->stage_T;
+        }
         {
             LaunchTimer t(ctx, 1);
             launch_scan(sa, s, t.start, t.stop);
@@ -2284,7 +2302,12 @@ static int run_project(imm3_query *q) {
                 q->sp_restore_pending = true; // (from the next run on)
                 q->sp_restore_survivors = total;
             }
-            records_drop_if_narrow(q, total); // (this run's rows then come from the bitmap the staging launch wrote as well)
+            records_drop_if_narrow(q, total); // (this run's rows then come from the bitmap)
+            if (!q->d_stage_rec && q->bitmap_lazy) { // ... which the staging launch did not store: the select chain runs once more, plainly (the offsets stand: same counts)
+                const int prc = run_select(q, false, false, false, true);
+                if (prc) return prc;
+                q->offsets_valid = true;
+            }
         }
         const unsigned long long want = std::min<unsigned long long>((unsigned long long)std::max<int64_t>(q->n_rows, 1), total + total / 8 + 1024);
         const int rc = ensure_row_capacity(q, want);
@@ -2336,6 +2359,8 @@ static int capture_note(imm3_query *q, int rc) {
     st.bitmap_valid = q->bitmap_valid;
     st.ran_single_pass = q->ran_single_pass;
     st.stage_written = q->stage_written;
+    st.bitmap_lazy = q->bitmap_lazy;
+    st.agg_select_skipped = q->agg_select_skipped;
     st.count_pending_scan = q->count_pending_scan;
     st.has_pfor_pass = q->has_pfor_pass;
     st.ran_agg = q->ran_agg;
@@ -2479,6 +2504,18 @@ static unsigned long long single_pass_flags(const unsigned long long *head) {
 // tiles scanned so far.  The reference never sees the batches behind the limit either (Project.scala:73-80); a caller that asks for
 // the segment's count or bitmap all the same gets them exact: the whole select runs now, once (the rows were emitted from the scanned
 // prefix and stay what they are -- they are the first `limit` survivors either way).
+// The last run was a records run that stored no bitmap (run_select: bitmap_lazy): a getter wants it -- the select chain runs once
+// more, plainly.  The rows that run emitted stay what they are (the same rows); a later re-gather takes them from the bitmap.
+static int settle_lazy_bitmap(imm3_query *q) {
+    if (q->bitmap_valid || !q->bitmap_lazy) return IMM3_OK;
+    if (q->ctx->capture) return fail(IMM3_ERR_STATE, "a graph capture is open on this context");
+    q->force_plain_select = true;
+    const int rc = run_select(q, false, false, false, true);
+    q->force_plain_select = false;
+    if (rc) return rc;
+    return IMM3_OK; // (offsets_valid stands: the offsets scan counted the same survivors from the records)
+}
+
 static int settle_whole_select(imm3_query *q) {
     if (!q->select_partial) return IMM3_OK;
     if (q->ctx->capture) return fail(IMM3_ERR_STATE, "a graph capture is open on this context");
@@ -2560,6 +2597,11 @@ extern "C" int imm3_query_bitmap(imm3_query *q, uint64_t *words_out, int64_t n_w
     if (!q) return fail(IMM3_ERR_ARG, "query is null");
     CTX_LIVE(q->ctx);
     if (!q->ran_select) return fail(IMM3_ERR_STATE, "imm3_query_run has not been called");
+    if (!q->bitmap_valid && q->bitmap_lazy) {
+        HIPCHK(hipSetDevice(q->ctx->device));
+        const int lrc = settle_lazy_bitmap(q);
+        if (lrc) return lrc;
+    }
     if (!q->bitmap_valid) return fail(IMM3_ERR_STATE, "the last run was count-only (imm3_query_run_count): it stored no bitmap");
     if (n_words < 0 || n_words > q->n_words) return fail(IMM3_ERR_ARG, "n_words exceeds the bitmap");
     if (n_words && !words_out) return fail(IMM3_ERR_ARG, "words_out is null");

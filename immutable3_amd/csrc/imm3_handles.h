@@ -88,6 +88,7 @@ struct imm3_ctx {
 struct QueryRunState {
     bool ran_select = false, ran_project = false, bitmap_valid = false, ran_single_pass = false, stage_written = false;
     bool count_pending_scan = false, has_pfor_pass = false, ran_agg = false, offsets_valid = false, select_partial = false;
+    bool bitmap_lazy = false, agg_select_skipped = false;
 };
 
 // A recorded sequence of query runs (hipGraph): launching it enqueues every kernel of those runs with one call.
@@ -249,6 +250,8 @@ struct imm3_query {
     int32_t stage_grid = 0, stage_T = 1, stage_max_slots = 0;
     int64_t stage_wave_cap = 0, stage_main_tiles = 0;
     bool stage_written = false;   // the last select run filled the records
+    bool bitmap_lazy = false;     // ... and stored NO bitmap (a records run of imm3_query_run: the records carry the positions, the offsets scan counts them): imm3_query_bitmap runs the select chain then
+    bool force_plain_select = false; // the next run_select stages nothing (settle_lazy_bitmap)
     // single-pass projection (k_filter_project, imm3_project.hip): planned at creation for the same queries as the records
     bool single_pass = false;
     int32_t sp_P = 0, sp_grid = 0;          // tiles per wave per span; work-groups (all resident: they wait on each other)

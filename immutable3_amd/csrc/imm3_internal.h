@@ -311,6 +311,11 @@ struct ScanArgs {
     int64_t n_tiles;
     unsigned long long *finish;  // the query's {total, n_emit, status, limit, tally, log ...} block when THIS kernel publishes the count, else null
     const unsigned long long *scanned_tiles; // a limit scan stopped early: tiles [0, *scanned_tiles) hold this run's bitmap lines, the rest count as empty; null: all
+    // A records run that stored NO bitmap (round 5): a tile's survivors = the length of its piece of its wave's arena, read from the
+    // staging launch's start table (one more entry per wave holds the arena's end) through the launch geometry, as k_emit finds it.
+    const uint32_t *rec_tile_start;          // null: the counts come from the bitmap
+    int64_t rec_n_waves, rec_main_tiles;
+    int32_t rec_max_slots, rec_T;
 };
 
 struct ProjCol {

@@ -137,7 +137,7 @@ __device__ __forceinline__ uint32_t finish_full_tile(const TileArgs &a, int64_t 
     }
     mine &= words_to_lanes(acc);
     if (lane >= kTileWords) mine = 0;
-    if (lane < kTileWords) { // 16 lanes x 8 B = one 128-B line
+    if (lane < kTileWords && (!STAGE || a.bitmap)) { // 16 lanes x 8 B = one 128-B line  (a staging launch may run without a bitmap: the records carry the positions)
         if (park) park[lane] = mine; // deferred: the line waits in LDS for the wave's next store burst
         else __builtin_nontemporal_store(mine, a.bitmap + w);
     }
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kBlockThreads, tile_min_waves(K0, K1, STAGE)) void 
     // the streaming loads -- HBM read/write turnarounds cost more than the 3 % of bytes the bitmap is (tools/filter_explore:
     // 67.3 -> 62.2 us).
     extern __shared__ __attribute__((aligned(16))) uint64_t s_park[]; // [kWavesPerBlock][a.defer_lines][16] when deferring
-    uint64_t *park = DEFER ? s_park + (size_t)wave * a.defer_lines * kTileWords : nullptr;
+    uint64_t *park = DEFER ? s_park + (size_t)wave * a.defer_lines * kTileWords : nullptr; // (a launch without a bitmap never takes a deferring instance: launch_filter_tile)
     if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x] = wall_clock64(); // instrumented pass of bench.py only
 #ifdef IMM3_ABLATE
     const unsigned long long cyc0 = clock64(); // (tools: shader cycles, for the clock the chip holds under this kernel)
@@ -267,6 +267,7 @@ __global__ __launch_bounds__(kBlockThreads, tile_min_waves(K0, K1, STAGE)) void 
         if constexpr (STAGE) {
             arena_flush<kRecDwords>(a, A, lds, wave_id, lane);
             for (uint32_t i = lane; i < A.slot; i += 64) a.tile_start[wave_id * a.max_slots + i] = tstart[i];
+            if (lane == 0) a.tile_start[wave_id * a.max_slots + A.slot] = A.arena_n; // (the arena's end: the last tile's length for the offsets scan)
         }
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) lane_total += __shfl_xor(lane_total, d);
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(kBlockThreads, tile_min_waves(K0, K1, STAGE)) void 
     if constexpr (STAGE) {
         arena_flush<kRecDwords>(a, A, lds, wave_id, lane);
         for (uint32_t i = lane; i < A.slot; i += 64) a.tile_start[wave_id * a.max_slots + i] = tstart[i];
+        if (lane == 0) a.tile_start[wave_id * a.max_slots + A.slot] = A.arena_n; // (the arena's end: the last tile's length for the offsets scan)
     }
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) lane_total += __shfl_xor(lane_total, d); // lanes 0..15 -> lane 0
@@ -510,18 +512,38 @@ __global__ __launch_bounds__(kChunkTiles) void k_scan(const ScanArgs a) {
     const int64_t live_tiles = a.scanned_tiles ? ((int64_t)*a.scanned_tiles < a.n_tiles ? (int64_t)*a.scanned_tiles : a.n_tiles) : a.n_tiles;
     const int64_t here = live_tiles - tile0 < 0 ? 0 : (live_tiles - tile0 < kChunkTiles ? live_tiles - tile0 : (int64_t)kChunkTiles);
     const int64_t pieces = here * (kTileWords / 2); // the bitmap is allocated in whole tiles
-#pragma unroll
-    for (int i = 0; i < kTileWords / 2; ++i) {
-        const int64_t q = (int64_t)i * kChunkTiles + t;
+    if (a.rec_tile_start) { // (block-uniform) no bitmap was stored: the tile's records in its wave's arena say how many rows survived
+        const int64_t tile = tile0 + t;
         uint32_t c = 0;
-        if (q < pieces) {
-            const uint4 v = p[q];
-            c = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+        if (tile < a.n_tiles) {
+            int64_t w, slot; // which wave of the staging launch took this tile, and as its how-manieth (k_emit finds it the same way)
+            if (tile < a.rec_main_tiles) {
+                const int64_t g = tile / a.rec_T;
+                w = g % a.rec_n_waves;
+                slot = (g / a.rec_n_waves) * a.rec_T + tile % a.rec_T;
+            } else {
+                const int64_t idx = tile - a.rec_main_tiles, n_groups = a.rec_main_tiles / a.rec_T;
+                w = idx % a.rec_n_waves;
+                slot = (w < n_groups ? ((n_groups - 1 - w) / a.rec_n_waves + 1) * a.rec_T : 0) + idx / a.rec_n_waves;
+            }
+            const uint32_t *ts = a.rec_tile_start + w * a.rec_max_slots + slot;
+            c = ts[1] - ts[0];
         }
-        c += __shfl_xor(c, 1);
-        c += __shfl_xor(c, 2);
-        c += __shfl_xor(c, 4);
-        if ((t & 7) == 0) s_cnt[q >> 3] = c; // tile q / 8 of the chunk
+        s_cnt[t] = c;
+    } else {
+#pragma unroll
+        for (int i = 0; i < kTileWords / 2; ++i) {
+            const int64_t q = (int64_t)i * kChunkTiles + t;
+            uint32_t c = 0;
+            if (q < pieces) {
+                const uint4 v = p[q];
+                c = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+            }
+            c += __shfl_xor(c, 1);
+            c += __shfl_xor(c, 2);
+            c += __shfl_xor(c, 4);
+            if ((t & 7) == 0) s_cnt[q >> 3] = c; // tile q / 8 of the chunk
+        }
     }
     __syncthreads();
     const int64_t tile = tile0 + t;
@@ -941,7 +963,8 @@ int filter_grid(int64_t units, bool generic, bool any_i32, int grid_blocks) {
 
 #define IMM3_TILE_CASE(k0, k1, k2, T)                                                           \
     if (a.kinds[0] == k0 && a.kinds[1] == k1 && a.kinds[2] == k2) {                             \
-        if (a.stage_rec && a.tile_rows) return false; /* (table queries do not stage) */                 \
+        if (!a.bitmap && a.defer_lines) return false; /* (a deferring instance parks bitmap lines and stores them: it needs the bitmap) */ \
+        else if (a.stage_rec && a.tile_rows) return false; /* (table queries do not stage) */            \
         else if (a.stage_rec && a.defer_lines) IMM3_LAUNCH_LDS((k_filter_tile<k0, k1, k2, T, false, true, true>), grid, kBlockThreads, \
                              (size_t)kWavesPerBlock * (size_t)a.defer_lines * kTileWords * sizeof(uint64_t), s, ev0, ev1, a); \
         else if (a.stage_rec) IMM3_LAUNCH((k_filter_tile<k0, k1, k2, T, false, false, true>), grid, kBlockThreads, s, ev0, ev1, a); \

@@ -302,7 +302,7 @@ int records_setup(imm3_query *q) {
     if (T > 0 && max_slots <= kMaxArenaSlots) {
         q->stage_grid = (int32_t)grid;
         q->stage_T = T;
-        q->stage_max_slots = (int32_t)std::max<int64_t>(max_slots, 1);
+        q->stage_max_slots = (int32_t)std::max<int64_t>(max_slots, 1) + 1; // (+ 1: behind a wave's tile starts sits its arena's end -- the last tile's length, for an offsets scan without a bitmap)
         q->stage_wave_cap = (int64_t)q->stage_max_slots * kTileRows; // (skewing the arena bases off their 128 KiB-aligned stride changed nothing)
         q->stage_main_tiles = main_tiles;
         void *d = nullptr;

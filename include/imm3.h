@@ -305,7 +305,12 @@ int imm3_query_fetch_rows(imm3_query *q, uint32_t *row_index_out, void *const *c
  *     reference never looks at batches behind the limit either): behind imm3_query_run its bitmap (0) and count (1) cover the
  *     scanned prefix of the segment only -- the rows (2, 3, 16+j) are complete.  imm3_query_count, imm3_query_bitmap,
  *     imm3_query_run_select / _run_count, imm3_query_log_counts and imm3_comm_allreduce_count give the whole segment's: the host
- *     getters run the whole select when the last run stopped early. */
+ *     getters run the whole select when the last run stopped early;
+ *   - the BITMAP (0) is written by imm3_query_run_select always, and by imm3_query_run whenever the plan reads it; two plans do
+ *     not: an unlimited projection that goes through survivor records (the records carry the positions; imm3_query_plan out[4])
+ *     and an aggregation whose select chain rides in the aggregation launch.  imm3_query_bitmap materialises it on demand (the
+ *     select chain runs once more); a DEVICE consumer of pointer 0 calls imm3_query_run_select.  The COUNT (1) is exact behind
+ *     every imm3_query_run -- except for such an aggregation, where imm3_query_join_count / imm3_query_count produce it. */
 int imm3_query_device_ptr(imm3_query *q, int32_t which, void **ptr);
 
 /* ---- multi-GPU: the count reduce.  Segments shard one per GPU -- segment s belongs to GPU s mod G -- and
