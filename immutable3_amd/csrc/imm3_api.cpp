@@ -2213,6 +2213,8 @@ static int launch_limit_gather_for(imm3_query *q) {
     g.cap_rows = q->cap_rows;
     g.row_index = q->d_row_index;
     g.n_proj = (int32_t)q->proj.size();
+    g.fault_wg = ctx->fault_wg;        // (tools' build only: imm3_ctx_inject_fault)
+    g.max_polls = ctx->fault_max_polls;
     for (size_t j = 0; j < q->proj.size(); ++j) {
         const SegCol &sc = q->seg->cols[(size_t)q->used[(size_t)q->proj[j]]];
         g.proj[j].src = col_flat(sc);
@@ -2237,8 +2239,10 @@ static int run_project(imm3_query *q) {
         if (rc) return rc;
         q->offsets_valid = false; // (no offsets scan has run on this bitmap)
         q->ran_project = true;
+        q->limit_gather_ran = true;
         return IMM3_OK;
     }
+    q->limit_gather_ran = false;
     if (q->n_tiles > 0) {
         ScanArgs sa;
         std::memset(&sa, 0, sizeof(sa));
@@ -2628,7 +2632,23 @@ static int settle_rows(imm3_query *q, uint64_t *rows) {
         if (src) return src;
     }
     unsigned long long emit = 0;
-    if (q->n_tiles > 0) {
+    if (q->n_tiles > 0 && q->limit_gather_ran) {
+        // k_limit_gather's look-back is bounded: a launch whose wait ran out tagged finish[kFinishLimitGaveUp] with its run and
+        // wrote only some of the rows -- gather them the two-launch way (one copy brings the row count, the epoch and the tag)
+        unsigned long long head[kFinishLimitGaveUp + 1];
+        HIPCHK(hipMemcpyAsync(head, q->d_total, sizeof(head), hipMemcpyDeviceToHost, q->ctx->stream));
+        HIPCHK(hipStreamSynchronize(q->ctx->stream));
+        emit = head[1];
+        if (head[kFinishLimitGaveUp] == (((head[kFinishEpoch] & 0x7FFFFFULL) << 1) | 1ULL)) {
+            ++q->limit_gather_gave_up;
+            q->limit_gather_ran = false;
+            int rc = scan_offsets(q);
+            if (rc) return rc;
+            rc = launch_project(q);
+            if (rc) return rc;
+            HIPCHK(hipStreamSynchronize(q->ctx->stream));
+        }
+    } else if (q->n_tiles > 0) {
         HIPCHK(hipMemcpyAsync(&emit, q->d_n_emit, sizeof(emit), hipMemcpyDeviceToHost, q->ctx->stream));
         HIPCHK(hipStreamSynchronize(q->ctx->stream));
     }
@@ -2691,10 +2711,10 @@ extern "C" int imm3_query_device_ptr(imm3_query *q, int32_t which, void **ptr) {
 
 extern "C" int imm3_query_plan(const imm3_query *q, int64_t *out, int32_t n) {
     if (!q || !out) return fail(IMM3_ERR_ARG, "null argument");
-    const int64_t v[10] = {q->single_pass ? 1 : 0, q->sp_P, q->sp_grid, q->sp_spans, q->d_stage_rec ? 1 : 0,
+    const int64_t v[11] = {q->single_pass ? 1 : 0, q->sp_P, q->sp_grid, q->sp_spans, q->d_stage_rec ? 1 : 0,
                            (q->single_pass || q->d_stage_rec) ? rec_layout(q->stage_kinds, -1).dwords : 0, q->ran_single_pass ? 1 : 0, (int64_t)q->run_syncs,
-                           (int64_t)q->sp_abandoned_runs, (int64_t)q->sp_busy_runs};
-    for (int32_t i = 0; i < n && i < 10; ++i) out[i] = v[i];
+                           (int64_t)q->sp_abandoned_runs, (int64_t)q->sp_busy_runs, (int64_t)q->limit_gather_gave_up};
+    for (int32_t i = 0; i < n && i < 11; ++i) out[i] = v[i];
     return IMM3_OK;
 }
 

@@ -235,6 +235,8 @@ struct imm3_query {
     uint32_t out_cap = 0;
     bool ran_agg = false;
     bool agg_fusable = false;          // the select chain is closed intervals over <= 2 dense int8 / int32 columns of one uniform segment (or empty): the aggregation kernel can evaluate it itself
+    bool limit_gather_ran = false;     // the last projection was k_limit_gather's one launch: settle_rows looks at its give-up tag
+    uint64_t limit_gather_gave_up = 0; // ... and how often it had to gather the rows again with k_scan + k_gather
     bool agg_select_skipped = false;   // the last run fused the select into the aggregation launch: bitmap and count do not exist until a getter asks (settle_agg_select)
     int32_t agg_first_form = imm3::AGG_FORM_LANES; // first kernel form to try: raised past the forms this query's keys overflowed
     // select-only runs: the count reduce goes to ctx->aux, fenced by these events

@@ -234,6 +234,7 @@ constexpr int kFinishDense = 9;         // finish[9]: single-pass projection: ra
 // launch that first looks at the rows selected so far and leaves at once when the limit has been reached.
 constexpr int kFinishLimitRows = 11;    // finish[11]: rows selected by the chunks of this run so far
 constexpr int kFinishLimitTiles = 12;   // finish[12]: tiles those chunks scanned (the offsets scan and the gather stop there)
+constexpr int kFinishLimitGaveUp = 13;  // finish[13]: k_limit_gather's look-back ran into its poll cap in the run with this tag: gather with k_scan + k_gather
 constexpr int kDescValueBits = 36, kDescFlagShift = 36, kDescEpochShift = 38;
 constexpr unsigned long long kDescValueMask = (1ULL << kDescValueBits) - 1;
 constexpr unsigned long long kDescEpochMask = (1ULL << (64 - kDescEpochShift)) - 1;
@@ -348,9 +349,10 @@ struct GatherArgs {
 // k_limit_gather: the offsets scan and the gather of a SMALL `limit` in one launch, over the tiles a limit scan got to.
 constexpr int kLimitGatherMaxChunks = 64;   // chunks of 256 tiles per work-group at most (the launch has one work-group per CU)
 constexpr int64_t kLimitGatherMaxRows = 4096;
+constexpr uint32_t kLimitGatherMaxPolls = 1u << 18; // look-back polls (with s_sleep 4, ~0.5 us each) before the launch gives its rows up
 struct LimitGatherArgs {
     const uint64_t *bitmap;
-    const unsigned long long *finish;  // [kFinishLimitTiles] = tiles scanned, [kFinishEpoch] = the run's tag
+    unsigned long long *finish;        // [kFinishLimitTiles] = tiles scanned, [kFinishEpoch] = the run's tag; [kFinishLimitGaveUp] is written
     unsigned long long *wg_state;      // [grid]: (tag << 40) | survivors of the work-group's tiles
     int64_t n_tiles;
     int64_t limit;
@@ -358,7 +360,8 @@ struct LimitGatherArgs {
     uint32_t *row_index;
     ProjCol proj[kMaxProj];
     int32_t n_proj;
-    int32_t pad;
+    int32_t fault_wg;                  // tools' build (-DIMM3_ABLATE, imm3_ctx_inject_fault): this work-group never publishes its count (-1: none)
+    uint32_t max_polls, pad;           // tools' build: the poll cap (0: kLimitGatherMaxPolls)
 };
 
 // launchers (imm3_kernels.hip)

@@ -1015,7 +1015,8 @@ void launch_total(const TotalArgs &a, hipStream_t s, hipEvent_t ev0, hipEvent_t 
 // that were scanned, in one launch instead of k_scan + k_gather (7 + 9 us for ten rows).  Work-group b takes a CONTIGUOUS piece of
 // the scanned tiles (K chunks of 256 tiles, K from the scanned-tile word): it counts its survivors, publishes the count tagged with
 // the run, and adds up the counts of the work-groups before it -- which were dispatched before it, so the wait cannot deadlock
-// whatever is resident -- to know its first output row.  A work-group whose first row is already behind the limit leaves; the few
+// whatever is resident; it is bounded all the same (kLimitGatherMaxPolls: a device shared with a long-running kernel of another
+// process can hold a lower work-group back) and a wait that runs out raises finish[kFinishLimitGaveUp] -- to know its first output row.  A work-group whose first row is already behind the limit leaves; the few
 // that are not walk their tiles again (the lines are in the L2) and emit row numbers and column values row by row.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kChunkTiles) void k_limit_gather(const LimitGatherArgs a) {
@@ -1067,24 +1068,43 @@ __global__ __launch_bounds__(kChunkTiles) void k_limit_gather(const LimitGatherA
         if (t == 0) s_chunk_total[k] = total;
         mine += total;
     }
-    if (t == 0) __hip_atomic_store(a.wg_state + blockIdx.x, (tag << 40) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef IMM3_ABLATE
+    const uint32_t poll_cap = a.max_polls ? a.max_polls : kLimitGatherMaxPolls;
+    if (t == 0 && (int)blockIdx.x != a.fault_wg)
+#else
+    const uint32_t poll_cap = kLimitGatherMaxPolls;
+    if (t == 0)
+#endif
+        __hip_atomic_store(a.wg_state + blockIdx.x, (tag << 40) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the survivors before this work-group's tiles: the counts of the work-groups before it (enough of them: once the sum has
     // reached the limit the rest does not matter)
     if (wave == 0) {
         unsigned long long base = 0;
+        bool gave_up = false;
         for (int64_t b0 = 0; b0 < (int64_t)blockIdx.x && base < (unsigned long long)a.limit; b0 += 64) {
             const int64_t b = b0 + lane;
             unsigned long long v = 0;
+            bool late = false;
             if (b < (int64_t)blockIdx.x) {
-                do v = __hip_atomic_load(a.wg_state + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while ((v >> 40) != tag);
-                v &= (1ULL << 40) - 1ULL;
+                // bounded, as the projection's look-back waits are (imm3_project.hip desc_wait): ~0.2 s of polls, then the rows
+                // of this launch are given up and the host gathers them with k_scan + k_gather (settle_rows)
+                for (uint32_t polls = 0;; ++polls) {
+                    v = __hip_atomic_load(a.wg_state + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((v >> 40) == tag) break;
+                    if (polls > poll_cap) { late = true; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                v = late ? 0ULL : v & ((1ULL << 40) - 1ULL);
             }
+            if (__ballot(late)) { gave_up = true; break; } // (wave-uniform)
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
             base += v;
         }
-        if (lane == 0) s_base = base;
+        if (lane == 0) {
+            if (gave_up) a.finish[kFinishLimitGaveUp] = tag; // (tagged with the run: a stale word of an earlier run is not this one)
+            s_base = gave_up ? ~0ULL : base;                 // (behind every limit: the work-group leaves below)
+        }
     }
     __syncthreads();
     unsigned long long base = s_base;

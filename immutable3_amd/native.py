@@ -616,11 +616,11 @@ class DeviceQuery:
 
     def plan(self) -> dict:
         """How the library planned this query (include/imm3_diag.h: imm3_query_plan)."""
-        v = np.zeros(10, np.int64)
-        _check(load().imm3_query_plan(self._h, v.ctypes.data, 10))
+        v = np.zeros(11, np.int64)
+        _check(load().imm3_query_plan(self._h, v.ctypes.data, 11))
         return {"single_pass": bool(v[0]), "P": int(v[1]), "grid": int(v[2]), "spans": int(v[3]), "records": bool(v[4]),
                 "rec_dwords": int(v[5]), "ran_single_pass": bool(v[6]), "run_syncs": int(v[7]),
-                "abandoned_runs": int(v[8]), "busy_runs": int(v[9])}
+                "abandoned_runs": int(v[8]), "busy_runs": int(v[9]), "limit_gather_gave_up": int(v[10])}
 
     def device_ptr(self, which: int) -> int:
         p = C.c_void_p()

@@ -65,7 +65,8 @@ int imm3_plan_predict(int64_t n_rows, const int32_t *pred_width, const int32_t *
  * imm3_query_run has waited for the device so far (an unreserved unlimited projection: once, on its first run);
  * out[8] / out[9] = single-pass runs of this query whose rows a getter had to gather from the bitmap because the launch gave up on
  * them: a look-back wait timed out (the query keeps the bitmap path from then on) / another launch of the kernel owned the device
- * (that run only).  n <= 10 values. */
+ * (that run only); out[10] = runs whose small-limit gather (k_limit_gather) ran into its look-back poll cap, so that a getter
+ * gathered the rows again with k_scan + k_gather.  n <= 11 values. */
 int imm3_query_plan(const imm3_query *q, int64_t *out, int32_t n);
 
 /* ---- fault injection into the single-pass projection kernel (k_filter_project, csrc/imm3_project.hip) ----

@@ -303,6 +303,28 @@ for variant, want_grid in ((0, cus - 8), (16, cus)):
     finally:
         ctx.set_tuning(0, 0)
 print("co-resident kernel ok", flush=True)
+# ---- 7. the small-limit gather (k_limit_gather: offsets scan + gather in one launch): its look-back over the counts of the
+# lower-numbered work-groups is bounded; a launch whose wait ran out tags the finish block and a getter gathers with k_scan + k_gather
+LIM = 100
+for wg in (0, 3):
+    q = native.DeviceQuery(ctx, seg, [1, 0], sels, [1, 0], LIM)
+    q.run()
+    idx, vals = q.fetch_rows()
+    assert (idx == rows[:LIM]).all() and q.plan()["limit_gather_gave_up"] == 0, ("limit baseline", q.plan())
+    ctx.inject_fault(wg, 0, 200)
+    t0 = time.time()
+    q.run(); ctx.sync()
+    assert time.time() - t0 < 5.0
+    idx, vals = q.fetch_rows()
+    ctx.inject_fault(-1, -1, 0)
+    assert idx.size == LIM and (idx == rows[:LIM]).all(), ("limit gather gave up", wg)
+    assert vals[0].tobytes() == np.ascontiguousarray(a[rows[:LIM]]).tobytes() and vals[1].tobytes() == np.ascontiguousarray(c[rows[:LIM]]).tobytes()
+    assert q.plan()["limit_gather_gave_up"] == 1, q.plan()
+    q.run()
+    idx, vals = q.fetch_rows()
+    assert (idx == rows[:LIM]).all() and q.plan()["limit_gather_gave_up"] == 1, q.plan()
+    q.close()
+print("limit gather ok", flush=True)
 comm.close(); seg.close(); ctx.close()
 print("FAULT-INJECTION-OK", flush=True)
 '''
