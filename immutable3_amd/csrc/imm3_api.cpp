@@ -1763,9 +1763,13 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
         a.block_partials = q->d_block_partials;
         a.tile_rows = q->table ? q->table->d_tile_rows : nullptr; // table query: address the columns through the tile table
         bool any_i32 = false;
-        for (int k = 0; k < kMaxTileCols; ++k) any_i32 |= (a.kinds[k] == TK_I32);
+        int narrow_bytes = 0;
+        for (int k = 0; k < kMaxTileCols; ++k) {
+            any_i32 |= (a.kinds[k] == TK_I32);
+            narrow_bytes += a.kinds[k] == TK_I8 ? 1 : (a.kinds[k] == TK_S2 ? 2 : 0);
+        }
         bool stamped = false;
-        grid = filter_grid(q->n_tiles, false, any_i32, ctx->grid_blocks); // (no column at all: the store-only kernel also likes 1536 groups, 9.9 vs 17.2 us)
+        grid = filter_grid(q->n_tiles, false, any_i32, ctx->grid_blocks, narrow_bytes); // (no column at all: the store-only kernel also likes 1536 groups, 9.9 vs 17.2 us)
         if (q->stage_written) grid = q->stage_grid; // fixed at creation: the arena layout depends on it
         // A select chain that is ONE tile pass also reduces its count in the kernel (one relaxed atomic per work-group into a
         // two-level tally, finish_add): no k_total launch.  Variant 7 = never; variant 13 = only at <= 512 work-groups (what
@@ -1808,7 +1812,7 @@ static int run_select(imm3_query *q, bool overlap_total, bool count_in_scan = fa
                 c.finish = q->d_total;
                 c.chunked = tile0 == 0 ? 2 : 1; // (the first chunk starts the running words over)
                 c.stamps = nullptr;
-                const int cgrid = filter_grid(c.n_tiles, false, any_i32, ctx->grid_blocks);
+                const int cgrid = filter_grid(c.n_tiles, false, any_i32, ctx->grid_blocks, narrow_bytes);
                 c.defer_lines = ctx->filter_variant == 12 ? 0 : (cgrid <= 1024 ? kDeferLines : 16);
                 LaunchTimer t(ctx, 0);
                 if (!launch_filter_tile(c, cgrid, s, t.start, t.stop)) return fail(IMM3_ERR_ARG, "internal: no tile kernel for this column combination");

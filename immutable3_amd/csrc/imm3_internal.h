@@ -471,7 +471,7 @@ void launch_group_collect(const AggArgs &a, hipStream_t s);
 constexpr int kSubTallies = 32;                       // in-kernel count reduce: sub-tallies (finish_add, imm3_device.h)
 constexpr int kFinishWords = 16 + kSubTallies * 16;   // u64 words of a query's `finish` block: header (9 used, padded to a 128-byte line) + one line per sub-tally
 constexpr int kMaxFilterGrid = 4096; // capacity of block_partials
-int filter_grid(int64_t units, bool generic, bool any_i32, int grid_blocks);
+int filter_grid(int64_t units, bool generic, bool any_i32, int grid_blocks, int narrow_row_bytes = 0); // narrow_row_bytes: bytes per row of a launch without an int32 column
 // ev0/ev1: optional events stamped with the kernel's own start/end (hipExtLaunchKernelGGL), else null
 // ---- PFOR_INT blocks (imm3_codec.hip) ----
 struct PforArgs {

@@ -40,6 +40,9 @@ struct ColRegs { // TK_NONE: no column
     __device__ __forceinline__ bool row(const void *, const TileCol &, int64_t) { return true; }
     __device__ __forceinline__ uint32_t value(int) const { return 0u; }
     __device__ __forceinline__ uint32_t rowval(const void *, int64_t) const { return 0u; }
+    __device__ __forceinline__ void load_lane_rows(const void *, int64_t, int) {}
+    __device__ __forceinline__ void load_lane_rows_split(const void *, int64_t, int) {}
+    __device__ __forceinline__ uint32_t lane_mask(const TileCol &) const { return 0xFFFFu; }
 };
 
 template <>
@@ -92,6 +95,9 @@ struct ColRegs<TK_I32> {
     __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return in_closed(((const IMM3_GLOBAL int32_t *)data)[r], c.lo, c.hi); }
     __device__ __forceinline__ uint32_t value(int j) const { return (uint32_t)v[j]; }
     __device__ __forceinline__ uint32_t rowval(const void *data, int64_t r) const { return ((const IMM3_GLOBAL uint32_t *)data)[r]; }
+    __device__ __forceinline__ void load_lane_rows(const void *data, int64_t row0, int lane) { load(data, row0, lane); } // (never in-lane: lane_tile())
+    __device__ __forceinline__ void load_lane_rows_split(const void *data, int64_t row0, int lane) { load(data, row0, lane); }
+    __device__ __forceinline__ uint32_t lane_mask(const TileCol &) const { return 0xFFFFu; }
 };
 
 template <>
@@ -126,6 +132,49 @@ struct ColRegs<TK_I8> {
     __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return in_closed((int32_t)((const IMM3_GLOBAL int8_t *)data)[r], c.lo, c.hi); }
     __device__ __forceinline__ uint32_t value(int j) const { return v[j]; }
     __device__ __forceinline__ uint32_t rowval(const void *data, int64_t r) const { return ((const IMM3_GLOBAL uint8_t *)data)[r]; }
+    // IN-LANE evaluation (k_filter_tile's narrow-only instances: lane_tile() there says why): `raw` holds rows 16 * lane .. + 15 of
+    // the tile; bit k of the result = row 16 * lane + k passes.  No transpose, no ballot: sub (SDWA byte select) + compare + one
+    // add-with-carry that shifts the compare's bit in -- three vector instructions per row, nothing else.
+    __device__ __forceinline__ void load_lane_rows(const void *data, int64_t row0, int lane) { load(data, row0, lane); }
+    // ... beside a 2-byte-string column (whose dense loads give the lane rows 8 lane .. + 7 and 512 + 8 lane .. + 7): the same rows,
+    // as two 8-byte loads -- bits 0..7 / 8..15 of lane_mask() are then those two runs
+    __device__ __forceinline__ void load_lane_rows_split(const void *data, int64_t row0, int lane) {
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        const IMM3_GLOBAL v2i *p = (const IMM3_GLOBAL v2i *)((const IMM3_GLOBAL int8_t *)data + row0) + lane;
+        const v2i a = __builtin_nontemporal_load(p), b = __builtin_nontemporal_load(p + 64);
+        raw[0] = a[0]; raw[1] = a[1]; raw[2] = b[0]; raw[3] = b[1];
+    }
+    // Four rows (one dword) per asm block: the compiler's own code for `m = 2 m + in_closed(row)` is select + shift-or per row behind
+    // the subtract and the compare (4 instructions and an s_nop: a compare's mask may not be read by the very next vector
+    // instructions); v_addc_co_u32 m, m, m, mask does shift and insert in one, and four rows interleaved keep every mask three
+    // instructions away from its reader, so no s_nop either.
+    static __device__ __forceinline__ void rows4(uint32_t &m, int32_t dword, uint32_t lo, uint32_t range) {
+        uint32_t t0, t1, t2, t3;
+        uint64_t s0, s1, s2, s3;
+        asm("v_sub_u32_sdwa %[t0], sext(%[r]), %[lo] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+            "v_sub_u32_sdwa %[t1], sext(%[r]), %[lo] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+            "v_sub_u32_sdwa %[t2], sext(%[r]), %[lo] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+            "v_sub_u32_sdwa %[t3], sext(%[r]), %[lo] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+            "v_cmp_ge_u32_e64 %[s0], %[rg], %[t0]\n\t"
+            "v_cmp_ge_u32_e64 %[s1], %[rg], %[t1]\n\t"
+            "v_cmp_ge_u32_e64 %[s2], %[rg], %[t2]\n\t"
+            "v_cmp_ge_u32_e64 %[s3], %[rg], %[t3]\n\t"
+            "v_addc_co_u32_e64 %[m], %[s0], %[m], %[m], %[s0]\n\t"
+            "v_addc_co_u32_e64 %[m], %[s1], %[m], %[m], %[s1]\n\t"
+            "v_addc_co_u32_e64 %[m], %[s2], %[m], %[m], %[s2]\n\t"
+            "v_addc_co_u32_e64 %[m], %[s3], %[m], %[m], %[s3]"
+            : [m] "+v"(m), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3)
+            : [r] "v"(dword), [lo] "s"(lo), [rg] "s"(range));
+    }
+    __device__ __forceinline__ uint32_t lane_mask(const TileCol &c) const {
+        const uint32_t lo = (uint32_t)c.lo, range = (uint32_t)c.hi - (uint32_t)c.lo; // in_closed(): (x - lo) <= (hi - lo), unsigned
+        uint32_t m = 0;
+        rows4(m, raw[3], lo, range); // (row 15 first: each step shifts the rows so far up)
+        rows4(m, raw[2], lo, range);
+        rows4(m, raw[1], lo, range);
+        rows4(m, raw[0], lo, range);
+        return m;
+    }
 };
 
 template <>
@@ -188,6 +237,39 @@ struct ColRegs<TK_S2> {
     __device__ __forceinline__ bool row(const void *data, const TileCol &c, int64_t r) { return hit(c, ((const IMM3_GLOBAL uint16_t *)data)[r]); }
     __device__ __forceinline__ uint32_t value(int j) const { return v[j]; }
     __device__ __forceinline__ uint32_t rowval(const void *data, int64_t r) const { return ((const IMM3_GLOBAL uint16_t *)data)[r]; }
+    // in-lane evaluation (see ColRegs<TK_I8>): the dense loads of load() leave the lane rows 8 lane .. + 7 (raw[0]) and
+    // 512 + 8 lane .. + 7 (raw[1]); bits 0..7 / 8..15 of lane_mask() are those two runs.  (The lane's 16 CONSECUTIVE rows -- 32
+    // contiguous bytes, two 16-byte loads at a 32-byte lane stride -- measured slower: each instruction touches every 128-byte line
+    // of the tile, S2 over 100 M rows 35.3 -> 41.2 us.)
+    __device__ __forceinline__ void load_lane_rows_split(const void *data, int64_t row0, int lane) { load(data, row0, lane); }
+    // four rows (two dwords) per asm block, as ColRegs<TK_I8>::rows4: compare (SDWA word select) + add-with-carry per row
+    static __device__ __forceinline__ void rows4(uint32_t &m, int32_t d_hi, int32_t d_lo, uint32_t value) {
+        uint64_t s0, s1, s2, s3;
+        asm("v_cmp_eq_u32_sdwa %[s0], %[a], %[v] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+            "v_cmp_eq_u32_sdwa %[s1], %[a], %[v] src0_sel:WORD_0 src1_sel:DWORD\n\t"
+            "v_cmp_eq_u32_sdwa %[s2], %[b], %[v] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+            "v_cmp_eq_u32_sdwa %[s3], %[b], %[v] src0_sel:WORD_0 src1_sel:DWORD\n\t"
+            "v_addc_co_u32_e64 %[m], %[s0], %[m], %[m], %[s0]\n\t"
+            "v_addc_co_u32_e64 %[m], %[s1], %[m], %[m], %[s1]\n\t"
+            "v_addc_co_u32_e64 %[m], %[s2], %[m], %[m], %[s2]\n\t"
+            "v_addc_co_u32_e64 %[m], %[s3], %[m], %[m], %[s3]"
+            : [m] "+v"(m), [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2), [s3] "=&s"(s3)
+            : [a] "v"(d_hi), [b] "v"(d_lo), [v] "s"(value));
+    }
+    __device__ __forceinline__ uint32_t value_mask(uint32_t value) const {
+        uint32_t m = 0;
+        rows4(m, raw[1][3], raw[1][2], value); // (row 15 first)
+        rows4(m, raw[1][1], raw[1][0], value);
+        rows4(m, raw[0][3], raw[0][2], value);
+        rows4(m, raw[0][1], raw[0][0], value);
+        return m;
+    }
+    __device__ __forceinline__ uint32_t lane_mask(const TileCol &c) const {
+        if (c.n_match == 1) return value_mask(c.match[0]); // (the one-value list the SQL front end produces)
+        uint32_t m = 0;
+        for (int i = 0; i < c.n_match; ++i) m |= value_mask(c.match[i]); // IN-list: one 16-bit mask per value
+        return m;
+    }
 };
 
 // ---- survivor records ---------------------------------------------------------------------------------------
