@@ -155,7 +155,7 @@ def test_tables_and_limit_chunks(ctx):
         q = native.DeviceQuery(ctx, seg, [0], [(0, GT, 125.0)], [0], limit)
         q.run()
         idx, vals = q.fetch_rows()
-        assert idx.tolist() == rows_[:limit].tolist() and vals[0].view(np.int8).tolist() == a0[rows_[:limit]].tolist()
+        assert idx.tolist() == rows_[:limit].tolist() and vals[0].view(np.int8).reshape(-1).tolist() == a0[rows_[:limit]].tolist()
         assert q.count() == rows_.size
         q.close()
     seg.close()
