@@ -120,7 +120,7 @@ c3 = one_launch("c3_range_age_id_project", "k_filter_project<0, 1, 3, false>")
 # the table instance: C5's passes (8 x 100 M rows, ~0.9 ms) and the README-shaped table (100 M rows, ~0.12 ms)
 c5 = one_launch("c5", "k_filter_project<0, 1, 3, true>", ("big", 400.0), units=8)
 rt = one_launch("readme_table_c3", "k_filter_project<0, 1, 3, true>", ("small", 400.0))
-cfgs = {"c4_match_state_project": ("k_filter_tile<2, 3, 3, *, false, true, true>", "k_emit<1, 2>")}
+cfgs = {"c4_match_state_project": ("k_filter_tile<2, 3, 3, *, false, false, true>", "k_emit<1, 2>")}
 scan = kernel("k_scan")
 for name, (fk, ek) in cfgs.items():
     f, e = kernel(fk), kernel(ek)
