@@ -2045,9 +2045,7 @@ static int run_single_pass(imm3_query *q) {
     }
     a.P = q->sp_P;
     a.n_rows = q->n_rows;
-    // (a segment whose plan carries tile descriptors runs the table instance over itself: single_pass_setup says why)
-    const bool as_table = q->table || (q->d_tile_desc && ctx->filter_variant != 21 && single_pass_gathers(q) == 0);
-    if (as_table) {
+    if (q->table) {
         if (!q->d_tile_desc) return fail(IMM3_ERR_STATE, "internal: table query planned as one launch without its tile descriptors");
         a.tile_desc = q->d_tile_desc;
         a.n_rows = q->n_tiles * kTileRows; // (virtual rows: what the tiles span; the kernel takes a tile's valid rows from its descriptor)
@@ -2107,7 +2105,7 @@ static int run_single_pass(imm3_query *q) {
         if (chained) HIPCHK(hipStreamWaitEvent(s, dev->last, 0));
         {
             LaunchTimer t(ctx, 0);
-            const bool launched = as_table ? launch_filter_project_table(a, q->sp_grid, s, t.start, t.stop) : launch_filter_project(a, q->sp_grid, s, t.start, t.stop);
+            const bool launched = q->table ? launch_filter_project_table(a, q->sp_grid, s, t.start, t.stop) : launch_filter_project(a, q->sp_grid, s, t.start, t.stop);
             if (!launched) return fail(IMM3_ERR_ARG, "internal: no single-pass kernel for this column combination");
         }
         HIPCHK(hipGetLastError());

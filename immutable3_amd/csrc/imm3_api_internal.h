@@ -25,7 +25,6 @@ void single_pass_set_P(imm3_query *q, int32_t P);
 void single_pass_pick_P(imm3_query *q, double sigma, bool sure);
 void single_pass_adapt(imm3_query *q, uint64_t survivors, int64_t dense_ranges);
 int single_pass_setup(imm3_query *q);
-int single_pass_gathers(const imm3_query *q);
 PlanDensity plan_density_for(const imm3_query *q, uint64_t survivors);
 double plan_cost_three_launches(const imm3_query *q, const PlanDensity &d, bool records_possible, bool *use_records);
 int single_pass_stream_columns(imm3_query *q, uint64_t survivors);

@@ -278,7 +278,6 @@ bool launch_filter_project(const ProjectArgs &a, int grid, hipStream_t s, hipEve
 bool launch_filter_project_table(const ProjectArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1); // a.tile_desc set
 // the per-query tile descriptors of a table query, from the table's per-column tile pointers (null pointer: no such column)
 void launch_project_tile_desc(const uint32_t *tile_rows, const void *const *p0, const void *const *p1, const void *const *p2, ProjectTile *out, int64_t n_tiles, hipStream_t s);
-void launch_project_tile_desc_flat(const void *b0, int w0, const void *b1, int w1, const void *b2, int w2, int64_t n_rows, ProjectTile *out, int64_t n_tiles, hipStream_t s);
 int project_max_grid(const int32_t *kinds, int P);   // resident work-groups of the instance on the current device (0: none)
 int project_rec_dwords(const int32_t *kinds);
 

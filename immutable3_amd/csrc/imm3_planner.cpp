@@ -111,22 +111,6 @@ void single_pass_adapt(imm3_query *q, uint64_t survivors, int64_t dense_ranges) 
     single_pass_pick_P(q, sigma, dense_ranges > 0);
 }
 
-// SELECT-list columns the one launch would have to GATHER: every mention that is not the first mention of a tile column (the
-// launch's arguments are filled the same way: run_single_pass).
-int single_pass_gathers(const imm3_query *q) {
-    bool taken[kMaxTileCols] = {false, false, false};
-    int ng = 0;
-    for (size_t j = 0; j < q->proj.size(); ++j) {
-        const int32_t sci = q->used[(size_t)q->proj[j]];
-        int k_pred = -1;
-        for (int k = 0; k < kMaxTileCols; ++k)
-            if (q->stage_seg_col[k] == sci && !taken[k]) { k_pred = k; break; }
-        if (k_pred >= 0) taken[k_pred] = true;
-        else ++ng;
-    }
-    return ng;
-}
-
 // Plans the one-launch projection for the tile columns in q->stage_kinds: P, the grid, the descriptor allocation.
 // q->single_pass stays false when the kernel cannot run here (no instance, no resident work-group).
 int single_pass_setup(imm3_query *q) {
@@ -182,36 +166,6 @@ int single_pass_setup(imm3_query *q) {
     if (me != hipSuccess) {
         pool_release(ctx, d);
         HIPCHK(me);
-    }
-    // A SEGMENT's one launch runs the table instance as well, over the segment seen as a table of its own tiles (round 5): that
-    // instance's tile loop is the leaner one -- one descriptor ahead through the scalar cache instead of 64-bit tile arithmetic and a
-    // rolled partial-tile path, fewer spilled SGPRs in the loop -- and measured 3-5 % faster on the same rows (C3's query over one
-    // 100 M-row segment: 118-122 us as a table of one segment against 120-126; profiles/r05_table_probe.txt).  32 bytes of
-    // descriptor per 1024-row tile.  Not with gathered SELECT-list columns (the table instance has no gather walk); tuning 21 keeps
-    // the segment instance.
-    if (!q->table && !q->d_tile_desc && ctx->filter_variant != 21 && single_pass_gathers(q) == 0) {
-        void *td = nullptr;
-        const hipError_t te = pool_alloc(ctx, &td, (size_t)q->n_tiles * sizeof(ProjectTile));
-        if (te != hipSuccess) {
-            pool_release(ctx, d);
-            HIPCHK(te);
-        }
-        const void *b[kMaxTileCols] = {nullptr, nullptr, nullptr};
-        int w[kMaxTileCols] = {0, 0, 0};
-        for (int k = 0; k < kMaxTileCols; ++k)
-            if (q->stage_kinds[k] != TK_NONE && q->stage_seg_col[k] >= 0) {
-                const SegCol &sc = q->seg->cols[(size_t)q->stage_seg_col[k]];
-                b[k] = col_flat(sc);
-                w[k] = sc.width;
-            }
-        launch_project_tile_desc_flat(b[0], w[0], b[1], w[1], b[2], w[2], q->n_rows, (ProjectTile *)td, q->n_tiles, ctx->stream);
-        const hipError_t le = hipGetLastError();
-        if (le != hipSuccess) {
-            pool_release(ctx, d);
-            pool_release(ctx, td);
-            HIPCHK(le);
-        }
-        q->d_tile_desc = (ProjectTile *)td;
     }
     if (q->table && !q->d_tile_desc) { // the launch's view of the tile table: one descriptor per tile (built on the device from the table's per-column pointers)
         void *td = nullptr;

@@ -1448,25 +1448,6 @@ void launch_project_tile_desc(const uint32_t *tile_rows, const void *const *p0, 
     if (n_tiles <= 0) return;
     hipLaunchKernelGGL(k_project_tile_desc, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, s, tile_rows, p0, p1, p2, out, n_tiles);
 }
-// ONE segment seen as a table of its own tiles (a segment's one-launch projection runs the table instance too: run_single_pass
-// says why): tile t of a flat column starts t * 1024 * width bytes in, the last tile holds the rows that are left.
-__global__ __launch_bounds__(256) void k_project_tile_desc_flat(const uint8_t *b0, int w0, const uint8_t *b1, int w1, const uint8_t *b2, int w2, int64_t n_rows, ProjectTile *out, int64_t n_tiles) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tiles) return;
-    ProjectTile d;
-    d.p[0] = b0 ? b0 + t * kTileRows * w0 : nullptr;
-    d.p[1] = b1 ? b1 + t * kTileRows * w1 : nullptr;
-    d.p[2] = b2 ? b2 + t * kTileRows * w2 : nullptr;
-    const int64_t left = n_rows - t * kTileRows;
-    d.rows = (uint32_t)(left < kTileRows ? (left > 0 ? left : 0) : kTileRows);
-    d.pad = 0u;
-    out[t] = d;
-}
-void launch_project_tile_desc_flat(const void *b0, int w0, const void *b1, int w1, const void *b2, int w2, int64_t n_rows, ProjectTile *out, int64_t n_tiles, hipStream_t s) {
-    if (n_tiles <= 0) return;
-    hipLaunchKernelGGL(k_project_tile_desc_flat, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, s, (const uint8_t *)b0, w0, (const uint8_t *)b1, w1, (const uint8_t *)b2, w2, n_rows, out,
-                       n_tiles);
-}
 #else
 bool launch_filter_project(const ProjectArgs &a, int grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
 #define IMM3_PROJECT_CASE(k0, k1, k2)                                                               \
