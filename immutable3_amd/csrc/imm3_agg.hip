@@ -14,6 +14,7 @@
 // value bytes big-endian-packed into a u64 == lexicographic byte order == String.compareTo for ASCII.
 #include "imm3_internal.h"
 #include "imm3_device.h"
+#include "imm3_tile.h"
 #include <atomic>
 #include <hip/hip_ext.h>
 
@@ -701,6 +702,18 @@ __device__ __forceinline__ uint32_t lane_row_value(const v4i_t (&r)[W == 4 ? 4 :
     else return ((uint32_t)r[0][i >> 2] >> (8 * (i & 3))) & 0xFFu;
 }
 
+// Bit i = row i of the lane's sixteen int8 rows lies in [lo, lo + span]: three vector instructions per row (subtract with byte
+// select, compare, add-with-carry as shift-and-insert; imm3_tile.h: ColRegs<TK_I8>::rows4 -- the compiler's own code for the loop is
+// five and a wait state).
+__device__ __forceinline__ uint32_t int8_rows_mask(const v4i_t &rows, uint32_t lo, uint32_t span) {
+    uint32_t m = 0;
+    ColRegs<TK_I8>::rows4(m, rows[3], lo, span); // (row 15 first: each step shifts the rows so far up)
+    ColRegs<TK_I8>::rows4(m, rows[2], lo, span);
+    ColRegs<TK_I8>::rows4(m, rows[1], lo, span);
+    ColRegs<TK_I8>::rows4(m, rows[0], lo, span);
+    return m;
+}
+
 // The same with a RUN-TIME row index (the sparse walk of k_group_agg_lanes: every lane takes its own next selected row).  Registers
 // cannot be indexed per lane, so the element is picked with byte permutes (v_perm_b32 selects any four bytes of a register pair)
 // and a few conditional moves: 5 vector instructions for a 1-byte column, ~11 for a 2-byte one, ~19 for int32.
@@ -886,12 +899,10 @@ __global__ __launch_bounds__(1024) void k_group_agg_lanes(const AggArgs a, const
 #pragma unroll
                             for (int i = 0; i < 16; ++i) ok |= ((lane_row_value<4>(r.vr, i) - lo) <= span ? 1u : 0u) << i;
                         } else if constexpr (VW == 1) {
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) ok |= (((uint32_t)(int32_t)(int8_t)lane_row_value<1>(r.vr, i) - lo) <= span ? 1u : 0u) << i;
+                            ok = int8_rows_mask(r.vr[0], lo, span);
                         }
                     } else {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) ok |= (((uint32_t)(int32_t)(int8_t)lane_row_value<1>(r.pr, i) - lo) <= span ? 1u : 0u) << i;
+                        ok = int8_rows_mask(r.pr[0], lo, span);
                     }
                     bits &= ok;
                 }
