@@ -317,7 +317,9 @@ int imm3_query_device_ptr(imm3_query *q, int32_t which, void **ptr);
  * every GPU runs its own PipelineThreads (Engine.scala:176-180); bitmaps, row lists and oids stay where they were
  * produced.  The ONE exchange is the selected-row count, summed over the GPUs with one 8-byte
  * ncclAllReduce(sum, ncclUint64) over RCCL / xGMI, ordered behind the scans that produce the counts.
- * RCCL is bound at run time (librccl.so.1); a single-GPU host never needs it.
+ * RCCL is bound at run time (librccl.so.1, or the library the environment variable IMM3_RCCL_LIB names -- the test suite's
+ * two-rank loopback transport); a single-GPU host never needs it.  While a communicator of more than one rank is attached to a
+ * context, that context's one-launch projections leave one CU per XCD to the collective's kernel.
  *   one process per GPU : rank 0 calls imm3_comm_unique_id, the host hands the 128 bytes to every rank (any channel:
  *                         a file, a socket, a key-value store), every rank calls imm3_comm_create
  *   one process, G GPUs : imm3_comm_create_all over one context per device (the JVM host's shape: one Engine, one

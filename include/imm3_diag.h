@@ -47,7 +47,10 @@ int imm3_ctx_measure_read_gbps(imm3_ctx *ctx, uint64_t bytes, int32_t iters, dou
  * 12 = the plan made at creation stands whatever the cost model predicts (tests of one plan's kernels; P still adapts),
  * 14 = a `limit` query scans the whole segment in one launch instead of in chunks behind a limit-reached word (decided per run),
  * 15 = a small limit behind a limit scan takes k_scan + k_gather instead of the one fused launch (k_limit_gather),
- * 200 + P = fixed tiles per range. */
+ * 16 = one-launch projections use every CU even while a communicator whose collectives launch kernels is attached (default: one
+ * CU per XCD is left to the collective's kernel), 17 = an aggregation's select chain runs as its own launch instead of inside the
+ * aggregation launch, 19 = a projection through survivor records stores its bitmap in the staging launch (default: the bitmap is
+ * materialised when imm3_query_bitmap asks), 200 + P = fixed tiles per range. */
 int imm3_ctx_set_tuning(imm3_ctx *ctx, int32_t filter_variant, int32_t grid_blocks);
 
 /* The projection planner's cost model (csrc/imm3_plan.h): predicted microseconds of one run's kernels under plan A (one launch), B
