@@ -129,7 +129,7 @@ def test_tables_and_limit_chunks(ctx):
     parts = [narrow_columns(rng, m) for m in rows]
     segs = [native.DeviceSegment(ctx, [c.native() for c in raw_cols(a, st, blocks_of(m, 1024))]) for (a, st), m in zip(parts, rows)]
     table = native.DeviceTable(ctx, segs)
-    for name in ("I8", "I8+I8", "S2", "I8+S2", "I8+I8+S2"):
+    for name in ("I8", "I8+I8", "S2", "I8+S2", "I8+I8+S2", "I8 x4", "I8 x4 + S2"):  # (the last two: a second pass ANDs into the first's words)
         used, sels, mask = CASES[name]
         q = native.DeviceQuery(ctx, table, used, sels(None), (), 0, 1024)
         q.run()
