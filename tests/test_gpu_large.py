@@ -83,6 +83,36 @@ def test_partition_and_fusion_100m(big):
     assert c_none == N and (w_none == full).all()
 
 
+def test_narrow_only_chains_100m(big):
+    """The in-lane instances of the scan + select kernel (int8 / 2-byte strings only: csrc/imm3_kernels.hip, lane_tile) at the full
+    size, against numpy: the whole bitmap, the count, the count-only run, complements and the AND of single-column filters."""
+    from immutable3_amd import native
+    ctx, seg, ids, age, st = big
+    codes = st.view("<u2").reshape(-1)
+    ca, ny = int.from_bytes(b"CA", "little"), int.from_bytes(b"NY", "little")
+    def run(used, sels):
+        q = native.DeviceQuery(ctx, seg, used, sels)
+        q.run()
+        w, c = q.bitmap(), q.count()
+        q.run_count()
+        assert q.count() == c
+        q.close()
+        return w, c
+    def words(keep):
+        return np.packbits(keep, bitorder="little").view("<u8")           # (N is a multiple of 64)
+    k_age = (age > 18) & (age < 30)
+    k_st = (codes == ca) | (codes == ny)
+    w_age, c_age = run([1], [(0, GT, 18.0), (0, LT, 30.0)])
+    assert c_age == int(k_age.sum()) and (w_age == words(k_age)).all()
+    w_st, c_st = run([2], [(0, MATCH, [b"CA", b"NY"])])
+    assert c_st == int(k_st.sum()) and (w_st == words(k_st)).all()
+    w_both, c_both = run([1, 2], [(0, GT, 18.0), (0, LT, 30.0), (1, MATCH, [b"CA", b"NY"])])
+    assert ((w_age & w_st) == w_both).all() and c_both == popcount(w_both) == int((k_age & k_st).sum())
+    w_lo, c_lo = run([1], [(0, LT, 19.0)])
+    w_hi, c_hi = run([1], [(0, GT, 18.0)])
+    assert c_lo + c_hi == N and not (w_lo & w_hi).any() and ((w_lo | w_hi) == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+
+
 def test_c4_match_project_100m(big):
     from immutable3_amd import native
     ctx, seg, ids, age, st = big
